@@ -1,0 +1,186 @@
+/*
+ * lhvi.h -- C ABI of the MI355X (gfx950) message-passing library `liblhvi.so`.
+ *
+ * This is the drop-in boundary of the hot path.  The reference
+ * (leodd/Lifted-Hybrid-Variational-Inference) has no FFI: its boundary is the Python method surface
+ * of the solver classes.  Each entry point below replaces the *body* of one of those methods and
+ * cites it; the Python classes in lifted-hybrid-variational-inference_amd/lhvi/ keep the reference's
+ * signatures and call these through ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types; every pointer inside the structs and every array argument is a
+ *     DEVICE pointer (hipMalloc'd or a torch tensor's data_ptr()); the structs themselves live on the host.
+ *   - all calls are asynchronous on the caller's `hipStream_t` (passed as void*; NULL = default stream),
+ *     allocate nothing, keep no global state, and are re-entrant per stream.
+ *   - return 0 on success, a negative LHVI_E_* code otherwise; nothing throws across the boundary.
+ *   - all floating point is IEEE fp64, like the reference (Python floats).
+ *   - a Gaussian message is two doubles (mu, var); var = NaN encodes the reference's `None`
+ *     variance (pure linear term, GaBP.py:126), var = +Inf the vacuous message (GaBP.py:138).
+ */
+#ifndef LHVI_H
+#define LHVI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LHVI_ABI_VERSION 1
+#define LHVI_MAX_ARITY 6
+
+/* error codes */
+#define LHVI_OK 0
+#define LHVI_E_ARG (-1)        /* null pointer / negative size / inconsistent struct */
+#define LHVI_E_LAUNCH (-2)     /* hipLaunch failed; see lhvi_last_hip_error() */
+#define LHVI_E_UNSUPPORTED (-3)/* e.g. arity > LHVI_MAX_ARITY, n not supported */
+#define LHVI_E_NODEVICE (-4)   /* no HIP device visible */
+
+/* potential kinds (pot_kind[]); parameter layouts are documented in csrc/potential.hpp */
+#define LHVI_POT_GENERIC 0
+#define LHVI_POT_TABLE 1
+#define LHVI_POT_GAUSSIAN 2
+#define LHVI_POT_QUADRATIC 3
+#define LHVI_POT_HYBRID_QUADRATIC 4
+#define LHVI_POT_LINEAR_GAUSSIAN 5
+#define LHVI_POT_X2 6
+#define LHVI_POT_XY 7
+#define LHVI_POT_MLN 8
+#define LHVI_POT_MLN_HARD 9
+#define LHVI_POT_IMAGE_NODE 10
+#define LHVI_POT_IMAGE_EDGE 11
+
+/* Flat factor graph (ground or lifted).  Built by lhvi/flat.py from Graph / CompressedGraph objects
+ * (Graph.py:137-209, CompressedGraphWithObs.py:178-271).  Edges are (factor, argument) incidences,
+ * factor-major: the edges of factor f are fac_ptr[f] .. fac_ptr[f+1]-1 in argument order. */
+typedef struct lhvi_graph {
+    int32_t V, F, E, nnz;       /* nnz = length of var_edge (== E unless a lifted factor repeats a cluster) */
+    const int32_t* fac_ptr;     /* [F+1] */
+    const int32_t* edge_var;    /* [E] variable of edge e */
+    const int32_t* edge_fac;    /* [E] factor of edge e */
+    const int32_t* edge_canon;  /* [E] canonical edge of the (factor, variable) pair, or NULL if all e */
+    const int32_t* var_ptr;     /* [V+1] */
+    const int32_t* var_edge;    /* [nnz] canonical edge ids in rv.nb order */
+    const double* edge_count;   /* [E] lifted multiplicity rv.count[f], or NULL (ground: all 1) */
+    const int32_t* fac_pot;     /* [F] index into the potential table */
+    const double* var_value;    /* [V] evidence value, NaN = hidden */
+    const int32_t* var_dom;     /* [V] domain id */
+    const double* var_mult;     /* [V] |cluster| (len(rv.rvs)), or NULL */
+    const double* fac_mult;     /* [F] |cluster| (len(f.factors)), or NULL */
+    int32_t D;                  /* number of domains */
+    const int32_t* dom_cont;    /* [D] 1 = continuous */
+    const double* dom_lo;       /* [D] */
+    const double* dom_hi;       /* [D] */
+    const int32_t* dom_ptr;     /* [D+1] into dom_val */
+    const double* dom_val;      /* discrete: the states; continuous: the integral points */
+} lhvi_graph_t;
+
+/* Potential table: one row per distinct (potential object, scope domains). */
+typedef struct lhvi_pots {
+    int32_t P;
+    const int32_t* kind;        /* [P] LHVI_POT_* */
+    const int32_t* off;         /* [P+1] into param */
+    const double* param;
+} lhvi_pots_t;
+
+int lhvi_version(void);
+const char* lhvi_strerror(int code);
+int lhvi_last_hip_error(void);       /* hipError_t of the last failed launch on this thread */
+int lhvi_device_count(void);
+
+/* ---- Gaussian BP (GaBP.py / GaLBP.py) ----------------------------------------------------------
+ * f2v / v2f: [E][2] doubles (mu, var), indexed by edge id. */
+
+/* all messages (mu,var) = (0,1): GaBP.py:142-145, GaLBP.py:154-157 */
+int lhvi_gabp_init(const lhvi_graph_t* g, double* f2v, double* v2f, void* stream);
+/* variable -> factor half sweep: GaBP.message_rv_to_f GaBP.py:20-35, GaLBP.py:21-39 */
+int lhvi_gabp_v2f(const lhvi_graph_t* g, const double* f2v, double* v2f, void* stream);
+/* factor -> variable half sweep: GaBP.message_f_to_rv GaBP.py:37-138, GaLBP.py:41-142 */
+int lhvi_gabp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const double* v2f, double* f2v, void* stream);
+/* `iterations` flooding sweeps; the last one skips f2v: GaBP.run GaBP.py:140-169, GaLBP.run GaLBP.py:159-181 */
+int lhvi_gabp_run(const lhvi_graph_t* g, const lhvi_pots_t* pots, double* f2v, double* v2f, int iterations, void* stream);
+/* per-variable product of incoming messages -> mu_var [V][2]; evidence rows get (value, 0):
+ * GaBP.get_belief_params GaBP.py:187-200, GaLBP.map GaLBP.py:201-217 */
+int lhvi_gabp_marginals(const lhvi_graph_t* g, const double* f2v, double* mu_var, void* stream);
+
+/* ---- Particle BP (EPBPLogVersion.py / HybridLBPLogVersion.py) -----------------------------------
+ * Log messages are tabulated per edge: f2v [E][n+T] (first n = at the variable's particles, next T = at
+ * the variable's integral points), v2f [E][n]. */
+
+#define LHVI_PBP_EP 1u            /* proposal_approximation == 'EP' (else 'simple') */
+#define LHVI_PBP_EPBP_DISCRETE 2u /* EPBP applies importance weights to discrete rvs too (EPBP.py:157) */
+
+typedef struct lhvi_pbp {
+    int32_t n;                  /* particle slots per variable */
+    int32_t T;                  /* integral-point slots per variable (max over domains) */
+    uint32_t flags;
+    double var_threshold;       /* EPBP 3, HybridLBP 5 */
+    double max_log_value;       /* 700 */
+    const double* particles;    /* [V][n] current sample */
+    const double* old_particles;/* [V][n] sample the v2f messages were computed on */
+    const int32_t* np;          /* [V] valid particles: n (continuous hidden), #states (discrete hidden), 0 (observed) */
+    const uint8_t* uniq;        /* [V][n] 1 = first occurrence of that value among the variable's particles */
+    const double* q;            /* [V][2] proposal (mu, var) */
+} lhvi_pbp_t;
+
+/* uniq[v][j] = no i<j with particles[v][i] == particles[v][j]  (dict-key collapse, EPBP.py:236-242) */
+int lhvi_pbp_uniq(const lhvi_graph_t* g, int32_t n, const double* particles, const int32_t* np, uint8_t* uniq, void* stream);
+/* EPBP.message_rv_to_f + important_weight + log_message_balance: EPBP.py:156-174,204-215; HLBP.py:173-191,225-236 */
+int lhvi_pbp_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* v2f, void* stream);
+/* EPBP.message_f_to_rv at the new particles + integral points: EPBP.py:176-194,275-285; HLBP.py:193-215 */
+int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f, double* f2v, void* stream);
+/* update_proposal (sites eta [E][2] in/out, q [V][2] in/out): EPBP.py:83-154; HLBP.py:100-171 */
+int lhvi_pbp_proposal(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* eta, double* q, void* stream);
+/* initial_proposal: q=(0,5), sites (0, 5*deg): EPBP.py:72-81; HLBP.py:89-98 */
+int lhvi_pbp_init(const lhvi_graph_t* g, const lhvi_pbp_t* s, double* eta, double* q, double* f2v, double* v2f, void* stream);
+/* generate_sample with a counter-based device RNG keyed (seed, variable gid, iteration, j): EPBP.py:61-70.
+ * var_gid may be NULL (gid = local index).  Parity runs inject host particles instead. */
+int lhvi_pbp_resample(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int64_t* var_gid, uint64_t seed, uint32_t iteration, double* particles_out, void* stream);
+/* belief_rv(x) = sum_f message_f_to_rv(x, f, rv, sample) at arbitrary points: EPBP.py:196-202; HLBP.py:313-317.
+ * qvar [nq] variable ids, x [nq][npts], out [nq][npts]; uses s->particles as the partners' sample. */
+int lhvi_pbp_belief_points(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f,
+                           int32_t nq, const int32_t* qvar, int32_t npts, const double* x, double* out, void* stream);
+
+/* ---- Mixture variational inference (VarInference.py / LiftedVarInference.py) --------------------- */
+
+typedef struct lhvi_vi {
+    int32_t K;                  /* mixture components */
+    int32_t T;                  /* Gauss-Hermite points */
+    int32_t Dmax;               /* max #states of a discrete variable (row stride of eta_d) */
+    int32_t quirks;             /* 1 = reproduce VarInference.py:147-150 */
+    const double* gh_x;         /* [T] hermgauss nodes */
+    const double* gh_w;         /* [T] weights / sqrt(pi) */
+    const double* w;            /* [K] softmax(w_tau) */
+    const double* eta_c;        /* [V][K][2] (mu, var) for continuous hidden variables */
+    const double* eta_d;        /* [V][K][Dmax] category probabilities for discrete hidden variables */
+} lhvi_vi_t;
+
+/* gradient_w_tau / gradient_mu_var / gradient_category_tau / free_energy: VarInference.py:57-195,
+ * LiftedVarInference.py:59-199.  Outputs: g_w [K] (already softmax-projected), g_c [V][K][2],
+ * g_d [V][K][Dmax] (already projected), fe [1].  ws: workspace of lhvi_vi_workspace_bytes() bytes. */
+size_t lhvi_vi_workspace_bytes(const lhvi_graph_t* g, const lhvi_vi_t* p);
+int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t* p,
+                 double* g_w, double* g_c, double* g_d, double* fe, void* ws, size_t ws_bytes, void* stream);
+/* ADAM_update body: VarInference.py:255-287.  theta/m/s/g are flat arrays of `count` doubles;
+ * clip_stride>0 clamps every element with index % clip_stride == clip_stride-1 to >= clip_min (variances). */
+int lhvi_adam_step(double* theta, double* m, double* s, const double* g, int64_t count, int32_t t,
+                   double lr, double b1, double b2, double eps, int32_t clip_stride, double clip_min, void* stream);
+/* softmax over rows of `cols` valid entries (stride `stride`): VarInference.py:32-38 */
+int lhvi_softmax_rows(const double* tau, double* out, int64_t rows, int32_t cols, int32_t stride, void* stream);
+
+/* ---- Colour refinement (CompressedGraphWithObs.py / CompressedGraphSorted.py) --------------------
+ * One half-round each; colours are dense int32 ids.  ws: lhvi_color_workspace_bytes(g) bytes. */
+size_t lhvi_color_workspace_bytes(const lhvi_graph_t* g);
+/* SuperF.split_by_structure CGWO.py:152-175: signature = (old colour, nb rv colours [sorted iff symmetric]) */
+int lhvi_color_refine_factors(const lhvi_graph_t* g, const uint8_t* pot_symmetric_per_factor, const int32_t* rv_color,
+                              const int32_t* f_color, int32_t* f_color_out, int32_t* n_colors_out,
+                              void* ws, size_t ws_bytes, void* stream);
+/* SuperRV.split_by_structure CGWO.py:47-76: signature = (old colour, sorted multiset of nb factor colours) */
+int lhvi_color_refine_rvs(const lhvi_graph_t* g, const int32_t* f_color, const int32_t* rv_color,
+                          int32_t* rv_color_out, int32_t* n_colors_out, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LHVI_H */

@@ -1,0 +1,225 @@
+// gabp.hip -- Gaussian belief propagation sweep (ground GaBP and lifted GaLBP) for gfx950.
+//
+// Reference semantics: GaBP.py:20-169,187-200 and GaLBP.py:21-217 (restated in SURVEY.md Appendix A.1/A.2).
+// Messages are (mu, var) pairs of fp64; var = NaN encodes the reference's `None` (pure linear term).
+// The schedule is flooding: each half sweep reads only the other half's buffer, so both kernels are
+// embarrassingly parallel and bound by HBM bandwidth (76 B/edge/sweep algorithmic).
+//
+// Floating point: contraction is disabled in this file so a*b+c is rounded twice like CPython does;
+// sums run in rv.nb order.  That makes the ground sweep bit-identical to the reference on the fixtures.
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace lhvi {
+
+__global__ void __launch_bounds__(BLOCK) gabp_init_kernel(int64_t n2, double* __restrict__ a, double* __restrict__ b) {
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n2) { st2(a, i, 0.0, 1.0); st2(b, i, 0.0, 1.0); }
+}
+
+// One thread per variable-CSR slot k = (variable v, incident edge e).  The d threads of a degree-d
+// variable sit in adjacent lanes and walk the same d incoming messages, so after the first touch the
+// reads are same-address broadcasts out of L1.  Leave-one-out is a direct sum (no total-minus-own
+// cancellation), in rv.nb order like GaBP.py:23-29 / GaLBP.py:24-34.
+__global__ void __launch_bounds__(BLOCK) gabp_v2f_kernel(lhvi_graph_t g, const double* __restrict__ f2v,
+                                                        double* __restrict__ v2f) {
+    int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= g.nnz) return;
+    const int e = g.var_edge[k];
+    const int v = g.edge_var[e];
+    if (!is_hidden(g.var_value[v])) {          // observed rv sends nothing (returns None)
+        st2(v2f, e, NAN, NAN);
+        return;
+    }
+    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    double H = 0.0, P = 0.0;
+    for (int j = lo; j < hi; ++j) {
+        const int ej = g.var_edge[j];
+        double c;
+        if (g.edge_count) {                     // lifted: own factor enters count-1 times
+            c = g.edge_count[ej];
+            if (j == k) c -= 1.0;
+        } else {
+            if (j == k) continue;               // ground: own factor skipped
+            c = 1.0;
+        }
+        const double2 m = ld2(f2v, ej);
+        if (m.y != m.y) {                       // var is None: linear term only
+            H -= g.edge_count ? m.x * c : m.x;
+        } else {
+            const double p = 1.0 / m.y;
+            if (g.edge_count) { H += p * m.x * c; P += p * c; }
+            else              { H += p * m.x;     P += p; }
+        }
+    }
+    const double var = 1.0 / P;
+    st2(v2f, e, var * H, var);
+}
+
+// closed forms of GaBP.message_f_to_rv (GaBP.py:37-138).  (u, s): partner's v->f message when the
+// partner is hidden; y: its evidence value otherwise.
+__device__ __forceinline__ double2 f2v_closed_form(int kind, const double* __restrict__ par, int arity, int pos,
+                                                   bool partner_hidden, double u, double s, double y) {
+    const double INF = __builtin_huge_val();
+    if (kind == LHVI_POT_X2) {
+        const double h = par[0], sg = par[1];
+        if (h == 0.0) return make_double2(0.0, INF);
+        return make_double2(0.0, sg / h);
+    }
+    if (arity != 2) return make_double2(0.0, INF);
+    if (kind == LHVI_POT_GAUSSIAN) {
+        if ((int)par[0] != 2) return make_double2(0.0, INF);
+        const double* mu = par + 1;
+        const double* a = par + 1 + 2 + 4;       // sig ** -1 as computed by np.matrix (GaBP.py:44)
+        double a1, a2, a3, u1, u2;
+        if (pos == 1) { a1 = a[0]; a2 = a[1]; a3 = a[3]; u1 = mu[0]; u2 = mu[1]; }
+        else          { a1 = a[3]; a2 = a[1]; a3 = a[0]; u1 = mu[1]; u2 = mu[0]; }
+        if (partner_hidden) {
+            const double a4 = 1.0 / s;
+            const double temp = a3 * (a4 + a1) - a2 * a2;
+            const double m = a2 * a4 * (u1 - u) / temp + u2;
+            const double v = 1.0 / (a3 - a2 * a2 / (a4 + a1));
+            return make_double2(m, v);
+        }
+        return make_double2(-u2 - a2 * (y - u1) / a3, 1.0 / a3);
+    }
+    if (kind == LHVI_POT_LINEAR_GAUSSIAN) {
+        const double h = par[0], s1 = par[1];
+        if (h == 0.0) return make_double2(0.0, INF);
+        const double h2 = h * h;
+        if (partner_hidden) {
+            if (pos == 0) return make_double2(u / h, (s1 + s) / h2);
+            return make_double2(u * h, s1 + s * h2);
+        }
+        if (pos == 0) return make_double2(y / h, s1 / h2);
+        return make_double2(h * y, s1);
+    }
+    if (kind == LHVI_POT_XY) {
+        const double h = par[0], s1 = par[1];
+        if (h == 0.0) return make_double2(0.0, INF);
+        if (partner_hidden) {
+            const double m = 2.0 * s1 * u / (h * s);
+            const double v = -4.0 * (s1 * s1) / (h * h * s);
+            return make_double2(m, v);
+        }
+        return make_double2(h * y / (2.0 * s1), NAN);   // (mu, None)
+    }
+    return make_double2(0.0, INF);
+}
+
+// One thread per edge (factor-major, so a factor's two edges are adjacent lanes and the partner's
+// message is a neighbouring 16-byte load).
+__global__ void __launch_bounds__(BLOCK) gabp_f2v_kernel(lhvi_graph_t g, lhvi_pots_t pots,
+                                                        const double* __restrict__ v2f, double* __restrict__ f2v) {
+    int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= g.E) return;
+    if (canon(g.edge_canon, e) != e) return;     // alias of a repeated cluster: the canonical edge owns the message
+    const int v = g.edge_var[e];
+    if (!is_hidden(g.var_value[v])) return;       // message to an observed rv is never produced (GaBP.py:39-40)
+    const int f = g.edge_fac[e];
+    const int base = g.fac_ptr[f];
+    const int arity = g.fac_ptr[f + 1] - base;
+    const int pos = e - base;
+    const int pot = g.fac_pot[f];
+    const int kind = pots.kind[pot];
+    const double* par = pots.param + pots.off[pot];
+    bool partner_hidden = false;
+    double u = 0.0, s = 0.0, y = 0.0;
+    if (arity == 2) {
+        const int pe = base + (1 - pos);
+        const int pv = g.edge_var[pe];
+        y = g.var_value[pv];
+        partner_hidden = is_hidden(y);
+        if (partner_hidden) {
+            const double2 m = ld2(v2f, canon(g.edge_canon, pe));
+            u = m.x; s = m.y;
+        }
+    }
+    const double2 out = f2v_closed_form(kind, par, arity, pos, partner_hidden, u, s, y);
+    st2(f2v, e, out.x, out.y);
+}
+
+// Per-variable product of all incoming messages (GaBP.py:187-200, GaLBP.py:201-217).
+__global__ void __launch_bounds__(BLOCK) gabp_marginal_kernel(lhvi_graph_t g, const double* __restrict__ f2v,
+                                                             double* __restrict__ out) {
+    int v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v >= g.V) return;
+    const double val = g.var_value[v];
+    if (!is_hidden(val)) { st2(out, v, val, 0.0); return; }
+    double H = 0.0, P = 0.0;
+    for (int j = g.var_ptr[v]; j < g.var_ptr[v + 1]; ++j) {
+        const int ej = g.var_edge[j];
+        const double2 m = ld2(f2v, ej);
+        if (g.edge_count) {
+            const double c = g.edge_count[ej];
+            if (m.y != m.y) H -= m.x * c;
+            else { const double p = 1.0 / m.y; H += p * m.x * c; P += p * c; }
+        } else {
+            if (m.y != m.y) H -= m.x;
+            else { const double p = 1.0 / m.y; H += p * m.x; P += p; }
+        }
+    }
+    const double var = 1.0 / P;
+    st2(out, v, var * H, var);
+}
+
+static int validate(const lhvi_graph_t* g) {
+    if (!g) return LHVI_E_ARG;
+    if (g->V < 0 || g->F < 0 || g->E < 0 || g->nnz < 0) return LHVI_E_ARG;
+    if (g->E > 0 && (!g->fac_ptr || !g->edge_var || !g->edge_fac || !g->var_ptr || !g->var_edge ||
+                     !g->fac_pot || !g->var_value)) return LHVI_E_ARG;
+    return LHVI_OK;
+}
+
+}  // namespace lhvi
+
+using namespace lhvi;
+
+extern "C" {
+
+int lhvi_gabp_init(const lhvi_graph_t* g, double* f2v, double* v2f, void* stream) {
+    if (int rc = validate(g)) return rc;
+    if (g->E == 0) return LHVI_OK;
+    if (!f2v || !v2f) return LHVI_E_ARG;
+    hipLaunchKernelGGL(gabp_init_kernel, dim3(grid_for(g->E)), dim3(BLOCK), 0, as_stream(stream), (int64_t)g->E, f2v, v2f);
+    return check_launch();
+}
+
+int lhvi_gabp_v2f(const lhvi_graph_t* g, const double* f2v, double* v2f, void* stream) {
+    if (int rc = validate(g)) return rc;
+    if (g->nnz == 0) return LHVI_OK;
+    if (!f2v || !v2f) return LHVI_E_ARG;
+    hipLaunchKernelGGL(gabp_v2f_kernel, dim3(grid_for(g->nnz)), dim3(BLOCK), 0, as_stream(stream), *g, f2v, v2f);
+    return check_launch();
+}
+
+int lhvi_gabp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const double* v2f, double* f2v, void* stream) {
+    if (int rc = validate(g)) return rc;
+    if (!pots || (g->F > 0 && (!pots->kind || !pots->off))) return LHVI_E_ARG;
+    if (g->E == 0) return LHVI_OK;
+    if (!f2v || !v2f) return LHVI_E_ARG;
+    hipLaunchKernelGGL(gabp_f2v_kernel, dim3(grid_for(g->E)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, v2f, f2v);
+    return check_launch();
+}
+
+int lhvi_gabp_run(const lhvi_graph_t* g, const lhvi_pots_t* pots, double* f2v, double* v2f, int iterations, void* stream) {
+    if (iterations < 0) return LHVI_E_ARG;
+    if (int rc = lhvi_gabp_init(g, f2v, v2f, stream)) return rc;
+    for (int i = 0; i < iterations; ++i) {
+        if (int rc = lhvi_gabp_v2f(g, f2v, v2f, stream)) return rc;
+        if (i < iterations - 1)
+            if (int rc = lhvi_gabp_f2v(g, pots, v2f, f2v, stream)) return rc;
+    }
+    return LHVI_OK;
+}
+
+int lhvi_gabp_marginals(const lhvi_graph_t* g, const double* f2v, double* mu_var, void* stream) {
+    if (int rc = validate(g)) return rc;
+    if (g->V == 0) return LHVI_OK;
+    if (!f2v || !mu_var) return LHVI_E_ARG;
+    hipLaunchKernelGGL(gabp_marginal_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, as_stream(stream), *g, f2v, mu_var);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+"""ctypes binding of ``liblhvi.so`` (the C ABI declared in ``include/lhvi.h``).
+
+PyTorch-ROCm is used only as the device allocator / stream provider: tensors are created with torch,
+their ``data_ptr()`` goes into the C structs, and launches run on ``torch.cuda.current_stream()``.
+There is no CPU fallback: if the library is missing or no GPU is visible, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'liblhvi.so')
+
+c_i32p = C.c_void_p
+c_f64p = C.c_void_p
+
+
+class LhviError(RuntimeError):
+    pass
+
+
+class GraphStruct(C.Structure):
+    _fields_ = [
+        ('V', C.c_int32), ('F', C.c_int32), ('E', C.c_int32), ('nnz', C.c_int32),
+        ('fac_ptr', C.c_void_p), ('edge_var', C.c_void_p), ('edge_fac', C.c_void_p), ('edge_canon', C.c_void_p),
+        ('var_ptr', C.c_void_p), ('var_edge', C.c_void_p), ('edge_count', C.c_void_p), ('fac_pot', C.c_void_p),
+        ('var_value', C.c_void_p), ('var_dom', C.c_void_p), ('var_mult', C.c_void_p), ('fac_mult', C.c_void_p),
+        ('D', C.c_int32),
+        ('dom_cont', C.c_void_p), ('dom_lo', C.c_void_p), ('dom_hi', C.c_void_p), ('dom_ptr', C.c_void_p),
+        ('dom_val', C.c_void_p),
+    ]
+
+
+class PotsStruct(C.Structure):
+    _fields_ = [('P', C.c_int32), ('kind', C.c_void_p), ('off', C.c_void_p), ('param', C.c_void_p)]
+
+
+class PbpStruct(C.Structure):
+    _fields_ = [
+        ('n', C.c_int32), ('T', C.c_int32), ('flags', C.c_uint32),
+        ('var_threshold', C.c_double), ('max_log_value', C.c_double),
+        ('particles', C.c_void_p), ('old_particles', C.c_void_p), ('np', C.c_void_p), ('uniq', C.c_void_p),
+        ('q', C.c_void_p),
+    ]
+
+
+class ViStruct(C.Structure):
+    _fields_ = [
+        ('K', C.c_int32), ('T', C.c_int32), ('Dmax', C.c_int32), ('quirks', C.c_int32),
+        ('gh_x', C.c_void_p), ('gh_w', C.c_void_p), ('w', C.c_void_p), ('eta_c', C.c_void_p), ('eta_d', C.c_void_p),
+    ]
+
+
+PBP_EP = 1
+PBP_EPBP_DISCRETE = 2
+
+_G, _P, _S, _VI = C.POINTER(GraphStruct), C.POINTER(PotsStruct), C.POINTER(PbpStruct), C.POINTER(ViStruct)
+_vp, _i32, _i64, _u32, _u64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/lhvi.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    'lhvi_version': (C.c_int, []),
+    'lhvi_strerror': (C.c_char_p, [C.c_int]),
+    'lhvi_last_hip_error': (C.c_int, []),
+    'lhvi_device_count': (C.c_int, []),
+    'lhvi_gabp_init': (C.c_int, [_G, _vp, _vp, _vp]),
+    'lhvi_gabp_v2f': (C.c_int, [_G, _vp, _vp, _vp]),
+    'lhvi_gabp_f2v': (C.c_int, [_G, _P, _vp, _vp, _vp]),
+    'lhvi_gabp_run': (C.c_int, [_G, _P, _vp, _vp, C.c_int, _vp]),
+    'lhvi_gabp_marginals': (C.c_int, [_G, _vp, _vp, _vp]),
+    'lhvi_pbp_uniq': (C.c_int, [_G, _i32, _vp, _vp, _vp, _vp]),
+    'lhvi_pbp_v2f': (C.c_int, [_G, _S, _vp, _vp, _vp]),
+    'lhvi_pbp_f2v': (C.c_int, [_G, _P, _S, _vp, _vp, _vp]),
+    'lhvi_pbp_proposal': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp]),
+    'lhvi_pbp_init': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp, _vp]),
+    'lhvi_pbp_resample': (C.c_int, [_G, _S, _vp, _u64, _u32, _vp, _vp]),
+    'lhvi_pbp_belief_points': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
+    'lhvi_vi_workspace_bytes': (_sz, [_G, _VI]),
+    'lhvi_vi_grad': (C.c_int, [_G, _P, _VI, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'lhvi_adam_step': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64, _f64, _i32, _f64, _vp]),
+    'lhvi_softmax_rows': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    'lhvi_color_workspace_bytes': (_sz, [_G]),
+    'lhvi_color_refine_factors': (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'lhvi_color_refine_rvs': (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+MISSING = []
+
+
+def lib():
+    """Load liblhvi.so once; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LhviError('HIP extension %s not built; run `python -c "import __graft_entry__ as g; g.build()"`'
+                            % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                MISSING.append(name)        # build() and tests/test_abi.py require this list to be empty
+                continue
+            fn.restype, fn.argtypes = res, args
+        if handle.lhvi_version() != 1:
+            raise LhviError('liblhvi.so ABI version mismatch')
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        l = lib()
+        raise LhviError('liblhvi: %s (code %d, hipError %d)' % (l.lhvi_strerror(rc).decode(), rc, l.lhvi_last_hip_error()))
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise LhviError('no MI355X/HIP device visible: the lhvi solvers have no CPU fallback '
+                        '(the CPU restatement lives in oracle/ and is test infrastructure only)')
+    return torch
+
+
+def stream_ptr():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def to_dev(a, device=None):
+    torch = require_gpu()
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device or 'cuda', non_blocking=False)
+
+
+class DeviceGraph:
+    """A ``FlatGraph`` resident in HBM plus the two C structs that point into it."""
+
+    def __init__(self, flat, device=None):
+        require_gpu()
+        self.flat = flat
+        t = {}
+        for name in ('fac_ptr', 'edge_var', 'edge_fac', 'var_ptr', 'var_edge', 'fac_pot', 'var_value', 'var_dom',
+                     'dom_cont', 'dom_lo', 'dom_hi', 'dom_ptr', 'dom_val', 'pot_kind', 'pot_off', 'pot_param'):
+            t[name] = to_dev(getattr(flat, name), device)
+        has_alias = bool((flat.edge_canon != np.arange(flat.E, dtype=np.int32)).any())
+        t['edge_canon'] = to_dev(flat.edge_canon, device) if has_alias else None
+        t['edge_count'] = to_dev(flat.edge_count, device) if flat.lifted else None
+        t['var_mult'] = to_dev(flat.var_mult, device) if flat.lifted else None
+        t['fac_mult'] = to_dev(flat.fac_mult, device) if flat.lifted else None
+        self.t = t
+        self.device = t['fac_ptr'].device
+        g = GraphStruct()
+        g.V, g.F, g.E, g.nnz = flat.V, flat.F, flat.E, int(flat.var_edge.size)
+        for name in ('fac_ptr', 'edge_var', 'edge_fac', 'edge_canon', 'var_ptr', 'var_edge', 'edge_count', 'fac_pot',
+                     'var_value', 'var_dom', 'var_mult', 'fac_mult', 'dom_cont', 'dom_lo', 'dom_hi', 'dom_ptr',
+                     'dom_val'):
+            setattr(g, name, ptr(t[name]))
+        g.D = int(flat.dom_cont.size)
+        self.g = g
+        p = PotsStruct()
+        p.P = int(flat.pot_kind.size)
+        p.kind, p.off, p.param = ptr(t['pot_kind']), ptr(t['pot_off']), ptr(t['pot_param'])
+        self.p = p
+
+    def zeros(self, *shape, dtype=None):
+        torch = _torch()
+        return torch.zeros(*shape, dtype=dtype or torch.float64, device=self.device)
+
+    def empty(self, *shape, dtype=None):
+        torch = _torch()
+        return torch.empty(*shape, dtype=dtype or torch.float64, device=self.device)

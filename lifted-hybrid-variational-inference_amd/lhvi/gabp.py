@@ -1,0 +1,140 @@
+"""Gaussian belief propagation on the GPU: ``GaBP`` (ground) and ``GaLBP`` (lifted).
+
+Same constructor / method surface as the reference (``GaBP.py:7-216``, ``GaLBP.py:8-217``):
+``GaBP(g).run(iteration)``, ``.belief(x, rv)``, ``.get_belief_params(rv)``, ``.map(rv)``, attribute
+``.message``.  ``run`` flattens the object graph once, keeps both message buffers resident in HBM and
+issues the flooding sweeps through ``lhvi_gabp_run`` (hand-written HIP, ``csrc/gabp.hip``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _abi
+from .flat import flatten
+
+
+def _norm_pdf_var(x, mu, var):
+    # GaBP.norm_pdf (GaBP.py:14-18): note the normaliser uses the variance, not its square root
+    u = x - mu
+    return np.exp(-u * u * 0.5 / var) / (2.506628274631 * var)
+
+
+class _GaussianSweep:
+    """State shared by the ground and the lifted solver: flat graph, device buffers, result cache."""
+
+    verbose = False
+
+    def _check_degrees(self, flat):
+        # the reference raises ZeroDivisionError (0 ** -1) when a hidden variable has no other incoming
+        # message to multiply (GaBP.py:31) -- keep the error instead of producing NaN
+        hidden = flat.var_hidden
+        incoming = np.zeros(flat.V)
+        np.add.at(incoming, flat.edge_var[flat.var_edge], flat.edge_count[flat.var_edge])
+        if np.any(hidden & (incoming <= 1) & (np.diff(flat.var_ptr) > 0)):
+            raise ZeroDivisionError('0.0 cannot be raised to a negative power')
+
+    def _sweep(self, graph_like, iteration):
+        flat = flatten(graph_like)
+        self._check_degrees(flat)
+        dg = _abi.DeviceGraph(flat)
+        f2v = dg.empty(flat.E, 2)
+        v2f = dg.empty(flat.E, 2)
+        mv = dg.empty(flat.V, 2)
+        l = _abi.lib()
+        s = _abi.stream_ptr()
+        _abi.check(l.lhvi_gabp_run(dg.g, dg.p, _abi.ptr(f2v), _abi.ptr(v2f), int(iteration), s))
+        _abi.check(l.lhvi_gabp_marginals(dg.g, _abi.ptr(f2v), _abi.ptr(mv), s))
+        self.flat, self.dg = flat, dg
+        self.f2v_dev, self.v2f_dev, self.mu_var_dev = f2v, v2f, mv
+        self._f2v = f2v.cpu().numpy()
+        self._v2f = v2f.cpu().numpy()
+        self._mu_var = mv.cpu().numpy()
+        self._message = None
+
+    @property
+    def message(self):
+        """dict keyed (f, rv) / (rv, f) -> [mu, var] like the reference; built lazily from the device arrays"""
+        if self._message is None:
+            self._message = _message_dict(self.flat, self._f2v, self._v2f)
+        return self._message
+
+    @message.setter
+    def message(self, value):
+        self._message = value
+
+    def _params(self, rv_flat):
+        i = self.flat.var_index[rv_flat]
+        return float(self._mu_var[i, 0]), float(self._mu_var[i, 1])
+
+
+def _message_dict(flat, f2v, v2f):
+    out = {}
+    none = lambda m: [float(m[0]), None if np.isnan(m[1]) else float(m[1])]
+    for k in range(flat.var_edge.size):
+        e = int(flat.var_edge[k])
+        rv, f = flat.rvs[flat.edge_var[e]], flat.factors[flat.edge_fac[e]]
+        if rv.value is None:
+            out[(f, rv)] = none(f2v[e])
+            out[(rv, f)] = none(v2f[e])
+        else:
+            out[(f, rv)] = [0, 1]       # never updated by the reference (GaBP.py:163-165)
+            out[(rv, f)] = None
+    return out
+
+
+class GaBP(_GaussianSweep):
+    """Ground Gaussian BP (``GaBP.py``)."""
+
+    def __init__(self, g=None):
+        self.g = g
+        self._message = {}
+
+    def run(self, iteration=10, log_enable=False):
+        self._sweep(self.g, iteration)
+
+    def get_belief_params(self, rv):
+        assert rv.value is None
+        return self._params(rv)
+
+    def belief(self, x, rv):
+        if rv.value is not None:
+            return 1 if x == rv.value else 0
+        mu, var = self._params(rv)
+        return _norm_pdf_var(x, mu, var)
+
+    def map(self, rv):
+        return rv.value if rv.value is not None else self._params(rv)[0]
+
+    norm_pdf = staticmethod(_norm_pdf_var)
+
+
+class GaLBP(_GaussianSweep):
+    """Lifted Gaussian BP (``GaLBP.py``): colour passing, then the same sweep with ``count`` exponents."""
+
+    def __init__(self, g=None):
+        from .lifting import CompressedGraph
+        self.g = CompressedGraph(g)
+        self._message = {}
+
+    def run(self, iteration=10, log_enable=False):
+        # colour passing exactly as GaLBP.run does it (GaLBP.py:146-151)
+        self.g.init_cluster()
+        prev = -1
+        while len(self.g.rvs) != prev:
+            prev = len(self.g.rvs)
+            self.g.split_factors()
+            self.g.split_rvs()
+        self._sweep(self.g, iteration)
+
+    def belief(self, x, ground_rv):
+        rv = ground_rv.cluster
+        if rv.value is not None:
+            return 1 if x == rv.value else 0
+        mu, var = self._params(rv)
+        return _norm_pdf_var(x, mu, var)
+
+    def map(self, ground_rv):
+        rv = ground_rv.cluster
+        return rv.value if rv.value is not None else self._params(rv)[0]
+
+    norm_pdf = staticmethod(_norm_pdf_var)

@@ -1,0 +1,386 @@
+"""Colour passing (lifting): ``CompressedGraph`` with the reference's object surface, refined on the GPU.
+
+Reference: ``CompressedGraphWithObs.py:8-271`` (used by GaLBP / HybridLBP / LiftedVarInference) and
+``CompressedGraphSorted.py:12-209`` (deterministic ids, ``sharing_count``, ``rvs_list``).  SURVEY.md note
+N1 asks for the union of both surfaces on one object, which ``SuperRV`` / ``SuperF`` here provide.
+
+Split of labour
+  host   : initial colours (domain identity / hidden-vs-evidence / evidence value; potential ``__eq__``),
+           building ``SuperRV`` / ``SuperF`` objects from the final colour arrays;
+  device : every refinement half-round (``lhvi_color_refine_factors`` / ``lhvi_color_refine_rvs``,
+           ``csrc/color.hip``) on the ground graph's CSR arrays, colours resident in HBM.
+Only the induced partition is defined by the reference (cluster objects carry no stable ids), so new
+colours are dense ranks; ``SuperRV.id`` / ``SuperF.id`` are those ranks.
+"""
+from __future__ import annotations
+
+from collections import Counter
+
+import numpy as np
+
+from . import _abi
+from .flat import flatten
+
+
+class SuperRV:
+    """Cluster of ground rvs (``CompressedGraphWithObs.py:8-45``; ids as in ``CompressedGraphSorted.py:13-32``)."""
+
+    def __init__(self, rvs, domain=None, value=None, cid=-1):
+        self.rvs = rvs
+        first = next(iter(rvs))
+        self.domain = first.domain if domain is None else domain
+        self.value = self.get_value(rvs) if value is None and first.value is not None else value
+        self.variance = None if self.value is None else self.get_variance()
+        self.nb = None
+        self.N = 0
+        self.count = None
+        self.id = cid
+        for rv in rvs:
+            rv.cluster = self
+
+    def __lt__(self, other):
+        return self.id < other.id
+
+    @staticmethod
+    def get_value(rvs):
+        total = 0
+        for rv in rvs:
+            total += rv.value
+        return total / len(rvs)
+
+    def get_variance(self):
+        return np.var(tuple(rv.value for rv in self.rvs))
+
+    @property
+    def sharing_count(self):
+        return len(self.rvs)
+
+    @property
+    def domain_type(self):
+        return next(iter(self.rvs)).domain_type
+
+    @property
+    def dstates(self):
+        return next(iter(self.rvs)).dstates
+
+    @property
+    def values(self):
+        return next(iter(self.rvs)).values
+
+    def update_nb(self, representative=None):
+        rv = representative if representative is not None else min(self.rvs)
+        self.count = Counter(f.cluster for f in rv.nb)
+        self.nb = tuple(self.count)
+        self.N = rv.N
+
+    def __repr__(self):
+        return 'SuperRV#%d(%d rvs)' % (self.id, len(self.rvs))
+
+
+class SuperF:
+    """Cluster of ground factors (``CompressedGraphWithObs.py:133-150``)."""
+
+    def __init__(self, factors, cid=-1):
+        self.factors = factors
+        first = next(iter(factors))
+        self.potential = first.potential
+        self.log_potential_fun = getattr(first, 'log_potential_fun', None)
+        self.nb = None
+        self.id = cid
+        for f in factors:
+            f.cluster = self
+
+    def __lt__(self, other):
+        return self.id < other.id
+
+    @property
+    def sharing_count(self):
+        return len(self.factors)
+
+    @property
+    def domain_type(self):
+        return next(iter(self.factors)).domain_type
+
+    @property
+    def nb_domain_types(self):
+        return next(iter(self.factors)).nb_domain_types
+
+    def update_nb(self, representative=None):
+        f = representative if representative is not None else min(self.factors)
+        self.nb = tuple(rv.cluster for rv in f.nb)
+
+    def __repr__(self):
+        return 'SuperF#%d(%d factors)' % (self.id, len(self.factors))
+
+
+def initial_colors(g, is_split_cont_evidence=True):
+    """Host side of ``CompressedGraph.init_cluster`` (``CompressedGraphWithObs.py:187-234``) as dense ids.
+
+    rvs: one colour per (Domain object, hidden) and per (Domain object, evidence value) -- or one per
+    (Domain object, 'evidence') for continuous domains when ``is_split_cont_evidence`` is False.
+    factors: one colour per potential under the potential's own ``__hash__`` / ``__eq__``.
+    """
+    rvs, factors = list(g.rvs), list(g.factors)
+    table, rv_color = {}, np.zeros(len(rvs), dtype=np.int32)
+    for i, rv in enumerate(rvs):
+        if rv.value is None:
+            key = (id(rv.domain), 'h')
+        elif not is_split_cont_evidence and rv.domain.continuous:
+            key = (id(rv.domain), 'e')
+        else:
+            key = (id(rv.domain), 'v', rv.value)
+        rv_color[i] = table.setdefault(key, len(table))
+    ptable, f_color = {}, np.zeros(len(factors), dtype=np.int32)
+    for i, f in enumerate(factors):
+        f_color[i] = ptable.setdefault(f.potential, len(ptable))
+    return rv_color, f_color
+
+
+class CompressedGraph:
+    """Colour-passing compression of a ground ``Graph`` (``CompressedGraphWithObs.py:178-271``)."""
+
+    def __init__(self, graph):
+        self.g = graph
+        self.clustered_evidence = set()
+        self._rv_color = None
+        self._f_color = None
+        self._objects = None
+        self._dev = None
+
+    # ---- device plumbing ---------------------------------------------------------------------
+    def _device(self):
+        if self._dev is None:
+            flat = flatten(self.g)
+            dg = _abi.DeviceGraph(flat)
+            sym = np.array([1 if getattr(f.potential, 'symmetric', False) else 0 for f in flat.factors], dtype=np.uint8)
+            l = _abi.lib()
+            ws_bytes = int(l.lhvi_color_workspace_bytes(dg.g))
+            torch = _abi.require_gpu()
+            self._dev = dict(flat=flat, dg=dg, sym=_abi.to_dev(sym) if sym.size else None,
+                             ws=torch.empty(ws_bytes, dtype=torch.uint8, device=dg.device), ws_bytes=ws_bytes,
+                             res=torch.zeros(2, dtype=torch.int32, device=dg.device))
+        return self._dev
+
+    def _upload_colors(self):
+        d = self._device()
+        if 'rvc' not in d:
+            d['rvc'] = _abi.to_dev(self._rv_color)
+            d['fc'] = _abi.to_dev(self._f_color)
+            d['rvc2'] = d['rvc'].clone()
+            d['fc2'] = d['fc'].clone()
+        return d
+
+    # ---- reference API -----------------------------------------------------------------------
+    def init_cluster(self, is_split_cont_evidence=True):
+        self._rv_color, self._f_color = initial_colors(self.g, is_split_cont_evidence)
+        self.num_rv_clusters = int(self._rv_color.max()) + 1 if self._rv_color.size else 0
+        self.num_factor_clusters = int(self._f_color.max()) + 1 if self._f_color.size else 0
+        self._objects = None
+        if self._dev is not None:
+            for k in ('rvc', 'fc', 'rvc2', 'fc2'):
+                self._dev.pop(k, None)
+        self.clustered_evidence = set()
+        self._coarse_evidence = not is_split_cont_evidence
+
+    def split_factors(self):
+        d = self._upload_colors()
+        l = _abi.lib()
+        _abi.check(l.lhvi_color_refine_factors(d['dg'].g, _abi.ptr(d['sym']), _abi.ptr(d['rvc']), _abi.ptr(d['fc']),
+                                               _abi.ptr(d['fc2']), _abi.ptr(d['res']), _abi.ptr(d['ws']),
+                                               d['ws_bytes'], _abi.stream_ptr()))
+        n, collision = (int(x) for x in d['res'].cpu())
+        if collision:
+            raise _abi.LhviError('colour refinement fingerprint collision (factor side)')
+        d['fc'], d['fc2'] = d['fc2'], d['fc']
+        self.num_factor_clusters = n
+        self._objects = None
+
+    def split_rvs(self):
+        d = self._upload_colors()
+        l = _abi.lib()
+        _abi.check(l.lhvi_color_refine_rvs(d['dg'].g, _abi.ptr(d['fc']), _abi.ptr(d['rvc']), _abi.ptr(d['rvc2']),
+                                           _abi.ptr(d['res']), _abi.ptr(d['ws']), d['ws_bytes'], _abi.stream_ptr()))
+        n, collision = (int(x) for x in d['res'].cpu())
+        if collision:
+            raise _abi.LhviError('colour refinement fingerprint collision (variable side)')
+        d['rvc'], d['rvc2'] = d['rvc2'], d['rvc']
+        self.num_rv_clusters = n
+        self._objects = None
+
+    def run(self):
+        """``CompressedGraph.run`` (``CompressedGraphWithObs.py:264-271``): refine until #rv clusters is stable."""
+        self.init_cluster(is_split_cont_evidence=True)
+        prev = -1
+        while prev != self.num_rv_clusters:
+            prev = self.num_rv_clusters
+            self.split_factors()
+            self.split_rvs()
+        return self
+
+    # ---- colours / objects -------------------------------------------------------------------
+    def colors(self):
+        """(rv_color, f_color) as host int32 arrays aligned with ``list(g.rvs)`` / ``list(g.factors)``"""
+        if self._dev is not None and 'rvc' in self._dev:
+            self._rv_color = self._dev['rvc'].cpu().numpy()
+            self._f_color = self._dev['fc'].cpu().numpy()
+        return self._rv_color, self._f_color
+
+    def set_colors(self, rv_color, f_color):
+        """Inject a partition (tests use this to exercise the host logic without a GPU)."""
+        self._rv_color = np.asarray(rv_color, dtype=np.int32)
+        self._f_color = np.asarray(f_color, dtype=np.int32)
+        self.num_rv_clusters = int(self._rv_color.max()) + 1 if self._rv_color.size else 0
+        self.num_factor_clusters = int(self._f_color.max()) + 1 if self._f_color.size else 0
+        self._objects = None
+        if self._dev is not None:
+            for k in ('rvc', 'fc', 'rvc2', 'fc2'):
+                self._dev.pop(k, None)
+
+    def _build(self):
+        if self._objects is None:
+            rv_color, f_color = self.colors()
+            self._objects = build_lifted_objects(self.g, rv_color, f_color)
+        return self._objects
+
+    @property
+    def rvs(self):
+        return self._build()[0]
+
+    @property
+    def factors(self):
+        return self._build()[1]
+
+    @property
+    def rvs_list(self):
+        return sorted(self.rvs)
+
+    @property
+    def factors_list(self):
+        return sorted(self.factors)
+
+
+def build_lifted_objects(g, rv_color, f_color):
+    """``SuperRV`` / ``SuperF`` sets for a partition; cluster representative = member with the smallest id."""
+    rvs, factors = list(g.rvs), list(g.factors)
+    groups = {}
+    for rv, c in zip(rvs, rv_color.tolist()):
+        groups.setdefault(c, []).append(rv)
+    fgroups = {}
+    for f, c in zip(factors, f_color.tolist()):
+        fgroups.setdefault(c, []).append(f)
+    super_rvs = [SuperRV(set(members), cid=c) for c, members in sorted(groups.items())]
+    super_fs = [SuperF(set(members), cid=c) for c, members in sorted(fgroups.items())]
+    for s in super_rvs:
+        s.update_nb()
+    for s in super_fs:
+        s.update_nb()
+    # keep a deterministic iteration order (the reference uses sets; solvers only rely on membership)
+    return _OrderedSet(super_rvs), _OrderedSet(super_fs)
+
+
+class _OrderedSet(list):
+    """list with set-like membership helpers; iteration order = ascending cluster id"""
+
+    def __contains__(self, x):
+        return any(x is y for y in self)
+
+
+def lift_flat(flat, rv_color, f_color):
+    """Lifted ``FlatGraph`` straight from a ground ``FlatGraph`` and a partition, without Python objects
+    (vectorised; the 10M-edge path).  Representative of a cluster = its first ground member; lifted edges
+    are the representative factor's incidences; ``count`` comes from the representative variable's
+    incident factor colours (``SuperRV.update_nb``, ``CompressedGraphWithObs.py:41-45``)."""
+    from .flat import FlatGraph
+    rv_color = np.asarray(rv_color, dtype=np.int64)
+    f_color = np.asarray(f_color, dtype=np.int64)
+    nV, nF = int(rv_color.max()) + 1, int(f_color.max()) + 1
+    rep_v = np.full(nV, flat.V, dtype=np.int64)
+    np.minimum.at(rep_v, rv_color, np.arange(flat.V))
+    rep_f = np.full(nF, flat.F, dtype=np.int64)
+    np.minimum.at(rep_f, f_color, np.arange(flat.F))
+    arity = (flat.fac_ptr[1:] - flat.fac_ptr[:-1])[rep_f]
+    fac_ptr = np.zeros(nF + 1, dtype=np.int32)
+    np.cumsum(arity, out=fac_ptr[1:])
+    E = int(fac_ptr[-1])
+    edge_fac = np.repeat(np.arange(nF, dtype=np.int32), arity)
+    edge_pos = (np.arange(E) - fac_ptr[edge_fac]).astype(np.int32)
+    g_edge = flat.fac_ptr[rep_f][edge_fac] + edge_pos
+    edge_var = rv_color[flat.edge_var[g_edge]].astype(np.int32)
+    # canonical edge of each (factor, variable) pair
+    pair = edge_fac.astype(np.int64) * nV + edge_var
+    order = np.argsort(pair, kind='stable')
+    first = np.ones(E, dtype=bool)
+    first[1:] = pair[order][1:] != pair[order][:-1]
+    canon_sorted = np.maximum.accumulate(np.where(first, order, 0))
+    # within a run the first element (stable sort) is the smallest edge id
+    run_start = np.maximum.accumulate(np.where(first, np.arange(E), 0))
+    edge_canon = np.empty(E, dtype=np.int32)
+    edge_canon[order] = order[run_start]
+    del canon_sorted
+    # variable side: the representative ground rv's incident factors, grouped by factor colour in first-seen order
+    var_ptr = np.zeros(nV + 1, dtype=np.int32)
+    var_edge, counts = [], np.ones(E, dtype=np.float64)
+    pair_to_edge = {}
+    for e in np.flatnonzero(edge_canon == np.arange(E)):
+        pair_to_edge[(int(edge_fac[e]), int(edge_var[e]))] = int(e)
+    for c in range(nV):
+        v = rep_v[c]
+        seen = {}
+        for k in range(flat.var_ptr[v], flat.var_ptr[v + 1]):
+            fc = int(f_color[flat.edge_fac[flat.var_edge[k]]])
+            seen[fc] = seen.get(fc, 0) + 1
+        for fc, cnt in seen.items():
+            e = pair_to_edge[(fc, c)]
+            var_edge.append(e)
+            counts[e] = cnt
+        var_ptr[c + 1] = len(var_edge)
+    edge_count = counts[edge_canon]
+    mult_v = np.bincount(rv_color, minlength=nV).astype(np.float64)
+    mult_f = np.bincount(f_color, minlength=nF).astype(np.float64)
+    # evidence value of a cluster: running sum of member values / size (SuperRV.get_value)
+    val = flat.var_value[rep_v].copy()
+    obs = ~np.isnan(val)
+    if obs.any():
+        sums = np.zeros(nV)
+        vv = np.where(np.isnan(flat.var_value), 0.0, flat.var_value)
+        np.add.at(sums, rv_color, vv)      # sequential accumulation in ground order
+        val[obs] = sums[obs] / mult_v[obs]
+    return FlatGraph(
+        V=nV, F=nF, E=E, fac_ptr=fac_ptr, edge_var=edge_var, edge_fac=edge_fac, edge_pos=edge_pos,
+        edge_canon=edge_canon, var_ptr=var_ptr, var_edge=np.array(var_edge, dtype=np.int32).reshape(-1),
+        edge_count=edge_count, lifted=True, fac_pot=flat.fac_pot[rep_f].astype(np.int32),
+        pot_kind=flat.pot_kind, pot_off=flat.pot_off, pot_param=flat.pot_param,
+        var_value=val, var_dom=flat.var_dom[rep_v].astype(np.int32), var_mult=mult_v, fac_mult=mult_f,
+        dom_cont=flat.dom_cont, dom_lo=flat.dom_lo, dom_hi=flat.dom_hi, dom_ptr=flat.dom_ptr, dom_val=flat.dom_val,
+        potentials=flat.potentials, domains=flat.domains)
+
+
+def refine_flat(flat, symmetric, rv_color, f_color, max_rounds=1000):
+    """Colour passing on flat arrays entirely on the device (the large-graph path: no Python objects).
+    Same loop as ``CompressedGraph.run``: factor half-round, rv half-round, until #rv colours is stable."""
+    torch = _abi.require_gpu()
+    dg = _abi.DeviceGraph(flat)
+    l = _abi.lib()
+    ws_bytes = int(l.lhvi_color_workspace_bytes(dg.g))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dg.device)
+    res = torch.zeros(2, dtype=torch.int32, device=dg.device)
+    sym = _abi.to_dev(np.asarray(symmetric, dtype=np.uint8))
+    rvc = _abi.to_dev(np.asarray(rv_color, dtype=np.int32))
+    fc = _abi.to_dev(np.asarray(f_color, dtype=np.int32))
+    rvc2, fc2 = rvc.clone(), fc.clone()
+    n_rv = int(rvc.max().item()) + 1 if flat.V else 0
+    prev = -1
+    rounds = 0
+    while prev != n_rv and rounds < max_rounds:
+        prev = n_rv
+        _abi.check(l.lhvi_color_refine_factors(dg.g, _abi.ptr(sym), _abi.ptr(rvc), _abi.ptr(fc), _abi.ptr(fc2),
+                                               _abi.ptr(res), _abi.ptr(ws), ws_bytes, _abi.stream_ptr()))
+        fc, fc2 = fc2, fc
+        _abi.check(l.lhvi_color_refine_rvs(dg.g, _abi.ptr(fc), _abi.ptr(rvc), _abi.ptr(rvc2), _abi.ptr(res),
+                                           _abi.ptr(ws), ws_bytes, _abi.stream_ptr()))
+        rvc, rvc2 = rvc2, rvc
+        n_rv, collision = (int(x) for x in res.cpu())
+        if collision:
+            raise _abi.LhviError('colour refinement fingerprint collision')
+        rounds += 1
+    return rvc.cpu().numpy(), fc.cpu().numpy()

@@ -1,0 +1,113 @@
+"""Synthetic model generators for the BASELINE.json configurations.
+
+Small object-graph builders (used by tests / smoke) and vectorised flat-array builders for the large
+benchmark graphs, which never materialise per-variable Python objects.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .graph import Domain, F, Graph, RV
+from .potentials import LinearGaussianPotential, X2Potential
+
+
+def gaussian_chain(n=10, coeff=0.9, sig=1.0, evidence=1.5):
+    """cfg 1: n-node Gaussian chain; every hidden node also gets a unary X2 prior so that no hidden
+    variable has degree 1 (the reference divides by zero there)."""
+    d = Domain((-10, 10), continuous=True, integral_points=np.linspace(-10, 10, 32))
+    rvs = [RV(d, evidence if i == 0 else None) for i in range(n)]
+    lin = LinearGaussianPotential(coeff, sig)
+    x2 = X2Potential(1.0, 4.0)
+    fs = [F(lin, [rvs[i], rvs[i + 1]]) for i in range(n - 1)]
+    fs += [F(x2, [rvs[i]]) for i in range(1, n)]
+    g = Graph()
+    g.rvs, g.factors = rvs, fs
+    g.init_nb()
+    return g, rvs
+
+
+# ---------------------------------------------------------------------------------------------
+# flat-array generators (no Python objects per node)
+# ---------------------------------------------------------------------------------------------
+from .flat import build_flat  # noqa: E402
+from . import potentials as _P  # noqa: E402
+
+
+def _random_pairing(V, deg, rng):
+    """random `deg`-regular multigraph by pairing variable stubs; self-pairs are re-drawn"""
+    stubs = np.repeat(np.arange(V, dtype=np.int32), deg)
+    rng.shuffle(stubs)
+    a, b = stubs[0::2].copy(), stubs[1::2].copy()
+    bad = a == b
+    while bad.any():
+        b[bad] = rng.integers(0, V, size=int(bad.sum()))
+        bad = a == b
+    return a, b
+
+
+def random_gaussian_mrf(V=20000, deg=4, seed=0, evidence_ratio=0.1):
+    """random pairwise Gaussian MRF mixing every closed-form potential kind of GaBP.message_f_to_rv, plus one
+    unary X2 prior per variable (keeps precisions positive and degrees >= 2)"""
+    rng = np.random.default_rng(seed)
+    a, b = _random_pairing(V, deg, rng)
+    Fp = a.size
+    dom = Domain((-10, 10), continuous=True, integral_points=np.linspace(-10, 10, 32))
+    specs = []
+    for _ in range(8):    # Gaussian 2x2 with |rho| < 1
+        s0, s1 = rng.uniform(4, 12, size=2)
+        rho = rng.uniform(-0.7, 0.7)
+        specs.append(_P.GaussianPotential([0., 0.], [[s0, rho * np.sqrt(s0 * s1)], [rho * np.sqrt(s0 * s1), s1]])
+                     .device_spec((dom, dom)))
+    for _ in range(8):
+        specs.append((_P.POT_LINEAR_GAUSSIAN, [float(rng.uniform(0.2, 0.9)), float(rng.uniform(1, 3))]))
+    for _ in range(8):
+        specs.append((_P.POT_XY, [float(rng.uniform(-0.3, 0.3)), float(rng.uniform(1, 3))]))
+    x2_first = len(specs)
+    for _ in range(4):
+        specs.append((_P.POT_X2, [float(rng.uniform(0.5, 1.5)), float(rng.uniform(1, 3))]))
+    fac_pot = np.concatenate([rng.integers(0, x2_first, size=Fp), rng.integers(x2_first, len(specs), size=V)])
+    fac_ptr = np.concatenate([np.arange(0, 2 * Fp + 1, 2), 2 * Fp + np.arange(1, V + 1)]).astype(np.int32)
+    edge_var = np.concatenate([np.stack([a, b], axis=1).ravel(), np.arange(V, dtype=np.int32)])
+    value = np.full(V, np.nan)
+    ev = rng.random(V) < evidence_ratio
+    value[ev] = rng.uniform(-3, 3, size=int(ev.sum()))
+    return build_flat(fac_ptr, edge_var, fac_pot, specs, value, np.zeros(V, dtype=np.int32), [dom])
+
+
+def rgm_flat(C=100, B=50, n_values=0, evidence_ratio=0.2, seed=0):
+    """cfg 2 / cfg 5: the RGM template (Demo/Data/RGM/Generator.py:18-33) grounded straight into arrays:
+    recession(1) -p1- market(C) -p2- loss(C,B) -p3- revenue(B).  Returns (flat, symmetric, rv_color0, f_color0).
+    Evidence on a random subset; values ~U(-30,30), or drawn from ``n_values`` distinct values when
+    ``n_values`` > 0 so that colour passing compresses."""
+    rng = np.random.default_rng(seed)
+    V = 1 + C + C * B + B
+    rec, market, loss, revenue = 0, 1, 1 + C, 1 + C + C * B
+    c_idx = np.arange(C, dtype=np.int32)
+    cb_c = np.repeat(c_idx, B)
+    cb_b = np.tile(np.arange(B, dtype=np.int32), C)
+    f1 = np.stack([np.full(C, rec, dtype=np.int32), market + c_idx], axis=1)
+    f2 = np.stack([market + cb_c, loss + cb_c * B + cb_b], axis=1)
+    f3 = np.stack([loss + cb_c * B + cb_b, revenue + cb_b], axis=1)
+    edge_var = np.concatenate([f1.ravel(), f2.ravel(), f3.ravel()]).astype(np.int32)
+    F = C + 2 * C * B
+    fac_ptr = np.arange(0, 2 * F + 1, 2, dtype=np.int32)
+    fac_pot = np.concatenate([np.zeros(C), np.ones(C * B), np.full(C * B, 2)]).astype(np.int32)
+    dom = Domain((-50, 50), continuous=True, integral_points=np.linspace(-50, 50, 100))
+    specs = [_P.GaussianPotential([0., 0.], s).device_spec((dom, dom)) for s in
+             ([[10., -7.], [-7., 10.]], [[10., 5.], [5., 10.]], [[10., 7.], [7., 10.]])]
+    value = np.full(V, np.nan)
+    ev = rng.random(V) < evidence_ratio
+    # keep every hidden variable's degree >= 2 (loss nodes have degree 2 already; all others larger)
+    if n_values > 0:
+        pool = np.round(rng.uniform(-30, 30, size=n_values), 3)
+        value[ev] = rng.choice(pool, size=int(ev.sum()))
+    else:
+        value[ev] = rng.uniform(-30, 30, size=int(ev.sum()))
+    flat = build_flat(fac_ptr, edge_var, fac_pot, specs, value, np.zeros(V, dtype=np.int32), [dom])
+    # initial colours (CompressedGraph.init_cluster): hidden vs one colour per distinct evidence value
+    rv_color = np.zeros(V, dtype=np.int32)
+    if ev.any():
+        _, inv = np.unique(value[ev], return_inverse=True)
+        rv_color[ev] = 1 + inv
+    sym = np.zeros(F, dtype=np.uint8)
+    return flat, sym, rv_color, fac_pot.copy()

@@ -1,0 +1,136 @@
+"""Python face of the CPU oracle.
+
+TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module; the product package never does (tests/test_no_oracle_in_product.py
+greps for it).  The arithmetic lives in ``oracle/c/*.c`` (plain C, flat arrays, each function citing the
+reference lines it restates) and, for the integer colour refinement, in the pure-Python functions below.
+Pinned against the golden vectors in ``tests/golden`` captured from the reference by
+``oracle/capture_golden.py``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, 'liboracle.so')
+
+
+def build():
+    subprocess.check_call(['make', '-s', '-C', _HERE, 'liboracle.so'])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = C.CDLL(_LIB)
+    return _lib
+
+
+class OGraph(C.Structure):
+    _fields_ = [('V', C.c_int32), ('F', C.c_int32), ('E', C.c_int32), ('nnz', C.c_int32),
+                ('fac_ptr', C.c_void_p), ('edge_var', C.c_void_p), ('edge_fac', C.c_void_p),
+                ('edge_canon', C.c_void_p), ('var_ptr', C.c_void_p), ('var_edge', C.c_void_p),
+                ('edge_count', C.c_void_p), ('fac_pot', C.c_void_p), ('var_value', C.c_void_p),
+                ('pot_kind', C.c_void_p), ('pot_off', C.c_void_p), ('pot_param', C.c_void_p)]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class HostGraph:
+    """keeps the numpy arrays of a FlatGraph alive next to the C struct that points at them"""
+
+    def __init__(self, flat):
+        self.flat = flat
+        self.arrs = {k: np.ascontiguousarray(getattr(flat, k)) for k in
+                     ('fac_ptr', 'edge_var', 'edge_fac', 'edge_canon', 'var_ptr', 'var_edge', 'edge_count', 'fac_pot',
+                      'var_value', 'pot_kind', 'pot_off', 'pot_param')}
+        g = OGraph()
+        g.V, g.F, g.E, g.nnz = flat.V, flat.F, flat.E, int(flat.var_edge.size)
+        for k, a in self.arrs.items():
+            if k == 'edge_count' and not flat.lifted:
+                setattr(g, k, None)
+            else:
+                setattr(g, k, _p(a))
+        self.g = g
+
+
+def gabp_run(flat, iterations):
+    """(f2v [E,2], v2f [E,2], mu_var [V,2]) after ``iterations`` flooding sweeps (GaBP.run / GaLBP.run)"""
+    hg = HostGraph(flat)
+    f2v = np.zeros((flat.E, 2))
+    v2f = np.zeros((flat.E, 2))
+    mv = np.zeros((flat.V, 2))
+    l = lib()
+    l.oracle_gabp_run(C.byref(hg.g), _p(f2v), _p(v2f), C.c_int(iterations))
+    l.oracle_gabp_marginals(C.byref(hg.g), _p(f2v), _p(mv))
+    return f2v, v2f, mv
+
+
+def gabp_half_sweeps(flat, f2v, v2f):
+    """one v2f half sweep then one f2v half sweep on copies; returns (v2f', f2v')"""
+    hg = HostGraph(flat)
+    f2v, v2f = f2v.copy(), v2f.copy()
+    l = lib()
+    l.oracle_gabp_v2f(C.byref(hg.g), _p(f2v), _p(v2f))
+    l.oracle_gabp_f2v(C.byref(hg.g), _p(v2f), _p(f2v))
+    return v2f, f2v
+
+
+# ---- colour refinement (integer, exact) --------------------------------------------------------
+def _dense(keys):
+    table, out = {}, np.zeros(len(keys), dtype=np.int32)
+    for i, k in enumerate(keys):
+        out[i] = table.setdefault(k, len(table))
+    return out, len(table)
+
+
+def refine_factors(flat, symmetric, rv_color, f_color):
+    """SuperF.split_by_structure for every cluster (CompressedGraphWithObs.py:152-175): clusters never merge, so
+    the old colour is part of the key; the scope's colours are sorted iff the potential is symmetric."""
+    keys = []
+    for f in range(flat.F):
+        nb = tuple(int(rv_color[flat.edge_var[e]]) for e in range(flat.fac_ptr[f], flat.fac_ptr[f + 1]))
+        if symmetric[f]:
+            nb = tuple(sorted(nb))
+        keys.append((int(f_color[f]), nb))
+    return _dense(keys)
+
+
+def refine_rvs(flat, f_color, rv_color):
+    """SuperRV.split_by_structure (CompressedGraphWithObs.py:47-76): key = sorted multiset of the colours of the
+    incident factors (argument position ignored), within the old cluster."""
+    keys = []
+    for v in range(flat.V):
+        nb = sorted(int(f_color[flat.edge_fac[flat.var_edge[k]]]) for k in range(flat.var_ptr[v], flat.var_ptr[v + 1]))
+        keys.append((int(rv_color[v]), tuple(nb)))
+    return _dense(keys)
+
+
+def color_passing(flat, symmetric, rv_color, f_color):
+    """CompressedGraph.run loop (CompressedGraphWithObs.py:264-271): stop when #rv clusters is unchanged"""
+    rv_color, f_color = np.asarray(rv_color), np.asarray(f_color)
+    n_rv = int(rv_color.max()) + 1 if rv_color.size else 0
+    prev = -1
+    while prev != n_rv:
+        prev = n_rv
+        f_color, _ = refine_factors(flat, symmetric, rv_color, f_color)
+        rv_color, n_rv = refine_rvs(flat, f_color, rv_color)
+    return rv_color, f_color
+
+
+def canonical_labels(color):
+    """label every item with the smallest index sharing its colour (the form the golden files use)"""
+    color = np.asarray(color)
+    first = {}
+    for i, c in enumerate(color.tolist()):
+        first.setdefault(c, i)
+    return [first[c] for c in color.tolist()]
