@@ -14,21 +14,8 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include "oracle.h"
 
-#define POT_GAUSSIAN 2
-#define POT_LINEAR_GAUSSIAN 5
-#define POT_X2 6
-#define POT_XY 7
-
-typedef struct {
-    int32_t V, F, E, nnz;
-    const int32_t *fac_ptr, *edge_var, *edge_fac, *edge_canon, *var_ptr, *var_edge;
-    const double *edge_count; /* NULL on a ground graph */
-    const int32_t *fac_pot;
-    const double *var_value;
-    const int32_t *pot_kind, *pot_off;
-    const double *pot_param;
-} ograph_t;
 
 static int hidden(double v) { return v != v; }
 

@@ -34,6 +34,7 @@ sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 import modelio  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import Graph as RG  # noqa: E402  (reference modules)
 import Potential as RP  # noqa: E402

@@ -38,7 +38,17 @@ class OGraph(C.Structure):
                 ('fac_ptr', C.c_void_p), ('edge_var', C.c_void_p), ('edge_fac', C.c_void_p),
                 ('edge_canon', C.c_void_p), ('var_ptr', C.c_void_p), ('var_edge', C.c_void_p),
                 ('edge_count', C.c_void_p), ('fac_pot', C.c_void_p), ('var_value', C.c_void_p),
-                ('pot_kind', C.c_void_p), ('pot_off', C.c_void_p), ('pot_param', C.c_void_p)]
+                ('pot_kind', C.c_void_p), ('pot_off', C.c_void_p), ('pot_param', C.c_void_p),
+                ('var_dom', C.c_void_p), ('var_mult', C.c_void_p), ('fac_mult', C.c_void_p),
+                ('dom_cont', C.c_void_p), ('dom_lo', C.c_void_p), ('dom_hi', C.c_void_p),
+                ('dom_ptr', C.c_void_p), ('dom_val', C.c_void_p)]
+
+
+class OPbp(C.Structure):
+    _fields_ = [('n', C.c_int32), ('T', C.c_int32), ('flags', C.c_uint32),
+                ('var_threshold', C.c_double), ('max_log_value', C.c_double),
+                ('particles', C.c_void_p), ('old_particles', C.c_void_p), ('np', C.c_void_p),
+                ('uniq', C.c_void_p), ('q', C.c_void_p)]
 
 
 def _p(a):
@@ -52,11 +62,12 @@ class HostGraph:
         self.flat = flat
         self.arrs = {k: np.ascontiguousarray(getattr(flat, k)) for k in
                      ('fac_ptr', 'edge_var', 'edge_fac', 'edge_canon', 'var_ptr', 'var_edge', 'edge_count', 'fac_pot',
-                      'var_value', 'pot_kind', 'pot_off', 'pot_param')}
+                      'var_value', 'pot_kind', 'pot_off', 'pot_param', 'var_dom', 'var_mult', 'fac_mult',
+                      'dom_cont', 'dom_lo', 'dom_hi', 'dom_ptr', 'dom_val')}
         g = OGraph()
         g.V, g.F, g.E, g.nnz = flat.V, flat.F, flat.E, int(flat.var_edge.size)
         for k, a in self.arrs.items():
-            if k == 'edge_count' and not flat.lifted:
+            if k in ('edge_count', 'var_mult', 'fac_mult') and not flat.lifted:
                 setattr(g, k, None)
             else:
                 setattr(g, k, _p(a))
@@ -134,3 +145,96 @@ def canonical_labels(color):
     for i, c in enumerate(color.tolist()):
         first.setdefault(c, i)
     return [first[c] for c in color.tolist()]
+
+
+# ---- particle BP --------------------------------------------------------------------------------
+PBP_EP = 1
+PBP_EPBP_DISCRETE = 2
+
+
+def pbp_counts(flat, n):
+    """valid particle count per variable: n (continuous hidden), #states (discrete hidden), 0 (observed)"""
+    nst = flat.var_nstates
+    return np.where(flat.var_hidden, np.where(flat.var_cont, n, nst), 0).astype(np.int32)
+
+
+def pbp_T(flat):
+    sizes = np.diff(flat.dom_ptr)
+    cont = flat.dom_cont.astype(bool)
+    return int(sizes[cont].max()) if cont.any() else 0
+
+
+class PbpOracle:
+    """Flat-array twin of EPBP / HybridLBP state; every method is one reference function applied to all edges."""
+
+    def __init__(self, flat, n, ep, epbp, var_threshold):
+        self.flat, self.hg = flat, HostGraph(flat)
+        self.n, self.T = n, pbp_T(flat)
+        self.S = self.n + self.T
+        self.flags = (PBP_EP if ep else 0) | (PBP_EPBP_DISCRETE if epbp else 0)
+        self.var_threshold = float(var_threshold)
+        self.np = pbp_counts(flat, n)
+        self.particles = np.zeros((flat.V, n))
+        self.old_particles = np.zeros((flat.V, n))
+        self.uniq = np.zeros((flat.V, n), dtype=np.uint8)
+        self.q = np.full((flat.V, 2), np.nan)
+        self.eta = np.full((flat.E, 2), np.nan)
+        self.f2v = np.zeros((flat.E, self.S))
+        self.v2f = np.zeros((flat.E, n))
+
+    def _s(self):
+        s = OPbp()
+        s.n, s.T, s.flags = self.n, self.T, self.flags
+        s.var_threshold, s.max_log_value = self.var_threshold, 700.0
+        s.particles, s.old_particles = _p(self.particles), _p(self.old_particles)
+        s.np, s.uniq, s.q = _p(self.np), _p(self.uniq), _p(self.q)
+        return s
+
+    def set_particles(self, particles):
+        """install a new sample (rows of observed variables are ignored); discrete rows = the domain states"""
+        self.old_particles = self.particles
+        p = np.array(particles, dtype=np.float64)
+        flat = self.flat
+        for v in np.flatnonzero(flat.var_hidden & ~flat.var_cont):
+            d = flat.var_dom[v]
+            vals = flat.dom_val[flat.dom_ptr[d]:flat.dom_ptr[d + 1]]
+            p[v, :vals.size] = vals
+        self.particles = np.ascontiguousarray(np.nan_to_num(p, nan=0.0))
+        self.uniq = np.zeros((flat.V, self.n), dtype=np.uint8)
+        lib().oracle_pbp_uniq(C.byref(self.hg.g), C.c_int(self.n), _p(self.particles), _p(self.np), _p(self.uniq))
+
+    def init(self):
+        lib().oracle_pbp_init(C.byref(self.hg.g), C.byref(self._s()), _p(self.eta), _p(self.q), _p(self.f2v), _p(self.v2f))
+
+    def step_v2f(self):
+        lib().oracle_pbp_v2f(C.byref(self.hg.g), C.byref(self._s()), _p(self.f2v), _p(self.v2f))
+
+    def step_proposal(self):
+        lib().oracle_pbp_proposal(C.byref(self.hg.g), C.byref(self._s()), _p(self.f2v), _p(self.eta), _p(self.q))
+
+    def step_f2v(self):
+        lib().oracle_pbp_f2v(C.byref(self.hg.g), C.byref(self._s()), _p(self.v2f), _p(self.f2v))
+
+    def belief_points(self, qvar, x):
+        qvar = np.ascontiguousarray(qvar, dtype=np.int32)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros_like(x)
+        lib().oracle_pbp_belief_points(C.byref(self.hg.g), C.byref(self._s()), _p(self.v2f), C.c_int(qvar.size),
+                                       _p(qvar), C.c_int(x.shape[1]), _p(x), _p(out))
+        return out
+
+    def run(self, iterations, samples, on_iteration=None):
+        """EPBP.run / HybridLBP.run(c2f=-1) with injected samples: samples[0] is the initial draw, samples[i+1] the
+        draw of iteration i (EPBP.py:225-289)."""
+        self.init()
+        self.set_particles(samples[0])
+        for i in range(iterations):
+            self.step_v2f()
+            if i < iterations - 1:
+                self.step_proposal()
+                self.set_particles(samples[i + 1])
+                if on_iteration:
+                    on_iteration(i, self)     # v2f of iteration i, proposal updated, new particles installed
+                self.step_f2v()
+            elif on_iteration:
+                on_iteration(i, self)

@@ -1,0 +1,107 @@
+"""CPU suite: the particle-BP oracle reproduces the vectors captured from the reference's EPBP / HybridLBP."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import modelio
+from test_oracle_golden import API, _initial
+from lhvi import lifting
+from lhvi.flat import flatten
+from oracle import oracle
+
+EPBP_CASES = ['epbp_kalman_simple', 'epbp_kalman_ep', 'epbp_kalman_n64', 'epbp_hybrid_ep', 'epbp_hybrid_simple']
+HLBP_CASES = ['hlbp_rgm_small', 'hlbp_hybrid', 'hlbp_kalman_full']
+
+# fp64 tolerance of the log-message tables: the oracle fuses nothing and follows the reference's operation
+# order, so differences come only from libm (pow(e,x) vs CPython's) and the exact-rational mean
+RTOL, ATOL = 1e-9, 1e-9
+
+
+def load_npz(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, 'pbp_%s.npz' % name))
+    meta = json.loads(str(z['meta']))
+    return z, meta
+
+
+def check_against_snapshots(z, meta, flat, orc_factory, iterations):
+    n = meta['n']
+    K = z['sample'].shape[0]
+    assert K == iterations          # initial draw + one per non-final iteration
+    seen = []
+
+    def on_it(i, o):
+        want_v2f = z['v2f'][i]
+        hid = flat.var_hidden[flat.edge_var]
+        npv = o.np[flat.edge_var]
+        for e in np.flatnonzero(hid):
+            np.testing.assert_allclose(o.v2f[e, :npv[e]], want_v2f[e, :npv[e]], rtol=RTOL, atol=ATOL,
+                                       err_msg='v2f it %d edge %d' % (i, e))
+        if i < iterations - 1:
+            cont = flat.var_hidden & flat.var_cont
+            np.testing.assert_allclose(o.q[cont], z['q'][i][cont], rtol=1e-9, atol=1e-12, err_msg='q it %d' % i)
+            ce = cont[flat.edge_var]
+            np.testing.assert_allclose(o.eta[ce], z['eta'][i][ce], rtol=1e-9, atol=1e-12, err_msg='eta it %d' % i)
+        if i > 0:
+            # f2v computed in iteration i-1 is tabulated on sample i (+ grid)
+            want = z['f2v'][i]
+            for e in np.flatnonzero(hid):
+                v = flat.edge_var[e]
+                got = o.f2v_prev[e]
+                np.testing.assert_allclose(got[:npv[e]], want[e, :npv[e]], rtol=RTOL, atol=ATOL)
+                if flat.var_cont[v]:
+                    T = flat.var_nstates[v]
+                    np.testing.assert_allclose(got[n:n + T], want[e, n:n + T], rtol=RTOL, atol=ATOL)
+        seen.append(i)
+
+    o = orc_factory()
+    orig_f2v = o.step_f2v
+
+    def step_f2v():
+        orig_f2v()
+        o.f2v_prev = o.f2v.copy()
+    o.step_f2v = step_f2v
+    o.f2v_prev = None
+    o.run(iterations, [z['sample'][k] for k in range(K)], on_it)
+    assert seen == list(range(iterations))
+    return o
+
+
+@pytest.mark.parametrize('name', EPBP_CASES)
+def test_epbp_oracle_matches_reference(golden_dir, name):
+    z, meta = load_npz(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    flat = flatten(g, require_device_potentials=True)
+    o = check_against_snapshots(
+        z, meta, flat,
+        lambda: oracle.PbpOracle(flat, meta['n'], ep=meta['approx'] == 'EP', epbp=True, var_threshold=3),
+        meta['iterations'])
+    # post-sweep queries: belief_rv at recorded points
+    hid = np.flatnonzero(flat.var_hidden)
+    got = o.belief_points(hid, z['query_x'][hid])
+    np.testing.assert_allclose(got, z['query_logb'][hid], rtol=1e-9, atol=1e-8)
+
+
+@pytest.mark.parametrize('name', HLBP_CASES)
+def test_hlbp_oracle_matches_reference(golden_dir, name):
+    z, meta = load_npz(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    gflat = flatten(g)
+    sym, rv0, f0 = _initial(gflat, g)
+    rv_color, f_color = oracle.color_passing(gflat, sym, rv0, f0)
+    assert oracle.canonical_labels(rv_color) == z['rv_label'].tolist()
+    assert oracle.canonical_labels(f_color) == z['f_label'].tolist()
+    cg = lifting.CompressedGraph(g)
+    cg.set_colors(rv_color, f_color)
+    flat = flatten(cg, require_device_potentials=True)
+    rep = np.array([rvs.index(min(c.rvs)) for c in flat.rvs])
+    samples = [z['samples'][k][rep] for k in range(z['samples'].shape[0])]
+    o = oracle.PbpOracle(flat, meta['n'], ep=meta['approx'] == 'EP', epbp=False, var_threshold=5)
+    o.run(meta['iterations'], samples)
+    cl = np.array([flat.var_index[rv.cluster] for rv in rvs])
+    hid = np.flatnonzero(gflat.var_hidden)
+    np.testing.assert_allclose(o.q[cl][gflat.var_hidden & gflat.var_cont],
+                               z['final_q'][gflat.var_hidden & gflat.var_cont], rtol=1e-9)
+    got = o.belief_points(cl[hid], z['query_x'][hid])
+    np.testing.assert_allclose(got, z['query_logb'][hid], rtol=1e-9, atol=1e-8)
