@@ -1,0 +1,393 @@
+"""Particle belief propagation on the GPU: ``EPBP`` (ground) and ``HybridLBP`` (lifted).
+
+Same surface as the reference (``EPBPLogVersion.py:14-394``, ``HybridLBPLogVersion.py:15-536``):
+``EPBP(g, n, proposal_approximation).run(iteration)``, ``.belief(x, rv, ...)``, ``.probability(a, b, rv)``,
+``.map(rv)``, attributes ``.message .sample .q .eta_message``; class attributes ``var_threshold`` /
+``max_log_value`` keep the reference's values.
+
+``run`` keeps all state (particles, log-message tables, proposals) resident in HBM and issues one sweep as
+four launches through the C ABI (``csrc/pbp.hip``): v2f, proposal, resample, f2v.
+
+Sampling.  The reference draws particles with ``scipy.stats.norm(...).rvs`` on NumPy's global RNG while
+iterating ``g.rvs`` (``EPBPLogVersion.py:61-70``).  ``sampler='host'`` (default) reproduces exactly that stream
+(``standard_normal(n) * sqrt(var) + mu`` in ``g.rvs`` order), so a seeded run matches the reference draw for
+draw when ``g.rvs`` is ordered; ``sampler='device'`` uses the counter-based Philox generator of
+``lhvi_pbp_resample`` (no host round trip; what the benchmark uses); a callable
+``sampler(k, flat, q) -> [V, n] array`` injects particles (parity tests inject the reference's draws).
+"""
+from __future__ import annotations
+
+from math import e, log, sqrt
+
+import numpy as np
+
+from . import _abi
+from .flat import flatten
+
+
+class _ParticleSweep:
+    var_threshold = 3
+    max_log_value = 700
+    _epbp_discrete = True
+    verbose = False
+
+    # ---- set-up ------------------------------------------------------------------------------
+    def _setup(self, graph_like, flat=None):
+        flat = flat if flat is not None else flatten(graph_like, require_device_potentials=True)
+        self.flat = flat
+        self.dg = dg = _abi.DeviceGraph(flat)
+        torch = _abi.require_gpu()
+        n = self.n
+        sizes = np.diff(flat.dom_ptr)
+        cont = flat.dom_cont.astype(bool)
+        self.T = int(sizes[cont].max()) if cont.any() else 0
+        nst = flat.var_nstates
+        if (flat.var_hidden & ~flat.var_cont & (nst > n)).any():
+            raise _abi.LhviError('a discrete variable has more states than particle slots n=%d' % n)
+        self.np_host = np.where(flat.var_hidden, np.where(flat.var_cont, n, nst), 0).astype(np.int32)
+        self.np_dev = _abi.to_dev(self.np_host)
+        S = n + self.T
+        self.f2v = dg.zeros(flat.E, S)
+        self.v2f = dg.zeros(flat.E, n)
+        self.eta = dg.zeros(flat.E, 2)
+        self.q_dev = dg.zeros(flat.V, 2)
+        self.particles = dg.zeros(flat.V, n)
+        self.old_particles = dg.zeros(flat.V, n)
+        self.uniq = torch.zeros(flat.V, n, dtype=torch.uint8, device=dg.device)
+        self.flags = (_abi.PBP_EP if self.proposal_approximation == 'EP' else 0) | \
+                     (_abi.PBP_EPBP_DISCRETE if self._epbp_discrete else 0)
+        self._views = {}
+        self._draws = 0
+
+    def _struct(self):
+        s = _abi.PbpStruct()
+        s.n, s.T, s.flags = self.n, self.T, self.flags
+        s.var_threshold, s.max_log_value = float(self.var_threshold), float(self.max_log_value)
+        s.particles, s.old_particles = _abi.ptr(self.particles), _abi.ptr(self.old_particles)
+        s.np, s.uniq, s.q = _abi.ptr(self.np_dev), _abi.ptr(self.uniq), _abi.ptr(self.q_dev)
+        return s
+
+    # ---- sampling ----------------------------------------------------------------------------
+    def _host_draw(self):
+        """the reference's generate_sample stream: NumPy global RNG, g.rvs order (EPBP:61-70)"""
+        flat = self.flat
+        q = self.q_dev.cpu().numpy()
+        out = np.zeros((flat.V, self.n))
+        for v in range(flat.V):
+            if not flat.var_hidden[v]:
+                continue
+            d = flat.var_dom[v]
+            if flat.dom_cont[d]:
+                z = np.random.standard_normal(self.n)
+                out[v] = np.clip(z * sqrt(q[v, 1]) + q[v, 0], flat.dom_lo[d], flat.dom_hi[d])
+        return out
+
+    def _install(self, host_particles):
+        flat = self.flat
+        p = np.nan_to_num(np.array(host_particles, dtype=np.float64), nan=0.0)
+        for v in np.flatnonzero(flat.var_hidden & ~flat.var_cont):
+            d = flat.var_dom[v]
+            vals = flat.dom_val[flat.dom_ptr[d]:flat.dom_ptr[d + 1]]
+            p[v, :vals.size] = vals
+        self.old_particles, self.particles = self.particles, self.old_particles
+        self.particles.copy_(_abi.to_dev(p))
+
+    def _generate_sample(self):
+        l, st = _abi.lib(), _abi.stream_ptr()
+        k = self._draws
+        self._draws += 1
+        if self.sampler == 'device':
+            self.old_particles, self.particles = self.particles, self.old_particles
+            s = self._struct()
+            _abi.check(l.lhvi_pbp_resample(self.dg.g, s, _abi.ptr(getattr(self, 'var_gid', None)),
+                                           int(self.seed), int(k), _abi.ptr(self.particles), st))
+        elif callable(self.sampler):
+            self._install(self.sampler(k, self.flat, self.q_dev.cpu().numpy()))
+        else:
+            self._install(self._host_draw())
+        _abi.check(l.lhvi_pbp_uniq(self.dg.g, self.n, _abi.ptr(self.particles), _abi.ptr(self.np_dev),
+                                   _abi.ptr(self.uniq), st))
+        self._views = {}
+
+    # ---- the sweep (EPBP.run EPBP:225-289; HybridLBP.run with c2f=-1 HLBP:430-536) -------------
+    def _run_sweeps(self, iteration):
+        l, st, g, p = _abi.lib(), _abi.stream_ptr(), self.dg.g, self.dg.p
+        _abi.check(l.lhvi_pbp_init(g, self._struct(), _abi.ptr(self.eta), _abi.ptr(self.q_dev), _abi.ptr(self.f2v),
+                                   _abi.ptr(self.v2f), st))
+        self._generate_sample()
+        for i in range(iteration):
+            self.sweep(last=(i == iteration - 1))
+        self._views = {}
+
+    def sweep(self, last=False):
+        """one flooding sweep: v2f, and unless `last`: proposal update, new sample, f2v"""
+        l, st, g, p = _abi.lib(), _abi.stream_ptr(), self.dg.g, self.dg.p
+        _abi.check(l.lhvi_pbp_v2f(g, self._struct(), _abi.ptr(self.f2v), _abi.ptr(self.v2f), st))
+        if not last:
+            _abi.check(l.lhvi_pbp_proposal(g, self._struct(), _abi.ptr(self.f2v), _abi.ptr(self.eta),
+                                           _abi.ptr(self.q_dev), st))
+            self._generate_sample()
+            _abi.check(l.lhvi_pbp_f2v(g, p, self._struct(), _abi.ptr(self.v2f), _abi.ptr(self.f2v), st))
+
+    # ---- dict views with the reference's keys ------------------------------------------------------
+    def _host(self, name):
+        if name not in self._views:
+            self._views[name] = getattr(self, name).cpu().numpy()
+        return self._views[name]
+
+    @property
+    def sample(self):
+        flat, P = self.flat, self._host('particles')
+        out = {}
+        for v, rv in enumerate(flat.rvs):
+            if flat.var_hidden[v]:
+                out[rv] = P[v].copy() if flat.var_cont[v] else rv.domain.values
+        return out
+
+    @property
+    def q(self):
+        flat, Q = self.flat, self._host('q_dev')
+        return {rv: (float(Q[v, 0]), float(Q[v, 1])) for v, rv in enumerate(flat.rvs)
+                if flat.var_hidden[v] and (flat.var_cont[v] or self._epbp_discrete)}
+
+    @property
+    def eta_message(self):
+        flat, E = self.flat, self._host('eta')
+        out = {}
+        for k in range(flat.var_edge.size):
+            e = int(flat.var_edge[k])
+            v = flat.edge_var[e]
+            if flat.var_hidden[v] and (flat.var_cont[v] or self._epbp_discrete):
+                out[(flat.factors[flat.edge_fac[e]], flat.rvs[v])] = (float(E[e, 0]), float(E[e, 1]))
+        return out
+
+    @property
+    def message(self):
+        """log messages as dicts keyed by point, like the reference (built on demand; large graphs: use .f2v/.v2f)"""
+        flat, n = self.flat, self.n
+        F2V, V2F, P = self._host('f2v'), self._host('v2f'), self._host('particles')
+        out = {}
+        for k in range(flat.var_edge.size):
+            e = int(flat.var_edge[k])
+            v = flat.edge_var[e]
+            if not flat.var_hidden[v]:
+                continue
+            rv, f = flat.rvs[v], flat.factors[flat.edge_fac[e]]
+            npv = self.np_host[v]
+            pts = [float(x) for x in P[v, :npv]]
+            m = {x: float(F2V[e, j]) for j, x in enumerate(pts)}
+            if flat.var_cont[v]:
+                d = flat.var_dom[v]
+                grid = flat.dom_val[flat.dom_ptr[d]:flat.dom_ptr[d + 1]]
+                m.update({float(x): float(F2V[e, n + t]) for t, x in enumerate(grid)})
+            out[(f, rv)] = m
+            out[(rv, f)] = {x: float(V2F[e, j]) for j, x in enumerate(pts)}
+        return out
+
+    # ---- queries (A8) ------------------------------------------------------------------------
+    def _belief_rv_points(self, v, xs):
+        """belief_rv(x) for one variable index at a batch of points, on the device (EPBP:196-202)"""
+        torch = _abi.require_gpu()
+        xs = np.atleast_1d(np.asarray(xs, dtype=np.float64))
+        qvar = _abi.to_dev(np.array([v], dtype=np.int32))
+        x = _abi.to_dev(xs.reshape(1, -1))
+        out = torch.empty_like(x)
+        _abi.check(_abi.lib().lhvi_pbp_belief_points(self.dg.g, self.dg.p, self._struct(), _abi.ptr(self.v2f), 1,
+                                                     _abi.ptr(qvar), int(xs.size), _abi.ptr(x), _abi.ptr(out),
+                                                     _abi.stream_ptr()))
+        return out.cpu().numpy().reshape(-1)
+
+    def belief_rv_batch(self, rvs, xs):
+        """log-beliefs of many variables at `xs[i]` points each, one launch (extension, not in the reference)"""
+        torch = _abi.require_gpu()
+        idx = np.array([self._var_of(rv) for rv in rvs], dtype=np.int32)
+        x = _abi.to_dev(np.asarray(xs, dtype=np.float64).reshape(len(rvs), -1))
+        out = torch.empty_like(x)
+        _abi.check(_abi.lib().lhvi_pbp_belief_points(self.dg.g, self.dg.p, self._struct(), _abi.ptr(self.v2f),
+                                                     len(rvs), _abi.ptr(_abi.to_dev(idx)), int(x.shape[1]),
+                                                     _abi.ptr(x), _abi.ptr(out), _abi.stream_ptr()))
+        return out.cpu().numpy()
+
+    def log_message_balance(self, message):
+        """EPBP.log_message_balance (EPBP:204-215) on a host dict (used by log_area)"""
+        values = list(message.values())
+        mean_m = float(np.mean(values))
+        max_m = max(values)
+        shift = max_m - self.max_log_value if max_m - mean_m > self.max_log_value else mean_m
+        for k in message:
+            message[k] = message[k] - shift
+        return shift
+
+    def _log_area(self, v, a, b, npts, shift=None):
+        """EPBP.log_area (EPBP:291-308): trapezoid of exp(belief_rv - shift) on linspace(a, b, npts)"""
+        x = np.linspace(a, b, npts)
+        d = x[1] - x[0]
+        y = dict(enumerate(self._belief_rv_points(v, x).tolist()))
+        if shift is None:
+            shift = self.log_message_balance(y)
+        else:
+            y = {k: val - shift for k, val in y.items()}
+        res, prev = 0, e ** y[0]
+        for i in range(1, npts):
+            cur = e ** y[i]
+            res += (prev + cur) * d
+            prev = cur
+        return res * 0.5, shift
+
+    @staticmethod
+    def message_normalization(message):
+        z = 0
+        for k, v in message.items():
+            z = z + v
+        for k, v in message.items():
+            message[k] = v / z
+
+    @staticmethod
+    def norm_pdf(x, mu, sig):
+        u = (x - mu) / sig
+        return np.exp(-u * u * 0.5) / (2.506628274631 * sig)
+
+
+class EPBP(_ParticleSweep):
+    """Expectation particle BP on a ground graph (``EPBPLogVersion.py``)."""
+
+    var_threshold = 3
+    max_log_value = 700
+    _epbp_discrete = True
+
+    def __init__(self, g=None, n=50, proposal_approximation='EP', sampler='host', seed=0):
+        self.g = g
+        self.n = n
+        self.proposal_approximation = proposal_approximation
+        self.sampler, self.seed = sampler, seed
+        self.cache = dict()
+
+    def run(self, iteration=10, log_enable=False):
+        self._setup(self.g)
+        self.cache = dict()
+        self._run_sweeps(iteration)
+
+    def _var_of(self, rv):
+        return self.flat.var_index[rv]
+
+    def belief_rv(self, x, rv, sample=None):
+        return float(self._belief_rv_points(self._var_of(rv), [x])[0])
+
+    def belief(self, x, rv, log_belief=False, inf_integral=False):
+        """EPBP.belief (EPBP:310-354): normaliser by adaptive quadrature of exp(belief_rv)"""
+        if rv.value is not None:
+            if log_belief:
+                return 0 if x == rv.value else -np.inf
+            return 1 if x == rv.value else 0
+        v = self._var_of(rv)
+        if rv.domain.continuous:
+            if rv in self.cache:
+                z, shift = self.cache[rv]
+            else:
+                from scipy.integrate import quad
+                lb, ub = (-np.inf, np.inf) if inf_integral else (rv.domain.values[0] - 20, rv.domain.values[1] + 20)
+                z = quad(lambda val: e ** float(self._belief_rv_points(v, [val])[0]), lb, ub)[0]
+                shift = 0
+                self.cache[rv] = (z, shift)
+            logz = log(z)
+            lb_x = float(self._belief_rv_points(v, [x])[0]) - shift - logz
+            return lb_x if log_belief else e ** lb_x
+        vals = rv.domain.values
+        b = dict(zip(vals, (e ** t for t in self._belief_rv_points(v, vals).tolist())))
+        self.message_normalization(b)
+        return log(b[x]) if log_belief else b[x]
+
+    def probability(self, a, b, rv):
+        if rv.value is None and rv.domain.continuous:
+            v = self._var_of(rv)
+            z, shift = self._log_area(v, rv.domain.values[0], rv.domain.values[1], 20)
+            num, _ = self._log_area(v, a, b, 5, shift)
+            return num / z
+        return None
+
+    def map(self, rv):
+        if rv.value is not None:
+            return rv.value
+        v = self._var_of(rv)
+        if rv.domain.continuous:
+            from scipy.optimize import fminbound
+            return fminbound(lambda val: -float(self._belief_rv_points(v, [val])[0]),
+                             rv.domain.values[0], rv.domain.values[1], disp=False)
+        pts = list(self.sample[rv])
+        vals = self._belief_rv_points(v, pts)
+        return pts[int(np.argmax(vals))]
+
+
+class HybridLBP(_ParticleSweep):
+    """Lifted particle BP (``HybridLBPLogVersion.py``): colour passing, then the counted sweep."""
+
+    var_threshold = 5
+    max_log_value = 700
+    _epbp_discrete = False
+
+    def __init__(self, g, n=50, k_mean_k=2, k_mean_iteration=10, proposal_approximation='EP', sampler='host', seed=0):
+        from .lifting import CompressedGraph
+        self.g = CompressedGraph(g)
+        self.n = n
+        self.k_mean_k = k_mean_k
+        self.k_mean_iteration = k_mean_iteration
+        self.proposal_approximation = proposal_approximation
+        self.sampler, self.seed = sampler, seed
+        self.query_cache = dict()
+
+    def run(self, iteration=10, log_enable=False, c2f=-1):
+        if c2f != -1:
+            raise NotImplementedError('coarse-to-fine lifting (c2f >= 0) is a "next" row of the scope table '
+                                      '(SURVEY.md section 8(f) rank 2); only c2f=-1 runs on the GPU so far')
+        self.g.init_cluster(True)
+        prev = -1
+        while self.g.num_rv_clusters != prev:         # HLBP:433-438
+            prev = self.g.num_rv_clusters
+            self.g.split_factors()
+            self.g.split_rvs()
+        self._setup(self.g)
+        self.query_cache = dict()
+        self._run_sweeps(iteration)
+        self.g.split_factors()                          # HLBP:536 (a no-op on a stable partition)
+
+    def _var_of(self, ground_rv):
+        return self.flat.var_index[ground_rv.cluster]
+
+    def belief_rv_query(self, x, rv, sample=None):
+        return float(self._belief_rv_points(self._var_of(rv), [x])[0])
+
+    def belief(self, x, rv, inf_integral=False):
+        """HybridLBP.belief (HLBP:343-382): 20-point trapezoid normaliser, cached per cluster"""
+        if rv.value is not None:
+            return 1 if x == rv.value else 0
+        sig, v = rv.cluster, self._var_of(rv)
+        if rv.domain.continuous:
+            if sig not in self.query_cache:
+                self.query_cache[sig] = self._log_area(v, rv.domain.values[0], rv.domain.values[1], 20)
+            z, shift = self.query_cache[sig]
+            return e ** (float(self._belief_rv_points(v, [x])[0]) - shift - log(z))
+        if sig not in self.query_cache:
+            vals = rv.domain.values
+            b = dict(zip(vals, (e ** t for t in self._belief_rv_points(v, vals).tolist())))
+            self.message_normalization(b)
+            self.query_cache[sig] = b
+        return self.query_cache[sig][x]
+
+    def probability(self, a, b, rv):
+        if rv.value is None and rv.domain.continuous:
+            v = self._var_of(rv)
+            z, shift = self._log_area(v, rv.domain.values[0], rv.domain.values[1], 20)
+            num, _ = self._log_area(v, a, b, 5, shift)
+            return num / z
+        return None
+
+    def map(self, rv):
+        if rv.value is not None:
+            return rv.value
+        v = self._var_of(rv)
+        if rv.domain.continuous:
+            from scipy.optimize import fminbound
+            return fminbound(lambda val: -float(self._belief_rv_points(v, [val])[0]),
+                             rv.domain.values[0], rv.domain.values[1], disp=False)
+        vals = list(rv.domain.values)
+        return vals[int(np.argmax(self._belief_rv_points(v, vals)))]

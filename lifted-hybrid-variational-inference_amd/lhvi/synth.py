@@ -111,3 +111,43 @@ def rgm_flat(C=100, B=50, n_values=0, evidence_ratio=0.2, seed=0):
         rv_color[ev] = 1 + inv
     sym = np.zeros(F, dtype=np.uint8)
     return flat, sym, rv_color, fac_pot.copy()
+
+
+def hybrid_mrf_flat(V=250000, deg=4, seed=0, frac_discrete=0.2, evidence_ratio=0.1, T=32, pool=64):
+    """cfg 4 (and, at V=2.5M, the 10M-edge headline graph): random sparse hybrid pairwise MRF.
+
+    80 % continuous variables on [-10, 10] (T integral points), 20 % binary; `deg`-regular random pairing;
+    potentials by scope type, coefficients ~U(0.2, 1):
+      (cont, cont)  QuadraticPotential  exp(-a x^2 - b y^2 + c x y + ...), |c| < sqrt(ab)  (XY / X2 style)
+      (disc, cont)  HybridQuadraticPotential, one (A, b, c) per state, discrete argument first
+      (disc, disc)  2x2 TablePotential
+    10 % of the variables are observed."""
+    rng = np.random.default_rng(seed)
+    dc = Domain((-10, 10), continuous=True, integral_points=np.linspace(-10, 10, T))
+    db = Domain((0, 1))
+    is_disc = rng.random(V) < frac_discrete
+    a, b = _random_pairing(V, deg, rng)
+    # discrete argument first for mixed scopes
+    swap = ~is_disc[a] & is_disc[b]
+    a, b = np.where(swap, b, a), np.where(swap, a, b)
+    F = a.size
+    specs = []
+    for _ in range(pool):
+        p, q = rng.uniform(0.2, 1.0, size=2) * 0.5
+        c = rng.uniform(-0.9, 0.9) * np.sqrt(p * q)
+        specs.append((_P.POT_QUADRATIC, [2.0, -p, c / 2, c / 2, -q, rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), 0.0]))
+    for _ in range(pool):
+        A = -rng.uniform(0.2, 1.0, size=2) * 0.5
+        specs.append((_P.POT_HYBRID_QUADRATIC, [1.0, 1.0, 2.0] + A.tolist() + rng.uniform(-1, 1, size=2).tolist()
+                      + rng.uniform(-0.5, 0.5, size=2).tolist()))
+    for _ in range(pool):
+        specs.append((_P.POT_TABLE, [2.0, 2.0, 2.0] + rng.uniform(0.2, 1.0, size=4).tolist()))
+    kind = np.where(is_disc[a] & is_disc[b], 2, np.where(is_disc[a], 1, 0))
+    fac_pot = (kind * pool + rng.integers(0, pool, size=F)).astype(np.int32)
+    fac_ptr = np.arange(0, 2 * F + 1, 2, dtype=np.int32)
+    edge_var = np.stack([a, b], axis=1).ravel().astype(np.int32)
+    value = np.full(V, np.nan)
+    ev = rng.random(V) < evidence_ratio
+    value[ev & ~is_disc] = rng.uniform(-5, 5, size=int((ev & ~is_disc).sum()))
+    value[ev & is_disc] = rng.integers(0, 2, size=int((ev & is_disc).sum()))
+    return build_flat(fac_ptr, edge_var, fac_pot, specs, value, is_disc.astype(np.int32), [dc, db])

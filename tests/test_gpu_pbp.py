@@ -1,0 +1,163 @@
+"""GPU parity: particle BP (EPBP / HybridLBP) through the C ABI vs the golden vectors captured from the
+reference, and vs the C oracle on a larger random hybrid MRF."""
+import numpy as np
+import pytest
+
+import modelio
+from test_oracle_golden import API
+from test_oracle_pbp import EPBP_CASES, HLBP_CASES, load_npz
+
+pytestmark = pytest.mark.gpu
+
+# Tolerance of the log-message tables (fp64).  The kernels fold phi and the incoming log message into one exp and
+# use shuffle-tree reductions, so they differ from CPython's left-to-right sums by rounding only.
+RTOL, ATOL = 1e-9, 1e-8
+
+
+@pytest.fixture(scope='module')
+def api():
+    from lhvi import _abi
+    _abi.require_gpu()
+    return _abi
+
+
+def _injector(samples):
+    return lambda k, flat, q: samples[k]
+
+
+def _init(api, bp):
+    api.check(api.lib().lhvi_pbp_init(bp.dg.g, bp._struct(), api.ptr(bp.eta), api.ptr(bp.q_dev), api.ptr(bp.f2v),
+                                      api.ptr(bp.v2f), api.stream_ptr()))
+    bp._generate_sample()
+
+
+@pytest.mark.parametrize('name', EPBP_CASES)
+def test_epbp_matches_reference_golden(api, golden_dir, name):
+    from lhvi.pbp import EPBP
+    z, meta = load_npz(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    n, its = meta['n'], meta['iterations']
+    K = z['sample'].shape[0]
+    bp = EPBP(g, n=n, proposal_approximation=meta['approx'], sampler=_injector([z['sample'][k] for k in range(K)]))
+    # drive the sweeps one by one to compare every iteration's tables
+    bp._setup(g)
+    _init(api, bp)
+    flat = bp.flat
+    hid_e = np.flatnonzero(flat.var_hidden[flat.edge_var])
+    npe = bp.np_host[flat.edge_var]
+    cont = flat.var_hidden & flat.var_cont
+    for i in range(its):
+        if i > 0:    # f2v of iteration i-1, tabulated on sample i and the grid
+            got, want = bp.f2v.cpu().numpy(), z['f2v'][i]
+            for e in hid_e:
+                np.testing.assert_allclose(got[e, :npe[e]], want[e, :npe[e]], rtol=RTOL, atol=ATOL)
+                v = flat.edge_var[e]
+                if flat.var_cont[v]:
+                    T = flat.var_nstates[v]
+                    np.testing.assert_allclose(got[e, n:n + T], want[e, n:n + T], rtol=RTOL, atol=ATOL)
+        bp.sweep(last=(i == its - 1))
+        got, want = bp.v2f.cpu().numpy(), z['v2f'][i]
+        for e in hid_e:
+            np.testing.assert_allclose(got[e, :npe[e]], want[e, :npe[e]], rtol=RTOL, atol=ATOL, err_msg='v2f it %d' % i)
+        if i < its - 1:
+            np.testing.assert_allclose(bp.q_dev.cpu().numpy()[cont], z['q'][i][cont], rtol=1e-9, atol=1e-12)
+            ce = cont[flat.edge_var]
+            np.testing.assert_allclose(bp.eta.cpu().numpy()[ce], z['eta'][i][ce], rtol=1e-9, atol=1e-12)
+    # queries: belief_rv at recorded points, MAP, normalised belief
+    hid = [i for i, rv in enumerate(rvs) if rv.value is None]
+    got = bp.belief_rv_batch([rvs[i] for i in hid], z['query_x'][hid])
+    np.testing.assert_allclose(got, z['query_logb'][hid], rtol=1e-9, atol=1e-7)
+    for i in hid[:6]:
+        # fminbound stops at xtol=1e-5 and follows the same iterates while the objective agrees to ~1e-9
+        assert bp.map(rvs[i]) == pytest.approx(z['map'][i], abs=1e-4)
+    for i, x0, want in z['belief']:
+        # "marginals within 1e-5 of the CPU reference" (BASELINE.json north_star)
+        assert bp.belief(x0, rvs[int(i)]) == pytest.approx(want, rel=1e-5, abs=1e-7)
+
+
+@pytest.mark.parametrize('name', HLBP_CASES)
+def test_hlbp_matches_reference_golden(api, golden_dir, name):
+    from lhvi.pbp import HybridLBP
+    from oracle import oracle
+    z, meta = load_npz(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    samples = z['samples']
+
+    def inject(k, flat, q):
+        rep = np.array([rvs.index(min(c.rvs)) for c in flat.rvs])
+        return samples[k][rep]
+
+    bp = HybridLBP(g, n=meta['n'], proposal_approximation=meta['approx'], sampler=inject)
+    bp.run(meta['iterations'])
+    rv_color, f_color = bp.g.colors()
+    assert oracle.canonical_labels(rv_color) == z['rv_label'].tolist()     # integer partition: exact
+    assert oracle.canonical_labels(f_color) == z['f_label'].tolist()
+    hid = [i for i, rv in enumerate(rvs) if rv.value is None]
+    got = bp.belief_rv_batch([rvs[i] for i in hid], z['query_x'][hid])
+    np.testing.assert_allclose(got, z['query_logb'][hid], rtol=1e-9, atol=1e-7)
+    Q = bp.q
+    for i in hid:
+        if rvs[i].domain.continuous:
+            np.testing.assert_allclose(Q[rvs[i].cluster], z['final_q'][i], rtol=1e-9)
+    for i in hid[:6]:
+        assert bp.map(rvs[i]) == pytest.approx(z['map'][i], abs=1e-4)
+        assert bp.belief(z['query_x'][i][2], rvs[i]) == pytest.approx(z['belief_mid'][i], rel=1e-5, abs=1e-7)
+
+
+def test_epbp_host_sampler_reproduces_reference_stream(api, golden_dir):
+    """same np.random.seed, ordered g.rvs -> the host sampler draws the reference's particles bit for bit"""
+    from lhvi.pbp import EPBP
+    z, meta = load_npz(golden_dir, 'epbp_kalman_simple')
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    np.random.seed(meta['seed'])
+    bp = EPBP(g, n=meta['n'], proposal_approximation=meta['approx'])
+    bp.run(meta['iterations'])
+    P = bp.particles.cpu().numpy()
+    hid = bp.flat.var_hidden
+    np.testing.assert_allclose(P[hid], z['sample'][-1][hid], rtol=1e-9, atol=1e-9)
+    got = bp.belief_rv_batch([rv for rv in rvs if rv.value is None], z['query_x'][hid])
+    np.testing.assert_allclose(got, z['query_logb'][hid], rtol=1e-8, atol=1e-6)
+
+
+def test_pbp_sweep_matches_oracle_on_random_hybrid_mrf(api):
+    """cfg-4 style random hybrid pairwise MRF (n=64, T=32) at a size the C oracle finishes in seconds;
+    device-generated particles are downloaded and fed to the oracle so both see identical inputs"""
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    from oracle import oracle
+    flat = synth.hybrid_mrf_flat(V=3000, deg=4, seed=7)
+    bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=5)
+    bp._setup(None, flat=flat)
+    _init(api, bp)
+    o = oracle.PbpOracle(flat, 64, ep=False, epbp=True, var_threshold=3)
+    o.init()
+    o.set_particles(bp.particles.cpu().numpy())
+    assert (o.uniq == bp.uniq.cpu().numpy()).all()
+    hid_e = flat.var_hidden[flat.edge_var]
+    for i in range(3):
+        bp.sweep(last=False)
+        o.step_v2f()
+        o.step_proposal()
+        o.set_particles(bp.particles.cpu().numpy())
+        o.step_f2v()
+        np.testing.assert_allclose(bp.v2f.cpu().numpy()[hid_e], o.v2f[hid_e], rtol=1e-9, atol=1e-8)
+        np.testing.assert_allclose(bp.q_dev.cpu().numpy()[flat.var_hidden], o.q[flat.var_hidden], rtol=1e-9, atol=1e-12)
+        got, want = bp.f2v.cpu().numpy()[hid_e], o.f2v[hid_e]
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-8)
+
+
+def test_device_sampler_statistics(api):
+    """Philox/Box-Muller particles: mean/variance of the clipped normal draws, determinism per (seed, iteration)"""
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    flat = synth.hybrid_mrf_flat(V=4000, deg=4, seed=1)
+    runs = []
+    for _ in range(2):
+        bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=9)
+        bp._setup(None, flat=flat)
+        _init(api, bp)
+        runs.append(bp.particles.cpu().numpy())
+    cont = flat.var_hidden & flat.var_cont
+    x = runs[0][cont].ravel()
+    assert abs(x.mean()) < 0.02 and abs(x.var() - 5.0) < 0.1      # q = (0, 5), bounds +-10 (4.5 sigma)
+    assert (runs[0] == runs[1]).all()
