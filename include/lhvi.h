@@ -110,6 +110,8 @@ int lhvi_gabp_marginals(const lhvi_graph_t* g, const double* f2v, double* mu_var
 
 #define LHVI_PBP_EP 1u            /* proposal_approximation == 'EP' (else 'simple') */
 #define LHVI_PBP_EPBP_DISCRETE 2u /* EPBP applies importance weights to discrete rvs too (EPBP.py:157) */
+#define LHVI_PBP_SKIP_FAST 4u     /* lhvi_pbp_f2v: do not launch the quadratic-family kernel (profiling aid) */
+#define LHVI_PBP_SKIP_GENERIC 8u  /* lhvi_pbp_f2v: do not launch the generic-potential kernel (profiling aid) */
 
 typedef struct lhvi_pbp {
     int32_t n;                  /* particle slots per variable */

@@ -183,80 +183,155 @@ __device__ double f2v_point_generic(const lhvi_graph_t& g, const lhvi_pots_t& po
     return res > 0.0 ? log(res) : -700.0;
 }
 
-// One wavefront (= one 64-thread workgroup) per edge.
-__global__ void __launch_bounds__(WAVE) pbp_f2v_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
-                                                      const double* __restrict__ v2f, double* __restrict__ f2v) {
+// exp for the f2v inner loop: same reduction and degree-11 polynomial as the ocml routine (|r| <= ln2/2,
+// < 1 ulp), with the range checks replaced by one clamp -- the argument is log(phi) + log-message, and anything
+// below -745 underflows to zero either way; overflow saturates to +inf through ldexp like exp() does.
+__device__ __forceinline__ double exp_core(double t) {
+    t = fmax(t, -745.2);
+    const double k = rint(t * 1.4426950408889634);
+    double r = fma(k, -6.93147180369123816490e-01, t);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 2.5052108385441718775e-8;
+    p = fma(p, r, 2.7557319223985890653e-7);
+    p = fma(p, r, 2.7557319223985890653e-6);
+    p = fma(p, r, 2.4801587301587301587e-5);
+    p = fma(p, r, 1.9841269841269841270e-4);
+    p = fma(p, r, 1.3888888888888888889e-3);
+    p = fma(p, r, 8.3333333333333333333e-3);
+    p = fma(p, r, 4.1666666666666666667e-2);
+    p = fma(p, r, 1.6666666666666666667e-1);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+
+// Edge classes of the f -> v half sweep.  FAST edges have a term of the form
+//     log phi + m_j = a_j + b_j * X1 + k_j * X2 + C        (j = partner particle, X1/X2/C = per output point)
+//   (1) continuous target, log phi quadratic in it (Gaussian / Quadratic / LinearGaussian / XY / HybridQuadratic with
+//       the discrete partner): X1 = x, X2 = x^2, C = 0, (a, b, k) = coefficients given the partner particle + message;
+//   (2) discrete target of a HybridQuadratic(1 disc, 1 cont): X1 = b_d, X2 = A_d, C = c_d, (a, b, k) = (m_j, y_j, y_j^2).
+// Everything else (tables, MLN formulas, arity != 2) takes the GENERIC kernel.
+enum { EDGE_SKIP = 0, EDGE_FAST_CONT = 1, EDGE_FAST_DISC = 2, EDGE_GENERIC = 3 };
+
+__device__ __forceinline__ int classify_edge(const lhvi_graph_t& g, const lhvi_pots_t& pots, int e) {
+    if (canon(g.edge_canon, e) != e) return EDGE_SKIP;
+    const int tv = g.edge_var[e];
+    if (!is_hidden(g.var_value[tv])) return EDGE_SKIP;
+    const int f = g.edge_fac[e], base = g.fac_ptr[f], arity = g.fac_ptr[f + 1] - base, pos = e - base;
+    if (arity != 2) return EDGE_GENERIC;
+    const int pv = g.edge_var[base + (1 - pos)];
+    if (pv == tv) return EDGE_GENERIC;
+    const int pot = g.fac_pot[f], kind = pots.kind[pot];
+    const double* par = pots.param + pots.off[pot];
+    const bool tcont = g.dom_cont[g.var_dom[tv]] != 0, pcont = g.dom_cont[g.var_dom[pv]] != 0;
+    if (kind == LHVI_POT_HYBRID_QUADRATIC) {
+        if ((int)par[0] != 1 || (int)par[1] != 1) return EDGE_GENERIC;
+        if (pos == 1 && tcont && !pcont) return EDGE_FAST_CONT;
+        if (pos == 0 && !tcont && pcont) return EDGE_FAST_DISC;
+        return EDGE_GENERIC;
+    }
+    Quad2 q;
+    if (tcont && quad2_of(kind, par, 0, q)) return EDGE_FAST_CONT;
+    return EDGE_GENERIC;
+}
+
+// FAST edges: one wavefront (= one 64-thread workgroup) per edge.  Partner coefficients are staged in LDS in
+// tiles of 64; each lane owns one output point per round and accumulates sum_j exp(.) with two independent chains.
+// A final partial round splits the partner range over idle lanes and folds the partial sums with shuffles, so
+// n + T = 96 points on 64 lanes still keeps every lane busy.
+__global__ void __launch_bounds__(WAVE) pbp_f2v_fast_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
+                                                           const double* __restrict__ v2f, double* __restrict__ f2v) {
     __shared__ double sh_a[WAVE], sh_b[WAVE], sh_k[WAVE];
     const int e = blockIdx.x;
     const int lane = threadIdx.x;
-    if (canon(g.edge_canon, e) != e) return;
+    const int cls = classify_edge(g, pots, e);
+    if (cls != EDGE_FAST_CONT && cls != EDGE_FAST_DISC) return;
     const int tv = g.edge_var[e];
-    if (!is_hidden(g.var_value[tv])) return;
     const int n = s.n, S = s.n + s.T;
     const int d = g.var_dom[tv];
-    const bool cont = g.dom_cont[d] != 0;
     const int np = s.np[tv];
     const int gb = g.dom_ptr[d];
-    const int T = cont ? g.dom_ptr[d + 1] - gb : 0;
+    const int T = (cls == EDGE_FAST_CONT) ? g.dom_ptr[d + 1] - gb : 0;
     const int npts = np + T;
     double* out = f2v + (int64_t)e * S;
-
-    const int f = g.edge_fac[e], base = g.fac_ptr[f], arity = g.fac_ptr[f + 1] - base, pos = e - base;
+    const int f = g.edge_fac[e], base = g.fac_ptr[f], pos = e - base;
     const int pot = g.fac_pot[f], kind = pots.kind[pot];
     const double* par = pots.param + pots.off[pot];
+    const int pe = base + (1 - pos);
+    const int pv = g.edge_var[pe];
+    const int pce = canon(g.edge_canon, pe);
+    const double pval = g.var_value[pv];
+    const bool partner_hidden = is_hidden(pval);
+    const int nj = partner_hidden ? s.np[pv] : 1;
 
-    // ---- fast path: pairwise, continuous target, log phi quadratic in the target --------------
-    bool fast = false;
-    int pv = 0, pe = 0, nj = 0;
-    bool partner_hidden = false, partner_cont = false;
-    if (arity == 2 && cont) {
-        pe = base + (1 - pos);
-        pv = g.edge_var[pe];
-        partner_cont = g.dom_cont[g.var_dom[pv]] != 0;
-        partner_hidden = is_hidden(g.var_value[pv]);
-        Quad2 q0;
-        fast = quad2_of(kind, par, 0, q0) && pv != tv;
-        if (kind == LHVI_POT_HYBRID_QUADRATIC) fast = fast && pos == 1 && !partner_cont;
-        nj = partner_hidden ? s.np[pv] : 1;
-    }
-    if (fast) {
-        const int pce = canon(g.edge_canon, pe);
-        for (int p0 = 0; p0 < npts; p0 += 64) {
-            const int rem = npts - p0;
-            int width = 64;
-            if (rem <= 32) { width = 1; while (width < rem) width <<= 1; }
-            const int split = 64 / width, sub = lane / width, pl = lane % width;
-            const int p = p0 + pl;
-            const bool valid = pl < rem;
-            const double x = !valid ? 0.0 : (p < np ? s.particles[(int64_t)tv * n + p] : g.dom_val[gb + p - np]);
-            double acc = 0.0;
-            for (int j0 = 0; j0 < nj; j0 += 64) {      // tiles of 64 partner particles staged in LDS
-                const int jn = min(64, nj - j0);
-                __syncthreads();
-                if (lane < jn) {
-                    const int j = j0 + lane;
-                    double y, m;
-                    if (partner_hidden) { y = s.old_particles[(int64_t)pv * n + j]; m = v2f[(int64_t)pce * n + j]; }
-                    else { y = g.var_value[pv]; m = 0.0; }
+    for (int p0 = 0; p0 < npts; p0 += 64) {
+        const int rem = npts - p0;
+        int width = 64;
+        if (rem <= 32) { width = 1; while (width < rem) width <<= 1; }
+        const int split = 64 / width, sub = lane / width, pl = lane % width;
+        const int p = p0 + pl;
+        const bool valid = pl < rem;
+        double X1 = 0.0, X2 = 0.0, C = 0.0;
+        if (valid) {
+            if (cls == EDGE_FAST_CONT) {
+                X1 = p < np ? s.particles[(int64_t)tv * n + p] : g.dom_val[gb + p - np];
+                X2 = X1 * X1;
+            } else {
+                const int nst = (int)par[2];
+                const int st = (int)s.particles[(int64_t)tv * n + p];     // HybridQuadratic indexes by the state value
+                X2 = par[3 + st]; X1 = par[3 + nst + st]; C = par[3 + 2 * nst + st];
+            }
+        }
+        double acc0 = 0.0, acc1 = 0.0;
+        for (int j0 = 0; j0 < nj; j0 += 64) {
+            const int jn = min(64, nj - j0);
+            __syncthreads();
+            if (lane < jn) {
+                const int j = j0 + lane;
+                double y = pval, m = 0.0;
+                if (partner_hidden) { y = s.old_particles[(int64_t)pv * n + j]; m = v2f[(int64_t)pce * n + j]; }
+                double a, b, k;
+                if (cls == EDGE_FAST_CONT) {
                     Quad2 q;
                     quad2_of(kind, par, (kind == LHVI_POT_HYBRID_QUADRATIC) ? (int)y : 0, q);
-                    double a, b, k;
                     if (pos == 0) { a = (q.a11 * y + q.b1) * y + q.c + m; b = q.axy * y + q.b0; k = q.a00; }
                     else          { a = (q.a00 * y + q.b0) * y + q.c + m; b = q.axy * y + q.b1; k = q.a11; }
-                    sh_a[lane] = a; sh_b[lane] = b; sh_k[lane] = k;
-                }
-                __syncthreads();
-                const int chunk = (jn + split - 1) / split;
-                const int jb = sub * chunk, je = min(jn, jb + chunk);
-                for (int j = jb; j < je; ++j)
-                    acc += exp(fma(fma(sh_k[j], x, sh_b[j]), x, sh_a[j]));
+                } else { a = m; b = y; k = y * y; }
+                sh_a[lane] = a; sh_b[lane] = b; sh_k[lane] = k;
             }
-            for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
-            if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log(acc) : -700.0;
+            __syncthreads();
+            const int chunk = (jn + split - 1) / split;
+            const int jb = sub * chunk, je = min(jn, jb + chunk);
+            int j = jb;
+            for (; j + 1 < je; j += 2) {
+                const double t0 = fma(sh_k[j], X2, fma(sh_b[j], X1, sh_a[j])) + C;
+                const double t1 = fma(sh_k[j + 1], X2, fma(sh_b[j + 1], X1, sh_a[j + 1])) + C;
+                acc0 += exp_core(t0);
+                acc1 += exp_core(t1);
+            }
+            if (j < je) acc0 += exp_core(fma(sh_k[j], X2, fma(sh_b[j], X1, sh_a[j])) + C);
         }
-        return;
+        double acc = acc0 + acc1;
+        for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+        if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log(acc) : -700.0;
     }
-    // ---- generic path -------------------------------------------------------------------------
+}
+
+// GENERIC edges: one wavefront per edge, lane = output point, sequential joint loop per lane.
+__global__ void __launch_bounds__(WAVE) pbp_f2v_generic_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
+                                                              const double* __restrict__ v2f, double* __restrict__ f2v) {
+    const int e = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (classify_edge(g, pots, e) != EDGE_GENERIC) return;
+    const int tv = g.edge_var[e];
+    const int n = s.n, S = s.n + s.T;
+    const int d = g.var_dom[tv];
+    const int np = s.np[tv];
+    const int gb = g.dom_ptr[d];
+    const int T = g.dom_cont[d] ? g.dom_ptr[d + 1] - gb : 0;
+    const int npts = np + T;
+    double* out = f2v + (int64_t)e * S;
     for (int p = lane; p < npts; p += 64) {
         const double x = p < np ? s.particles[(int64_t)tv * n + p] : g.dom_val[gb + p - np];
         const int xi = p < np ? p : p - np;
@@ -424,7 +499,10 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     if (int rc = validate_pbp(g, s)) return rc;
     if (!pots || !v2f || !f2v || !s->old_particles) return LHVI_E_ARG;
     if (g->E == 0) return LHVI_OK;
-    hipLaunchKernelGGL(pbp_f2v_kernel, dim3(g->E), dim3(WAVE), 0, as_stream(stream), *g, *pots, *s, v2f, f2v);
+    if (!(s->flags & LHVI_PBP_SKIP_FAST))
+        hipLaunchKernelGGL(pbp_f2v_fast_kernel, dim3(g->E), dim3(WAVE), 0, as_stream(stream), *g, *pots, *s, v2f, f2v);
+    if (!(s->flags & LHVI_PBP_SKIP_GENERIC))
+        hipLaunchKernelGGL(pbp_f2v_generic_kernel, dim3(g->E), dim3(WAVE), 0, as_stream(stream), *g, *pots, *s, v2f, f2v);
     return check_launch();
 }
 

@@ -119,15 +119,25 @@ class _ParticleSweep:
             self.sweep(last=(i == iteration - 1))
         self._views = {}
 
-    def sweep(self, last=False):
-        """one flooding sweep: v2f, and unless `last`: proposal update, new sample, f2v"""
+    def sweep(self, last=False, f2v_events=None):
+        """one flooding sweep: v2f, and unless `last`: proposal update, new sample, f2v.
+        `f2v_events`: optional (start, end) torch.cuda.Event pair recorded around the f2v launch on its stream"""
         l, st, g, p = _abi.lib(), _abi.stream_ptr(), self.dg.g, self.dg.p
         _abi.check(l.lhvi_pbp_v2f(g, self._struct(), _abi.ptr(self.f2v), _abi.ptr(self.v2f), st))
         if not last:
             _abi.check(l.lhvi_pbp_proposal(g, self._struct(), _abi.ptr(self.f2v), _abi.ptr(self.eta),
                                            _abi.ptr(self.q_dev), st))
             self._generate_sample()
-            _abi.check(l.lhvi_pbp_f2v(g, p, self._struct(), _abi.ptr(self.v2f), _abi.ptr(self.f2v), st))
+            if f2v_events:      # time the dominant (quadratic-family) kernel alone: two calls, one kernel each
+                s = self._struct()
+                s.flags |= _abi.PBP_SKIP_GENERIC
+                f2v_events[0].record()
+                _abi.check(l.lhvi_pbp_f2v(g, p, s, _abi.ptr(self.v2f), _abi.ptr(self.f2v), st))
+                f2v_events[1].record()
+                s.flags = (s.flags & ~_abi.PBP_SKIP_GENERIC) | _abi.PBP_SKIP_FAST
+                _abi.check(l.lhvi_pbp_f2v(g, p, s, _abi.ptr(self.v2f), _abi.ptr(self.f2v), st))
+            else:
+                _abi.check(l.lhvi_pbp_f2v(g, p, self._struct(), _abi.ptr(self.v2f), _abi.ptr(self.f2v), st))
 
     # ---- dict views with the reference's keys ------------------------------------------------------
     def _host(self, name):
