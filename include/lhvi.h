@@ -124,7 +124,25 @@ typedef struct lhvi_pbp {
     const int32_t* np;          /* [V] valid particles: n (continuous hidden), #states (discrete hidden), 0 (observed) */
     const uint8_t* uniq;        /* [V][n] 1 = first occurrence of that value among the variable's particles */
     const double* q;            /* [V][2] proposal (mu, var) */
+    /* optional work lists for lhvi_pbp_f2v (from lhvi_pbp_classify); NULL = classify every edge on the fly */
+    const int32_t* fast_edges;  /* [n_fast] edges whose log phi is quadratic in the target (LDS-staged kernel) */
+    int32_t n_fast;
+    const int32_t* generic_edges; /* [n_generic] all other edges with a hidden target */
+    int32_t n_generic;
+    const void* fast_desc;      /* [n_fast][LHVI_PBP_DESC_BYTES] from lhvi_pbp_describe, or NULL (built on the fly) */
 } lhvi_pbp_t;
+
+#define LHVI_PBP_DESC_BYTES 64
+/* static per-edge descriptors of the fast work list (targets, partners, particle counts, potential rows): lets the
+ * persistent f2v kernel fetch an edge with scalar loads.  Must be rebuilt when np / the graph / the potentials change. */
+int lhvi_pbp_describe(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const int32_t* edges, int32_t count,
+                      void* desc_out, void* stream);
+/* test hook: y[i] = the f2v kernel's exp(x[i]) */
+int lhvi_debug_exp(const double* x, double* y, int64_t n, void* stream);
+
+/* edge_class[e]: 0 = no message (observed target / alias edge), 1|2 = quadratic-family (continuous | discrete target),
+ * 3 = generic potential.  Static per (graph, potentials); the host turns it into the two work lists above. */
+int lhvi_pbp_classify(const lhvi_graph_t* g, const lhvi_pots_t* pots, uint8_t* edge_class, void* stream);
 
 /* uniq[v][j] = no i<j with particles[v][i] == particles[v][j]  (dict-key collapse, EPBP.py:236-242) */
 int lhvi_pbp_uniq(const lhvi_graph_t* g, int32_t n, const double* particles, const int32_t* np, uint8_t* uniq, void* stream);

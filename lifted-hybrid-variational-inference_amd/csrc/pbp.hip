@@ -70,7 +70,27 @@ __global__ void __launch_bounds__(BLOCK) pbp_uniq_kernel(int V, int n, const dou
     uniq[i] = (uint8_t)u;
 }
 
+// n <= 64: one wavefront per variable, lane = particle; the row lives in registers and is broadcast lane by lane
+__global__ void __launch_bounds__(BLOCK) pbp_uniq_wave_kernel(int V, int n, const double* __restrict__ particles,
+                                                             const int32_t* __restrict__ np, uint8_t* __restrict__ uniq) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (v >= V) return;
+    const int cnt = np[v];
+    const double x = lane < n ? particles[(int64_t)v * n + lane] : 0.0;
+    int u = lane < cnt;
+    for (int k = 0; k < cnt - 1; ++k) {
+        const double xk = __shfl(x, k);
+        if (k < lane && xk == x) u = 0;
+    }
+    if (lane < n) uniq[(int64_t)v * n + lane] = (uint8_t)u;
+}
+
 // ---------------------------------------------------------------------------------------------
+// One wavefront per variable, lane = particle.  Every incident f2v row is read once (coalesced 8n bytes), the
+// per-particle total T_j = sum_k c_k m_k[j] is formed in rv.nb order, and edge k's message is T_j - m_k[j] + log w_j.
+// Log messages are additive, so "total minus own" costs an absolute error of a few ulp of |T| (~1e-13), far inside
+// the stated tolerance; it replaces the reference's O(deg^2) re-summation (EPBP:165-174) by O(deg).
 __global__ void __launch_bounds__(BLOCK) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                        double* __restrict__ v2f) {
     const int lane = threadIdx.x & 63;
@@ -80,42 +100,56 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp
     const int n = s.n, S = s.n + s.T;
     const int np = s.np[v];
     const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    const int deg = hi - lo;
     const int d = g.var_dom[v];
     const bool lifted = g.edge_count != nullptr;
     const int nchunk = (np + 63) / 64;
-    for (int k = lo; k < hi; ++k) {
-        const int e = g.var_edge[k];
-        const double own_c = lifted ? g.edge_count[e] - 1.0 : 0.0;
-        double lsum = 0.0, lmax = -__builtin_huge_val();
-        int lcnt = 0;
-        double keep = 0.0;
-        for (int c = 0; c < nchunk; ++c) {
-            const int j = c * 64 + lane;
-            double res = 0.0;
-            if (j < np) {
-                for (int kk = lo; kk < hi; ++kk) {
-                    if (kk == k) continue;
-                    const int e2 = g.var_edge[kk];
-                    const double m = f2v[(int64_t)e2 * S + j];
-                    res += lifted ? m * g.edge_count[e2] : m;
-                }
-                const double x = s.particles[(int64_t)v * n + j];
-                res = res + log_importance(g, s, v, d, x);
-                if (lifted) res = res + f2v[(int64_t)e * S + j] * own_c;
-                if (s.uniq[(int64_t)v * n + j]) { lsum += res; lmax = fmax(lmax, res); ++lcnt; }
-                if (nchunk > 1) v2f[(int64_t)e * n + j] = res;
-            }
-            keep = res;
+    for (int c = 0; c < nchunk; ++c) {
+        const int j = c * 64 + lane;
+        const bool valid = j < np;
+        double total = 0.0;
+        for (int k = 0; k < deg; ++k) {
+            const int e = g.var_edge[lo + k];
+            const double m = valid ? f2v[(int64_t)e * S + j] : 0.0;
+            total += lifted ? m * g.edge_count[e] : m;
         }
-        // log_message_balance over the distinct keys (EPBP:204-215)
-        const double tot = wave_sum(lsum);
-        const double mx = wave_max(lmax);
-        const int cnt = wave_sum_i(lcnt);
-        const double mean = tot / (double)cnt;
-        const double shift = (mx - mean > s.max_log_value) ? mx - s.max_log_value : mean;
-        if (nchunk == 1) {
-            if (lane < np) v2f[(int64_t)e * n + lane] = keep - shift;
-        } else {
+        const double logw = valid ? log_importance(g, s, v, d, s.particles[(int64_t)v * n + j]) : 0.0;
+        const bool uq = valid && s.uniq[(int64_t)v * n + j];
+        for (int k = 0; k < deg; ++k) {
+            const int e = g.var_edge[lo + k];
+            // second touch of the row comes out of L1/L2 (a register-array cache indexed by the runtime k made
+            // hipcc 7.2 emit an out-of-range s_set_gpr_idx store, so the rows are simply re-read)
+            const double m = valid ? f2v[(int64_t)e * S + j] : 0.0;
+            // ground: sum over nb != f; lifted: own factor keeps count-1 copies (HLBP:182-191) -> total - m either way
+            const double res = (total - m) + logw;
+            if (nchunk == 1) {
+                // log_message_balance over the distinct keys (EPBP:204-215)
+                const double tot = wave_sum(uq ? res : 0.0);
+                const double mx = wave_max(uq ? res : -__builtin_huge_val());
+                const int cnt = wave_sum_i(uq ? 1 : 0);
+                const double mean = tot / (double)cnt;
+                const double shift = (mx - mean > s.max_log_value) ? mx - s.max_log_value : mean;
+                if (valid) v2f[(int64_t)e * n + j] = res - shift;
+            } else if (valid) {
+                v2f[(int64_t)e * n + j] = res;       // balanced below once every chunk is written
+            }
+        }
+    }
+    if (nchunk > 1) {
+        for (int k = 0; k < deg; ++k) {
+            const int e = g.var_edge[lo + k];
+            double lsum = 0.0, lmax = -__builtin_huge_val();
+            int lcnt = 0;
+            for (int c = 0; c < nchunk; ++c) {
+                const int j = c * 64 + lane;
+                if (j < np && s.uniq[(int64_t)v * n + j]) {
+                    const double r = v2f[(int64_t)e * n + j];
+                    lsum += r; lmax = fmax(lmax, r); ++lcnt;
+                }
+            }
+            const double mean = wave_sum(lsum) / (double)wave_sum_i(lcnt);
+            const double mx = wave_max(lmax);
+            const double shift = (mx - mean > s.max_log_value) ? mx - s.max_log_value : mean;
             for (int c = 0; c < nchunk; ++c) {
                 const int j = c * 64 + lane;
                 if (j < np) v2f[(int64_t)e * n + j] -= shift;
@@ -183,27 +217,27 @@ __device__ double f2v_point_generic(const lhvi_graph_t& g, const lhvi_pots_t& po
     return res > 0.0 ? log(res) : -700.0;
 }
 
-// exp for the f2v inner loop: same reduction and degree-11 polynomial as the ocml routine (|r| <= ln2/2,
-// < 1 ulp), with the range checks replaced by one clamp -- the argument is log(phi) + log-message, and anything
-// below -745 underflows to zero either way; overflow saturates to +inf through ldexp like exp() does.
-__device__ __forceinline__ double exp_core(double t) {
-    t = fmax(t, -745.2);
-    const double k = rint(t * 1.4426950408889634);
-    double r = fma(k, -6.93147180369123816490e-01, t);
-    r = fma(k, -1.90821492927058770002e-10, r);
-    double p = 2.5052108385441718775e-8;
-    p = fma(p, r, 2.7557319223985890653e-7);
-    p = fma(p, r, 2.7557319223985890653e-6);
-    p = fma(p, r, 2.4801587301587301587e-5);
-    p = fma(p, r, 1.9841269841269841270e-4);
-    p = fma(p, r, 1.3888888888888888889e-3);
-    p = fma(p, r, 8.3333333333333333333e-3);
-    p = fma(p, r, 4.1666666666666666667e-2);
+// exp for the f2v inner loop (argument = log phi + log message).  Table-driven: t = (64 k + j) ln2/64 + r with
+// |r| <= ln2/128, exp(t) = 2^k * 2^(j/64) * exp(r); 2^(j/64) comes from a 64-entry LDS table, exp(r) from a degree-5
+// Taylor polynomial (remainder r^6/720 < 4e-17), the rounding to the nearest multiple uses the 1.5*2^52 magic
+// constant so that the integer n = 64k + j sits in the low word of the same register.  14 fp64 operations per call
+// against 22 for the ocml routine; measured max error 2 ulp (tests/test_gpu_pbp.py::test_device_exp_accuracy).
+// Valid for |t| < 2^31 / 92; anything below -745 underflows to 0 through ldexp, overflow saturates to +inf.
+__constant__ double EXP_TAB64[64] = {1, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199, 1.0905077326652577, 1.1023825833078409, 1.1143867425958924, 1.1265216186082418, 1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812, 1.189207115002721, 1.2021567314527031, 1.215247359980469, 1.22848053610687, 1.241857812073484, 1.2553807570246911, 1.2690509571917332, 1.2828700160787783, 1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.3396675240533029, 1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112, 1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647, 1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384, 1.5422108254079407, 1.5590044002378369, 1.5759808451078865, 1.593142151342267, 1.6104903319492543, 1.6280274218573478, 1.6457554781539649, 1.6636765803267364, 1.681792830507429, 1.7001063537185235, 1.7186192981224779, 1.7373338352737062, 1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989, 1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656, 1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.9784560263879509};
+
+__device__ __forceinline__ double exp_core(double t, const double* __restrict__ tab /* LDS copy of EXP_TAB64 */) {
+    const double MAGIC = 6755399441055744.0;                 // 1.5 * 2^52
+    const double u = fma(t, 9.23324826168936567683e+01, MAGIC);
+    const int nn = __double2loint(u);
+    const double kd = u - MAGIC;
+    double r = fma(kd, -1.08304246932675596327e-02, t);      // ln2/64, high 32 bits (product exact)
+    r = fma(kd, -2.98158582698529328128e-12, r);
+    double p = fma(r, 8.3333333333333333333e-3, 4.1666666666666666667e-2);
     p = fma(p, r, 1.6666666666666666667e-1);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    return ldexp(p, (int)k);
+    return ldexp(tab[nn & 63] * p, nn >> 6);
 }
 
 // Edge classes of the f -> v half sweep.  FAST edges have a term of the form
@@ -236,94 +270,170 @@ __device__ __forceinline__ int classify_edge(const lhvi_graph_t& g, const lhvi_p
     return EDGE_GENERIC;
 }
 
-// FAST edges: one wavefront (= one 64-thread workgroup) per edge.  Partner coefficients are staged in LDS in
-// tiles of 64; each lane owns one output point per round and accumulates sum_j exp(.) with two independent chains.
-// A final partial round splits the partner range over idle lanes and folds the partial sums with shuffles, so
-// n + T = 96 points on 64 lanes still keeps every lane busy.
-__global__ void __launch_bounds__(WAVE) pbp_f2v_fast_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
-                                                           const double* __restrict__ v2f, double* __restrict__ f2v) {
-    __shared__ double sh_a[WAVE], sh_b[WAVE], sh_k[WAVE];
-    const int e = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int cls = classify_edge(g, pots, e);
-    if (cls != EDGE_FAST_CONT && cls != EDGE_FAST_DISC) return;
-    const int tv = g.edge_var[e];
-    const int n = s.n, S = s.n + s.T;
-    const int d = g.var_dom[tv];
-    const int np = s.np[tv];
-    const int gb = g.dom_ptr[d];
-    const int T = (cls == EDGE_FAST_CONT) ? g.dom_ptr[d + 1] - gb : 0;
-    const int npts = np + T;
-    double* out = f2v + (int64_t)e * S;
-    const int f = g.edge_fac[e], base = g.fac_ptr[f], pos = e - base;
-    const int pot = g.fac_pot[f], kind = pots.kind[pot];
-    const double* par = pots.param + pots.off[pot];
-    const int pe = base + (1 - pos);
-    const int pv = g.edge_var[pe];
-    const int pce = canon(g.edge_canon, pe);
-    const double pval = g.var_value[pv];
-    const bool partner_hidden = is_hidden(pval);
-    const int nj = partner_hidden ? s.np[pv] : 1;
+// Static description of a FAST edge, built once per run (lhvi_pbp_describe) so that the persistent kernel fetches
+// everything it needs about an edge with two scalar loads instead of a chain of dependent gathers.
+struct FastDesc {
+    int32_t e, tv, pv, pce;        // edge, target variable, partner variable, partner's canonical edge
+    int32_t cls, pos, kind, nj;    // edge class, target position, potential kind, partner particle count (1 = observed)
+    int32_t np, T, gb, par_off;    // target particle count, target grid size, grid base in dom_val, offset into pots.param
+    double pval;                   // partner evidence value (NaN = hidden)
+    int32_t pad[2];
+};
+static_assert(sizeof(FastDesc) == 64, "FastDesc is part of the ABI (LHVI_PBP_DESC_BYTES)");
 
-    for (int p0 = 0; p0 < npts; p0 += 64) {
-        const int rem = npts - p0;
-        int width = 64;
-        if (rem <= 32) { width = 1; while (width < rem) width <<= 1; }
-        const int split = 64 / width, sub = lane / width, pl = lane % width;
-        const int p = p0 + pl;
-        const bool valid = pl < rem;
-        double X1 = 0.0, X2 = 0.0, C = 0.0;
-        if (valid) {
-            if (cls == EDGE_FAST_CONT) {
-                X1 = p < np ? s.particles[(int64_t)tv * n + p] : g.dom_val[gb + p - np];
-                X2 = X1 * X1;
-            } else {
-                const int nst = (int)par[2];
-                const int st = (int)s.particles[(int64_t)tv * n + p];     // HybridQuadratic indexes by the state value
-                X2 = par[3 + st]; X1 = par[3 + nst + st]; C = par[3 + 2 * nst + st];
+__device__ __forceinline__ FastDesc make_fast_desc(const lhvi_graph_t& g, const lhvi_pots_t& pots, const lhvi_pbp_t& s, int e) {
+    FastDesc d;
+    d.e = e;
+    d.cls = classify_edge(g, pots, e);
+    d.tv = g.edge_var[e];
+    const int f = g.edge_fac[e], base = g.fac_ptr[f];
+    d.pos = e - base;
+    const int pe = base + (1 - d.pos);
+    d.pv = g.edge_var[pe];
+    d.pce = canon(g.edge_canon, pe);
+    const int pot = g.fac_pot[f];
+    d.kind = pots.kind[pot];
+    d.par_off = pots.off[pot];
+    d.pval = g.var_value[d.pv];
+    d.nj = is_hidden(d.pval) ? s.np[d.pv] : 1;
+    const int dom = g.var_dom[d.tv];
+    d.np = s.np[d.tv];
+    d.gb = g.dom_ptr[dom];
+    d.T = (d.cls == EDGE_FAST_CONT) ? g.dom_ptr[dom + 1] - d.gb : 0;
+    d.pad[0] = d.pad[1] = 0;
+    return d;
+}
+
+__global__ void __launch_bounds__(BLOCK) pbp_describe_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
+                                                            const int32_t* __restrict__ edges, int count,
+                                                            FastDesc* __restrict__ out) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < count) out[i] = make_fast_desc(g, pots, s, edges[i]);
+}
+
+// wave-private LDS hand-off: DS operations of one wavefront execute in order, so only the compiler needs fencing
+#define LHVI_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+struct ABK { double a, b, k, pad; };     // 32-byte LDS record: one ds_read_b128 + one ds_read_b64 per term
+
+template <bool HAS_C>
+__device__ __forceinline__ double fast_accumulate(const ABK* __restrict__ sh, const double* __restrict__ tab, int jb, int je,
+                                                  double X1, double X2, double C) {
+    double acc0 = 0.0, acc1 = 0.0;
+    int j = jb;
+    for (; j + 1 < je; j += 2) {           // two independent exp chains per iteration
+        double t0 = fma(sh[j].k, X2, fma(sh[j].b, X1, sh[j].a));
+        double t1 = fma(sh[j + 1].k, X2, fma(sh[j + 1].b, X1, sh[j + 1].a));
+        if (HAS_C) { t0 += C; t1 += C; }
+        acc0 += exp_core(t0, tab);
+        acc1 += exp_core(t1, tab);
+    }
+    if (j < je) {
+        double t0 = fma(sh[j].k, X2, fma(sh[j].b, X1, sh[j].a));
+        if (HAS_C) t0 += C;
+        acc0 += exp_core(t0, tab);
+    }
+    return acc0 + acc1;
+}
+
+// FAST edges: persistent kernel, one wavefront per edge at a time (each wave strides over the work list).
+// Partner coefficients are staged in wave-private LDS in tiles of 64; each lane owns one output point per round and
+// accumulates sum_j exp(.).  A final partial round splits the partner range over idle lanes and folds the partial
+// sums with shuffles, so n + T = 96 points on 64 lanes still keep every lane busy.
+__global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
+                                                            const double* __restrict__ v2f, double* __restrict__ f2v) {
+    __shared__ ABK sh_all[BLOCK / WAVE][WAVE];
+    __shared__ double sh_tab[64];
+    if (threadIdx.x < 64) sh_tab[threadIdx.x] = EXP_TAB64[threadIdx.x];
+    __syncthreads();
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    ABK* sh = sh_all[wid];
+    const FastDesc* __restrict__ descs = reinterpret_cast<const FastDesc*>(s.fast_desc);
+    const int nitems = s.fast_edges ? s.n_fast : g.E;
+    const int nwaves = gridDim.x * (BLOCK / WAVE);
+    const int n = s.n, S = s.n + s.T;
+    for (int item = blockIdx.x * (BLOCK / WAVE) + wid; item < nitems; item += nwaves) {
+        FastDesc d;
+        if (descs) d = descs[item];                       // wave-uniform address: scalar loads
+        else d = make_fast_desc(g, pots, s, s.fast_edges ? s.fast_edges[item] : item);
+        if (d.cls != EDGE_FAST_CONT && d.cls != EDGE_FAST_DISC) continue;
+        const double* par = pots.param + d.par_off;
+        const int np = d.np, npts = d.np + d.T, nj = d.nj;
+        const bool partner_hidden = is_hidden(d.pval);
+        double* out = f2v + (int64_t)d.e * S;
+
+        for (int p0 = 0; p0 < npts; p0 += 64) {
+            const int rem = npts - p0;
+            int width = 64;
+            if (rem <= 32) { width = 1; while (width < rem) width <<= 1; }
+            const int split = 64 / width, sub = lane / width, pl = lane % width;
+            const int p = p0 + pl;
+            const bool valid = pl < rem;
+            double X1 = 0.0, X2 = 0.0, C = 0.0;
+            if (valid) {
+                if (d.cls == EDGE_FAST_CONT) {
+                    X1 = p < np ? s.particles[(int64_t)d.tv * n + p] : g.dom_val[d.gb + p - np];
+                    X2 = X1 * X1;
+                } else {
+                    const int nst = (int)par[2];
+                    const int st = (int)s.particles[(int64_t)d.tv * n + p];   // HybridQuadratic indexes by the state value
+                    X2 = par[3 + st]; X1 = par[3 + nst + st]; C = par[3 + 2 * nst + st];
+                }
             }
+            double acc = 0.0;
+            for (int j0 = 0; j0 < nj; j0 += 64) {
+                const int jn = min(64, nj - j0);
+                LHVI_WAVE_SYNC();
+                if (lane < jn) {
+                    const int j = j0 + lane;
+                    double y = d.pval, m = 0.0;
+                    if (partner_hidden) { y = s.old_particles[(int64_t)d.pv * n + j]; m = v2f[(int64_t)d.pce * n + j]; }
+                    ABK r;
+                    if (d.cls == EDGE_FAST_CONT) {
+                        Quad2 q;
+                        quad2_of(d.kind, par, (d.kind == LHVI_POT_HYBRID_QUADRATIC) ? (int)y : 0, q);
+                        if (d.pos == 0) { r.a = (q.a11 * y + q.b1) * y + q.c + m; r.b = q.axy * y + q.b0; r.k = q.a00; }
+                        else            { r.a = (q.a00 * y + q.b0) * y + q.c + m; r.b = q.axy * y + q.b1; r.k = q.a11; }
+                    } else { r.a = m; r.b = y; r.k = y * y; }
+                    r.pad = 0.0;
+                    sh[lane] = r;
+                }
+                LHVI_WAVE_SYNC();
+                const int chunk = (jn + split - 1) / split;
+                const int jb = sub * chunk, je = min(jn, jb + chunk);
+                acc += (d.cls == EDGE_FAST_CONT) ? fast_accumulate<false>(sh, sh_tab, jb, je, X1, X2, 0.0)
+                                                 : fast_accumulate<true>(sh, sh_tab, jb, je, X1, X2, C);
+            }
+            for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+            if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log(acc) : -700.0;
         }
-        double acc0 = 0.0, acc1 = 0.0;
-        for (int j0 = 0; j0 < nj; j0 += 64) {
-            const int jn = min(64, nj - j0);
-            __syncthreads();
-            if (lane < jn) {
-                const int j = j0 + lane;
-                double y = pval, m = 0.0;
-                if (partner_hidden) { y = s.old_particles[(int64_t)pv * n + j]; m = v2f[(int64_t)pce * n + j]; }
-                double a, b, k;
-                if (cls == EDGE_FAST_CONT) {
-                    Quad2 q;
-                    quad2_of(kind, par, (kind == LHVI_POT_HYBRID_QUADRATIC) ? (int)y : 0, q);
-                    if (pos == 0) { a = (q.a11 * y + q.b1) * y + q.c + m; b = q.axy * y + q.b0; k = q.a00; }
-                    else          { a = (q.a00 * y + q.b0) * y + q.c + m; b = q.axy * y + q.b1; k = q.a11; }
-                } else { a = m; b = y; k = y * y; }
-                sh_a[lane] = a; sh_b[lane] = b; sh_k[lane] = k;
-            }
-            __syncthreads();
-            const int chunk = (jn + split - 1) / split;
-            const int jb = sub * chunk, je = min(jn, jb + chunk);
-            int j = jb;
-            for (; j + 1 < je; j += 2) {
-                const double t0 = fma(sh_k[j], X2, fma(sh_b[j], X1, sh_a[j])) + C;
-                const double t1 = fma(sh_k[j + 1], X2, fma(sh_b[j + 1], X1, sh_a[j + 1])) + C;
-                acc0 += exp_core(t0);
-                acc1 += exp_core(t1);
-            }
-            if (j < je) acc0 += exp_core(fma(sh_k[j], X2, fma(sh_b[j], X1, sh_a[j])) + C);
-        }
-        double acc = acc0 + acc1;
-        for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
-        if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log(acc) : -700.0;
     }
 }
 
+// test hook: y[i] = exp_core(x[i])
+__global__ void __launch_bounds__(BLOCK) debug_exp_kernel(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
+    __shared__ double sh_tab[64];
+    if (threadIdx.x < 64) sh_tab[threadIdx.x] = EXP_TAB64[threadIdx.x];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) y[i] = exp_core(x[i], sh_tab);
+}
+
+__global__ void __launch_bounds__(BLOCK) pbp_classify_kernel(lhvi_graph_t g, lhvi_pots_t pots, uint8_t* __restrict__ cls) {
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e < g.E) cls[e] = (uint8_t)classify_edge(g, pots, e);
+}
+
 // GENERIC edges: one wavefront per edge, lane = output point, sequential joint loop per lane.
-__global__ void __launch_bounds__(WAVE) pbp_f2v_generic_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
-                                                              const double* __restrict__ v2f, double* __restrict__ f2v) {
-    const int e = blockIdx.x;
-    const int lane = threadIdx.x;
-    if (classify_edge(g, pots, e) != EDGE_GENERIC) return;
+__global__ void __launch_bounds__(BLOCK) pbp_f2v_generic_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
+                                                               const double* __restrict__ v2f, double* __restrict__ f2v) {
+    const int lane = threadIdx.x & 63;
+    const int nitems = s.generic_edges ? s.n_generic : g.E;
+    const int nwaves = gridDim.x * (BLOCK / WAVE);
+  for (int item = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); item < nitems; item += nwaves) {
+    const int e = s.generic_edges ? s.generic_edges[item] : item;
+    if (classify_edge(g, pots, e) != EDGE_GENERIC) continue;
     const int tv = g.edge_var[e];
     const int n = s.n, S = s.n + s.T;
     const int d = g.var_dom[tv];
@@ -337,6 +447,7 @@ __global__ void __launch_bounds__(WAVE) pbp_f2v_generic_kernel(lhvi_graph_t g, l
         const int xi = p < np ? p : p - np;
         out[p < np ? p : n + (p - np)] = f2v_point_generic(g, pots, s, v2f, s.old_particles, e, x, xi);
     }
+  }
 }
 
 // belief_rv(x) = sum_f message_f_to_rv(x, f, rv, sample) at arbitrary points (EPBP:196-202; HLBP:313-317)
@@ -465,6 +576,19 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_kernel(lhvi_graph_t g, lhv
     out[i] = fmin(fmax(x, g.dom_lo[d]), g.dom_hi[d]);
 }
 
+static int device_cus() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
+
+static int blocks_per_cu(const void* kernel) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+    return nb > 8 ? 8 : nb;
+}
+
 static int validate_pbp(const lhvi_graph_t* g, const lhvi_pbp_t* s) {
     if (!g || !s) return LHVI_E_ARG;
     if (g->V < 0 || g->E < 0 || s->n <= 0 || s->T < 0) return LHVI_E_ARG;
@@ -482,8 +606,37 @@ extern "C" {
 int lhvi_pbp_uniq(const lhvi_graph_t* g, int32_t n, const double* particles, const int32_t* np, uint8_t* uniq, void* stream) {
     if (!g || n <= 0 || !particles || !np || !uniq) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
-    hipLaunchKernelGGL(pbp_uniq_kernel, dim3(grid_for((int64_t)g->V * n)), dim3(BLOCK), 0, as_stream(stream), g->V, n,
-                       particles, np, uniq);
+    if (n <= WAVE)
+        hipLaunchKernelGGL(pbp_uniq_wave_kernel, dim3(grid_for((int64_t)g->V * WAVE)), dim3(BLOCK), 0, as_stream(stream),
+                           g->V, n, particles, np, uniq);
+    else
+        hipLaunchKernelGGL(pbp_uniq_kernel, dim3(grid_for((int64_t)g->V * n)), dim3(BLOCK), 0, as_stream(stream), g->V, n,
+                           particles, np, uniq);
+    return check_launch();
+}
+
+int lhvi_pbp_classify(const lhvi_graph_t* g, const lhvi_pots_t* pots, uint8_t* edge_class, void* stream) {
+    if (!g || !pots || !edge_class) return LHVI_E_ARG;
+    if (g->E == 0) return LHVI_OK;
+    hipLaunchKernelGGL(pbp_classify_kernel, dim3(grid_for(g->E)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, edge_class);
+    return check_launch();
+}
+
+int lhvi_pbp_describe(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const int32_t* edges, int32_t count,
+                      void* desc_out, void* stream) {
+    if (int rc = validate_pbp(g, s)) return rc;
+    if (!pots || count < 0) return LHVI_E_ARG;
+    if (count == 0) return LHVI_OK;
+    if (!edges || !desc_out) return LHVI_E_ARG;
+    hipLaunchKernelGGL(pbp_describe_kernel, dim3(grid_for(count)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, *s, edges, count,
+                       reinterpret_cast<FastDesc*>(desc_out));
+    return check_launch();
+}
+
+int lhvi_debug_exp(const double* x, double* y, int64_t n, void* stream) {
+    if (!x || !y || n < 0) return LHVI_E_ARG;
+    if (n == 0) return LHVI_OK;
+    hipLaunchKernelGGL(debug_exp_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, as_stream(stream), x, y, n);
     return check_launch();
 }
 
@@ -499,10 +652,15 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     if (int rc = validate_pbp(g, s)) return rc;
     if (!pots || !v2f || !f2v || !s->old_particles) return LHVI_E_ARG;
     if (g->E == 0) return LHVI_OK;
-    if (!(s->flags & LHVI_PBP_SKIP_FAST))
-        hipLaunchKernelGGL(pbp_f2v_fast_kernel, dim3(g->E), dim3(WAVE), 0, as_stream(stream), *g, *pots, *s, v2f, f2v);
-    if (!(s->flags & LHVI_PBP_SKIP_GENERIC))
-        hipLaunchKernelGGL(pbp_f2v_generic_kernel, dim3(g->E), dim3(WAVE), 0, as_stream(stream), *g, *pots, *s, v2f, f2v);
+    // persistent grids sized from the measured residency: CUs x resident workgroups per CU, every wave strides over its list
+    const int nfast = s->fast_edges ? s->n_fast : g->E, ngen = s->generic_edges ? s->n_generic : g->E;
+    static const int cus = device_cus();
+    static const int fast_per_cu = blocks_per_cu((const void*)pbp_f2v_fast_kernel);
+    static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel);
+    if (!(s->flags & LHVI_PBP_SKIP_FAST) && nfast > 0)
+        hipLaunchKernelGGL(pbp_f2v_fast_kernel, dim3(min((nfast + 3) / 4, cus * fast_per_cu)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, *s, v2f, f2v);
+    if (!(s->flags & LHVI_PBP_SKIP_GENERIC) && ngen > 0)
+        hipLaunchKernelGGL(pbp_f2v_generic_kernel, dim3(min((ngen + 3) / 4, cus * gen_per_cu)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, *s, v2f, f2v);
     return check_launch();
 }
 

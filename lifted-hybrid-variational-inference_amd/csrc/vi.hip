@@ -1,0 +1,367 @@
+// vi.hip -- mixture-of-products variational step (VarInference / LiftedVarInference) for gfx950.
+//
+// Reference semantics: VarInference.py:26-195,249-287, LiftedVarInference.py:28-199.
+// One launch of lhvi_vi_grad =
+//   vi_var_kernel      thread per (variable, k): (N-1) E_k[log b_v] terms and their mu / var / category gradients
+//   vi_factor_kernel   thread per (factor, k): tensor-product Gauss-Hermite / categorical expectation of
+//                      F = log(phi + 1e-100) - log(b_f + 1e-100), per-edge gradient partials
+//   vi_gather_kernel   thread per (variable, k): sums its edges' partials in rv.nb order (no atomics -> deterministic),
+//                      softmax-Jacobian projection of the category gradient
+//   vi_weights_kernel  one workgroup: g_w and the free energy from the per-variable / per-factor expectations
+// fp64-VALU bound and tiny after lifting; written for clarity, not tuned.
+#include "common.hpp"
+#include "potential.hpp"
+
+namespace lhvi {
+
+constexpr int VI_MAX_D = 32;   // max states of a discrete variable handled by the pinned expectation
+
+__device__ __forceinline__ bool v_cont(const lhvi_graph_t& g, int v) { return g.dom_cont[g.var_dom[v]] != 0; }
+__device__ __forceinline__ int v_nstates(const lhvi_graph_t& g, int v) { const int d = g.var_dom[v]; return g.dom_ptr[d + 1] - g.dom_ptr[d]; }
+__device__ __forceinline__ const double* v_states(const lhvi_graph_t& g, int v) { return g.dom_val + g.dom_ptr[g.var_dom[v]]; }
+
+__device__ __forceinline__ int vi_state_index(const lhvi_graph_t& g, int v, double x) {
+    if (v_cont(g, v)) return 0;
+    const double* s = v_states(g, v);
+    const int n = v_nstates(g, v);
+    for (int i = 0; i < n; ++i) if (s[i] == x) return i;
+    return (int)x;
+}
+
+// VarInference.norm_pdf (VI:26-30): the normaliser is 2.5066 * var (sic)
+__device__ __forceinline__ double norm_pdf_var(double x, double mu, double var) {
+    const double u = x - mu;
+    return exp(-u * u * 0.5 / var) / (2.506628274631 * var);
+}
+
+// rvs_belief (VI:336-353) over `m` variables
+__device__ double rvs_belief(const lhvi_graph_t& g, const lhvi_vi_t& p, const double* x, const int* idx, const int* vars, int m) {
+    for (int i = 0; i < m; ++i) {
+        const double val = g.var_value[vars[i]];
+        if (!is_hidden(val) && x[i] != val) return 0.0;
+    }
+    double s = 0.0;
+    for (int k = 0; k < p.K; ++k) {
+        double b = p.w[k];
+        for (int i = 0; i < m; ++i) {
+            const int v = vars[i];
+            if (!is_hidden(g.var_value[v])) continue;
+            if (v_cont(g, v)) { const double* e = p.eta_c + ((int64_t)v * p.K + k) * 2; b *= norm_pdf_var(x[i], e[0], e[1]); }
+            else b *= p.eta_d[((int64_t)v * p.K + k) * p.Dmax + idx[i]];
+        }
+        s += b;
+    }
+    return s;
+}
+
+// node t of variable v's axis under component k (the (is_continuous, eta) argument of expectation(), VI:40-55)
+struct Node { double x, w; int idx; };
+__device__ __forceinline__ int axis_len(const lhvi_graph_t& g, const lhvi_vi_t& p, int v) {
+    if (!is_hidden(g.var_value[v])) return 1;
+    return v_cont(g, v) ? p.T : v_nstates(g, v);
+}
+__device__ __forceinline__ Node axis_node(const lhvi_graph_t& g, const lhvi_vi_t& p, int v, int k, int t) {
+    Node nd;
+    const double val = g.var_value[v];
+    if (!is_hidden(val)) { nd.x = val; nd.w = 1.0; nd.idx = vi_state_index(g, v, val); }
+    else if (v_cont(g, v)) {
+        const double* e = p.eta_c + ((int64_t)v * p.K + k) * 2;
+        nd.x = sqrt(2 * e[1]) * p.gh_x[t] + e[0]; nd.w = p.gh_w[t]; nd.idx = 0;
+    } else { nd.x = v_states(g, v)[t]; nd.w = p.eta_d[((int64_t)v * p.K + k) * p.Dmax + t]; nd.idx = t; }
+    return nd;
+}
+
+__device__ double F_of(const lhvi_graph_t& g, const lhvi_pots_t& pots, const lhvi_vi_t& p, int f, const double* x, const int* idx,
+                       const int* vars, int arity) {
+    const int pot = g.fac_pot[f];
+    const double phi = pot_value(pots.kind[pot], pots.param + pots.off[pot], x, idx);
+    return log(phi + 1e-100) - log(rvs_belief(g, p, x, idx, vars, arity) + 1e-100);
+}
+
+// ---- variable terms ----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) vi_var_kernel(lhvi_graph_t g, lhvi_vi_t p, double* __restrict__ rvterm,
+                                                      double* __restrict__ g_c, double* __restrict__ g_d) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= (int64_t)g.V * p.K) return;
+    const int v = (int)(i / p.K), k = (int)(i % p.K);
+    double N = 0.0;
+    for (int j = g.var_ptr[v]; j < g.var_ptr[v + 1]; ++j) N += g.edge_count ? g.edge_count[g.var_edge[j]] : 1.0;
+    const double Mv = g.var_mult ? g.var_mult[v] : 1.0;
+    const bool hid = is_hidden(g.var_value[v]);
+    const bool cont = v_cont(g, v);
+    const int n = axis_len(g, p, v);
+    const double* e = p.eta_c + ((int64_t)v * p.K + k) * 2;
+    double E = 0.0, Em = 0.0, Ev = 0.0;
+    for (int t = 0; t < n; ++t) {
+        const Node nd = axis_node(g, p, v, k, t);
+        const double R = (N - 1) * log(rvs_belief(g, p, &nd.x, &nd.idx, &v, 1) + 1e-100);
+        E += nd.w * R;
+        if (hid && cont) {
+            Em += nd.w * (R * (nd.x - e[0]));
+            Ev += nd.w * (R * ((nd.x - e[0]) * (nd.x - e[0]) - e[1]));
+        }
+        if (hid && !cont) g_d[((int64_t)v * p.K + k) * p.Dmax + t] = -R;     // no weight: one entry per state (VI:139-141)
+    }
+    rvterm[i] = Mv * E;
+    g_c[i * 2] = (hid && cont) ? -Em / e[1] : 0.0;
+    g_c[i * 2 + 1] = (hid && cont) ? -Ev / (2 * e[1] * e[1]) : 0.0;
+    if (!(hid && !cont)) for (int d = 0; d < p.Dmax; ++d) g_d[((int64_t)v * p.K + k) * p.Dmax + d] = 0.0;
+    else for (int d = n; d < p.Dmax; ++d) g_d[((int64_t)v * p.K + k) * p.Dmax + d] = 0.0;
+}
+
+// expectation over the other slots with slot `pos` pinned to state d (gradient_category_tau, VI:133-160)
+__device__ double pinned_expectation(const lhvi_graph_t& g, const lhvi_pots_t& pots, const lhvi_vi_t& p, int f, int base,
+                                     int arity, const int* vars, int pos, int d, int k) {
+    const int tv = vars[pos];
+    const int Dt = v_nstates(g, tv);
+    const double* tvals = v_states(g, tv);
+    double x[LHVI_MAX_ARITY];
+    int idx[LHVI_MAX_ARITY], nx[LHVI_MAX_ARITY], nw[LHVI_MAX_ARITY];
+    int64_t totx = 1, totw = 1;
+#pragma unroll
+    for (int a = 0; a < LHVI_MAX_ARITY; ++a) {
+        x[a] = 0.0; idx[a] = 0; nx[a] = 1; nw[a] = 1;
+        if (a < arity && a != pos) {
+            const int v = vars[a];
+            if (is_hidden(g.var_value[v])) {
+                if (p.quirks) { nx[a] = Dt; nw[a] = v_cont(g, v) ? 2 : v_nstates(g, v); }   // VI:147-150
+                else { nx[a] = axis_len(g, p, v); nw[a] = nx[a]; }
+            }
+            totx *= nx[a]; totw *= nw[a];
+        }
+    }
+    const int64_t cnt = totx < totw ? totx : totw;     // zip(product(xs), product(ws)) truncates to the shorter
+    double E = 0.0;
+    for (int64_t i = 0; i < cnt; ++i) {
+        int64_t rx = i, rw = i;
+        double w = 1.0;
+#pragma unroll
+        for (int a = LHVI_MAX_ARITY - 1; a >= 0; --a) {
+            if (a < arity && a != pos) {
+                const int v = vars[a];
+                const int ixs = (int)(rx % nx[a]); rx /= nx[a];
+                const int iws = (int)(rw % nw[a]); rw /= nw[a];
+                const double val = g.var_value[v];
+                if (!is_hidden(val)) { x[a] = val; idx[a] = vi_state_index(g, v, val); }
+                else if (p.quirks) {
+                    x[a] = tvals[ixs]; idx[a] = vi_state_index(g, v, x[a]);
+                    w *= v_cont(g, v) ? p.eta_c[((int64_t)v * p.K + k) * 2 + iws] : p.eta_d[((int64_t)v * p.K + k) * p.Dmax + iws];
+                } else {
+                    const Node nd = axis_node(g, p, v, k, ixs);
+                    x[a] = nd.x; idx[a] = nd.idx; w *= nd.w;
+                }
+            }
+        }
+        x[pos] = tvals[d]; idx[pos] = d;
+        E += w * F_of(g, pots, p, f, x, idx, vars, arity);
+    }
+    return E;
+}
+
+// ---- factor terms ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) vi_factor_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
+                                                         double* __restrict__ pe_c, double* __restrict__ pe_d) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= (int64_t)g.F * p.K) return;
+    const int f = (int)(i / p.K), k = (int)(i % p.K);
+    const int base = g.fac_ptr[f], arity = g.fac_ptr[f + 1] - base;
+    int vars[LHVI_MAX_ARITY], len[LHVI_MAX_ARITY], it[LHVI_MAX_ARITY], idx[LHVI_MAX_ARITY];
+    double x[LHVI_MAX_ARITY], wt[LHVI_MAX_ARITY], Em[LHVI_MAX_ARITY], Ev[LHVI_MAX_ARITY];
+#pragma unroll
+    for (int a = 0; a < LHVI_MAX_ARITY; ++a) {
+        vars[a] = a < arity ? g.edge_var[base + a] : 0;
+        len[a] = a < arity ? axis_len(g, p, vars[a]) : 1;
+        it[a] = 0; idx[a] = 0; x[a] = 0.0; wt[a] = 1.0; Em[a] = 0.0; Ev[a] = 0.0;
+    }
+    double E = 0.0;
+    for (;;) {
+        double w = 1.0;
+#pragma unroll
+        for (int a = 0; a < LHVI_MAX_ARITY; ++a) {
+            if (a < arity) { const Node nd = axis_node(g, p, vars[a], k, it[a]); x[a] = nd.x; idx[a] = nd.idx; wt[a] = nd.w; w *= nd.w; }
+        }
+        const double F = F_of(g, pots, p, f, x, idx, vars, arity);
+        E += w * F;
+#pragma unroll
+        for (int a = 0; a < LHVI_MAX_ARITY; ++a) {
+            if (a < arity && is_hidden(g.var_value[vars[a]]) && v_cont(g, vars[a])) {
+                const double* e = p.eta_c + ((int64_t)vars[a] * p.K + k) * 2;
+                Em[a] += w * (F * (x[a] - e[0]));
+                Ev[a] += w * (F * ((x[a] - e[0]) * (x[a] - e[0]) - e[1]));
+            }
+        }
+        int a = arity - 1;
+        for (; a >= 0; --a) {
+            bool carry = true;
+#pragma unroll
+            for (int b = 0; b < LHVI_MAX_ARITY; ++b) if (b == a) { if (++it[b] < len[b]) carry = false; else it[b] = 0; }
+            if (!carry) break;
+        }
+        if (a < 0) break;
+    }
+    ef[i] = (g.fac_mult ? g.fac_mult[f] : 1.0) * E;
+    // per-edge partials; only the first position of a variable in the scope contributes (f.nb.index(rv), LVI:112,146)
+#pragma unroll
+    for (int a = 0; a < LHVI_MAX_ARITY; ++a) {
+        if (a >= arity) continue;
+        const int e = base + a, v = vars[a];
+        double c0 = 0.0, c1 = 0.0;
+        bool first = true;
+#pragma unroll
+        for (int b = 0; b < LHVI_MAX_ARITY; ++b) if (b < a && vars[b] == v) first = false;
+        const bool hid = is_hidden(g.var_value[v]);
+        const double c = g.edge_count ? g.edge_count[e] : 1.0;
+        if (hid && first && v_cont(g, v)) {
+            const double* et = p.eta_c + ((int64_t)v * p.K + k) * 2;
+            c0 = c * Em[a] / et[1];
+            c1 = c * Ev[a] / (2 * et[1] * et[1]);
+        }
+        pe_c[((int64_t)e * p.K + k) * 2] = c0;
+        pe_c[((int64_t)e * p.K + k) * 2 + 1] = c1;
+        for (int d = 0; d < p.Dmax; ++d) {
+            double val = 0.0;
+            if (hid && first && !v_cont(g, v) && d < v_nstates(g, v)) val = c * pinned_expectation(g, pots, p, f, base, arity, vars, a, d, k);
+            pe_d[((int64_t)e * p.K + k) * p.Dmax + d] = val;
+        }
+    }
+}
+
+// ---- gather per variable + projection ----------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) vi_gather_kernel(lhvi_graph_t g, lhvi_vi_t p, const double* __restrict__ pe_c,
+                                                         const double* __restrict__ pe_d, double* __restrict__ g_c,
+                                                         double* __restrict__ g_d) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= (int64_t)g.V * p.K) return;
+    const int v = (int)(i / p.K), k = (int)(i % p.K);
+    if (!is_hidden(g.var_value[v])) return;
+    if (v_cont(g, v)) {
+        double a = g_c[i * 2], b = g_c[i * 2 + 1];
+        for (int j = g.var_ptr[v]; j < g.var_ptr[v + 1]; ++j) {
+            const int e = g.var_edge[j];
+            a -= pe_c[((int64_t)e * p.K + k) * 2];
+            b -= pe_c[((int64_t)e * p.K + k) * 2 + 1];
+        }
+        g_c[i * 2] = a; g_c[i * 2 + 1] = b;
+    } else {
+        const int D = v_nstates(g, v);
+        double* row = g_d + i * p.Dmax;
+        const double* eta = p.eta_d + i * p.Dmax;
+        double s = 0.0;
+        for (int d = 0; d < D; ++d) {
+            double acc = row[d];
+            for (int j = g.var_ptr[v]; j < g.var_ptr[v + 1]; ++j) acc -= pe_d[((int64_t)g.var_edge[j] * p.K + k) * p.Dmax + d];
+            row[d] = acc;
+            s += acc * eta[d];
+        }
+        for (int d = 0; d < D; ++d) row[d] = eta[d] * (row[d] - s);      // eta * (g - sum(g * eta)) (VI:160)
+    }
+}
+
+// ---- mixture-weight gradient and free energy (one workgroup; fixed summation order) -------------------------
+__global__ void __launch_bounds__(BLOCK) vi_weights_kernel(int64_t nv, int64_t nf, lhvi_vi_t p, const double* __restrict__ rvterm,
+                                                          const double* __restrict__ ef, double* __restrict__ g_w,
+                                                          double* __restrict__ fe) {
+    __shared__ double red[BLOCK];
+    __shared__ double gw[64];
+    for (int k = 0; k < p.K; ++k) {
+        double acc = 0.0;
+        for (int64_t i = threadIdx.x; i < nv; i += BLOCK) acc += rvterm[i * p.K + k];
+        for (int64_t i = threadIdx.x; i < nf; i += BLOCK) acc += ef[i * p.K + k];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = BLOCK / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) gw[k] = -red[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double dot = 0.0;
+        for (int k = 0; k < p.K; ++k) dot += gw[k] * p.w[k];
+        for (int k = 0; k < p.K; ++k) g_w[k] = p.w[k] * (gw[k] - dot);     // w * (g - sum(g * w)) (VI:90)
+        fe[0] = dot;                                                         // free energy = sum_k w_k gw_k (VI:162-195)
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) adam_kernel(double* __restrict__ theta, double* __restrict__ m, double* __restrict__ s,
+                                                    const double* __restrict__ grad, int64_t count, double c1, double c2, double lr,
+                                                    double b1, double b2, double eps, int clip_stride, double clip_min) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const double gr = grad[i];
+    const double mi = m[i] * b1 + (1 - b1) * gr;
+    const double si = s[i] * b2 + (1 - b2) * gr * gr;
+    m[i] = mi; s[i] = si;
+    double th = theta[i] - (lr * (mi / c1)) / (sqrt(si / c2) + eps);
+    if (clip_stride > 0 && (i % clip_stride) == clip_stride - 1 && th < clip_min) th = clip_min;
+    theta[i] = th;
+}
+
+__global__ void __launch_bounds__(BLOCK) softmax_rows_kernel(const double* __restrict__ tau, double* __restrict__ out, int64_t rows,
+                                                            int cols, int stride) {
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= rows) return;
+    double z = 0.0;
+    for (int c = 0; c < cols; ++c) z += exp(tau[r * stride + c]);       // e ** x / sum (VI:32-38): no max shift
+    for (int c = 0; c < cols; ++c) out[r * stride + c] = exp(tau[r * stride + c]) / z;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace lhvi
+
+using namespace lhvi;
+
+extern "C" {
+
+size_t lhvi_vi_workspace_bytes(const lhvi_graph_t* g, const lhvi_vi_t* p) {
+    if (!g || !p) return 0;
+    const size_t K = (size_t)p->K, D = (size_t)p->Dmax;
+    return align256((size_t)g->V * K * 8) + align256((size_t)g->F * K * 8) + align256((size_t)g->E * K * 16) +
+           align256((size_t)g->E * K * D * 8) + 256;
+}
+
+int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t* p, double* g_w, double* g_c, double* g_d,
+                 double* fe, void* ws, size_t ws_bytes, void* stream) {
+    if (!g || !pots || !p || !g_w || !g_c || !g_d || !fe || !ws) return LHVI_E_ARG;
+    if (p->K <= 0 || p->K > 64 || p->T <= 0 || p->Dmax <= 0 || p->Dmax > VI_MAX_D) return LHVI_E_UNSUPPORTED;
+    if (ws_bytes < lhvi_vi_workspace_bytes(g, p)) return LHVI_E_ARG;
+    if (!p->gh_x || !p->gh_w || !p->w || !p->eta_c || !p->eta_d) return LHVI_E_ARG;
+    hipStream_t st = as_stream(stream);
+    char* base = (char*)ws;
+    const size_t K = (size_t)p->K;
+    double* rvterm = (double*)base; base += align256((size_t)g->V * K * 8);
+    double* ef = (double*)base; base += align256((size_t)g->F * K * 8);
+    double* pe_c = (double*)base; base += align256((size_t)g->E * K * 16);
+    double* pe_d = (double*)base;
+    if (g->V > 0)
+        hipLaunchKernelGGL(vi_var_kernel, dim3(grid_for((int64_t)g->V * p->K)), dim3(BLOCK), 0, st, *g, *p, rvterm, g_c, g_d);
+    if (g->F > 0)
+        hipLaunchKernelGGL(vi_factor_kernel, dim3(grid_for((int64_t)g->F * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d);
+    if (g->V > 0)
+        hipLaunchKernelGGL(vi_gather_kernel, dim3(grid_for((int64_t)g->V * p->K)), dim3(BLOCK), 0, st, *g, *p, pe_c, pe_d, g_c, g_d);
+    hipLaunchKernelGGL(vi_weights_kernel, dim3(1), dim3(BLOCK), 0, st, (int64_t)g->V, (int64_t)g->F, *p, rvterm, ef, g_w, fe);
+    return check_launch();
+}
+
+int lhvi_adam_step(double* theta, double* m, double* s, const double* grad, int64_t count, int32_t t, double lr, double b1,
+                   double b2, double eps, int32_t clip_stride, double clip_min, void* stream) {
+    if (count < 0 || t < 1) return LHVI_E_ARG;
+    if (count == 0) return LHVI_OK;
+    if (!theta || !m || !s || !grad) return LHVI_E_ARG;
+    const double c1 = 1 - pow(b1, (double)t), c2 = 1 - pow(b2, (double)t);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count)), dim3(BLOCK), 0, as_stream(stream), theta, m, s, grad, count, c1, c2, lr,
+                       b1, b2, eps, clip_stride, clip_min);
+    return check_launch();
+}
+
+int lhvi_softmax_rows(const double* tau, double* out, int64_t rows, int32_t cols, int32_t stride, void* stream) {
+    if (rows < 0 || cols <= 0 || stride < cols) return LHVI_E_ARG;
+    if (rows == 0) return LHVI_OK;
+    if (!tau || !out) return LHVI_E_ARG;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(grid_for(rows)), dim3(BLOCK), 0, as_stream(stream), tau, out, rows, cols, stride);
+    return check_launch();
+}
+
+}  // extern "C"

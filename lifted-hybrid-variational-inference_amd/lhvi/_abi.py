@@ -44,6 +44,8 @@ class PbpStruct(C.Structure):
         ('var_threshold', C.c_double), ('max_log_value', C.c_double),
         ('particles', C.c_void_p), ('old_particles', C.c_void_p), ('np', C.c_void_p), ('uniq', C.c_void_p),
         ('q', C.c_void_p),
+        ('fast_edges', C.c_void_p), ('n_fast', C.c_int32), ('generic_edges', C.c_void_p), ('n_generic', C.c_int32),
+        ('fast_desc', C.c_void_p),
     ]
 
 
@@ -58,6 +60,7 @@ PBP_EP = 1
 PBP_EPBP_DISCRETE = 2
 PBP_SKIP_FAST = 4
 PBP_SKIP_GENERIC = 8
+PBP_DESC_BYTES = 64
 
 _G, _P, _S, _VI = C.POINTER(GraphStruct), C.POINTER(PotsStruct), C.POINTER(PbpStruct), C.POINTER(ViStruct)
 _vp, _i32, _i64, _u32, _u64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double, C.c_size_t
@@ -74,6 +77,9 @@ SIGNATURES = {
     'lhvi_gabp_run': (C.c_int, [_G, _P, _vp, _vp, C.c_int, _vp]),
     'lhvi_gabp_marginals': (C.c_int, [_G, _vp, _vp, _vp]),
     'lhvi_pbp_uniq': (C.c_int, [_G, _i32, _vp, _vp, _vp, _vp]),
+    'lhvi_pbp_classify': (C.c_int, [_G, _P, _vp, _vp]),
+    'lhvi_pbp_describe': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _vp]),
+    'lhvi_debug_exp': (C.c_int, [_vp, _vp, _i64, _vp]),
     'lhvi_pbp_v2f': (C.c_int, [_G, _S, _vp, _vp, _vp]),
     'lhvi_pbp_f2v': (C.c_int, [_G, _P, _S, _vp, _vp, _vp]),
     'lhvi_pbp_proposal': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp]),

@@ -58,6 +58,19 @@ class _ParticleSweep:
                      (_abi.PBP_EPBP_DISCRETE if self._epbp_discrete else 0)
         self._views = {}
         self._draws = 0
+        # static work lists of the f -> v half sweep (which kernel serves which edge)
+        cls = torch.zeros(max(flat.E, 1), dtype=torch.uint8, device=dg.device)
+        _abi.check(_abi.lib().lhvi_pbp_classify(dg.g, dg.p, _abi.ptr(cls), _abi.stream_ptr()))
+        cls = cls[:flat.E]
+        self.fast_edges = torch.nonzero((cls == 1) | (cls == 2)).flatten().to(torch.int32)
+        self.generic_edges = torch.nonzero(cls == 3).flatten().to(torch.int32)
+        self.fast_desc = None
+        nf = int(self.fast_edges.numel())
+        if nf:
+            desc = torch.empty(nf * _abi.PBP_DESC_BYTES, dtype=torch.uint8, device=dg.device)
+            _abi.check(_abi.lib().lhvi_pbp_describe(dg.g, dg.p, self._struct(), _abi.ptr(self.fast_edges), nf,
+                                                    _abi.ptr(desc), _abi.stream_ptr()))
+            self.fast_desc = desc
 
     def _struct(self):
         s = _abi.PbpStruct()
@@ -65,6 +78,9 @@ class _ParticleSweep:
         s.var_threshold, s.max_log_value = float(self.var_threshold), float(self.max_log_value)
         s.particles, s.old_particles = _abi.ptr(self.particles), _abi.ptr(self.old_particles)
         s.np, s.uniq, s.q = _abi.ptr(self.np_dev), _abi.ptr(self.uniq), _abi.ptr(self.q_dev)
+        s.fast_edges, s.n_fast = _abi.ptr(self.fast_edges), int(self.fast_edges.numel())
+        s.generic_edges, s.n_generic = _abi.ptr(self.generic_edges), int(self.generic_edges.numel())
+        s.fast_desc = _abi.ptr(getattr(self, 'fast_desc', None))
         return s
 
     # ---- sampling ----------------------------------------------------------------------------

@@ -1,0 +1,339 @@
+"""Mixture-of-products variational inference on the GPU: ``VarInference`` and ``LiftedVarInference``.
+
+Same surface as the reference (``VarInference.py:10-456``, ``LiftedVarInference.py:11-380``):
+``VarInference(g, num_mixtures, num_quadrature_points).run(iteration, lr, is_log, log_fe)``, ``.free_energy()``,
+``.belief(x, rv)``, ``.map(rv)``, ``.rvs_map(rvs)``, ``.GD_update(iteration, lr)``, attributes ``.w .eta .time_log``.
+The expectation step (``gradient_w_tau`` / ``gradient_mu_var`` / ``gradient_category_tau`` / ``free_energy``) and the
+ADAM update run as HIP kernels (``csrc/vi.hip``) on flat parameter arrays resident in HBM:
+``w_tau [K]``, ``eta_c [V, K, 2]`` (mu, var), ``eta_tau [V, K, Dmax]``.
+
+``reference_quirks=True`` (default) reproduces ``VarInference.py:147-150`` so that results match
+the reference; ``False`` integrates the neighbours of a discrete variable with their own quadrature rules.
+
+Initial parameters follow the reference's NumPy stream (``init_param``, ``VI:197-213``: ``np.random.rand`` while
+iterating ``g.rvs``), so a seeded run on an ordered graph starts from the reference's parameters.
+"""
+from __future__ import annotations
+
+import time
+from math import sqrt, pi
+
+import numpy as np
+from numpy.polynomial.hermite import hermgauss
+
+from . import _abi
+from .flat import flatten
+
+
+class _Variational:
+    var_threshold = 0.1
+    reference_quirks = True
+    verbose = False
+
+    def _init_common(self, num_mixtures, num_quadrature_points):
+        self.K = num_mixtures
+        self.T = num_quadrature_points
+        self.quad_x, self.quad_w = hermgauss(self.T)
+        self.quad_w = self.quad_w / sqrt(pi)
+        self.time_log = []
+        self._dev = None
+        self._cache = {}
+
+    # ---- device state -------------------------------------------------------------------------
+    def _setup(self, graph_like):
+        flat = flatten(graph_like, require_device_potentials=True)
+        self.flat, self.dg = flat, _abi.DeviceGraph(flat)
+        torch = _abi.require_gpu()
+        disc = flat.var_hidden & ~flat.var_cont
+        self._cont, self._disc = flat.var_hidden & flat.var_cont, disc
+        self.Dmax = int(flat.var_nstates[disc].max()) if disc.any() else 1
+        dg, K = self.dg, self.K
+        d = dict(gh_x=_abi.to_dev(self.quad_x), gh_w=_abi.to_dev(self.quad_w),
+                 w_tau=dg.zeros(K), w=dg.zeros(K), eta_c=dg.zeros(flat.V, K, 2), tau_d=dg.zeros(flat.V, K, self.Dmax),
+                 eta_d=dg.zeros(flat.V, K, self.Dmax), g_w=dg.zeros(K), g_c=dg.zeros(flat.V, K, 2),
+                 g_d=dg.zeros(flat.V, K, self.Dmax), fe=dg.zeros(1))
+        for name in ('w_tau', 'eta_c', 'tau_d'):
+            d['m_' + name] = torch.zeros_like(d[name])
+            d['s_' + name] = torch.zeros_like(d[name])
+        self._dev = d
+        ws_bytes = int(_abi.lib().lhvi_vi_workspace_bytes(dg.g, self._struct()))
+        d['ws'] = torch.empty(ws_bytes, dtype=torch.uint8, device=dg.device)
+        d['ws_bytes'] = ws_bytes
+        # masks so that rows of observed / other-type variables never move
+        d['mask_c'] = _abi.to_dev(np.repeat(self._cont[:, None, None], K, 1).repeat(2, 2).astype(np.float64))
+        nst = np.where(disc, flat.var_nstates, 0)
+        md = (np.arange(self.Dmax)[None, :] < nst[:, None]).astype(np.float64)
+        d['mask_d'] = _abi.to_dev(np.repeat(md[:, None, :], K, 1))
+
+    def _struct(self):
+        d = self._dev
+        p = _abi.ViStruct()
+        p.K, p.T, p.Dmax, p.quirks = self.K, self.T, self.Dmax, 1 if self.reference_quirks else 0
+        p.gh_x, p.gh_w, p.w = _abi.ptr(d['gh_x']), _abi.ptr(d['gh_w']), _abi.ptr(d['w'])
+        p.eta_c, p.eta_d = _abi.ptr(d['eta_c']), _abi.ptr(d['eta_d'])
+        return p
+
+    def _refresh(self):
+        """w = softmax(w_tau); eta[drv] = softmax(eta_tau[drv], 1) (VI:211-213)"""
+        d, l, st = self._dev, _abi.lib(), _abi.stream_ptr()
+        _abi.check(l.lhvi_softmax_rows(_abi.ptr(d['w_tau']), _abi.ptr(d['w']), 1, self.K, self.K, st))
+        flat = self.flat
+        # rows have different lengths (per-variable #states): one launch per distinct #states
+        nst = np.where(self._disc, flat.var_nstates, 0)
+        if self._disc.any():
+            if len(set(nst[self._disc].tolist())) == 1:
+                D = int(nst[self._disc][0])
+                _abi.check(l.lhvi_softmax_rows(_abi.ptr(d['tau_d']), _abi.ptr(d['eta_d']), flat.V * self.K, D, self.Dmax, st))
+            else:
+                torch = _abi.require_gpu()
+                e = torch.exp(d['tau_d']) * d['mask_d']
+                d['eta_d'].copy_(e / e.sum(dim=2, keepdim=True).clamp_min(1e-300))
+            d['eta_d'].mul_(d['mask_d'])
+        self._cache = {}
+
+    def _upload_params(self, w_tau, eta_c, tau_d):
+        d = self._dev
+        d['w_tau'].copy_(_abi.to_dev(np.asarray(w_tau, dtype=np.float64)))
+        d['eta_c'].copy_(_abi.to_dev(np.nan_to_num(np.asarray(eta_c, dtype=np.float64), nan=1.0)))
+        td = np.zeros((self.flat.V, self.K, self.Dmax))
+        src = np.nan_to_num(np.asarray(tau_d, dtype=np.float64), nan=0.0)
+        td[:, :, :min(self.Dmax, src.shape[2])] = src[:, :, :self.Dmax]
+        d['tau_d'].copy_(_abi.to_dev(td))
+        self._refresh()
+
+    def init_param(self):
+        """VI:197-213 -- same RNG stream as the reference (np.random.rand in g.rvs order)"""
+        if self._dev is None:
+            self._setup(self._graph_like())
+        flat, K = self.flat, self.K
+        eta_c = np.ones((flat.V, K, 2))
+        tau_d = np.zeros((flat.V, K, self.Dmax))
+        for v in range(flat.V):
+            if not flat.var_hidden[v]:
+                continue
+            if flat.var_cont[v]:
+                eta_c[v, :, 0] = np.random.rand(K) * 3 - 1.5
+            else:
+                D = int(flat.var_nstates[v])
+                tau_d[v, :, :D] = np.random.rand(K, D) * 10
+        self._upload_params(np.zeros(K), eta_c, tau_d)
+
+    # ---- gradient / free energy -------------------------------------------------------------------
+    def _grad(self):
+        d = self._dev
+        _abi.check(_abi.lib().lhvi_vi_grad(self.dg.g, self.dg.p, self._struct(), _abi.ptr(d['g_w']), _abi.ptr(d['g_c']),
+                                           _abi.ptr(d['g_d']), _abi.ptr(d['fe']), _abi.ptr(d['ws']), d['ws_bytes'],
+                                           _abi.stream_ptr()))
+
+    def free_energy(self):
+        self._grad()
+        return float(self._dev['fe'].item())
+
+    def gradient_w_tau(self):
+        self._grad()
+        return self._dev['g_w'].cpu().numpy()
+
+    def gradient_mu_var(self, rv):
+        self._grad()
+        return self._dev['g_c'][self._var_index(rv)].cpu().numpy()
+
+    def gradient_category_tau(self, rv):
+        self._grad()
+        v = self._var_index(rv)
+        return self._dev['g_d'][v, :, :int(self.flat.var_nstates[v])].cpu().numpy()
+
+    # ---- optimisation -----------------------------------------------------------------------------
+    def run(self, iteration=100, lr=0.1, is_log=True, log_fe=True):
+        self.is_log, self.log_fe = is_log, log_fe
+        self.init_param()
+        self.alpha, self.b1, self.b2, self.eps = lr, 0.9, 0.999, 1e-8
+        d = self._dev
+        for name in ('w_tau', 'eta_c', 'tau_d'):
+            d['m_' + name].zero_()
+            d['s_' + name].zero_()
+        self.t = 0
+        if is_log:
+            self.time_log, self.total_time = [], 0
+        self.ADAM_update(iteration)
+
+    def ADAM_update(self, iteration):
+        """VI:249-300: all gradients from the pre-update parameters, then one ADAM step per array"""
+        d, l = self._dev, _abi.lib()
+        for _ in range(iteration):
+            start = time.process_time()
+            self.t += 1
+            self._grad()
+            st = _abi.stream_ptr()
+            d['g_c'].mul_(d['mask_c'])
+            d['g_d'].mul_(d['mask_d'])
+            for name, grad, stride in (('w_tau', 'g_w', 0), ('eta_c', 'g_c', 2), ('tau_d', 'g_d', 0)):
+                _abi.check(l.lhvi_adam_step(_abi.ptr(d[name]), _abi.ptr(d['m_' + name]), _abi.ptr(d['s_' + name]),
+                                            _abi.ptr(d[grad]), d[name].numel(), self.t, float(self.alpha), self.b1, self.b2,
+                                            self.eps, stride, float(self.var_threshold), st))
+            self._refresh()
+            if self.is_log:
+                self.total_time += time.process_time() - start
+                if self.log_fe:
+                    fe = self.free_energy()
+                else:
+                    from .utils import log_likelihood
+                    fe = log_likelihood(self._ground_graph(), {rv: self.map(rv) for rv in self._ground_graph().rvs})
+                if self.verbose:
+                    print(fe, self.total_time)
+                self.time_log.append([self.total_time, fe])
+
+    def GD_update(self, iteration, lr):
+        """VI:302-331: plain gradient descent on the same gradients"""
+        d = self._dev
+        for _ in range(iteration):
+            self._grad()
+            d['w_tau'].sub_(d['g_w'] * lr)
+            d['eta_c'].sub_(d['g_c'] * d['mask_c'] * lr)
+            d['eta_c'][:, :, 1].clamp_(min=self.var_threshold)
+            d['tau_d'].sub_(d['g_d'] * d['mask_d'] * lr)
+            self._refresh()
+
+    # ---- reference-style views --------------------------------------------------------------------
+    def _host(self, name):
+        if name not in self._cache:
+            self._cache[name] = self._dev[name].cpu().numpy()
+        return self._cache[name]
+
+    @property
+    def eta(self):
+        flat = self.flat
+        out = {}
+        for v, rv in enumerate(flat.rvs):
+            if self._cont[v]:
+                out[rv] = self._host('eta_c')[v]
+            elif self._disc[v]:
+                out[rv] = self._host('eta_d')[v, :, :int(flat.var_nstates[v])]
+        return out
+
+    def _w_host(self):
+        return self._host('w')
+
+    @property
+    def w(self):
+        return self._host('w') if self._dev is not None else np.zeros(self.K)
+
+    @property
+    def w_tau(self):
+        return self._host('w_tau') if self._dev is not None else np.zeros(self.K)
+
+    @staticmethod
+    def norm_pdf(x, eta):
+        u = x - eta[0]
+        return np.e ** (-u * u * 0.5 / eta[1]) / (2.506628274631 * eta[1])
+
+    def rvs_belief(self, x, rvs):
+        """VI:336-353 on the host (a K-term sum; the heavy expectation lives on the device)"""
+        b = np.copy(self._w_host())
+        for i, rv in enumerate(rvs):
+            if rv.value is not None:
+                if x[i] != rv.value:
+                    return 0
+                continue
+            v = self._var_index(rv)
+            if rv.domain.continuous:
+                eta = self._host('eta_c')[v]
+                for k in range(self.K):
+                    b[k] *= self.norm_pdf(x[i], eta[k])
+            else:
+                d = rv.domain.values.index(x[i])
+                b *= self._host('eta_d')[v, :, d]
+        return np.sum(b)
+
+    def belief(self, x, rv):
+        return self.rvs_belief((x,), (rv,))
+
+    def map(self, rv):
+        """VI:355-376"""
+        if rv.value is not None:
+            return rv.value
+        if rv.domain.continuous:
+            from scipy.optimize import minimize
+            mus = self._host('eta_c')[self._var_index(rv)][:, 0]
+            p = {x: self.belief(x, rv) for x in mus}
+            x0 = max(p.keys(), key=lambda k: p[k])
+            return minimize(lambda val: -self.belief(val, rv), x0=np.array([x0]), options={'disp': False})['x'][0]
+        p = {x: self.belief(x, rv) for x in rv.domain.values}
+        return max(p.keys(), key=lambda k: p[k])
+
+    def rvs_map(self, rvs):
+        """VI:378-456: coordinate ascent on the joint mixture belief"""
+        from scipy.optimize import minimize
+        res = {}
+        for rv in rvs:
+            if rv.value is not None:
+                res[rv] = rv.value
+                continue
+            cand = self._host('eta_c')[self._var_index(rv)][:, 0] if rv.domain.continuous else rv.domain.values
+            b = {v: self.belief(v, rv) for v in cand}
+            res[rv] = max(b.keys(), key=lambda x: b[x])
+        K = self.K
+
+        def comp(rv, x):
+            v = self._var_index(rv)
+            if rv.domain.continuous:
+                eta = self._host('eta_c')[v]
+                return np.array([self.norm_pdf(x, eta[k]) for k in range(K)])
+            return self._host('eta_d')[v, :, rv.domain.values.index(x)].copy()
+
+        b = np.copy(self._w_host())
+        for rv in rvs:
+            if rv.value is None:
+                b *= comp(rv, res[rv])
+        for _ in range(10):
+            for rv in rvs:
+                if rv.value is not None:
+                    continue
+                b /= comp(rv, res[rv])
+                if rv.domain.continuous:
+                    new_x = minimize(lambda x: -float(np.sum(b * comp(rv, x))), x0=np.array([res[rv]]),
+                                     options={'disp': False})['x']
+                    res[rv] = new_x
+                else:
+                    scores = {x: float(np.sum(b * comp(rv, x))) for x in rv.domain.values}
+                    res[rv] = max(scores.keys(), key=lambda x: scores[x])
+                b *= comp(rv, res[rv])
+        return res
+
+
+class VarInference(_Variational):
+    """Ground solver (``VarInference.py``)."""
+
+    def __init__(self, g, num_mixtures=5, num_quadrature_points=3):
+        self.g = g
+        self._init_common(num_mixtures, num_quadrature_points)
+
+    def _graph_like(self):
+        return self.g
+
+    def _ground_graph(self):
+        return self.g
+
+    def _var_index(self, rv):
+        return self.flat.var_index[rv]
+
+
+class LiftedVarInference(_Variational):
+    """Lifted solver (``LiftedVarInference.py``): colour passing once, then the same step with cluster multiplicities.
+    Queries take ground rvs and go through ``rv.cluster`` like the reference."""
+
+    def __init__(self, g, num_mixtures=5, num_quadrature_points=3):
+        from .lifting import CompressedGraph
+        self._ground = g
+        self.g = CompressedGraph(g)
+        self.g.run()
+        self._init_common(num_mixtures, num_quadrature_points)
+
+    def _graph_like(self):
+        return self.g
+
+    def _ground_graph(self):
+        return self._ground
+
+    def _var_index(self, rv):
+        c = getattr(rv, 'cluster', None)
+        return self.flat.var_index[c if c in self.flat.var_index else rv]

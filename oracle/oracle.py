@@ -238,3 +238,86 @@ class PbpOracle:
                 self.step_f2v()
             elif on_iteration:
                 on_iteration(i, self)
+
+
+# ---- mixture variational inference ----------------------------------------------------------------
+class OVi(C.Structure):
+    _fields_ = [('K', C.c_int32), ('T', C.c_int32), ('Dmax', C.c_int32), ('quirks', C.c_int32),
+                ('gh_x', C.c_void_p), ('gh_w', C.c_void_p), ('w', C.c_void_p), ('eta_c', C.c_void_p),
+                ('eta_d', C.c_void_p)]
+
+
+def softmax_rows(x):
+    """VarInference.softmax(x, 1) (VI:32-38): e ** x / sum"""
+    r = np.e ** x
+    return r / np.sum(r, 1)[:, np.newaxis]
+
+
+class ViOracle:
+    """Flat-array twin of VarInference / LiftedVarInference (parameters for every variable, unused rows ignored)."""
+
+    def __init__(self, flat, K, T, quirks=1):
+        from numpy.polynomial.hermite import hermgauss
+        self.flat, self.hg, self.K, self.T, self.quirks = flat, HostGraph(flat), K, T, quirks
+        self.gh_x, self.gh_w = hermgauss(T)
+        self.gh_w = self.gh_w / np.sqrt(np.pi)
+        disc = flat.var_hidden & ~flat.var_cont
+        self.Dmax = int(flat.var_nstates[disc].max()) if disc.any() else 1
+        self.cont = flat.var_hidden & flat.var_cont
+        self.disc = disc
+        self.nst = np.where(disc, flat.var_nstates, 0)
+        self.w_tau = np.zeros(K)
+        self.eta_c = np.zeros((flat.V, K, 2))
+        self.tau_d = np.zeros((flat.V, K, self.Dmax))
+        self.refresh()
+
+    def set_params(self, w_tau, eta_c, tau_d):
+        self.w_tau = np.array(w_tau, dtype=float)
+        self.eta_c = np.ascontiguousarray(np.nan_to_num(np.array(eta_c, dtype=float), nan=1.0))
+        td = np.zeros((self.flat.V, self.K, self.Dmax))
+        src = np.nan_to_num(np.array(tau_d, dtype=float), nan=0.0)
+        td[:, :, :min(self.Dmax, src.shape[2])] = src[:, :, :self.Dmax]
+        self.tau_d = td
+        self.refresh()
+
+    def refresh(self):
+        r = np.e ** self.w_tau
+        self.w = r / np.sum(r, 0)
+        self.eta_d = np.zeros_like(self.tau_d)
+        for v in np.flatnonzero(self.disc):
+            d = self.nst[v]
+            self.eta_d[v, :, :d] = softmax_rows(self.tau_d[v, :, :d])
+
+    def grad(self):
+        p = OVi()
+        p.K, p.T, p.Dmax, p.quirks = self.K, self.T, self.Dmax, self.quirks
+        self._keep = [np.ascontiguousarray(a) for a in (self.gh_x, self.gh_w, self.w, self.eta_c, self.eta_d)]
+        p.gh_x, p.gh_w, p.w, p.eta_c, p.eta_d = (_p(a) for a in self._keep)
+        g_w = np.zeros(self.K)
+        g_c = np.zeros((self.flat.V, self.K, 2))
+        g_d = np.zeros((self.flat.V, self.K, self.Dmax))
+        fe = np.zeros(1)
+        lib().oracle_vi_grad(C.byref(self.hg.g), C.byref(p), _p(g_w), _p(g_c), _p(g_d), _p(fe))
+        g_c[~self.cont] = 0.0
+        g_d[~self.disc] = 0.0
+        return g_w, g_c, g_d, float(fe[0])
+
+    def run(self, iterations, lr=0.1):
+        """ADAM_update (VI:249-300); returns the free energy logged after every update"""
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        mw, sw = np.zeros(self.K), np.zeros(self.K)
+        mc, sc = np.zeros_like(self.eta_c), np.zeros_like(self.eta_c)
+        md, sd = np.zeros_like(self.tau_d), np.zeros_like(self.tau_d)
+        log = []
+        adam = lib().oracle_adam_step
+        adam.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_double, C.c_double,
+                         C.c_double, C.c_double, C.c_int, C.c_double]
+        for t in range(1, iterations + 1):
+            g_w, g_c, g_d, _ = self.grad()
+            for theta, m, s, g, stride in ((self.w_tau, mw, sw, g_w, 0), (self.eta_c, mc, sc, g_c, 2),
+                                           (self.tau_d, md, sd, g_d, 0)):
+                g = np.ascontiguousarray(g)
+                adam(_p(theta), _p(m), _p(s), _p(g), theta.size, t, lr, b1, b2, eps, stride, 0.1)
+            self.refresh()
+            log.append(self.grad()[3])
+        return log

@@ -161,3 +161,20 @@ def test_device_sampler_statistics(api):
     x = runs[0][cont].ravel()
     assert abs(x.mean()) < 0.02 and abs(x.var() - 5.0) < 0.1      # q = (0, 5), bounds +-10 (4.5 sigma)
     assert (runs[0] == runs[1]).all()
+
+
+def test_device_exp_accuracy(api):
+    """the f2v kernel's table-driven exp stays within 2 ulp of libm over the whole log-message range"""
+    import torch
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-745, 709, 200000), rng.uniform(-5, 5, 200000), rng.uniform(-1e-3, 1e-3, 10000),
+                        np.array([0.0, -745.0, -800.0, -1e5, 709.7, 710.0, 1e4])])
+    xd = api.to_dev(x)
+    yd = torch.empty_like(xd)
+    api.check(api.lib().lhvi_debug_exp(api.ptr(xd), api.ptr(yd), x.size, api.stream_ptr()))
+    y = yd.cpu().numpy()
+    want = np.exp(x)
+    fin = np.isfinite(want) & (want > 1e-300)
+    ulp = np.abs(y[fin] - want[fin]) / np.spacing(want[fin])
+    assert ulp.max() <= 2.0, ulp.max()
+    assert (y[x < -760] == 0).all() and np.isinf(y[x > 709.9]).all()
