@@ -130,6 +130,11 @@ typedef struct lhvi_pbp {
     const int32_t* generic_edges; /* [n_generic] all other edges with a hidden target */
     int32_t n_generic;
     const void* fast_desc;      /* [n_fast][LHVI_PBP_DESC_BYTES] from lhvi_pbp_describe, or NULL (built on the fly) */
+    /* edge-sharded runs only (all NULL on a single GPU): contributions of the variable's edges that live on other ranks */
+    const int32_t* bslot;       /* [V] row of a boundary variable in remote_m / remote_ph, -1 for interior variables */
+    const double* remote_m;     /* [nb][n] sum over remote edges of count * f2v[e][j] (particle part) */
+    const double* remote_ph;    /* [nb][2] sum over remote edges of count * (1/var, mu/var) of the sites */
+    const double* var_degree;   /* [V] global number of incoming messages (sum of counts over ALL ranks' edges) */
 } lhvi_pbp_t;
 
 #define LHVI_PBP_DESC_BYTES 64
@@ -152,6 +157,15 @@ int lhvi_pbp_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, 
 int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f, double* f2v, void* stream);
 /* update_proposal (sites eta [E][2] in/out, q [V][2] in/out): EPBP.py:83-154; HLBP.py:100-171 */
 int lhvi_pbp_proposal(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* eta, double* q, void* stream);
+/* Sharded form of lhvi_pbp_proposal: `partial` updates the local sites and writes, per variable, the information-form sum
+ * over its LOCAL edges ph[v] = (sum c/var, sum c*mu/var); after the boundary rows have been exchanged and summed into
+ * s->remote_ph, `finish` forms q[v] from ph[v] (+ remote) -- together they equal lhvi_pbp_proposal on the whole graph. */
+int lhvi_pbp_proposal_partial(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* eta, double* ph, void* stream);
+int lhvi_pbp_proposal_finish(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* ph, double* q, void* stream);
+/* out[i][0..n) = sum over the LOCAL edges of variable bvars[i] of count * f2v[e][j]; out[i][n..n+2) = ph[bvars[i]]:
+ * the row a rank sends to the other owners of a boundary variable (one all_to_all per sweep). */
+int lhvi_pbp_boundary_pack(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, const double* ph, int32_t nb,
+                           const int32_t* bvars, double* out, void* stream);
 /* initial_proposal: q=(0,5), sites (0, 5*deg): EPBP.py:72-81; HLBP.py:89-98 */
 int lhvi_pbp_init(const lhvi_graph_t* g, const lhvi_pbp_t* s, double* eta, double* q, double* f2v, double* v2f, void* stream);
 /* generate_sample with a counter-based device RNG keyed (seed, variable gid, iteration, j): EPBP.py:61-70.

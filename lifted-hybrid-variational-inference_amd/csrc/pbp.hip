@@ -108,6 +108,10 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp
         const int j = c * 64 + lane;
         const bool valid = j < np;
         double total = 0.0;
+        if (s.bslot && valid) {                      // edges of this variable that live on other ranks
+            const int bs = s.bslot[v];
+            if (bs >= 0) total = s.remote_m[(int64_t)bs * n + j];
+        }
         for (int k = 0; k < deg; ++k) {
             const int e = g.var_edge[lo + k];
             const double m = valid ? f2v[(int64_t)e * S + j] : 0.0;
@@ -477,8 +481,10 @@ __device__ __forceinline__ void gdiv(double a0, double a1, double b0, double b1,
 }
 
 // update_proposal (EPBP:83-154; HLBP:100-171): one wavefront per continuous hidden variable
+// ph_out != nullptr: sharded mode -- write the local information-form sums instead of q (lhvi_pbp_proposal_partial)
 __global__ void __launch_bounds__(BLOCK) pbp_proposal_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
-                                                            double* __restrict__ eta, double* __restrict__ q) {
+                                                            double* __restrict__ eta, double* __restrict__ q,
+                                                            double* __restrict__ ph_out) {
     const int lane = threadIdx.x & 63;
     const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
     if (v >= g.V) return;
@@ -488,9 +494,10 @@ __global__ void __launch_bounds__(BLOCK) pbp_proposal_kernel(lhvi_graph_t g, lhv
     const int gb = g.dom_ptr[d], T = g.dom_ptr[d + 1] - gb;
     const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
     double total = 0.0;
-    for (int k = lo; k < hi; ++k) total += g.edge_count ? g.edge_count[g.var_edge[k]] : 1.0;
+    if (s.var_degree) total = s.var_degree[v];
+    else for (int k = lo; k < hi; ++k) total += g.edge_count ? g.edge_count[g.var_edge[k]] : 1.0;
     const double min_sig = total * s.var_threshold;
-    const double q0 = q[2 * v], q1 = q[2 * v + 1];
+    const double q0 = s.q[2 * v], q1 = s.q[2 * v + 1];
     double pm = 0.0, ps = 0.0;
     for (int k = lo; k < hi; ++k) {
         const int e = g.var_edge[k];
@@ -521,9 +528,49 @@ __global__ void __launch_bounds__(BLOCK) pbp_proposal_kernel(lhvi_graph_t g, lhv
         if (g.edge_count) { const double c = g.edge_count[e]; ps += p * c; pm += p * mu * c; }
         else { ps += p; pm += p * mu; }
     }
+    if (ph_out) { if (lane == 0) { ph_out[2 * v] = ps; ph_out[2 * v + 1] = pm; } return; }
     ps = 1.0 / ps;
     if (lane == 0) { q[2 * v] = ps * pm; q[2 * v + 1] = ps; }
 }
+
+// q[v] from the local information-form sums plus the other ranks' (lhvi_pbp_proposal_finish)
+__global__ void __launch_bounds__(BLOCK) pbp_proposal_finish_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ ph,
+                                                                   double* __restrict__ q) {
+    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v >= g.V) return;
+    if (!is_hidden(g.var_value[v]) || !g.dom_cont[g.var_dom[v]]) return;
+    double ps = ph[2 * v], pm = ph[2 * v + 1];
+    if (s.bslot) {
+        const int bs = s.bslot[v];
+        if (bs >= 0) { ps += s.remote_ph[2 * bs]; pm += s.remote_ph[2 * bs + 1]; }
+    }
+    ps = 1.0 / ps;
+    q[2 * v] = ps * pm; q[2 * v + 1] = ps;
+}
+
+// one wavefront per boundary variable: row = [sum_local c * f2v[e][j] for j < n | ph[v]]
+__global__ void __launch_bounds__(BLOCK) pbp_boundary_pack_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
+                                                                 const double* __restrict__ ph, int nb,
+                                                                 const int32_t* __restrict__ bvars, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (i >= nb) return;
+    const int v = bvars[i];
+    const int n = s.n, S = s.n + s.T, W = s.n + 2;
+    const int np = is_hidden(g.var_value[v]) ? s.np[v] : 0;
+    for (int j = lane; j < n; j += 64) {
+        double tot = 0.0;
+        if (j < np)
+            for (int k = g.var_ptr[v]; k < g.var_ptr[v + 1]; ++k) {
+                const int e = g.var_edge[k];
+                const double m = f2v[(int64_t)e * S + j];
+                tot += g.edge_count ? m * g.edge_count[e] : m;
+            }
+        out[(int64_t)i * W + j] = tot;
+    }
+    if (lane < 2) out[(int64_t)i * W + n + lane] = ph[2 * v + lane];
+}
+
 
 // initial_proposal (EPBP:72-81; HLBP:89-98)
 __global__ void __launch_bounds__(BLOCK) pbp_init_kernel(lhvi_graph_t g, lhvi_pbp_t s, double* __restrict__ eta,
@@ -534,7 +581,8 @@ __global__ void __launch_bounds__(BLOCK) pbp_init_kernel(lhvi_graph_t g, lhvi_pb
     if (!g.dom_cont[g.var_dom[v]] && !(s.flags & LHVI_PBP_EPBP_DISCRETE)) return;
     q[2 * v] = 0.0; q[2 * v + 1] = 5.0;
     double total = 0.0;
-    for (int k = g.var_ptr[v]; k < g.var_ptr[v + 1]; ++k) total += g.edge_count ? g.edge_count[g.var_edge[k]] : 1.0;
+    if (s.var_degree) total = s.var_degree[v];
+    else for (int k = g.var_ptr[v]; k < g.var_ptr[v + 1]; ++k) total += g.edge_count ? g.edge_count[g.var_edge[k]] : 1.0;
     for (int k = g.var_ptr[v]; k < g.var_ptr[v + 1]; ++k) {
         const int e = g.var_edge[k];
         eta[2 * e] = 0.0; eta[2 * e + 1] = 5.0 * total;
@@ -668,7 +716,36 @@ int lhvi_pbp_proposal(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* 
     if (int rc = validate_pbp(g, s)) return rc;
     if (!f2v || !eta || !q) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
-    hipLaunchKernelGGL(pbp_proposal_kernel, dim3(grid_for((int64_t)g->V * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, eta, q);
+    hipLaunchKernelGGL(pbp_proposal_kernel, dim3(grid_for((int64_t)g->V * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, eta, q,
+                       (double*)nullptr);
+    return check_launch();
+}
+
+int lhvi_pbp_proposal_partial(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* eta, double* ph, void* stream) {
+    if (int rc = validate_pbp(g, s)) return rc;
+    if (!f2v || !eta || !ph || !s->q) return LHVI_E_ARG;
+    if (g->V == 0) return LHVI_OK;
+    hipLaunchKernelGGL(pbp_proposal_kernel, dim3(grid_for((int64_t)g->V * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, eta,
+                       (double*)nullptr, ph);
+    return check_launch();
+}
+
+int lhvi_pbp_proposal_finish(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* ph, double* q, void* stream) {
+    if (int rc = validate_pbp(g, s)) return rc;
+    if (!ph || !q || (s->bslot && !s->remote_ph)) return LHVI_E_ARG;
+    if (g->V == 0) return LHVI_OK;
+    hipLaunchKernelGGL(pbp_proposal_finish_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, as_stream(stream), *g, *s, ph, q);
+    return check_launch();
+}
+
+int lhvi_pbp_boundary_pack(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, const double* ph, int32_t nb,
+                           const int32_t* bvars, double* out, void* stream) {
+    if (int rc = validate_pbp(g, s)) return rc;
+    if (nb < 0) return LHVI_E_ARG;
+    if (nb == 0) return LHVI_OK;
+    if (!f2v || !ph || !bvars || !out) return LHVI_E_ARG;
+    hipLaunchKernelGGL(pbp_boundary_pack_kernel, dim3(grid_for((int64_t)nb * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, ph,
+                       nb, bvars, out);
     return check_launch();
 }
 

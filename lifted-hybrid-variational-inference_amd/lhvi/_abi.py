@@ -46,6 +46,7 @@ class PbpStruct(C.Structure):
         ('q', C.c_void_p),
         ('fast_edges', C.c_void_p), ('n_fast', C.c_int32), ('generic_edges', C.c_void_p), ('n_generic', C.c_int32),
         ('fast_desc', C.c_void_p),
+        ('bslot', C.c_void_p), ('remote_m', C.c_void_p), ('remote_ph', C.c_void_p), ('var_degree', C.c_void_p),
     ]
 
 
@@ -83,6 +84,9 @@ SIGNATURES = {
     'lhvi_pbp_v2f': (C.c_int, [_G, _S, _vp, _vp, _vp]),
     'lhvi_pbp_f2v': (C.c_int, [_G, _P, _S, _vp, _vp, _vp]),
     'lhvi_pbp_proposal': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp]),
+    'lhvi_pbp_proposal_partial': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp]),
+    'lhvi_pbp_proposal_finish': (C.c_int, [_G, _S, _vp, _vp, _vp]),
+    'lhvi_pbp_boundary_pack': (C.c_int, [_G, _S, _vp, _vp, _i32, _vp, _vp, _vp]),
     'lhvi_pbp_init': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp, _vp]),
     'lhvi_pbp_resample': (C.c_int, [_G, _S, _vp, _u64, _u32, _vp, _vp]),
     'lhvi_pbp_belief_points': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),

@@ -54,3 +54,190 @@ class SingleRunner:
 
     def f2v_joint_terms(self):
         return joint_terms(self.bp.flat, self.bp.np_host)
+
+
+# =================================================================================================
+# edge sharding
+# =================================================================================================
+class ShardPlan:
+    """Factor-partitioned shard of a ground ``FlatGraph`` for rank ``rank`` of ``world`` (pure NumPy, no GPU).
+
+    * factors ``[F*rank/world, F*(rank+1)/world)`` with all their edges are local;
+    * local variables = the variables those factors touch, renumbered in ascending global id (``var_gid``);
+    * ``var_degree`` = a variable's degree in the WHOLE graph (site clamp / initial site of the proposal);
+    * a local variable is a *boundary* variable when some of its edges live on another rank; ``bvars`` lists them
+      (ascending gid) and ``peer_rows[s]`` = the rows of ``bvars`` shared with rank ``s`` (ascending gid on both sides,
+      so the two ends of a pair agree on the order without communicating).
+    """
+
+    def __init__(self, flat, rank, world):
+        from .flat import build_flat
+        if flat.lifted or (flat.edge_canon != np.arange(flat.E)).any():
+            raise NotImplementedError('sharding expects a ground graph')
+        self.rank, self.world = rank, world
+        F = flat.F
+        bounds = (np.arange(world + 1, dtype=np.int64) * F) // world
+        self.f_lo, self.f_hi = int(bounds[rank]), int(bounds[rank + 1])
+        fac_owner = np.searchsorted(bounds, np.arange(F), side='right') - 1
+        edge_owner = fac_owner[flat.edge_fac]
+        e_lo, e_hi = int(flat.fac_ptr[self.f_lo]), int(flat.fac_ptr[self.f_hi])
+        self.e_lo, self.e_hi = e_lo, e_hi
+        local_edge_var = flat.edge_var[e_lo:e_hi]
+        gids = np.unique(local_edge_var)
+        self.var_gid = gids.astype(np.int64)
+        lid = np.full(flat.V, -1, dtype=np.int64)
+        lid[gids] = np.arange(gids.size)
+        degree = np.bincount(flat.edge_var, minlength=flat.V)
+        local_degree = np.bincount(local_edge_var, minlength=flat.V)
+        self.var_degree = degree[gids].astype(np.float64)
+        self.flat = build_flat(flat.fac_ptr[self.f_lo:self.f_hi + 1] - e_lo, lid[local_edge_var].astype(np.int32),
+                               flat.fac_pot[self.f_lo:self.f_hi], [], flat.var_value[gids], flat.var_dom[gids], flat.domains)
+        # the potential table is global and small: keep it whole so fac_pot stays valid
+        self.flat.pot_kind, self.flat.pot_off, self.flat.pot_param = flat.pot_kind, flat.pot_off, flat.pot_param
+        # boundary bookkeeping: which ranks own edges of each variable
+        is_b = degree[gids] > local_degree[gids]
+        self.bvars = np.flatnonzero(is_b).astype(np.int32)               # local ids, ascending gid
+        self.bslot = np.full(gids.size, -1, dtype=np.int32)
+        self.bslot[self.bvars] = np.arange(self.bvars.size, dtype=np.int32)
+        bg = gids[self.bvars]
+        # owner sets of boundary variables, from the (variable, owner) incidence
+        keys = np.unique(flat.edge_var.astype(np.int64) * world + edge_owner.astype(np.int64))
+        pair_var, pair_owner = keys // world, keys % world
+        self.peer_rows = {}
+        for s in range(world):
+            if s == rank:
+                continue
+            vs = pair_var[pair_owner == s]
+            shared = np.intersect1d(bg, vs, assume_unique=True)          # ascending gid
+            self.peer_rows[s] = np.searchsorted(bg, shared).astype(np.int64)
+
+    def send_counts(self):
+        return [0 if s == self.rank else int(self.peer_rows[s].size) for s in range(self.world)]
+
+
+class LoopbackGroup:
+    """In-process stand-in for the all-to-all of `world` simulated ranks (single-GPU parity tests of the sharded path)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.sends = [None] * world
+
+    def post(self, rank, send, counts):
+        self.sends[rank] = (send, counts)
+
+    def collect(self, rank, width):
+        import torch
+        out = []
+        for s in range(self.world):
+            if s == rank:
+                continue
+            send, counts = self.sends[s]
+            off = sum(counts[:rank])
+            out.append(send[off:off + counts[rank]])
+        return torch.cat(out) if out else self.sends[rank][0][:0]
+
+
+class ShardedRunner:
+    """One rank's part of the edge-sharded particle sweep (EPBP semantics).
+
+    Per sweep: [local sites + information-form partials] -> pack boundary rows -> ONE all_to_all -> accumulate the
+    remote rows -> v2f (with remote sums) -> proposal finish -> resample (Philox keyed by global id, so replicas of a
+    boundary variable draw identical particles without communicating) -> f2v (local).
+    """
+
+    def __init__(self, flat, n, seed, rank, world, proposal_approximation='simple', group=None):
+        import torch
+        from .pbp import EPBP
+        self.plan = plan = ShardPlan(flat, rank, world)
+        self.rank, self.world, self.group = rank, world, group
+        bp = EPBP(None, n=n, proposal_approximation=proposal_approximation, sampler='device', seed=seed)
+        bp._setup(None, flat=plan.flat)
+        self.bp = bp
+        dev = bp.dg.device
+        bp.var_gid = _abi.to_dev(plan.var_gid)
+        self.var_degree = _abi.to_dev(plan.var_degree)
+        self.bslot = _abi.to_dev(plan.bslot)
+        self.bvars = _abi.to_dev(plan.bvars)
+        nb = int(plan.bvars.size)
+        self.nb, self.W = nb, n + 2
+        self.ph = torch.zeros(plan.flat.V, 2, dtype=torch.float64, device=dev)
+        self.rows = torch.zeros(max(nb, 1), self.W, dtype=torch.float64, device=dev)
+        self.remote = torch.zeros(max(nb, 1), self.W, dtype=torch.float64, device=dev)
+        self.remote_m = torch.zeros(max(nb, 1), n, dtype=torch.float64, device=dev)
+        self.remote_ph = torch.zeros(max(nb, 1), 2, dtype=torch.float64, device=dev)
+        self.peer_rows = {s: torch.from_numpy(r).to(dev) for s, r in plan.peer_rows.items()}
+        self.counts = plan.send_counts()
+        self._send_index = torch.cat([self.peer_rows[s] for s in range(world) if s != rank]) if world > 1 else \
+            torch.zeros(0, dtype=torch.int64, device=dev)
+
+    def _struct(self):
+        s = self.bp._struct()
+        s.bslot, s.var_degree = _abi.ptr(self.bslot), _abi.ptr(self.var_degree)
+        s.remote_m, s.remote_ph = _abi.ptr(self.remote_m), _abi.ptr(self.remote_ph)
+        return s
+
+    def init(self):
+        bp = self.bp
+        _abi.check(_abi.lib().lhvi_pbp_init(bp.dg.g, self._struct(), _abi.ptr(bp.eta), _abi.ptr(bp.q_dev),
+                                            _abi.ptr(bp.f2v), _abi.ptr(bp.v2f), _abi.stream_ptr()))
+        bp._generate_sample()
+
+    # -- phase 1: everything that must precede the exchange -----------------------------------------
+    def pre(self):
+        bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
+        s = self._struct()
+        _abi.check(l.lhvi_pbp_proposal_partial(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.eta), _abi.ptr(self.ph), st))
+        _abi.check(l.lhvi_pbp_boundary_pack(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(self.ph), self.nb, _abi.ptr(self.bvars),
+                                            _abi.ptr(self.rows), st))
+        return self.rows.index_select(0, self._send_index) if self._send_index.numel() else self.rows[:0]
+
+    def exchange(self, send):
+        import torch
+        import torch.distributed as td
+        recv = torch.empty_like(send)          # symmetric: rows shared with s are sent to and received from s
+        td.all_to_all_single(recv, send, output_split_sizes=self.counts, input_split_sizes=self.counts)
+        return recv
+
+    # -- phase 2: accumulate the peers' rows (fixed peer order -> deterministic), then the rest of the sweep -------
+    def post(self, recv, f2v_events=None):
+        bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
+        self.remote.zero_()
+        off = 0
+        for s in range(self.world):
+            if s == self.rank:
+                continue
+            cnt = self.counts[s]
+            if cnt:
+                self.remote.index_add_(0, self.peer_rows[s], recv[off:off + cnt])
+            off += cnt
+        self.remote_m.copy_(self.remote[:, :bp.n])
+        self.remote_ph.copy_(self.remote[:, bp.n:])
+        s = self._struct()
+        _abi.check(l.lhvi_pbp_v2f(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.v2f), st))
+        _abi.check(l.lhvi_pbp_proposal_finish(bp.dg.g, s, _abi.ptr(self.ph), _abi.ptr(bp.q_dev), st))
+        bp._generate_sample()
+        s = self._struct()
+        if f2v_events:
+            s.flags |= _abi.PBP_SKIP_GENERIC
+            f2v_events[0].record()
+            _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
+            f2v_events[1].record()
+            s.flags = (s.flags & ~_abi.PBP_SKIP_GENERIC) | _abi.PBP_SKIP_FAST
+            _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
+        else:
+            _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
+
+    def sweep(self, f2v_events=None):
+        send = self.pre()
+        recv = self.exchange(send) if self.world > 1 else send
+        self.post(recv, f2v_events)
+
+    def local_edges(self):
+        return self.plan.flat.E
+
+    def work_fraction(self):
+        flat = self.plan.flat
+        return float(flat.var_hidden[flat.edge_var].mean())
+
+    def f2v_joint_terms(self):
+        return joint_terms(self.plan.flat, self.bp.np_host)
