@@ -133,7 +133,7 @@ typedef struct lhvi_pbp {
     /* edge-sharded runs only (all NULL on a single GPU): contributions of the variable's edges that live on other ranks */
     const int32_t* bslot;       /* [V] row of a boundary variable in remote_m / remote_ph, -1 for interior variables */
     const double* remote_m;     /* [nb][n] sum over remote edges of count * f2v[e][j] (particle part) */
-    const double* remote_ph;    /* [nb][2] sum over remote edges of count * (1/var, mu/var) of the sites */
+    const double* remote_ph;    /* [nb][2] sum over ALL ranks' edges (own included, fixed rank order) of count * (1/var, mu/var) */
     const double* var_degree;   /* [V] global number of incoming messages (sum of counts over ALL ranks' edges) */
 } lhvi_pbp_t;
 

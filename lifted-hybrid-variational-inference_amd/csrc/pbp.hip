@@ -541,8 +541,10 @@ __global__ void __launch_bounds__(BLOCK) pbp_proposal_finish_kernel(lhvi_graph_t
     if (!is_hidden(g.var_value[v]) || !g.dom_cont[g.var_dom[v]]) return;
     double ps = ph[2 * v], pm = ph[2 * v + 1];
     if (s.bslot) {
+        // boundary variable: remote_ph holds the COMPLETE sum over all ranks, accumulated in rank order by the host,
+        // so that every replica of the variable computes bit-identical q (and hence identical particles)
         const int bs = s.bslot[v];
-        if (bs >= 0) { ps += s.remote_ph[2 * bs]; pm += s.remote_ph[2 * bs + 1]; }
+        if (bs >= 0) { ps = s.remote_ph[2 * bs]; pm = s.remote_ph[2 * bs + 1]; }
     }
     ps = 1.0 / ps;
     q[2 * v] = ps * pm; q[2 * v + 1] = ps;

@@ -201,17 +201,23 @@ class ShardedRunner:
     # -- phase 2: accumulate the peers' rows (fixed peer order -> deterministic), then the rest of the sweep -------
     def post(self, recv, f2v_events=None):
         bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
+        # remote_m: the OTHER ranks' particle-part sums.  remote_ph: the complete information-form sum of a boundary
+        # variable accumulated in rank order (own row at its turn), so every replica of the variable forms bit-identical
+        # q and therefore draws bit-identical particles.
+        n = bp.n
         self.remote.zero_()
+        self.remote_ph.zero_()
         off = 0
         for s in range(self.world):
             if s == self.rank:
+                self.remote_ph.add_(self.rows[:, n:])
                 continue
             cnt = self.counts[s]
             if cnt:
                 self.remote.index_add_(0, self.peer_rows[s], recv[off:off + cnt])
+                self.remote_ph.index_add_(0, self.peer_rows[s], recv[off:off + cnt, n:])
             off += cnt
-        self.remote_m.copy_(self.remote[:, :bp.n])
-        self.remote_ph.copy_(self.remote[:, bp.n:])
+        self.remote_m.copy_(self.remote[:, :n])
         s = self._struct()
         _abi.check(l.lhvi_pbp_v2f(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.v2f), st))
         _abi.check(l.lhvi_pbp_proposal_finish(bp.dg.g, s, _abi.ptr(self.ph), _abi.ptr(bp.q_dev), st))

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from math import e, exp, pi, pow, sqrt  # noqa: F401  (re-exported like the reference module)
 
+import warnings
+
 import numpy as np
 
 from .graph import Potential
@@ -98,8 +100,10 @@ class GaussianPotential(Potential):
     def __init__(self, mu, sig, w=1):
         Potential.__init__(self, symmetric=False)
         self.mu = np.array(mu)
-        self.sig = np.matrix(sig)
-        self.prec = self.sig.I
+        with warnings.catch_warnings():     # np.matrix on purpose: GaBP inverts it as `sig ** -1` (GaBP.py:44)
+            warnings.simplefilter('ignore', PendingDeprecationWarning)
+            self.sig = np.matrix(sig)
+            self.prec = self.sig.I
         det = np.linalg.det(self.sig)
         if det == 0:
             raise NameError("The covariance matrix can't be singular")
@@ -121,7 +125,9 @@ class GaussianPotential(Potential):
         n = len(self.mu)
         # GaBP inverts the covariance itself as ``sig ** -1`` (GaBP.py:44); ship that matrix too so the
         # closed forms see the reference's bits rather than ``sig.I``'s
-        inv = np.asarray(self.sig ** -1)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', PendingDeprecationWarning)
+            inv = np.asarray(self.sig ** -1)
         return POT_GAUSSIAN, [float(n)] + self.mu.astype(np.float64).tolist() + \
             np.asarray(self.prec).ravel().tolist() + inv.ravel().tolist()
 

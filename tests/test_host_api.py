@@ -1,0 +1,153 @@
+"""CPU suite: host-side object model, potentials, MLN tracing, relational grounding, Kalman builder, flattening."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from lhvi import expr, graph as G, kalman, mln as M, potentials as P, relational as R
+from lhvi.flat import flatten
+import modelio
+from test_oracle_golden import API, load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_domain_defaults_and_identity():
+    d = G.Domain((-1, 1), continuous=True)
+    assert len(d.integral_points) == 30 and d.integral_points[0] == -1 and d.integral_points[-1] == 1
+    assert G.Domain((0, 1)) != G.Domain((0, 1))          # identity, like the reference
+
+
+def test_graph_init_nb_orders_by_factor_id():
+    d = G.Domain((0, 1))
+    a, b = G.RV(d), G.RV(d)
+    t = P.TablePotential(np.ones((2, 2)))
+    f1, f2, f3 = G.F(t, [a, b]), G.F(t, [b, a]), G.F(t, [a, b])
+    g = G.Graph()
+    g.rvs, g.factors = {a, b}, {f3, f1, f2}
+    g.init_nb()
+    assert a.nb == [f1, f2, f3] and a.N == 3 and g.rvs_list == [a, b]
+    g.init_rv_indices()
+    assert g.Nd == 2 and f1.disc_nb_idx == (0, 1) and f2.disc_nb_idx == (1, 0)
+
+
+def test_potential_values_and_equality():
+    assert P.LinearGaussianPotential(0.5, 2.0) == P.LinearGaussianPotential(0.5, 2.0)
+    assert P.XYPotential(0.5, 2.0) != P.X2Potential(0.5, 2.0)
+    assert hash(P.X2Potential(1, 4)) == hash(P.X2Potential(1, 4))
+    g1, g2 = P.GaussianPotential([0, 0], [[2, 0], [0, 2]]), P.GaussianPotential([0, 0], [[2, 0], [0, 2]])
+    assert g1 != g2                                       # identity for everything else
+    assert P.LinearGaussianPotential(0.9, 1.0).get((1.0, 1.5)) == pytest.approx(np.exp(-(1.5 - 0.9) ** 2 / 2))
+    assert P.XYPotential(0.4, 2.0).symmetric and not P.X2Potential(1, 1).symmetric
+    q = P.QuadraticPotential(np.array([[-1.0, 0.2], [0.2, -0.5]]), np.array([0.1, 0.3]), 0.2)
+    x = np.array([0.3, -0.7])
+    assert q.get(x) == pytest.approx(np.exp(x @ q.A @ x + q.b @ x + 0.2))
+    hq = P.HybridQuadraticPotential(np.array([[[-0.2]], [[-0.5]]]), np.array([[0.5], [-0.4]]), np.array([0.0, 0.3]))
+    assert hq.get((1, 2.0)) == pytest.approx(np.exp(-0.5 * 4 - 0.4 * 2 + 0.3))
+    assert g1.get((1.0, 1.0)) == pytest.approx(np.exp(-0.5))
+    A, b, c = g1.get_quadratic_params()
+    assert np.allclose(A, -0.25 * np.eye(2)) and np.allclose(b, 0) and c == 0
+
+
+def test_mln_ops_and_tracing():
+    assert M.imp_op(1, 0) == 0 and M.imp_op(0, 0) == 1 and M.bic_op(1, 1) == 1 and M.eq_op(2, 5) == -9
+    pot = M.MLNPotential(lambda x: x[0] * M.eq_op(x[1], x[2]), w=0.5)
+    assert pot.get((1, 2.0, 3.5)) == pytest.approx(np.e ** (-2.25 * 0.5))
+    rng = np.random.default_rng(0)
+    for name, f in modelio.FORMULAS.items():
+        arity = 3 if name in ('x0_eq12', 'any3') else 2 if name in ('x0_eq1c', 'nand') else 1
+        prog = expr.trace(f, arity)
+        for _ in range(20):
+            x = [float(rng.integers(0, 2)) if name in ('nand', 'any3') else float(rng.uniform(-3, 3)) for _ in range(arity)]
+            assert expr.run(prog, x) == pytest.approx(float(f(x)), rel=1e-15, abs=1e-15)
+    with pytest.raises(expr.FormulaNotTraceable):
+        expr.trace(lambda x: 1 if x[0] > 0 else 0, 1)
+    hard = M.MLNHardPotential(lambda x: x[0] - 0.5)
+    assert hard.get((1,)) == 1 and hard.get((0,)) == 0
+
+
+def test_relational_grounding_matches_rgm_template():
+    d = G.Domain((-50, 50), continuous=True, integral_points=np.linspace(-50, 50, 100))
+    p1, p2, p3 = (P.GaussianPotential([0., 0.], s) for s in ([[10., -7.], [-7., 10.]], [[10., 5.], [5., 10.]], [[10., 7.], [7., 10.]]))
+    C, B = 6, 4
+    lv_r, lv_c, lv_b = R.LV(('all',)), R.LV([f'c{i}' for i in range(C)]), R.LV([f'b{i}' for i in range(B)])
+    atoms = (R.Atom(d, (lv_r,), 'recession'), R.Atom(d, (lv_b,), 'revenue'), R.Atom(d, (lv_c, lv_b), 'loss'), R.Atom(d, (lv_c,), 'market'))
+    pfs = (R.ParamF(p1, nb=('recession($all)', 'market(c)')), R.ParamF(p2, nb=('market(c)', 'loss(c,b)')),
+           R.ParamF(p3, nb=('loss(c,b)', 'revenue(b)')))
+    rel = R.RelationalGraph(atoms, pfs)
+    g, table = rel.ground_graph()
+    assert len(g.rvs) == 1 + C + C * B + B and len(g.factors) == C + 2 * C * B
+    assert table[('recession', 'all')].N == C and table[('market', 'c0')].N == 1 + B and table[('loss', 'c1', 'b2')].N == 2
+    rel.add_evidence({('market', 'c0'): 1.5, ('loss', 'c1', 'b2'): -2.0})
+    assert table[('market', 'c0')].value == 1.5 and table[('revenue', 'b0')].value is None
+    # constraints and constants
+    db = G.Domain((0, 1))
+    lv_t = R.LV(['W', 'D', 'O'])
+    lv_s = R.LV(['s1', 's2'])
+    a = R.Atom(db, (lv_s, lv_t), 'SegType')
+    f0 = R.ParamF(M.MLNPotential(lambda x: M.or_op(M.neg_op(x[0]), M.neg_op(x[1])), w=3), nb=['SegType(s,t1)', 'SegType(s,t2)'],
+                  constrain=lambda s: s['t1'] != s['t2'])
+    f3 = R.ParamF(M.MLNPotential(lambda x: x[0], w=0.3), nb=['SegType(s,$W)'])
+    g2, t2 = R.RelationalGraph((a,), (f0, f3)).ground_graph()
+    assert len(g2.factors) == 2 * 6 + 2 and len(g2.rvs) == 6
+
+
+def test_kalman_builder_matches_reference_structure(golden_dir):
+    """same builder arguments as oracle/capture_golden.py::model_kalman -> same graph as the reference built"""
+    rec = load(golden_dir, 'gauss_g2_kalman')
+    n, T, seed = 4, 5, 0
+    rng = np.random.RandomState(seed)
+    A = rng.uniform(-0.5, 0.5, size=(n, n)) + np.eye(n) * 0.5
+    data = rng.uniform(-2, 2, size=(n, T))
+    data[rng.rand(n, T) < 0.3] = 5000
+    data[:, 0] = rng.uniform(-2, 2, size=n)
+    d = G.Domain((-8, 8), continuous=True, integral_points=np.linspace(-8, 8, 32))
+    g, table = kalman.KalmanFilter(d, A, 1.5, np.eye(n), 0.7).grounded_graph(T, data)
+    mine = modelio.dump_model(g)
+    want = rec['model']
+    assert mine['rvs'] == want['rvs']
+    assert [nb for _, nb in mine['factors']] == [nb for _, nb in want['factors']]
+    mp = [mine['potentials'][i] for i, _ in mine['factors']]
+    wp = [want['potentials'][i] for i, _ in want['factors']]
+    assert mp == wp
+
+
+def test_flatten_layout():
+    rec_g, rvs = __import__('lhvi.synth', fromlist=['x']).gaussian_chain(5)
+    flat = flatten(rec_g)
+    assert flat.V == 5 and flat.F == 8 and flat.E == 12 and not flat.lifted
+    for f in range(flat.F):
+        for e in range(flat.fac_ptr[f], flat.fac_ptr[f + 1]):
+            assert flat.edge_fac[e] == f and flat.edge_pos[e] == e - flat.fac_ptr[f]
+    for v, rv in enumerate(rvs):
+        fs = [flat.factors[flat.edge_fac[e]] for e in flat.var_edge[flat.var_ptr[v]:flat.var_ptr[v + 1]]]
+        assert fs == rv.nb                                      # variable CSR keeps rv.nb order
+    assert np.isnan(flat.var_value[1:]).all() and flat.var_value[0] == 1.5
+    assert len(flat.potentials) == 2
+
+
+def test_compat_modules_mirror_reference_imports():
+    compat = os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd', 'compat')
+    sys.path.insert(0, compat)
+    try:
+        for name in ('Graph', 'Potential', 'MLNPotential', 'RelationalGraph', 'KalmanFilter', 'CompressedGraphWithObs',
+                     'CompressedGraphSorted', 'GaBP', 'GaLBP', 'EPBPLogVersion', 'HybridLBPLogVersion', 'VarInference',
+                     'LiftedVarInference', 'utils'):
+            sys.modules.pop(name, None)
+            importlib.import_module(name)
+        ns = {}
+        exec('from RelationalGraph import *\nfrom MLNPotential import *\nfrom Potential import GaussianPotential\n'
+             'from GaBP import GaBP\nfrom EPBPLogVersion import EPBP\nfrom HybridLBPLogVersion import HybridLBP\n'
+             'from VarInference import VarInference as VI\nfrom LiftedVarInference import VarInference as LVI\n'
+             'from CompressedGraphSorted import CompressedGraphSorted\n'
+             'd = Domain((-1, 1), continuous=True, integral_points=linspace(-1, 1, 5))\n', ns)
+        assert ns['VI'] is not ns['LVI'] and ns['d'].continuous
+    finally:
+        sys.path.remove(compat)
+        for name in ('Graph', 'Potential', 'MLNPotential', 'RelationalGraph', 'KalmanFilter', 'utils', 'GaBP', 'GaLBP',
+                     'VarInference', 'LiftedVarInference', 'EPBPLogVersion', 'HybridLBPLogVersion',
+                     'CompressedGraphWithObs', 'CompressedGraphSorted'):
+            sys.modules.pop(name, None)
