@@ -152,27 +152,3 @@ def hybrid_mrf_flat(V=250000, deg=4, seed=0, frac_discrete=0.2, evidence_ratio=0
     value[ev & is_disc] = rng.integers(0, 2, size=int((ev & is_disc).sum()))
     return build_flat(fac_ptr, edge_var, fac_pot, specs, value, is_disc.astype(np.int32), [dc, db])
 
-
-def smoke_pbp():
-    """one small particle sweep on cuda:0 checked against the CPU oracle (used by __graft_entry__.smoke)"""
-    from . import _abi
-    from .pbp import EPBP
-    from oracle import oracle          # test infrastructure; smoke() is allowed to use it as the checker
-    flat = hybrid_mrf_flat(V=1500, deg=4, seed=11)
-    bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=2)
-    bp._setup(None, flat=flat)
-    _abi.check(_abi.lib().lhvi_pbp_init(bp.dg.g, bp._struct(), _abi.ptr(bp.eta), _abi.ptr(bp.q_dev), _abi.ptr(bp.f2v),
-                                        _abi.ptr(bp.v2f), _abi.stream_ptr()))
-    bp._generate_sample()
-    o = oracle.PbpOracle(flat, 64, ep=False, epbp=True, var_threshold=3)
-    o.init()
-    o.set_particles(bp.particles.cpu().numpy())
-    bp.sweep(last=False)
-    o.step_v2f()
-    o.step_proposal()
-    o.set_particles(bp.particles.cpu().numpy())
-    o.step_f2v()
-    hid = flat.var_hidden[flat.edge_var]
-    err = float(np.abs(bp.f2v.cpu().numpy()[hid] - o.f2v[hid]).max())
-    assert err < 1e-8, err
-    print('smoke ok: particle sweep on %d edges, max |f2v - oracle| = %.3g' % (flat.E, err))
