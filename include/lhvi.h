@@ -171,6 +171,9 @@ int lhvi_pbp_init(const lhvi_graph_t* g, const lhvi_pbp_t* s, double* eta, doubl
 /* generate_sample with a counter-based device RNG keyed (seed, variable gid, iteration, j): EPBP.py:61-70.
  * var_gid may be NULL (gid = local index).  Parity runs inject host particles instead. */
 int lhvi_pbp_resample(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int64_t* var_gid, uint64_t seed, uint32_t iteration, double* particles_out, void* stream);
+/* lhvi_pbp_resample followed by lhvi_pbp_uniq on the fresh particles, fused into one pass when n <= 64 */
+int lhvi_pbp_resample_uniq(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int64_t* var_gid, uint64_t seed, uint32_t iteration,
+                           double* particles_out, uint8_t* uniq_out, void* stream);
 /* belief_rv(x) = sum_f message_f_to_rv(x, f, rv, sample) at arbitrary points: EPBP.py:196-202; HLBP.py:313-317.
  * qvar [nq] variable ids, x [nq][npts], out [nq][npts]; uses s->particles as the partners' sample. */
 int lhvi_pbp_belief_points(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f,

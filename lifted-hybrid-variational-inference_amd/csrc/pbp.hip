@@ -41,19 +41,22 @@ __device__ __forceinline__ double norm_pdf_std(double x, double mu, double sig) 
     return exp(-u * u * 0.5) / (2.506628274631 * sig);
 }
 
-// log(important_weight(x, rv)) (EPBP:156-163, HLBP:173-180)
-__device__ __forceinline__ double log_importance(const lhvi_graph_t& g, const lhvi_pbp_t& s, int v, int d, double x) {
+// log(important_weight(x, rv)) (EPBP:156-163, HLBP:173-180).  For an interior particle the reference evaluates
+// log(1 / max(N(x; mu, sd), 1e-200)); with N = exp(-u^2/2) / (2.5066 sd) that is min(u^2/2 + log(2.5066 sd), -log 1e-200),
+// which needs one division per particle instead of exp + two divisions + log (log_sd_term is per variable).
+__device__ __forceinline__ double log_importance(const lhvi_graph_t& g, const lhvi_pbp_t& s, int v, int d, double x,
+                                                 double mu, double sd, double log_norm) {
+    const double LOG_1E200 = 460.51701859880916;       // -log(1e-200)
     if (g.dom_cont[d]) {
-        if (x == g.dom_lo[d] || x == g.dom_hi[d]) return log(1e-200);
+        if (x == g.dom_lo[d] || x == g.dom_hi[d]) return -LOG_1E200;
     } else {
         if (!(s.flags & LHVI_PBP_EPBP_DISCRETE)) return 0.0;
         const int b = g.dom_ptr[d];
         const int ns = g.dom_ptr[d + 1] - b;
-        if (x == g.dom_val[b] || (ns > 1 && x == g.dom_val[b + 1])) return log(1e-200);
+        if (x == g.dom_val[b] || (ns > 1 && x == g.dom_val[b + 1])) return -LOG_1E200;
     }
-    const double mu = s.q[2 * v], sd = sqrt(s.q[2 * v + 1]);
-    const double p = norm_pdf_std(x, mu, sd);
-    return log(1.0 / fmax(p, 1e-200));
+    const double u = (x - mu) / sd;
+    return fmin(u * u * 0.5 + log_norm, LOG_1E200);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -91,10 +94,15 @@ __global__ void __launch_bounds__(BLOCK) pbp_uniq_wave_kernel(int V, int n, cons
 // per-particle total T_j = sum_k c_k m_k[j] is formed in rv.nb order, and edge k's message is T_j - m_k[j] + log w_j.
 // Log messages are additive, so "total minus own" costs an absolute error of a few ulp of |T| (~1e-13), far inside
 // the stated tolerance; it replaces the reference's O(deg^2) re-summation (EPBP:165-174) by O(deg).
+// The first V2F_CACHE rows stay in registers (compile-time indices only: a runtime-indexed register array made
+// hipcc 7.2 emit an out-of-range s_set_gpr_idx store); their loads are issued back to back so that a degree-4
+// variable has four 512-byte rows in flight per wave instead of one.
+constexpr int V2F_CACHE = 8;
+
 __global__ void __launch_bounds__(BLOCK) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                        double* __restrict__ v2f) {
     const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
     if (v >= g.V) return;
     if (!is_hidden(g.var_value[v])) return;
     const int n = s.n, S = s.n + s.T;
@@ -104,26 +112,34 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp
     const int d = g.var_dom[v];
     const bool lifted = g.edge_count != nullptr;
     const int nchunk = (np + 63) / 64;
+    const double mu = s.q[2 * v], sd = sqrt(s.q[2 * v + 1]);
+    const double log_norm = log(2.506628274631 * sd);
     for (int c = 0; c < nchunk; ++c) {
         const int j = c * 64 + lane;
         const bool valid = j < np;
+        int ecache[V2F_CACHE];
+        double row[V2F_CACHE];
+#pragma unroll
+        for (int k = 0; k < V2F_CACHE; ++k) ecache[k] = k < deg ? g.var_edge[lo + k] : 0;
+#pragma unroll
+        for (int k = 0; k < V2F_CACHE; ++k) row[k] = (k < deg && valid) ? f2v[(int64_t)ecache[k] * S + j] : 0.0;
+        const double x = valid ? s.particles[(int64_t)v * n + j] : 0.0;
+        const bool uq = valid && s.uniq[(int64_t)v * n + j];
         double total = 0.0;
         if (s.bslot && valid) {                      // edges of this variable that live on other ranks
             const int bs = s.bslot[v];
             if (bs >= 0) total = s.remote_m[(int64_t)bs * n + j];
         }
-        for (int k = 0; k < deg; ++k) {
+#pragma unroll
+        for (int k = 0; k < V2F_CACHE; ++k)
+            if (k < deg) total += lifted ? row[k] * g.edge_count[ecache[k]] : row[k];
+        for (int k = V2F_CACHE; k < deg; ++k) {
             const int e = g.var_edge[lo + k];
             const double m = valid ? f2v[(int64_t)e * S + j] : 0.0;
             total += lifted ? m * g.edge_count[e] : m;
         }
-        const double logw = valid ? log_importance(g, s, v, d, s.particles[(int64_t)v * n + j]) : 0.0;
-        const bool uq = valid && s.uniq[(int64_t)v * n + j];
-        for (int k = 0; k < deg; ++k) {
-            const int e = g.var_edge[lo + k];
-            // second touch of the row comes out of L1/L2 (a register-array cache indexed by the runtime k made
-            // hipcc 7.2 emit an out-of-range s_set_gpr_idx store, so the rows are simply re-read)
-            const double m = valid ? f2v[(int64_t)e * S + j] : 0.0;
+        const double logw = valid ? log_importance(g, s, v, d, x, mu, sd, log_norm) : 0.0;
+        auto emit = [&](int e, double m) {
             // ground: sum over nb != f; lifted: own factor keeps count-1 copies (HLBP:182-191) -> total - m either way
             const double res = (total - m) + logw;
             if (nchunk == 1) {
@@ -137,6 +153,13 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp
             } else if (valid) {
                 v2f[(int64_t)e * n + j] = res;       // balanced below once every chunk is written
             }
+        };
+#pragma unroll
+        for (int k = 0; k < V2F_CACHE; ++k)
+            if (k < deg) emit(ecache[k], row[k]);
+        for (int k = V2F_CACHE; k < deg; ++k) {       // high-degree tail: second touch of the row comes out of L2
+            const int e = g.var_edge[lo + k];
+            emit(e, valid ? f2v[(int64_t)e * S + j] : 0.0);
         }
     }
     if (nchunk > 1) {
@@ -321,30 +344,53 @@ __global__ void __launch_bounds__(BLOCK) pbp_describe_kernel(lhvi_graph_t g, lhv
 struct ABK { double a, b, k, pad; };     // 32-byte LDS record: one ds_read_b128 + one ds_read_b64 per term
 
 template <bool HAS_C>
+__device__ __forceinline__ double fast_term(const ABK* __restrict__ sh, const double* __restrict__ tab, int j, double X1, double X2,
+                                            double C) {
+    double t = fma(sh[j].k, X2, fma(sh[j].b, X1, sh[j].a));
+    if (HAS_C) t += C;
+    return exp_core(t, tab);
+}
+
+// per-lane partner range [jb, je) (last partial round: the range is split across lane groups)
+template <bool HAS_C>
 __device__ __forceinline__ double fast_accumulate(const ABK* __restrict__ sh, const double* __restrict__ tab, int jb, int je,
                                                   double X1, double X2, double C) {
     double acc0 = 0.0, acc1 = 0.0;
     int j = jb;
     for (; j + 1 < je; j += 2) {           // two independent exp chains per iteration
-        double t0 = fma(sh[j].k, X2, fma(sh[j].b, X1, sh[j].a));
-        double t1 = fma(sh[j + 1].k, X2, fma(sh[j + 1].b, X1, sh[j + 1].a));
-        if (HAS_C) { t0 += C; t1 += C; }
-        acc0 += exp_core(t0, tab);
-        acc1 += exp_core(t1, tab);
+        acc0 += fast_term<HAS_C>(sh, tab, j, X1, X2, C);
+        acc1 += fast_term<HAS_C>(sh, tab, j + 1, X1, X2, C);
     }
-    if (j < je) {
-        double t0 = fma(sh[j].k, X2, fma(sh[j].b, X1, sh[j].a));
-        if (HAS_C) t0 += C;
-        acc0 += exp_core(t0, tab);
-    }
+    if (j < je) acc0 += fast_term<HAS_C>(sh, tab, j, X1, X2, C);
     return acc0 + acc1;
+}
+
+// full rounds: every lane walks the same partner range [0, jn) -> scalar loop control, LDS addresses with immediate
+// offsets, four independent exp chains per iteration
+template <bool HAS_C>
+__device__ __forceinline__ double fast_accumulate_uniform(const ABK* __restrict__ sh, const double* __restrict__ tab, int jn_,
+                                                          double X1, double X2, double C) {
+    const int jn = __builtin_amdgcn_readfirstlane(jn_);
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int j = 0;
+    for (; j + 4 <= jn; j += 4) {
+        acc0 += fast_term<HAS_C>(sh, tab, j, X1, X2, C);
+        acc1 += fast_term<HAS_C>(sh, tab, j + 1, X1, X2, C);
+        acc2 += fast_term<HAS_C>(sh, tab, j + 2, X1, X2, C);
+        acc3 += fast_term<HAS_C>(sh, tab, j + 3, X1, X2, C);
+    }
+    for (; j < jn; ++j) acc0 += fast_term<HAS_C>(sh, tab, j, X1, X2, C);
+    return (acc0 + acc1) + (acc2 + acc3);
 }
 
 // FAST edges: persistent kernel, one wavefront per edge at a time (each wave strides over the work list).
 // Partner coefficients are staged in wave-private LDS in tiles of 64; each lane owns one output point per round and
 // accumulates sum_j exp(.).  A final partial round splits the partner range over idle lanes and folds the partial
 // sums with shuffles, so n + T = 96 points on 64 lanes still keep every lane busy.
-__global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
+#ifndef LHVI_FAST_WAVES
+#define LHVI_FAST_WAVES 4
+#endif
+__global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
                                                             const double* __restrict__ v2f, double* __restrict__ f2v) {
     __shared__ ABK sh_all[BLOCK / WAVE][WAVE];
     __shared__ double sh_tab[64];
@@ -367,47 +413,77 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
         const bool partner_hidden = is_hidden(d.pval);
         double* out = f2v + (int64_t)d.e * S;
 
+        // issue every global load of this edge up front (one exposed round trip instead of one per phase):
+        // partner particle + message of the first tile, and this lane's output point of the first two rounds
+        double y0 = d.pval, m0 = 0.0;
+        if (partner_hidden && lane < nj) { y0 = s.old_particles[(int64_t)d.pv * n + lane]; m0 = v2f[(int64_t)d.pce * n + lane]; }
+        double xr[2] = {0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int rem = npts - 64 * r;
+            if (rem > 0) {
+                int lw = 6;
+                if (rem <= 32) { lw = 0; while ((1 << lw) < rem) ++lw; }
+                const int pl = lane & ((1 << lw) - 1), pp = 64 * r + pl;
+                if (pl < rem) xr[r] = pp < np ? s.particles[(int64_t)d.tv * n + pp] : g.dom_val[d.gb + pp - np];
+            }
+        }
+
+        auto stage = [&](int j0, int jn, double y, double m) {
+            LHVI_WAVE_SYNC();
+            if (lane < jn) {
+                ABK r;
+                if (d.cls == EDGE_FAST_CONT) {
+                    Quad2 q;
+                    quad2_of(d.kind, par, (d.kind == LHVI_POT_HYBRID_QUADRATIC) ? (int)y : 0, q);
+                    if (d.pos == 0) { r.a = (q.a11 * y + q.b1) * y + q.c + m; r.b = q.axy * y + q.b0; r.k = q.a00; }
+                    else            { r.a = (q.a00 * y + q.b0) * y + q.c + m; r.b = q.axy * y + q.b1; r.k = q.a11; }
+                } else { r.a = m; r.b = y; r.k = y * y; }
+                r.pad = 0.0;
+                sh[lane] = r;
+            }
+            LHVI_WAVE_SYNC();
+        };
+        const bool single_tile = nj <= 64;
+        if (single_tile) stage(0, nj, y0, m0);             // staged once per edge, reused by every round
+
         for (int p0 = 0; p0 < npts; p0 += 64) {
             const int rem = npts - p0;
-            int width = 64;
-            if (rem <= 32) { width = 1; while (width < rem) width <<= 1; }
-            const int split = 64 / width, sub = lane / width, pl = lane % width;
+            int lw = 6;                                   // log2(width): width = 64 for full rounds, else next pow2 >= rem
+            if (rem <= 32) { lw = 0; while ((1 << lw) < rem) ++lw; }
+            const int width = 1 << lw, split = 64 >> lw, sub = lane >> lw, pl = lane & (width - 1);
             const int p = p0 + pl;
             const bool valid = pl < rem;
+            double xv = 0.0;
+            if (p0 == 0) xv = xr[0];
+            else if (p0 == 64) xv = xr[1];
+            else if (valid) xv = p < np ? s.particles[(int64_t)d.tv * n + p] : g.dom_val[d.gb + p - np];
             double X1 = 0.0, X2 = 0.0, C = 0.0;
             if (valid) {
-                if (d.cls == EDGE_FAST_CONT) {
-                    X1 = p < np ? s.particles[(int64_t)d.tv * n + p] : g.dom_val[d.gb + p - np];
-                    X2 = X1 * X1;
-                } else {
+                if (d.cls == EDGE_FAST_CONT) { X1 = xv; X2 = xv * xv; }
+                else {
                     const int nst = (int)par[2];
-                    const int st = (int)s.particles[(int64_t)d.tv * n + p];   // HybridQuadratic indexes by the state value
+                    const int st = (int)xv;                                  // HybridQuadratic indexes by the state value
                     X2 = par[3 + st]; X1 = par[3 + nst + st]; C = par[3 + 2 * nst + st];
                 }
             }
             double acc = 0.0;
             for (int j0 = 0; j0 < nj; j0 += 64) {
                 const int jn = min(64, nj - j0);
-                LHVI_WAVE_SYNC();
-                if (lane < jn) {
-                    const int j = j0 + lane;
+                if (!single_tile) {
                     double y = d.pval, m = 0.0;
-                    if (partner_hidden) { y = s.old_particles[(int64_t)d.pv * n + j]; m = v2f[(int64_t)d.pce * n + j]; }
-                    ABK r;
-                    if (d.cls == EDGE_FAST_CONT) {
-                        Quad2 q;
-                        quad2_of(d.kind, par, (d.kind == LHVI_POT_HYBRID_QUADRATIC) ? (int)y : 0, q);
-                        if (d.pos == 0) { r.a = (q.a11 * y + q.b1) * y + q.c + m; r.b = q.axy * y + q.b0; r.k = q.a00; }
-                        else            { r.a = (q.a00 * y + q.b0) * y + q.c + m; r.b = q.axy * y + q.b1; r.k = q.a11; }
-                    } else { r.a = m; r.b = y; r.k = y * y; }
-                    r.pad = 0.0;
-                    sh[lane] = r;
+                    if (partner_hidden && lane < jn) { y = s.old_particles[(int64_t)d.pv * n + j0 + lane]; m = v2f[(int64_t)d.pce * n + j0 + lane]; }
+                    stage(j0, jn, y, m);
                 }
-                LHVI_WAVE_SYNC();
-                const int chunk = (jn + split - 1) / split;
-                const int jb = sub * chunk, je = min(jn, jb + chunk);
-                acc += (d.cls == EDGE_FAST_CONT) ? fast_accumulate<false>(sh, sh_tab, jb, je, X1, X2, 0.0)
-                                                 : fast_accumulate<true>(sh, sh_tab, jb, je, X1, X2, C);
+                if (split == 1) {
+                    acc += (d.cls == EDGE_FAST_CONT) ? fast_accumulate_uniform<false>(sh, sh_tab, jn, X1, X2, 0.0)
+                                                     : fast_accumulate_uniform<true>(sh, sh_tab, jn, X1, X2, C);
+                } else {
+                    const int chunk = (jn + split - 1) >> (6 - lw);
+                    const int jb = sub * chunk, je = min(jn, jb + chunk);
+                    acc += (d.cls == EDGE_FAST_CONT) ? fast_accumulate<false>(sh, sh_tab, jb, je, X1, X2, 0.0)
+                                                     : fast_accumulate<true>(sh, sh_tab, jb, je, X1, X2, C);
+                }
             }
             for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
             if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log(acc) : -700.0;
@@ -480,13 +556,16 @@ __device__ __forceinline__ void gdiv(double a0, double a1, double b0, double b1,
     mu = (a0 * (b1 + sig) - b0 * sig) / b1;
 }
 
-// update_proposal (EPBP:83-154; HLBP:100-171): one wavefront per continuous hidden variable
+// update_proposal (EPBP:83-154; HLBP:100-171): one wavefront per continuous hidden variable.  With T <= 32 integral
+// points the wave works on two incident edges at once (lanes 0-31 / 32-63), otherwise on one; the T-point moments are
+// shuffle reductions inside the lane group.  Each group accumulates the information-form sum of its edges; the groups
+// are folded at the end (summation order differs from the reference's edge order by rounding only).
 // ph_out != nullptr: sharded mode -- write the local information-form sums instead of q (lhvi_pbp_proposal_partial)
 __global__ void __launch_bounds__(BLOCK) pbp_proposal_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                             double* __restrict__ eta, double* __restrict__ q,
                                                             double* __restrict__ ph_out) {
     const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
     if (v >= g.V) return;
     const int d = g.var_dom[v];
     if (!is_hidden(g.var_value[v]) || !g.dom_cont[d]) return;
@@ -498,9 +577,14 @@ __global__ void __launch_bounds__(BLOCK) pbp_proposal_kernel(lhvi_graph_t g, lhv
     else for (int k = lo; k < hi; ++k) total += g.edge_count ? g.edge_count[g.var_edge[k]] : 1.0;
     const double min_sig = total * s.var_threshold;
     const double q0 = s.q[2 * v], q1 = s.q[2 * v + 1];
+    const int groups = T <= 32 ? 2 : 1;
+    const int width = 64 / groups;
+    const int grp = lane / width, tl = lane % width;
     double pm = 0.0, ps = 0.0;
-    for (int k = lo; k < hi; ++k) {
-        const int e = g.var_edge[k];
+    for (int k0 = lo; k0 < hi; k0 += groups) {
+        const int k = k0 + grp;
+        const bool live = k < hi;
+        const int e = live ? g.var_edge[k] : g.var_edge[k0];
         const double* msg = f2v + (int64_t)e * S + n;
         const double b0 = eta[2 * e], b1 = eta[2 * e + 1];
         const bool use_cav = (s.flags & LHVI_PBP_EP) && !(q1 >= b1);
@@ -508,26 +592,31 @@ __global__ void __launch_bounds__(BLOCK) pbp_proposal_kernel(lhvi_graph_t g, lhv
         if (use_cav) gdiv(q0, q1, b0, b1, c0, c1);
         const double csd = sqrt(c1);
         double z = 0.0, a = 0.0, b = 0.0;
-        for (int t = lane; t < T; t += 64) {
+        for (int t = tl; t < T; t += width) {
             const double xg = g.dom_val[gb + t];
             double w = exp(msg[t]);
             if (use_cav) w = w * norm_pdf_std(xg, c0, csd);
             z += w; a += w * xg; b += w * (xg * xg);
         }
-        z = wave_sum(z); a = wave_sum(a); b = wave_sum(b);
+        for (int off = width >> 1; off > 0; off >>= 1) {
+            z += __shfl_xor(z, off); a += __shfl_xor(a, off); b += __shfl_xor(b, off);
+        }
         double mu = a / z;
         double sig = b / z - mu * mu;
         if (use_cav) { const double m0 = mu, m1 = sig; gdiv(m0, m1, c0, c1, mu, sig); }
         if (0.0 < sig && sig < __builtin_huge_val()) {
             sig = fmax(sig, min_sig);
-            if (lane == 0) { eta[2 * e] = mu; eta[2 * e + 1] = sig; }
+            if (live && tl == 0) { eta[2 * e] = mu; eta[2 * e + 1] = sig; }
         } else {
             mu = b0; sig = b1;
         }
-        const double p = 1.0 / sig;
-        if (g.edge_count) { const double c = g.edge_count[e]; ps += p * c; pm += p * mu * c; }
-        else { ps += p; pm += p * mu; }
+        if (live) {
+            const double p = 1.0 / sig;
+            if (g.edge_count) { const double c = g.edge_count[e]; ps += p * c; pm += p * mu * c; }
+            else { ps += p; pm += p * mu; }
+        }
     }
+    if (groups == 2) { ps += __shfl_xor(ps, 32); pm += __shfl_xor(pm, 32); }
     if (ph_out) { if (lane == 0) { ph_out[2 * v] = ps; ph_out[2 * v + 1] = pm; } return; }
     ps = 1.0 / ps;
     if (lane == 0) { q[2 * v] = ps * pm; q[2 * v + 1] = ps; }
@@ -637,6 +726,36 @@ static int blocks_per_cu(const void* kernel) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
     return nb > 8 ? 8 : nb;
+}
+
+// generate_sample + the first-occurrence mask in one pass (n <= 64): one wavefront per variable, lane = particle;
+// the row never leaves registers and is broadcast lane by lane with v_readlane (exact equality test, like the dict keys)
+__global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g, lhvi_pbp_t s, const int64_t* __restrict__ gid,
+                                                                 uint64_t seed, uint32_t iteration, double* __restrict__ out,
+                                                                 uint8_t* __restrict__ uniq) {
+    const int lane = threadIdx.x & 63;
+    const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+    if (v >= g.V) return;
+    const int n = s.n;
+    const int cnt = s.np[v];
+    const int d = g.var_dom[v];
+    double x = 0.0;
+    if (lane < cnt) {
+        if (!g.dom_cont[d]) x = g.dom_val[g.dom_ptr[d] + lane];
+        else {
+            const double z = philox_normal(seed, gid ? (uint64_t)gid[v] : (uint64_t)v, (uint32_t)lane, iteration);
+            x = fmin(fmax(s.q[2 * v] + sqrt(s.q[2 * v + 1]) * z, g.dom_lo[d]), g.dom_hi[d]);
+        }
+        out[(int64_t)v * n + lane] = x;
+    }
+    const int xlo = __double2loint(x), xhi = __double2hiint(x);
+    int u = lane < cnt;
+    for (int k = 0; k < cnt - 1; ++k) {
+        const int klo = __builtin_amdgcn_readlane(xlo, k), khi = __builtin_amdgcn_readlane(xhi, k);
+        const double xk = __hiloint2double(khi, klo);
+        if (k < lane && xk == x) u = 0;
+    }
+    if (lane < n) uniq[(int64_t)v * n + lane] = (uint8_t)u;
 }
 
 static int validate_pbp(const lhvi_graph_t* g, const lhvi_pbp_t* s) {
@@ -771,6 +890,20 @@ int lhvi_pbp_resample(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int64_t*
     if (g->V == 0) return LHVI_OK;
     hipLaunchKernelGGL(pbp_resample_kernel, dim3(grid_for((int64_t)g->V * s->n)), dim3(BLOCK), 0, as_stream(stream), *g, *s,
                        var_gid, seed, iteration, particles_out);
+    return check_launch();
+}
+
+int lhvi_pbp_resample_uniq(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int64_t* var_gid, uint64_t seed, uint32_t iteration,
+                           double* particles_out, uint8_t* uniq_out, void* stream) {
+    if (int rc = validate_pbp(g, s)) return rc;
+    if (!particles_out || !uniq_out || !s->q) return LHVI_E_ARG;
+    if (g->V == 0) return LHVI_OK;
+    if (s->n > WAVE) {            // general n: two passes
+        if (int rc = lhvi_pbp_resample(g, s, var_gid, seed, iteration, particles_out, stream)) return rc;
+        return lhvi_pbp_uniq(g, s->n, particles_out, s->np, uniq_out, stream);
+    }
+    hipLaunchKernelGGL(pbp_resample_uniq_kernel, dim3(grid_for((int64_t)g->V * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s,
+                       var_gid, seed, iteration, particles_out, uniq_out);
     return check_launch();
 }
 

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'liblhvi.so')
+LIB_PATH = os.environ.get('LHVI_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'liblhvi.so')
 
 c_i32p = C.c_void_p
 c_f64p = C.c_void_p
@@ -89,6 +89,7 @@ SIGNATURES = {
     'lhvi_pbp_boundary_pack': (C.c_int, [_G, _S, _vp, _vp, _i32, _vp, _vp, _vp]),
     'lhvi_pbp_init': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp, _vp]),
     'lhvi_pbp_resample': (C.c_int, [_G, _S, _vp, _u64, _u32, _vp, _vp]),
+    'lhvi_pbp_resample_uniq': (C.c_int, [_G, _S, _vp, _u64, _u32, _vp, _vp, _vp]),
     'lhvi_pbp_belief_points': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     'lhvi_vi_workspace_bytes': (_sz, [_G, _VI]),
     'lhvi_vi_grad': (C.c_int, [_G, _P, _VI, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

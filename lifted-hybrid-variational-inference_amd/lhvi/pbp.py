@@ -64,6 +64,9 @@ class _ParticleSweep:
         cls = cls[:flat.E]
         self.fast_edges = torch.nonzero((cls == 1) | (cls == 2)).flatten().to(torch.int32)
         self.generic_edges = torch.nonzero(cls == 3).flatten().to(torch.int32)
+        pad = torch.zeros(1, dtype=torch.int32, device=dg.device)       # keeps the pointers non-null when a list is empty
+        self._fast_list = self.fast_edges if self.fast_edges.numel() else pad
+        self._generic_list = self.generic_edges if self.generic_edges.numel() else pad
         self.fast_desc = None
         nf = int(self.fast_edges.numel())
         if nf:
@@ -78,8 +81,8 @@ class _ParticleSweep:
         s.var_threshold, s.max_log_value = float(self.var_threshold), float(self.max_log_value)
         s.particles, s.old_particles = _abi.ptr(self.particles), _abi.ptr(self.old_particles)
         s.np, s.uniq, s.q = _abi.ptr(self.np_dev), _abi.ptr(self.uniq), _abi.ptr(self.q_dev)
-        s.fast_edges, s.n_fast = _abi.ptr(self.fast_edges), int(self.fast_edges.numel())
-        s.generic_edges, s.n_generic = _abi.ptr(self.generic_edges), int(self.generic_edges.numel())
+        s.fast_edges, s.n_fast = _abi.ptr(self._fast_list), int(self.fast_edges.numel())
+        s.generic_edges, s.n_generic = _abi.ptr(self._generic_list), int(self.generic_edges.numel())
         s.fast_desc = _abi.ptr(getattr(self, 'fast_desc', None))
         return s
 
@@ -115,8 +118,10 @@ class _ParticleSweep:
         if self.sampler == 'device':
             self.old_particles, self.particles = self.particles, self.old_particles
             s = self._struct()
-            _abi.check(l.lhvi_pbp_resample(self.dg.g, s, _abi.ptr(getattr(self, 'var_gid', None)),
-                                           int(self.seed), int(k), _abi.ptr(self.particles), st))
+            _abi.check(l.lhvi_pbp_resample_uniq(self.dg.g, s, _abi.ptr(getattr(self, 'var_gid', None)), int(self.seed),
+                                                int(k), _abi.ptr(self.particles), _abi.ptr(self.uniq), st))
+            self._views = {}
+            return
         elif callable(self.sampler):
             self._install(self.sampler(k, self.flat, self.q_dev.cpu().numpy()))
         else:
