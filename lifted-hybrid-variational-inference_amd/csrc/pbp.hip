@@ -244,27 +244,32 @@ __device__ double f2v_point_generic(const lhvi_graph_t& g, const lhvi_pots_t& po
     return res > 0.0 ? log(res) : -700.0;
 }
 
-// exp for the f2v inner loop (argument = log phi + log message).  Table-driven: t = (64 k + j) ln2/64 + r with
-// |r| <= ln2/128, exp(t) = 2^k * 2^(j/64) * exp(r); 2^(j/64) comes from a 64-entry LDS table, exp(r) from a degree-5
-// Taylor polynomial (remainder r^6/720 < 4e-17), the rounding to the nearest multiple uses the 1.5*2^52 magic
-// constant so that the integer n = 64k + j sits in the low word of the same register.  14 fp64 operations per call
-// against 22 for the ocml routine; measured max error 2 ulp (tests/test_gpu_pbp.py::test_device_exp_accuracy).
-// Valid for |t| < 2^31 / 92; anything below -745 underflows to 0 through ldexp, overflow saturates to +inf.
-__constant__ double EXP_TAB64[64] = {1, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199, 1.0905077326652577, 1.1023825833078409, 1.1143867425958924, 1.1265216186082418, 1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812, 1.189207115002721, 1.2021567314527031, 1.215247359980469, 1.22848053610687, 1.241857812073484, 1.2553807570246911, 1.2690509571917332, 1.2828700160787783, 1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.3396675240533029, 1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112, 1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647, 1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384, 1.5422108254079407, 1.5590044002378369, 1.5759808451078865, 1.593142151342267, 1.6104903319492543, 1.6280274218573478, 1.6457554781539649, 1.6636765803267364, 1.681792830507429, 1.7001063537185235, 1.7186192981224779, 1.7373338352737062, 1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989, 1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656, 1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.9784560263879509};
+// exp for the f2v inner loop (argument = log phi + log message).  Table-driven: t = n * (ln2/2048) + r with
+// |r| <= ln2/4096, exp(t) = 2^(n >> 11) * 2^((n & 2047)/2048) * exp(r).  The 2048-entry table of correctly rounded
+// 2^(j/2048) (16 KB) lives in LDS, exp(r) is the cubic Taylor polynomial (remainder r^4/24 < 4e-17), and the rounding to
+// the nearest multiple uses the 1.5*2^52 magic constant so that the integer n sits in the low word of the same register.
+// 12 fp64 operations per call against 22 for the ocml routine; measured max error 2 ulp
+// (tests/test_gpu_pbp.py::test_device_exp_accuracy).  Valid for |t| < 2^31 * ln2/2048 ~ 7e5; anything below -745
+// underflows to 0 through ldexp, overflow saturates to +inf.
+#include "exp_table.inc"
+constexpr int EXP_TAB_N = 1 << LHVI_EXP_TABLE_BITS;
 
-__device__ __forceinline__ double exp_core(double t, const double* __restrict__ tab /* LDS copy of EXP_TAB64 */) {
+__device__ __forceinline__ double exp_core(double t, const double* __restrict__ tab /* LDS copy of EXP_TAB */) {
     const double MAGIC = 6755399441055744.0;                 // 1.5 * 2^52
-    const double u = fma(t, 9.23324826168936567683e+01, MAGIC);
+    const double u = fma(t, LHVI_EXP_INV_STEP, MAGIC);
     const int nn = __double2loint(u);
     const double kd = u - MAGIC;
-    double r = fma(kd, -1.08304246932675596327e-02, t);      // ln2/64, high 32 bits (product exact)
-    r = fma(kd, -2.98158582698529328128e-12, r);
-    double p = fma(r, 8.3333333333333333333e-3, 4.1666666666666666667e-2);
-    p = fma(p, r, 1.6666666666666666667e-1);
-    p = fma(p, r, 0.5);
+    double r = fma(kd, -LHVI_EXP_STEP_HI, t);
+    r = fma(kd, -LHVI_EXP_STEP_LO, r);
+    double p = fma(r, 1.6666666666666666667e-1, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    return ldexp(tab[nn & 63] * p, nn >> 6);
+    return ldexp(tab[nn & (EXP_TAB_N - 1)] * p, nn >> LHVI_EXP_TABLE_BITS);
+}
+
+__device__ __forceinline__ void load_exp_table(double* __restrict__ tab) {
+    for (int i = threadIdx.x; i < EXP_TAB_N; i += blockDim.x) tab[i] = EXP_TAB[i];
+    __syncthreads();
 }
 
 // Edge classes of the f -> v half sweep.  FAST edges have a term of the form
@@ -366,21 +371,19 @@ __device__ __forceinline__ double fast_accumulate(const ABK* __restrict__ sh, co
 }
 
 // full rounds: every lane walks the same partner range [0, jn) -> scalar loop control, LDS addresses with immediate
-// offsets, four independent exp chains per iteration
+// offsets, two independent exp chains per iteration (four bought nothing at >= 4 waves/SIMD and cost a wave of occupancy)
 template <bool HAS_C>
 __device__ __forceinline__ double fast_accumulate_uniform(const ABK* __restrict__ sh, const double* __restrict__ tab, int jn_,
                                                           double X1, double X2, double C) {
     const int jn = __builtin_amdgcn_readfirstlane(jn_);
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    double acc0 = 0.0, acc1 = 0.0;
     int j = 0;
-    for (; j + 4 <= jn; j += 4) {
+    for (; j + 2 <= jn; j += 2) {
         acc0 += fast_term<HAS_C>(sh, tab, j, X1, X2, C);
         acc1 += fast_term<HAS_C>(sh, tab, j + 1, X1, X2, C);
-        acc2 += fast_term<HAS_C>(sh, tab, j + 2, X1, X2, C);
-        acc3 += fast_term<HAS_C>(sh, tab, j + 3, X1, X2, C);
     }
-    for (; j < jn; ++j) acc0 += fast_term<HAS_C>(sh, tab, j, X1, X2, C);
-    return (acc0 + acc1) + (acc2 + acc3);
+    if (j < jn) acc0 += fast_term<HAS_C>(sh, tab, j, X1, X2, C);
+    return acc0 + acc1;
 }
 
 // FAST edges: persistent kernel, one wavefront per edge at a time (each wave strides over the work list).
@@ -393,9 +396,8 @@ __device__ __forceinline__ double fast_accumulate_uniform(const ABK* __restrict_
 __global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
                                                             const double* __restrict__ v2f, double* __restrict__ f2v) {
     __shared__ ABK sh_all[BLOCK / WAVE][WAVE];
-    __shared__ double sh_tab[64];
-    if (threadIdx.x < 64) sh_tab[threadIdx.x] = EXP_TAB64[threadIdx.x];
-    __syncthreads();
+    __shared__ double sh_tab[EXP_TAB_N];
+    load_exp_table(sh_tab);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     ABK* sh = sh_all[wid];
@@ -468,7 +470,7 @@ __global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lh
                 }
             }
             double acc = 0.0;
-            for (int j0 = 0; j0 < nj; j0 += 64) {
+            for (int j0 = 0; j0 < ((s.flags & 16u) ? 0 : nj); j0 += 64) {     // flag 16: tuning aid, skips the term loop
                 const int jn = min(64, nj - j0);
                 if (!single_tile) {
                     double y = d.pval, m = 0.0;
@@ -493,9 +495,8 @@ __global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lh
 
 // test hook: y[i] = exp_core(x[i])
 __global__ void __launch_bounds__(BLOCK) debug_exp_kernel(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
-    __shared__ double sh_tab[64];
-    if (threadIdx.x < 64) sh_tab[threadIdx.x] = EXP_TAB64[threadIdx.x];
-    __syncthreads();
+    __shared__ double sh_tab[EXP_TAB_N];
+    load_exp_table(sh_tab);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n) y[i] = exp_core(x[i], sh_tab);
 }

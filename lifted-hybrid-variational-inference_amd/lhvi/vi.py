@@ -41,7 +41,10 @@ class _Variational:
 
     # ---- device state -------------------------------------------------------------------------
     def _setup(self, graph_like):
-        flat = flatten(graph_like, require_device_potentials=True)
+        self._setup_flat(flatten(graph_like, require_device_potentials=True))
+
+    def _setup_flat(self, flat):
+        """device state for a ready-made FlatGraph (large graphs built without Python objects)"""
         self.flat, self.dg = flat, _abi.DeviceGraph(flat)
         torch = _abi.require_gpu()
         disc = flat.var_hidden & ~flat.var_cont

@@ -1,0 +1,144 @@
+"""Secondary measurements for the other BASELINE.json configurations (cfg 1-5) and the Gaussian sweep roofline.
+Not the contract benchmark (that is bench.py); prints one JSON line per measurement."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
+import numpy as np, torch
+from lhvi import _abi, synth, lifting
+from lhvi.flat import flatten
+
+which = sys.argv[1:] or ['gauss', 'cfg2', 'cfg3', 'cfg5']
+
+
+def ev_time(fn, reps=5):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    fn()
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+
+def out(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+if 'gauss' in which:
+    # Gaussian sweep roofline: random pairwise Gaussian MRF, E = 10M edges (+ unary priors)
+    flat = synth.random_gaussian_mrf(V=2_000_000, deg=4, seed=0)
+    dg = _abi.DeviceGraph(flat)
+    f2v, v2f, mv = dg.empty(flat.E, 2), dg.empty(flat.E, 2), dg.empty(flat.V, 2)
+    l, st = _abi.lib(), _abi.stream_ptr()
+    _abi.check(l.lhvi_gabp_init(dg.g, _abi.ptr(f2v), _abi.ptr(v2f), st))
+    t_v = ev_time(lambda: _abi.check(l.lhvi_gabp_v2f(dg.g, _abi.ptr(f2v), _abi.ptr(v2f), st)))
+    t_f = ev_time(lambda: _abi.check(l.lhvi_gabp_f2v(dg.g, dg.p, _abi.ptr(v2f), _abi.ptr(f2v), st)))
+    bytes_sweep = 76.0 * flat.E
+    out(config='gaussian sweep, random pairwise MRF', edges=flat.E, v2f_ms=t_v, f2v_ms=t_f,
+        sweeps_per_s=1e3 / (t_v + t_f), algorithmic_GBs=bytes_sweep / ((t_v + t_f) * 1e-3) / 1e9,
+        hbm_frac=bytes_sweep / ((t_v + t_f) * 1e-3) / 8e12)
+    del dg, f2v, v2f, mv
+
+if 'cfg2' in which:
+    # cfg 2: RGM template C=100, B=50 (E=20 200), GaBP ground and GaLBP lifted, 20 sweeps
+    flat, sym, rv0, f0 = synth.rgm_flat(C=100, B=50, n_values=0, evidence_ratio=0.2, seed=0)
+    dg = _abi.DeviceGraph(flat)
+    f2v, v2f = dg.empty(flat.E, 2), dg.empty(flat.E, 2)
+    l, st = _abi.lib(), _abi.stream_ptr()
+    t = ev_time(lambda: _abi.check(l.lhvi_gabp_run(dg.g, dg.p, _abi.ptr(f2v), _abi.ptr(v2f), 20, st)))
+    out(config='cfg2 RGM C=100 B=50 ground GaBP', edges=flat.E, ms_20_sweeps=t, sweeps_per_s=20e3 / t)
+    t0 = time.perf_counter()
+    rvc, fc = lifting.refine_flat(flat, sym, rv0, f0)
+    torch.cuda.synchronize()
+    t_ref = time.perf_counter() - t0
+    lflat = lifting.lift_flat(flat, rvc, fc)
+    ldg = _abi.DeviceGraph(lflat)
+    lf2v, lv2f, lmv, mv = ldg.empty(lflat.E, 2), ldg.empty(lflat.E, 2), ldg.empty(lflat.V, 2), dg.empty(flat.V, 2)
+    t = ev_time(lambda: _abi.check(l.lhvi_gabp_run(ldg.g, ldg.p, _abi.ptr(lf2v), _abi.ptr(lv2f), 20, st)))
+    _abi.check(l.lhvi_gabp_marginals(ldg.g, _abi.ptr(lf2v), _abi.ptr(lmv), st))
+    _abi.check(l.lhvi_gabp_marginals(dg.g, _abi.ptr(f2v), _abi.ptr(mv), st))
+    hid = flat.var_hidden
+    err = float(np.abs(lmv.cpu().numpy()[rvc][hid, 0] - mv.cpu().numpy()[hid, 0]).max())
+    out(config='cfg2 RGM lifted GaLBP', ground_edges=flat.E, rv_clusters=int(rvc.max()) + 1, f_clusters=int(fc.max()) + 1,
+        lifted_edges=lflat.E, colour_passing_s=t_ref, ms_20_sweeps=t, max_abs_mu_diff_vs_ground=err)
+
+if 'cfg3' in which:
+    # cfg 3: paper-popularity HMLN (300 papers x 10 topics) through the object API, HybridLBP n=10, 10 sweeps
+    from lhvi.graph import Domain
+    from lhvi.relational import LV, Atom, ParamF, RelationalGraph
+    from lhvi.mln import MLNPotential, eq_op
+    from lhvi.pbp import HybridLBP
+    rng = np.random.default_rng(0)
+    P_, T_ = 300, 10
+    dom_b = Domain((0, 1))
+    dom_r = Domain((-15, 15), continuous=True, integral_points=np.linspace(0, 10, 32))
+    lvp, lvt = LV([f'p{i}' for i in range(P_)]), LV([f't{i}' for i in range(T_)])
+    atoms = (Atom(dom_b, (lvt, lvt), 'SameSession'), Atom(dom_b, (lvp, lvt), 'PaperIn'), Atom(dom_r, (lvt,), 'TopicPopularity'),
+             Atom(dom_r, (lvp,), 'PaperPopularity'))
+    pfs = (ParamF(MLNPotential(lambda x: eq_op(x[0], 1), w=0.3), nb=['PaperPopularity(p)']),
+           ParamF(MLNPotential(lambda x: x[0] * eq_op(x[1], x[2]), w=0.5), nb=['SameSession(t1,t2)', 'TopicPopularity(t1)', 'TopicPopularity(t2)'],
+                  constrain=lambda s: s['t1'] != s['t2']),
+           ParamF(MLNPotential(lambda x: x[0] * eq_op(x[1], x[2]), w=1), nb=['PaperIn(p,t)', 'PaperPopularity(p)', 'TopicPopularity(t)']))
+    rel = RelationalGraph(atoms, pfs)
+    g, table = rel.ground_graph()
+    data = {}
+    for i in rng.choice(P_, int(P_ * 0.7), replace=False):
+        data[('PaperPopularity', f'p{i}')] = float(rng.uniform(0, 10))
+    for i in rng.choice(T_, int(T_ * 0.7), replace=False):
+        data[('TopicPopularity', f't{i}')] = float(rng.uniform(0, 10))
+    for i in rng.choice(P_, int(P_ * 0.7), replace=False):
+        for j in rng.choice(T_, int(rng.integers(T_)), replace=False):
+            data[('PaperIn', f'p{i}', f't{j}')] = int(rng.integers(0, 2))
+    rel.add_evidence(data)
+    g.rvs, g.factors = sorted(g.rvs), sorted(g.factors)
+    g.init_nb()
+    E = sum(len(f.nb) for f in g.factors)
+    np.random.seed(0)
+    bp = HybridLBP(g, n=10, proposal_approximation='simple')
+    t0 = time.perf_counter()
+    bp.run(10)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out(config='cfg3 paper-popularity HMLN HybridLBP n=10 T=32 c2f=-1', rvs=len(g.rvs), factors=len(g.factors), edges=E,
+        rv_clusters=bp.g.num_rv_clusters, f_clusters=bp.g.num_factor_clusters, seconds_10_sweeps_incl_lifting=dt,
+        example_map=float(bp.map(table[('TopicPopularity', 't0')])))
+
+if 'cfg5' in which:
+    # cfg 5: RGM template at 10M ground edges, structured evidence; colour refinement on the device, then lifted VI
+    C, B = 2000, 1250
+    flat, sym, rv0, f0 = synth.rgm_flat(C=C, B=B, n_values=0, evidence_ratio=0.0, seed=0)
+    # structured evidence: markets and revenues observed from small value pools, a regular sub-lattice of losses observed
+    V = flat.V
+    val = np.full(V, np.nan)
+    market, loss, revenue = 1, 1 + C, 1 + C + C * B
+    c = np.arange(C); b = np.arange(B)
+    val[market + c[c % 4 == 0]] = (c[c % 4 == 0] // 4 % 5).astype(float) - 2.0
+    val[revenue + b[b % 5 == 0]] = (b[b % 5 == 0] // 5 % 4).astype(float) * 1.5
+    cc, bb = np.meshgrid(c[c % 8 == 1], b[b % 10 == 3], indexing='ij')
+    val[loss + (cc * B + bb).ravel()] = ((cc + bb) % 3).ravel().astype(float)
+    flat.var_value = val
+    rv0 = np.zeros(V, dtype=np.int32)
+    ob = ~np.isnan(val)
+    _, inv = np.unique(val[ob], return_inverse=True)
+    rv0[ob] = 1 + inv
+    t0 = time.perf_counter()
+    rvc, fc = lifting.refine_flat(flat, sym, rv0, f0)
+    torch.cuda.synchronize()
+    t_ref = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    lflat = lifting.lift_flat(flat, rvc, fc)
+    t_lift = time.perf_counter() - t0
+    from lhvi.vi import VarInference
+    vi = VarInference(None, 2, 3)
+    vi._setup_flat(lflat)
+    np.random.seed(0)
+    vi.init_param()
+    fe0 = vi.free_energy()
+    t0 = time.perf_counter()
+    vi.is_log, vi.log_fe = False, True
+    vi.alpha, vi.b1, vi.b2, vi.eps, vi.t = 0.1, 0.9, 0.999, 1e-8, 0
+    vi.ADAM_update(20)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out(config='cfg5 RGM 10M ground edges -> colour refinement -> LVI K=2 T=3', ground_edges=flat.E,
+        rv_clusters=int(rvc.max()) + 1, f_clusters=int(fc.max()) + 1, lifted_edges=lflat.E, colour_refinement_s=t_ref,
+        lift_flat_host_s=t_lift, adam_iterations_per_s=20 / dt, fe_start=fe0, fe_after_20=vi.free_energy())
