@@ -129,6 +129,7 @@ typedef struct lhvi_pbp {
     int32_t n_fast;
     const int32_t* generic_edges; /* [n_generic] all other edges with a hidden target */
     int32_t n_generic;
+    int32_t generic_pts_log2;   /* ceil(log2(max output points of a generic edge)), clamped to [0, 6]: lanes per edge */
     const void* fast_desc;      /* [n_fast][LHVI_PBP_DESC_BYTES] from lhvi_pbp_describe, or NULL (built on the fly) */
     /* edge-sharded runs only (all NULL on a single GPU): contributions of the variable's edges that live on other ranks */
     const int32_t* bslot;       /* [V] row of a boundary variable in remote_m / remote_ph, -1 for interior variables */

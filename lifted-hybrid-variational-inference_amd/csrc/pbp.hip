@@ -506,29 +506,38 @@ __global__ void __launch_bounds__(BLOCK) pbp_classify_kernel(lhvi_graph_t g, lhv
     if (e < g.E) cls[e] = (uint8_t)classify_edge(g, pots, e);
 }
 
-// GENERIC edges: one wavefront per edge, lane = output point, sequential joint loop per lane.
+// GENERIC edges: lane = output point, sequential joint loop per lane.  A wave serves 64 >> pts_log2 edges at once:
+// 2^pts_log2 lanes per edge (the host picks the smallest power of two that covers the largest point count in the work
+// list, so the 2-point messages of discrete x discrete table factors pack 32 edges into a wave); edges with more than
+// 64 points loop.
 __global__ void __launch_bounds__(BLOCK) pbp_f2v_generic_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
-                                                               const double* __restrict__ v2f, double* __restrict__ f2v) {
+                                                               const double* __restrict__ v2f, double* __restrict__ f2v,
+                                                               int pts_log2) {
     const int lane = threadIdx.x & 63;
+    const int per_wave = 64 >> pts_log2;                    // edges per wave
+    const int slot = lane >> pts_log2, pl = lane & ((1 << pts_log2) - 1);
     const int nitems = s.generic_edges ? s.n_generic : g.E;
+    const int ngroups = (nitems + per_wave - 1) / per_wave;
     const int nwaves = gridDim.x * (BLOCK / WAVE);
-  for (int item = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); item < nitems; item += nwaves) {
-    const int e = s.generic_edges ? s.generic_edges[item] : item;
-    if (classify_edge(g, pots, e) != EDGE_GENERIC) continue;
-    const int tv = g.edge_var[e];
-    const int n = s.n, S = s.n + s.T;
-    const int d = g.var_dom[tv];
-    const int np = s.np[tv];
-    const int gb = g.dom_ptr[d];
-    const int T = g.dom_cont[d] ? g.dom_ptr[d + 1] - gb : 0;
-    const int npts = np + T;
-    double* out = f2v + (int64_t)e * S;
-    for (int p = lane; p < npts; p += 64) {
-        const double x = p < np ? s.particles[(int64_t)tv * n + p] : g.dom_val[gb + p - np];
-        const int xi = p < np ? p : p - np;
-        out[p < np ? p : n + (p - np)] = f2v_point_generic(g, pots, s, v2f, s.old_particles, e, x, xi);
+    for (int grp = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); grp < ngroups; grp += nwaves) {
+        const int item = grp * per_wave + slot;
+        if (item >= nitems) continue;
+        const int e = s.generic_edges ? s.generic_edges[item] : item;
+        if (classify_edge(g, pots, e) != EDGE_GENERIC) continue;
+        const int tv = g.edge_var[e];
+        const int n = s.n, S = s.n + s.T;
+        const int d = g.var_dom[tv];
+        const int np = s.np[tv];
+        const int gb = g.dom_ptr[d];
+        const int T = g.dom_cont[d] ? g.dom_ptr[d + 1] - gb : 0;
+        const int npts = np + T;
+        double* out = f2v + (int64_t)e * S;
+        for (int p = pl; p < npts; p += (1 << pts_log2)) {
+            const double x = p < np ? s.particles[(int64_t)tv * n + p] : g.dom_val[gb + p - np];
+            const int xi = p < np ? p : p - np;
+            out[p < np ? p : n + (p - np)] = f2v_point_generic(g, pots, s, v2f, s.old_particles, e, x, xi);
+        }
     }
-  }
 }
 
 // belief_rv(x) = sum_f message_f_to_rv(x, f, rv, sample) at arbitrary points (EPBP:196-202; HLBP:313-317)
@@ -829,8 +838,13 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel);
     if (!(s->flags & LHVI_PBP_SKIP_FAST) && nfast > 0)
         hipLaunchKernelGGL(pbp_f2v_fast_kernel, dim3(min((nfast + 3) / 4, cus * fast_per_cu)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, *s, v2f, f2v);
-    if (!(s->flags & LHVI_PBP_SKIP_GENERIC) && ngen > 0)
-        hipLaunchKernelGGL(pbp_f2v_generic_kernel, dim3(min((ngen + 3) / 4, cus * gen_per_cu)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, *s, v2f, f2v);
+    if (!(s->flags & LHVI_PBP_SKIP_GENERIC) && ngen > 0) {
+        int pts_log2 = s->generic_edges ? s->generic_pts_log2 : 6;
+        if (pts_log2 < 0 || pts_log2 > 6) pts_log2 = 6;
+        const int groups = (ngen + (64 >> pts_log2) - 1) / (64 >> pts_log2);
+        hipLaunchKernelGGL(pbp_f2v_generic_kernel, dim3(min((groups + 3) / 4, cus * gen_per_cu)), dim3(BLOCK), 0, as_stream(stream), *g, *pots,
+                           *s, v2f, f2v, pts_log2);
+    }
     return check_launch();
 }
 

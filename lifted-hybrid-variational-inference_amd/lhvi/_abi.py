@@ -45,7 +45,7 @@ class PbpStruct(C.Structure):
         ('particles', C.c_void_p), ('old_particles', C.c_void_p), ('np', C.c_void_p), ('uniq', C.c_void_p),
         ('q', C.c_void_p),
         ('fast_edges', C.c_void_p), ('n_fast', C.c_int32), ('generic_edges', C.c_void_p), ('n_generic', C.c_int32),
-        ('fast_desc', C.c_void_p),
+        ('generic_pts_log2', C.c_int32), ('fast_desc', C.c_void_p),
         ('bslot', C.c_void_p), ('remote_m', C.c_void_p), ('remote_ph', C.c_void_p), ('var_degree', C.c_void_p),
     ]
 

@@ -67,6 +67,11 @@ class _ParticleSweep:
         pad = torch.zeros(1, dtype=torch.int32, device=dg.device)       # keeps the pointers non-null when a list is empty
         self._fast_list = self.fast_edges if self.fast_edges.numel() else pad
         self._generic_list = self.generic_edges if self.generic_edges.numel() else pad
+        # lanes per generic edge: smallest power of two covering its output points (particles + integral points)
+        ge = self.generic_edges.cpu().numpy()
+        tv = flat.edge_var[ge]
+        pts = self.np_host[tv] + np.where(flat.var_cont[tv], flat.var_nstates[tv], 0) if ge.size else np.zeros(0, dtype=int)
+        self.generic_pts_log2 = int(min(6, max(0, int(np.ceil(np.log2(max(int(pts.max()), 1)))) if ge.size else 6)))
         self.fast_desc = None
         nf = int(self.fast_edges.numel())
         if nf:
@@ -83,6 +88,7 @@ class _ParticleSweep:
         s.np, s.uniq, s.q = _abi.ptr(self.np_dev), _abi.ptr(self.uniq), _abi.ptr(self.q_dev)
         s.fast_edges, s.n_fast = _abi.ptr(self._fast_list), int(self.fast_edges.numel())
         s.generic_edges, s.n_generic = _abi.ptr(self._generic_list), int(self.generic_edges.numel())
+        s.generic_pts_log2 = int(getattr(self, 'generic_pts_log2', 6))
         s.fast_desc = _abi.ptr(getattr(self, 'fast_desc', None))
         return s
 
