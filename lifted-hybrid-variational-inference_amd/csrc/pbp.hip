@@ -346,43 +346,38 @@ __global__ void __launch_bounds__(BLOCK) pbp_describe_kernel(lhvi_graph_t g, lhv
 // wave-private LDS hand-off: DS operations of one wavefront execute in order, so only the compiler needs fencing
 #define LHVI_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-struct ABK { double a, b, k, pad; };     // 32-byte LDS record: one ds_read_b128 + one ds_read_b64 per term
+// LDS record of one partner particle: (a_j, b_j) as 16 bytes (one ds_read_b128 per term); the x^2 coefficient is
+//   MODE_CONST  the same for every j (continuous x continuous potentials): folded into the per-point constant K*x^2
+//   MODE_VARK   per j (HybridQuadratic with a discrete partner, nj = #states): read from a second LDS array
+//   MODE_DISC   b_j^2 (discrete target of a HybridQuadratic): t = a_j + b_j (X1 + b_j X2) + C
+enum { MODE_CONST = 0, MODE_VARK = 1, MODE_DISC = 2 };
+struct AB { double a, b; };
 
-template <bool HAS_C>
-__device__ __forceinline__ double fast_term(const ABK* __restrict__ sh, const double* __restrict__ tab, int j, double X1, double X2,
-                                            double C) {
-    double t = fma(sh[j].k, X2, fma(sh[j].b, X1, sh[j].a));
-    if (HAS_C) t += C;
+template <int MODE>
+__device__ __forceinline__ double fast_term(const AB* __restrict__ sh, const double* __restrict__ shk, const double* __restrict__ tab,
+                                            int j, double X1, double X2, double C) {
+    const AB r = sh[j];
+    double t;
+    if (MODE == MODE_CONST) t = fma(r.b, X1, r.a) + C;                 // C = k * x^2
+    else if (MODE == MODE_VARK) t = fma(shk[j], X2, fma(r.b, X1, r.a));
+    else t = fma(r.b, fma(r.b, X2, X1), r.a) + C;
     return exp_core(t, tab);
 }
 
-// per-lane partner range [jb, je) (last partial round: the range is split across lane groups)
-template <bool HAS_C>
-__device__ __forceinline__ double fast_accumulate(const ABK* __restrict__ sh, const double* __restrict__ tab, int jb, int je,
-                                                  double X1, double X2, double C) {
-    double acc0 = 0.0, acc1 = 0.0;
-    int j = jb;
-    for (; j + 1 < je; j += 2) {           // two independent exp chains per iteration
-        acc0 += fast_term<HAS_C>(sh, tab, j, X1, X2, C);
-        acc1 += fast_term<HAS_C>(sh, tab, j + 1, X1, X2, C);
-    }
-    if (j < je) acc0 += fast_term<HAS_C>(sh, tab, j, X1, X2, C);
-    return acc0 + acc1;
-}
-
-// full rounds: every lane walks the same partner range [0, jn) -> scalar loop control, LDS addresses with immediate
-// offsets, two independent exp chains per iteration (four bought nothing at >= 4 waves/SIMD and cost a wave of occupancy)
-template <bool HAS_C>
-__device__ __forceinline__ double fast_accumulate_uniform(const ABK* __restrict__ sh, const double* __restrict__ tab, int jn_,
-                                                          double X1, double X2, double C) {
+// every lane walks `jn` consecutive records starting at its own base (full rounds: the same base for all lanes; the
+// last partial round: one base per lane group) -> scalar loop control, LDS addresses with immediate offsets, two
+// independent exp chains per iteration (four bought nothing at >= 4 waves/SIMD and cost a wave of occupancy)
+template <int MODE>
+__device__ __forceinline__ double fast_accumulate_uniform(const AB* __restrict__ sh, const double* __restrict__ shk,
+                                                          const double* __restrict__ tab, int jn_, double X1, double X2, double C) {
     const int jn = __builtin_amdgcn_readfirstlane(jn_);
     double acc0 = 0.0, acc1 = 0.0;
     int j = 0;
     for (; j + 2 <= jn; j += 2) {
-        acc0 += fast_term<HAS_C>(sh, tab, j, X1, X2, C);
-        acc1 += fast_term<HAS_C>(sh, tab, j + 1, X1, X2, C);
+        acc0 += fast_term<MODE>(sh, shk, tab, j, X1, X2, C);
+        acc1 += fast_term<MODE>(sh, shk, tab, j + 1, X1, X2, C);
     }
-    if (j < jn) acc0 += fast_term<HAS_C>(sh, tab, j, X1, X2, C);
+    if (j < jn) acc0 += fast_term<MODE>(sh, shk, tab, j, X1, X2, C);
     return acc0 + acc1;
 }
 
@@ -395,12 +390,14 @@ __device__ __forceinline__ double fast_accumulate_uniform(const ABK* __restrict_
 #endif
 __global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
                                                             const double* __restrict__ v2f, double* __restrict__ f2v) {
-    __shared__ ABK sh_all[BLOCK / WAVE][WAVE];
+    __shared__ AB sh_all[BLOCK / WAVE][WAVE];
+    __shared__ double shk_all[BLOCK / WAVE][WAVE];
     __shared__ double sh_tab[EXP_TAB_N];
     load_exp_table(sh_tab);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    ABK* sh = sh_all[wid];
+    AB* sh = sh_all[wid];
+    double* shk = shk_all[wid];
     const FastDesc* __restrict__ descs = reinterpret_cast<const FastDesc*>(s.fast_desc);
     const int nitems = s.fast_edges ? s.n_fast : g.E;
     const int nwaves = gridDim.x * (BLOCK / WAVE);
@@ -431,18 +428,28 @@ __global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lh
             }
         }
 
+        // x^2 coefficient: constant per edge unless the partner is the discrete argument of a HybridQuadratic
+        const int mode = d.cls == EDGE_FAST_DISC ? MODE_DISC : (d.kind == LHVI_POT_HYBRID_QUADRATIC ? MODE_VARK : MODE_CONST);
+        double kconst = 0.0;
+        if (mode == MODE_CONST) { Quad2 q; quad2_of(d.kind, par, 0, q); kconst = d.pos == 0 ? q.a00 : q.a11; }
         auto stage = [&](int j0, int jn, double y, double m) {
             LHVI_WAVE_SYNC();
-            if (lane < jn) {
-                ABK r;
-                if (d.cls == EDGE_FAST_CONT) {
-                    Quad2 q;
-                    quad2_of(d.kind, par, (d.kind == LHVI_POT_HYBRID_QUADRATIC) ? (int)y : 0, q);
-                    if (d.pos == 0) { r.a = (q.a11 * y + q.b1) * y + q.c + m; r.b = q.axy * y + q.b0; r.k = q.a00; }
-                    else            { r.a = (q.a00 * y + q.b0) * y + q.c + m; r.b = q.axy * y + q.b1; r.k = q.a11; }
-                } else { r.a = m; r.b = y; r.k = y * y; }
-                r.pad = 0.0;
+            {
+                // records past the tile are padded with a term that underflows to exactly 0 (exp(-800)), so that every
+                // lane group can run the same uniform loop over ceil(jn / split) records without per-lane bounds
+                AB r;
+                r.a = -800.0; r.b = 0.0;
+                double kk = 0.0;
+                if (lane < jn) {
+                    if (d.cls == EDGE_FAST_CONT) {
+                        Quad2 q;
+                        quad2_of(d.kind, par, (d.kind == LHVI_POT_HYBRID_QUADRATIC) ? (int)y : 0, q);
+                        if (d.pos == 0) { r.a = (q.a11 * y + q.b1) * y + q.c + m; r.b = q.axy * y + q.b0; kk = q.a00; }
+                        else            { r.a = (q.a00 * y + q.b0) * y + q.c + m; r.b = q.axy * y + q.b1; kk = q.a11; }
+                    } else { r.a = m; r.b = y; }
+                }
                 sh[lane] = r;
+                if (mode == MODE_VARK) shk[lane] = kk;
             }
             LHVI_WAVE_SYNC();
         };
@@ -462,7 +469,7 @@ __global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lh
             else if (valid) xv = p < np ? s.particles[(int64_t)d.tv * n + p] : g.dom_val[d.gb + p - np];
             double X1 = 0.0, X2 = 0.0, C = 0.0;
             if (valid) {
-                if (d.cls == EDGE_FAST_CONT) { X1 = xv; X2 = xv * xv; }
+                if (d.cls == EDGE_FAST_CONT) { X1 = xv; X2 = xv * xv; C = kconst * X2; }
                 else {
                     const int nst = (int)par[2];
                     const int st = (int)xv;                                  // HybridQuadratic indexes by the state value
@@ -477,15 +484,13 @@ __global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lh
                     if (partner_hidden && lane < jn) { y = s.old_particles[(int64_t)d.pv * n + j0 + lane]; m = v2f[(int64_t)d.pce * n + j0 + lane]; }
                     stage(j0, jn, y, m);
                 }
-                if (split == 1) {
-                    acc += (d.cls == EDGE_FAST_CONT) ? fast_accumulate_uniform<false>(sh, sh_tab, jn, X1, X2, 0.0)
-                                                     : fast_accumulate_uniform<true>(sh, sh_tab, jn, X1, X2, C);
-                } else {
-                    const int chunk = (jn + split - 1) >> (6 - lw);
-                    const int jb = sub * chunk, je = min(jn, jb + chunk);
-                    acc += (d.cls == EDGE_FAST_CONT) ? fast_accumulate<false>(sh, sh_tab, jb, je, X1, X2, 0.0)
-                                                     : fast_accumulate<true>(sh, sh_tab, jb, je, X1, X2, C);
-                }
+                // lane group `sub` owns records [sub * chunk, (sub + 1) * chunk); split * chunk <= 64 always
+                const int chunk = (jn + split - 1) >> (6 - lw);
+                const AB* base = sh + sub * chunk;
+                const double* basek = shk + sub * chunk;
+                if (mode == MODE_CONST) acc += fast_accumulate_uniform<MODE_CONST>(base, basek, sh_tab, chunk, X1, X2, C);
+                else if (mode == MODE_VARK) acc += fast_accumulate_uniform<MODE_VARK>(base, basek, sh_tab, chunk, X1, X2, C);
+                else acc += fast_accumulate_uniform<MODE_DISC>(base, basek, sh_tab, chunk, X1, X2, C);
             }
             for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
             if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log(acc) : -700.0;
