@@ -36,6 +36,22 @@ def algorithmic_bytes_per_edge(n, T):
             'sweep': 32 * n + 16 * T + 16 + 12}
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/*_traffic.json, written by scripts/summarize_pmc.py with the gfx950 FETCH_SIZE correction); None if absent"""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json'))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if k.endswith(kernel):
+                best = v['hbm_bytes']
+    return best
+
+
 def cpu_baseline(n, T, seconds_target=15.0):
     """The CPU oracle (port of the reference's sweep, oracle/c/pbp_oracle.c) on a bounded sample of the same
     workload: same generator, smaller V; all host cores through OpenMP on the f2v half."""
@@ -149,7 +165,8 @@ def main():
                        'variables': V, 'particles': n, 'integral_points': T, 'proposal': 'simple',
                        'sharding': 'single GPU' if world == 1 else 'factor-partitioned edge shards, 1 all_to_all/sweep'},
             'roofline': {'bound': 'hbm', 'kernel': 'pbp_f2v_fast_kernel', 'achieved': f2v_gbs, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': f2v_gbs / HBM_PEAK_GBS, 'traffic': None,
+                         'unit': 'GB/s', 'frac': f2v_gbs / HBM_PEAK_GBS,
+                         'traffic': measured_traffic('pbp_f2v_fast_kernel') if world == 1 and args.edges == 10_000_000 else None,
                          'kernel_ms': f2v_ms, 'algorithmic_bytes_per_launch': f2v_bytes,
                          'note': 'f2v is fp64-VALU bound (arithmetic intensity ~140 flop/B); see fp64_valu',
                          'fp64_valu': {'achieved': f2v_tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
