@@ -1,0 +1,142 @@
+"""GPU edge cases through the C ABI: empty graph, everything observed, isolated / unary-only variables, high degree,
+ragged particle counts, argument validation."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def api():
+    from lhvi import _abi
+    _abi.require_gpu()
+    return _abi
+
+
+def _chain(n, observed=()):
+    from lhvi.graph import Domain, F, Graph, RV
+    from lhvi.potentials import LinearGaussianPotential, X2Potential
+    d = Domain((-10, 10), continuous=True, integral_points=np.linspace(-10, 10, 16))
+    rvs = [RV(d, 0.5 * i if i in observed else None) for i in range(n)]
+    fs = [F(LinearGaussianPotential(0.8, 1.0), [rvs[i], rvs[i + 1]]) for i in range(n - 1)]
+    fs += [F(X2Potential(1.0, 3.0), [rv]) for rv in rvs]
+    g = Graph()
+    g.rvs, g.factors = rvs, fs
+    g.init_nb()
+    return g, rvs
+
+
+def test_empty_graph_is_a_no_op(api):
+    from lhvi.graph import Graph
+    from lhvi.gabp import GaBP
+    g = Graph()
+    g.rvs, g.factors = [], []
+    bp = GaBP(g)
+    bp.run(3)
+    assert bp.message == {}
+
+
+def test_everything_observed(api):
+    from lhvi.gabp import GaBP
+    from lhvi.pbp import EPBP
+    g, rvs = _chain(4, observed=range(4))
+    bp = GaBP(g)
+    bp.run(5)
+    assert [bp.map(rv) for rv in rvs] == [rv.value for rv in rvs]
+    ep = EPBP(g, n=8, proposal_approximation='simple')
+    ep.run(3)
+    assert ep.map(rvs[2]) == rvs[2].value and ep.belief(rvs[2].value, rvs[2]) == 1
+
+
+def test_degree_one_hidden_variable_raises_like_the_reference(api):
+    from lhvi.graph import Domain, F, Graph, RV
+    from lhvi.potentials import LinearGaussianPotential
+    from lhvi.gabp import GaBP
+    d = Domain((-5, 5), continuous=True)
+    a, b = RV(d), RV(d, 1.0)
+    g = Graph()
+    g.rvs, g.factors = [a, b], [F(LinearGaussianPotential(1.0, 1.0), [a, b])]
+    g.init_nb()
+    with pytest.raises(ZeroDivisionError):
+        GaBP(g).run(3)
+
+
+def test_high_degree_hub_matches_oracle(api):
+    """star: one hub with 300 pairwise neighbours (exercises the O(deg) v2f path and long CSR rows)"""
+    from lhvi import synth, _abi
+    from lhvi.flat import build_flat
+    from lhvi.graph import Domain
+    from lhvi import potentials as P
+    from lhvi.pbp import EPBP
+    from oracle import oracle
+    D = 300
+    dom = Domain((-10, 10), continuous=True, integral_points=np.linspace(-10, 10, 32))
+    edge_var = np.stack([np.zeros(D, dtype=np.int32), np.arange(1, D + 1, dtype=np.int32)], axis=1).ravel()
+    edge_var = np.concatenate([edge_var, np.arange(D + 1, dtype=np.int32)])
+    fac_ptr = np.concatenate([np.arange(0, 2 * D + 1, 2), 2 * D + np.arange(1, D + 2)]).astype(np.int32)
+    specs = [(P.POT_LINEAR_GAUSSIAN, [0.7, 2.0]), (P.POT_X2, [1.0, 4.0])]
+    fac_pot = np.concatenate([np.zeros(D), np.ones(D + 1)]).astype(np.int32)
+    value = np.full(D + 1, np.nan)
+    value[5::7] = 1.0
+    flat = build_flat(fac_ptr, edge_var, fac_pot, specs, value, np.zeros(D + 1, dtype=np.int32), [dom])
+    n = 32
+    bp = EPBP(None, n=n, proposal_approximation='EP', sampler='device', seed=4)
+    bp._setup(None, flat=flat)
+    l, st = api.lib(), api.stream_ptr()
+    api.check(l.lhvi_pbp_init(bp.dg.g, bp._struct(), api.ptr(bp.eta), api.ptr(bp.q_dev), api.ptr(bp.f2v), api.ptr(bp.v2f), st))
+    bp._generate_sample()
+    o = oracle.PbpOracle(flat, n, ep=True, epbp=True, var_threshold=3)
+    o.init()
+    o.set_particles(bp.particles.cpu().numpy())
+    hid_e = flat.var_hidden[flat.edge_var]
+    for _ in range(2):
+        bp.sweep(last=False)
+        o.step_v2f(); o.step_proposal(); o.set_particles(bp.particles.cpu().numpy()); o.step_f2v()
+        np.testing.assert_allclose(bp.v2f.cpu().numpy()[hid_e][:, :n], o.v2f[hid_e], rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(bp.f2v.cpu().numpy()[hid_e], o.f2v[hid_e], rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(bp.q_dev.cpu().numpy()[flat.var_hidden], o.q[flat.var_hidden], rtol=1e-9, atol=1e-10)
+    # Gaussian sweep on the same star
+    dg = _abi.DeviceGraph(flat)
+    f2v, v2f, mv = dg.empty(flat.E, 2), dg.empty(flat.E, 2), dg.empty(flat.V, 2)
+    api.check(l.lhvi_gabp_run(dg.g, dg.p, api.ptr(f2v), api.ptr(v2f), 6, st))
+    api.check(l.lhvi_gabp_marginals(dg.g, api.ptr(f2v), api.ptr(mv), st))
+    _, _, omv = oracle.gabp_run(flat, 6)
+    np.testing.assert_allclose(mv.cpu().numpy(), omv, rtol=1e-11, atol=1e-12)
+
+
+def test_particle_counts_other_than_64(api):
+    """n = 5 (tiny), n = 100 (> one wavefront: chunked v2f, tiled f2v staging, generic uniq) vs the oracle"""
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    from oracle import oracle
+    flat = synth.hybrid_mrf_flat(V=400, deg=4, seed=9, T=20)
+    for n in (5, 100):
+        bp = EPBP(None, n=n, proposal_approximation='simple', sampler='device', seed=n)
+        bp._setup(None, flat=flat)
+        l, st = api.lib(), api.stream_ptr()
+        api.check(l.lhvi_pbp_init(bp.dg.g, bp._struct(), api.ptr(bp.eta), api.ptr(bp.q_dev), api.ptr(bp.f2v), api.ptr(bp.v2f), st))
+        bp._generate_sample()
+        o = oracle.PbpOracle(flat, n, ep=False, epbp=True, var_threshold=3)
+        o.init()
+        o.set_particles(bp.particles.cpu().numpy())
+        assert (o.uniq == bp.uniq.cpu().numpy()).all()
+        hid_e = flat.var_hidden[flat.edge_var]
+        for _ in range(2):
+            bp.sweep(last=False)
+            o.step_v2f(); o.step_proposal(); o.set_particles(bp.particles.cpu().numpy()); o.step_f2v()
+            np.testing.assert_allclose(bp.v2f.cpu().numpy()[hid_e], o.v2f[hid_e], rtol=1e-9, atol=1e-7)
+            np.testing.assert_allclose(bp.f2v.cpu().numpy()[hid_e], o.f2v[hid_e], rtol=1e-9, atol=1e-7)
+
+
+def test_argument_validation_returns_codes(api):
+    l = api.lib()
+    assert l.lhvi_gabp_v2f(None, None, None, None) == -1
+    g = api.GraphStruct()
+    g.V, g.E, g.F, g.nnz = 1, 2, 1, 2          # sizes without arrays
+    assert l.lhvi_gabp_v2f(C.byref(g), None, None, None) == -1
+    assert l.lhvi_adam_step(None, None, None, None, 10, 1, 0.1, 0.9, 0.999, 1e-8, 0, 0.0, None) == -1
+    assert l.lhvi_adam_step(None, None, None, None, 0, 1, 0.1, 0.9, 0.999, 1e-8, 0, 0.0, None) == 0
+    assert l.lhvi_softmax_rows(None, None, 4, 0, 0, None) == -1
+    assert l.lhvi_strerror(-3) == b'unsupported configuration'
