@@ -172,6 +172,10 @@ int lhvi_pbp_init(const lhvi_graph_t* g, const lhvi_pbp_t* s, double* eta, doubl
 /* generate_sample with a counter-based device RNG keyed (seed, variable gid, iteration, j): EPBP.py:61-70.
  * var_gid may be NULL (gid = local index).  Parity runs inject host particles instead. */
 int lhvi_pbp_resample(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int64_t* var_gid, uint64_t seed, uint32_t iteration, double* particles_out, void* stream);
+/* message_f_to_rv(x, f, rv, sample) for explicit (edge, point) pairs: qedge [nq] edge ids, x [nq][npts], out [nq][npts].
+ * HybridLBP.belief_rv_query (HLBP.py:313-317) sums these over a ground variable's factors. */
+int lhvi_pbp_edge_points(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f,
+                         int32_t nq, const int32_t* qedge, int32_t npts, const double* x, double* out, void* stream);
 /* lhvi_pbp_resample followed by lhvi_pbp_uniq on the fresh particles, fused into one pass when n <= 64 */
 int lhvi_pbp_resample_uniq(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int64_t* var_gid, uint64_t seed, uint32_t iteration,
                            double* particles_out, uint8_t* uniq_out, void* stream);

@@ -564,6 +564,19 @@ __global__ void __launch_bounds__(BLOCK) pbp_belief_kernel(lhvi_graph_t g, lhvi_
     out[i] = res;
 }
 
+// message_f_to_rv(x, f, rv, sample) for explicit (edge, point) pairs: the building block of belief_rv_query when the
+// caller walks a GROUND variable's factors itself (HLBP:313-317)
+__global__ void __launch_bounds__(BLOCK) pbp_edge_points_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
+                                                               const double* __restrict__ v2f, int nq,
+                                                               const int32_t* __restrict__ qedge, int npts,
+                                                               const double* __restrict__ x, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= (int64_t)nq * npts) return;
+    const int e = qedge[i / npts];
+    const double xv = x[i];
+    out[i] = f2v_point_generic(g, pots, s, v2f, s.particles, e, xv, state_index(g, g.edge_var[e], xv));
+}
+
 // ---------------------------------------------------------------------------------------------
 // gaussian_division (EPBP:43-47)
 __device__ __forceinline__ void gdiv(double a0, double a1, double b0, double b1, double& mu, double& sig) {
@@ -910,6 +923,17 @@ int lhvi_pbp_resample(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int64_t*
     if (g->V == 0) return LHVI_OK;
     hipLaunchKernelGGL(pbp_resample_kernel, dim3(grid_for((int64_t)g->V * s->n)), dim3(BLOCK), 0, as_stream(stream), *g, *s,
                        var_gid, seed, iteration, particles_out);
+    return check_launch();
+}
+
+int lhvi_pbp_edge_points(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f,
+                         int32_t nq, const int32_t* qedge, int32_t npts, const double* x, double* out, void* stream) {
+    if (int rc = validate_pbp(g, s)) return rc;
+    if (!pots || !v2f || nq < 0 || npts < 0) return LHVI_E_ARG;
+    if (nq == 0 || npts == 0) return LHVI_OK;
+    if (!qedge || !x || !out) return LHVI_E_ARG;
+    hipLaunchKernelGGL(pbp_edge_points_kernel, dim3(grid_for((int64_t)nq * npts)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, *s,
+                       v2f, nq, qedge, npts, x, out);
     return check_launch();
 }
 

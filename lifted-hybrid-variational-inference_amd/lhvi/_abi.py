@@ -89,6 +89,7 @@ SIGNATURES = {
     'lhvi_pbp_boundary_pack': (C.c_int, [_G, _S, _vp, _vp, _i32, _vp, _vp, _vp]),
     'lhvi_pbp_init': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp, _vp]),
     'lhvi_pbp_resample': (C.c_int, [_G, _S, _vp, _u64, _u32, _vp, _vp]),
+    'lhvi_pbp_edge_points': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     'lhvi_pbp_resample_uniq': (C.c_int, [_G, _S, _vp, _u64, _u32, _vp, _vp, _vp]),
     'lhvi_pbp_belief_points': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     'lhvi_vi_workspace_bytes': (_sz, [_G, _VI]),

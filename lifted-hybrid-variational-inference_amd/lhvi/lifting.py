@@ -136,6 +136,56 @@ def initial_colors(g, is_split_cont_evidence=True):
     return rv_color, f_color
 
 
+def split_evidence_colors(values, rv_color, k=2, iteration=10, epsilon=0.0, use_sqrt=True):
+    """``SuperRV.split_by_evidence`` (``CompressedGraphWithObs.py:78-130``) applied to every evidence cluster whose
+    spread exceeds ``epsilon`` -- ``sqrt(variance) > epsilon`` in ``CompressedGraph.split_evidence`` (CGWO:236-247),
+    ``variance > epsilon`` in ``HybridLBP.split_evidence`` (HLBP:250-266).  k-means over the distinct member values with
+    multiplicities; cluster 0 keeps the old colour, the others get fresh colours.
+
+    The reference seeds the centroids with the first k distinct values in the iteration order of a Python ``set`` of RV
+    objects, i.e. in an order that changes from run to run; here the order is the ground-variable order, which makes the
+    split deterministic (identical to the reference whenever the outcome does not depend on the seeding, e.g. when a
+    cluster holds at most k distinct values)."""
+    values = np.asarray(values, dtype=np.float64)
+    rv_color = np.array(rv_color, dtype=np.int32)
+    next_color = int(rv_color.max()) + 1 if rv_color.size else 0
+    observed = ~np.isnan(values)
+    for c in np.unique(rv_color[observed]):
+        members = np.flatnonzero((rv_color == c) & observed)
+        if members.size <= 1:
+            continue
+        vals = values[members]
+        var = np.var(vals)
+        if not ((np.sqrt(var) if use_sqrt else var) > epsilon):
+            continue
+        distinct, counts = [], {}
+        for v in vals.tolist():                     # insertion order = ground order
+            if v not in counts:
+                distinct.append(v)
+                counts[v] = 0
+            counts[v] += 1
+        kk = min(k, len(distinct))
+        if kk <= 1:
+            continue
+        centroids = np.array(distinct[:kk], dtype=np.float64)
+        table = np.zeros((kk, 2))
+        for _ in range(iteration):
+            for v in distinct:
+                idx = int(np.abs(centroids - v).argmin())
+                table[idx, 0] += v * counts[v]
+                table[idx, 1] += counts[v]
+            for idx in range(kk):
+                centroids[idx] = table[idx, 0] / table[idx, 1]
+            table.fill(0)
+        assign = np.array([int(np.abs(centroids - v).argmin()) for v in vals.tolist()])
+        for idx in range(1, kk):
+            sel = members[assign == idx]
+            if sel.size:
+                rv_color[sel] = next_color
+                next_color += 1
+    return rv_color
+
+
 class CompressedGraph:
     """Colour-passing compression of a ground ``Graph`` (``CompressedGraphWithObs.py:178-271``)."""
 
@@ -181,6 +231,22 @@ class CompressedGraph:
                 self._dev.pop(k, None)
         self.clustered_evidence = set()
         self._coarse_evidence = not is_split_cont_evidence
+
+    def split_evidence(self, k=2, iteration=10, epsilon=0, use_sqrt=True):
+        """k-means split of evidence clusters by value (CGWO:236-247; ``use_sqrt=False`` gives HLBP:250-266)"""
+        rv_color, f_color = self.colors()
+        values = np.array([np.nan if rv.value is None else float(rv.value) for rv in self.g.rvs], dtype=np.float64)
+        new = split_evidence_colors(values, rv_color, k, iteration, epsilon, use_sqrt)
+        self.set_colors(new, f_color)
+
+    def evidence_variances(self):
+        """np.var of the member values of every evidence cluster (``SuperRV.get_variance``)"""
+        rv_color, _ = self.colors()
+        values = np.array([np.nan if rv.value is None else float(rv.value) for rv in self.g.rvs], dtype=np.float64)
+        out = []
+        for c in np.unique(rv_color[~np.isnan(values)]):
+            out.append(float(np.var(values[(rv_color == c) & ~np.isnan(values)])))
+        return out
 
     def split_factors(self):
         d = self._upload_colors()

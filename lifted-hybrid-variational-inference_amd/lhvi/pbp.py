@@ -373,31 +373,91 @@ class HybridLBP(_ParticleSweep):
         self.query_cache = dict()
 
     def run(self, iteration=10, log_enable=False, c2f=-1):
-        if c2f != -1:
-            raise NotImplementedError('coarse-to-fine lifting (c2f >= 0) is a "next" row of the scope table '
-                                      '(SURVEY.md section 8(f) rank 2); only c2f=-1 runs on the GPU so far')
-        self.g.init_cluster(True)
-        prev = -1
-        while self.g.num_rv_clusters != prev:         # HLBP:433-438
-            prev = self.g.num_rv_clusters
-            self.g.split_factors()
-            self.g.split_rvs()
-        self._setup(self.g)
+        """``HybridLBP.run`` (HLBP:430-536).  ``c2f == -1``: colour passing to the stable partition, then the sweeps.
+        ``c2f >= 0``: coarse start (continuous evidence merged regardless of value), evidence clusters are split by
+        k-means while their variance exceeds a shrinking threshold, rv / factor clusters are refined once per sweep and
+        every new cluster inherits the messages, sites, proposal and particles of the cluster it came from."""
         self.query_cache = dict()
-        self._run_sweeps(iteration)
-        self.g.split_factors()                          # HLBP:536 (a no-op on a stable partition)
+        if c2f == -1:
+            self.g.init_cluster(True)
+            prev = -1
+            while self.g.num_rv_clusters != prev:         # HLBP:433-438
+                prev = self.g.num_rv_clusters
+                self.g.split_factors()
+                self.g.split_rvs()
+            self._setup(self.g)
+            self._run_sweeps(iteration)
+            self.g.split_factors()                          # HLBP:536 (a no-op on a stable partition)
+            return
+        from . import c2f as _c2f
+        engine = _DeviceEngine(self)
+
+        def draw(k, flat, q_host):
+            if callable(self.sampler):
+                return self.sampler(k, flat, q_host)
+            if self.sampler == 'device':
+                return None                       # engine.install draws on the device
+            out = np.zeros((flat.V, self.n))      # the reference's stream: standard_normal in cluster order (HLBP:75-87)
+            for v in range(flat.V):
+                if flat.var_hidden[v] and flat.var_cont[v]:
+                    dmn = flat.var_dom[v]
+                    z = np.random.standard_normal(self.n)
+                    out[v] = np.clip(z * sqrt(q_host[v, 1]) + q_host[v, 0], flat.dom_lo[dmn], flat.dom_hi[dmn])
+            return out
+
+        refiner = _c2f.DeviceRefiner(self.g.g)
+        st, flat, cg, rvc, fc, history = _c2f.run_c2f(self.g.g, engine, refiner, iteration, c2f, self.k_mean_k,
+                                                      self.k_mean_iteration, draw)
+        self.c2f_history = history
+        self.g = cg
+        # adopt the final factor-side state for the queries
+        self.__dict__.update({k: v for k, v in st.__dict__.items()})
+        self._views = {}
 
     def _var_of(self, ground_rv):
-        return self.flat.var_index[ground_rv.cluster]
+        return ground_rv                      # queries walk the GROUND rv's factors, like belief_rv_query (HLBP:313-317)
+
+    def _ground_edges(self, ground_rv):
+        """(lifted edge id, multiplicity) of every ground factor of `ground_rv`: edge = (f.cluster, position of the rv)"""
+        flat, acc = self.flat, {}
+        for f in ground_rv.nb:
+            fi = flat.fac_index[f.cluster]
+            pos = next(i for i, r in enumerate(f.nb) if r is ground_rv)
+            e = int(flat.edge_canon[flat.fac_ptr[fi] + pos])
+            acc[e] = acc.get(e, 0) + 1
+        return acc
+
+    def _belief_rv_points(self, ground_rv, xs):
+        """belief_rv_query(x, rv) = sum over the ground rv's factors f of message_f_to_rv(x, f.cluster, rv.cluster)"""
+        torch = _abi.require_gpu()
+        xs = np.atleast_1d(np.asarray(xs, dtype=np.float64))
+        acc = self._ground_edges(ground_rv)
+        edges = np.array(list(acc), dtype=np.int32)
+        mult = np.array([acc[e] for e in acc], dtype=np.float64)
+        x = _abi.to_dev(np.tile(xs, (edges.size, 1)))
+        out = torch.empty_like(x)
+        _abi.check(_abi.lib().lhvi_pbp_edge_points(self.dg.g, self.dg.p, self._struct(), _abi.ptr(self.v2f), int(edges.size),
+                                                   _abi.ptr(_abi.to_dev(edges)), int(xs.size), _abi.ptr(x), _abi.ptr(out),
+                                                   _abi.stream_ptr()))
+        return (out.cpu().numpy() * mult[:, None]).sum(axis=0)
+
+    def belief_rv_batch(self, rvs, xs):
+        xs = np.asarray(xs, dtype=np.float64).reshape(len(rvs), -1)
+        return np.stack([self._belief_rv_points(rv, x) for rv, x in zip(rvs, xs)])
 
     def belief_rv_query(self, x, rv, sample=None):
-        return float(self._belief_rv_points(self._var_of(rv), [x])[0])
+        return float(self._belief_rv_points(rv, [x])[0])
+
+    @property
+    def q(self):
+        flat, Q = self.flat, self._host('q_dev')
+        return {rv: (float(Q[v, 0]), float(Q[v, 1])) for v, rv in enumerate(flat.rvs) if flat.var_hidden[v] and flat.var_cont[v]}
 
     def belief(self, x, rv, inf_integral=False):
         """HybridLBP.belief (HLBP:343-382): 20-point trapezoid normaliser, cached per cluster"""
         if rv.value is not None:
             return 1 if x == rv.value else 0
-        sig, v = rv.cluster, self._var_of(rv)
+        sig, v = (rv.cluster, frozenset(self._ground_edges(rv).items())), self._var_of(rv)
         if rv.domain.continuous:
             if sig not in self.query_cache:
                 self.query_cache[sig] = self._log_area(v, rv.domain.values[0], rv.domain.values[1], 20)
@@ -428,3 +488,58 @@ class HybridLBP(_ParticleSweep):
                              rv.domain.values[0], rv.domain.values[1], disp=False)
         vals = list(rv.domain.values)
         return vals[int(np.argmax(self._belief_rv_points(v, vals)))]
+
+
+class _DeviceEngine:
+    """lhvi.c2f engine backed by the HIP kernels: every state is a solver-shaped object holding one lifted graph's arrays"""
+
+    _names = {'q': 'q_dev'}
+
+    def __init__(self, owner):
+        self.owner = owner
+        self.draws = 0
+
+    def make(self, flat):
+        o = self.owner
+        st = HybridLBP.__new__(HybridLBP)
+        st.n, st.proposal_approximation, st.sampler, st.seed = o.n, o.proposal_approximation, o.sampler, o.seed
+        st.query_cache = dict()
+        st._setup(None, flat=flat)
+        return st
+
+    def get(self, st, name):
+        return getattr(st, self._names.get(name, name))
+
+    def set(self, st, name, value):
+        setattr(st, self._names.get(name, name), value)
+
+    def init(self, st):
+        _abi.check(_abi.lib().lhvi_pbp_init(st.dg.g, st._struct(), _abi.ptr(st.eta), _abi.ptr(st.q_dev), _abi.ptr(st.f2v),
+                                            _abi.ptr(st.v2f), _abi.stream_ptr()))
+
+    def v2f(self, st):
+        _abi.check(_abi.lib().lhvi_pbp_v2f(st.dg.g, st._struct(), _abi.ptr(st.f2v), _abi.ptr(st.v2f), _abi.stream_ptr()))
+
+    def proposal(self, st):
+        _abi.check(_abi.lib().lhvi_pbp_proposal(st.dg.g, st._struct(), _abi.ptr(st.f2v), _abi.ptr(st.eta), _abi.ptr(st.q_dev),
+                                                _abi.stream_ptr()))
+
+    def f2v(self, st):
+        _abi.check(_abi.lib().lhvi_pbp_f2v(st.dg.g, st.dg.p, st._struct(), _abi.ptr(st.v2f), _abi.ptr(st.f2v), _abi.stream_ptr()))
+
+    def install(self, st, host_particles):
+        st._draws = self.draws
+        self.draws += 1
+        if host_particles is None:
+            st.sampler = 'device'
+        else:
+            st.sampler = lambda kk, flat, q: host_particles
+        st._generate_sample()
+
+    @staticmethod
+    def host(t):
+        return t.cpu().numpy()
+
+    @staticmethod
+    def gather(t, index):
+        return t.index_select(0, _abi.to_dev(np.asarray(index, dtype=np.int64))).contiguous()

@@ -177,6 +177,17 @@ void oracle_pbp_belief_points(const ograph_t *g, const opbp_t *s, const double *
     }
 }
 
+/* message_f_to_rv(x, f, rv, sample) for explicit (edge, point) pairs (HLBP.belief_rv_query sums these, HLBP:313-317) */
+void oracle_pbp_edge_points(const ograph_t *g, const opbp_t *s, const double *v2f, int nq, const int32_t *qedge,
+                            int npts, const double *x, double *out) {
+    for (int qi = 0; qi < nq; ++qi)
+        for (int p = 0; p < npts; ++p) {
+            double xv = x[(long)qi * npts + p];
+            int e = qedge[qi];
+            out[(long)qi * npts + p] = f2v_point(g, s, v2f, s->particles, e, xv, state_index(g, g->edge_var[e], xv));
+        }
+}
+
 /* gaussian_division (EPBP:43-47) */
 static void gdiv(double a0, double a1, double b0, double b1, double *mu, double *sig) {
     *sig = a1 * b1 / (b1 - a1);

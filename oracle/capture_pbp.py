@@ -145,6 +145,35 @@ def model_hybrid_small(cg, discrete_evidence=True):
     return g
 
 
+def model_rgm_c2f(cg, C=6, B=4):
+    """RGM template with continuous evidence drawn from exactly two distinct values: the coarse start
+    (init_cluster(False)) merges all of it, the first k-means split (k=2) separates the two values unambiguously, and
+    the per-iteration split_rvs / split_factors then refine the structure while messages are inherited"""
+    RG, RP = cg.RG, cg.RP
+    d = RG.Domain((-30, 30), continuous=True, integral_points=np.linspace(-30, 30, 24))
+    p1 = RP.GaussianPotential([0., 0.], [[10., -7.], [-7., 10.]])
+    p2 = RP.GaussianPotential([0., 0.], [[10., 5.], [5., 10.]])
+    p3 = RP.GaussianPotential([0., 0.], [[10., 7.], [7., 10.]])
+    rec = RG.RV(d)
+    market = [RG.RV(d) for _ in range(C)]
+    loss = [[RG.RV(d) for _ in range(B)] for _ in range(C)]
+    revenue = [RG.RV(d) for _ in range(B)]
+    market[0].value = 3.0
+    market[1].value = -2.0
+    market[4].value = 3.0
+    for c, b, v in ((2, 1, -2.0), (3, 1, -2.0), (5, 0, 3.0), (2, 3, 3.0), (0, 2, -2.0)):
+        loss[c][b].value = v
+    revenue[3].value = -2.0
+    fs = [RG.F(p1, [rec, m]) for m in market]
+    fs += [RG.F(p2, [market[c], loss[c][b]]) for c in range(C) for b in range(B)]
+    fs += [RG.F(p3, [loss[c][b], revenue[b]]) for c in range(C) for b in range(B)]
+    g = RG.Graph()
+    g.rvs = [rec] + market + [x for row in loss for x in row] + revenue
+    g.factors = fs
+    g.init_nb()
+    return g
+
+
 def model_rgm_small(cg, C=4, B=3, seed=5):
     """the RGM template at toy size, evidence from two distinct values so lifting has something to merge"""
     RG, RP = cg.RG, cg.RP
@@ -218,21 +247,58 @@ def capture_epbp(cg, name, g, n, its, approx, seed):
     print('wrote', path, os.path.getsize(path), 'bytes')
 
 
-def capture_hlbp(cg, name, g, n, its, approx, seed):
+def capture_hlbp(cg, name, g, n, its, approx, seed, c2f=-1):
     import HybridLBPLogVersion as RH
     np.random.seed(seed)
     bp = RH.HybridLBP(g, n=n, proposal_approximation=approx)
-    drawn = []
+    drawn, labels, draw_q, draw_msg, draw_eta = [], [], [], [], []
     orig = bp.generate_sample
 
     def wrapped():
         new = orig()
-        drawn.append(new)
+        # the draw, broadcast to the ground rvs NOW (cluster objects are reused and shrink when they split later)
+        sk = np.full((len(g.rvs), n), np.nan)
+        member = {}
+        for c, smp in new.items():
+            for rv in c.rvs:
+                member[id(rv)] = smp
+        for i, rv in enumerate(g.rvs):
+            if id(rv) in member:
+                arr = np.asarray(member[id(rv)], dtype=float)
+                sk[i, :len(arr)] = arr
+        drawn.append(sk)
+        # partition at the moment of the draw (coarse-to-fine runs refine it between draws)
+        labels.append([cg.partition_labels(g.rvs, bp.g.rvs, 'rvs'), cg.partition_labels(g.factors, bp.g.factors, 'factors')])
+        qk = np.full((len(g.rvs), 2), np.nan)          # proposals at the moment of the draw, per ground rv
+        member_q = {}
+        for c, val in bp.q.items():
+            for rv in c.rvs:
+                member_q[id(rv)] = val
+        for i, rv in enumerate(g.rvs):
+            if id(rv) in member_q:
+                qk[i] = member_q[id(rv)]
+        draw_q.append(qk)
+        # per ground rv and per ground factor of it: f->rv log message at the integral points and the site (eta)
+        T = max(len(rv.domain.integral_points) for rv in g.rvs if rv.domain.continuous)
+        deg = max(len(rv.nb) for rv in g.rvs)
+        mg = np.full((len(g.rvs), deg, T), np.nan)
+        et = np.full((len(g.rvs), deg, 2), np.nan)
+        for i, rv in enumerate(g.rvs):
+            if rv.value is not None or not rv.domain.continuous:
+                continue
+            for s_, f in enumerate(rv.nb):
+                key = (f.cluster, rv.cluster)
+                if key in bp.message:
+                    mg[i, s_] = [bp.message[key][x] for x in rv.domain.integral_points]
+                if key in bp.eta_message:
+                    et[i, s_] = bp.eta_message[key]
+        draw_msg.append(mg)
+        draw_eta.append(et)
         return new
 
     bp.generate_sample = wrapped
     with cg.quiet():
-        bp.run(its, c2f=-1)
+        bp.run(its, c2f=c2f)
     bp.generate_sample = orig
     rv_label = cg.partition_labels(g.rvs, bp.g.rvs, 'rvs')
     f_label = cg.partition_labels(g.factors, bp.g.factors, 'factors')
@@ -259,16 +325,13 @@ def capture_hlbp(cg, name, g, n, its, approx, seed):
             sample[i, :len(s)] = s
         if c in bp.q:
             q[i] = bp.q[c]
-    samples = np.full((len(drawn), V, n), np.nan)     # every draw, broadcast to the ground rvs of each cluster
-    for k, d in enumerate(drawn):
-        for i, rv in enumerate(g.rvs):
-            if rv.cluster in d:
-                sk = np.asarray(d[rv.cluster], dtype=float)
-                samples[k, i, :len(sk)] = sk
-    rec = dict(samples=samples, rv_label=np.array(rv_label), f_label=np.array(f_label), query_x=np.array(xs), query_logb=np.array(lb),
+    samples = np.array(drawn)                         # every draw, broadcast to the ground rvs at draw time
+    rec = dict(samples=samples, draw_q=np.array(draw_q), draw_f2v_grid=np.array(draw_msg), draw_eta=np.array(draw_eta),
+               draw_rv_labels=np.array([l[0] for l in labels]), draw_f_labels=np.array([l[1] for l in labels]),
+               rv_label=np.array(rv_label), f_label=np.array(f_label), query_x=np.array(xs), query_logb=np.array(lb),
                map=np.array(mp), belief_mid=np.array(bel), final_sample=sample, final_q=q,
                meta=json.dumps({'model': cg.modelio.dump_model(g), 'n': n, 'iterations': its, 'approx': approx,
-                                'seed': seed, 'solver': 'HybridLBP'}))
+                                'seed': seed, 'solver': 'HybridLBP', 'c2f': c2f}))
     path = os.path.join(cg.OUT, 'pbp_%s.npz' % name)
     np.savez_compressed(path, **rec)
     print('wrote', path, os.path.getsize(path), 'bytes')
@@ -283,3 +346,5 @@ def capture_pbp(cg):
     capture_hlbp(cg, 'hlbp_rgm_small', model_rgm_small(cg), 10, 4, 'EP', 21)
     capture_hlbp(cg, 'hlbp_hybrid', model_hybrid_small(cg, False), 10, 3, 'simple', 22)
     capture_hlbp(cg, 'hlbp_kalman_full', cg.model_kalman(3, 5, 1, False), 12, 4, 'EP', 23)
+    capture_hlbp(cg, 'hlbp_c2f_rgm', model_rgm_c2f(cg), 10, 5, 'EP', 24, c2f=0)
+    capture_hlbp(cg, 'hlbp_c2f_rgm_simple', model_rgm_c2f(cg), 12, 4, 'simple', 25, c2f=0)

@@ -223,6 +223,14 @@ class PbpOracle:
                                        _p(qvar), C.c_int(x.shape[1]), _p(x), _p(out))
         return out
 
+    def edge_points(self, qedge, x):
+        qedge = np.ascontiguousarray(qedge, dtype=np.int32)
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(qedge.size, -1)
+        out = np.zeros_like(x)
+        lib().oracle_pbp_edge_points(C.byref(self.hg.g), C.byref(self._s()), _p(self.v2f), C.c_int(qedge.size), _p(qedge),
+                                     C.c_int(x.shape[1]), _p(x), _p(out))
+        return out
+
     def run(self, iterations, samples, on_iteration=None):
         """EPBP.run / HybridLBP.run(c2f=-1) with injected samples: samples[0] is the initial draw, samples[i+1] the
         draw of iteration i (EPBP.py:225-289)."""

@@ -178,3 +178,39 @@ def test_device_exp_accuracy(api):
     ulp = np.abs(y[fin] - want[fin]) / np.spacing(want[fin])
     assert ulp.max() <= 2.0, ulp.max()
     assert (y[x < -760] == 0).all() and np.isinf(y[x > 709.9]).all()
+
+
+@pytest.mark.parametrize('name', ['hlbp_c2f_rgm', 'hlbp_c2f_rgm_simple'])
+def test_hlbp_coarse_to_fine_matches_reference(api, golden_dir, name):
+    """c2f=0: coarse start, per-sweep refinement with message inheritance; partitions and proposals at every draw and the
+    final log-beliefs / MAPs / normalised beliefs against the reference (its particles injected per cluster)"""
+    from lhvi.pbp import HybridLBP
+    from oracle import oracle
+    z, meta = load_npz(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    samples = z['samples']
+    q_at_draw = []
+
+    def inject(k, flat, q):
+        q_at_draw.append(q.copy())
+        return samples[k][flat.rep_ground]
+
+    bp = HybridLBP(g, n=meta['n'], proposal_approximation=meta['approx'], sampler=inject)
+    bp.run(meta['iterations'], c2f=meta['c2f'])
+    hist = bp.c2f_history
+    assert len(hist) == z['draw_rv_labels'].shape[0]
+    for k, (r, f) in enumerate(hist):
+        assert oracle.canonical_labels(r) == z['draw_rv_labels'][k].tolist(), 'rv partition at draw %d' % k     # exact
+        assert oracle.canonical_labels(f) == z['draw_f_labels'][k].tolist(), 'factor partition at draw %d' % k
+        want = z['draw_q'][k]
+        m = ~np.isnan(want[:, 0])
+        np.testing.assert_allclose(q_at_draw[k][r][m], want[m], rtol=1e-8, atol=1e-10, err_msg='q at draw %d' % k)
+    rv_color, f_color = bp.g.colors()
+    assert oracle.canonical_labels(rv_color) == z['rv_label'].tolist()
+    assert oracle.canonical_labels(f_color) == z['f_label'].tolist()
+    hid = [i for i, rv in enumerate(rvs) if rv.value is None]
+    got = bp.belief_rv_batch([rvs[i] for i in hid], z['query_x'][hid])
+    np.testing.assert_allclose(got, z['query_logb'][hid], rtol=1e-8, atol=1e-6)
+    for i in hid[:5]:
+        assert bp.map(rvs[i]) == pytest.approx(z['map'][i], abs=1e-4)
+        assert bp.belief(z['query_x'][i][2], rvs[i]) == pytest.approx(z['belief_mid'][i], rel=1e-5, abs=1e-7)

@@ -151,3 +151,21 @@ def test_compat_modules_mirror_reference_imports():
                      'VarInference', 'LiftedVarInference', 'EPBPLogVersion', 'HybridLBPLogVersion',
                      'CompressedGraphWithObs', 'CompressedGraphSorted'):
             sys.modules.pop(name, None)
+
+
+def test_split_evidence_colors_kmeans():
+    from lhvi.lifting import split_evidence_colors
+    vals = np.array([np.nan, 3.0, -2.0, 3.0, -2.0, -2.0, np.nan, 7.5])
+    col = np.array([0, 1, 1, 1, 1, 1, 0, 2], dtype=np.int32)
+    out = split_evidence_colors(vals, col, k=2, iteration=50, epsilon=0.0)
+    assert out[0] == out[6] == 0 and out[7] == 2
+    assert out[1] == out[3] and out[2] == out[4] == out[5] and out[1] != out[2]
+    assert set(out.tolist()) == {0, 1, 2, 3}
+    # below the threshold nothing moves; HLBP's variant compares the variance itself
+    assert (split_evidence_colors(vals, col, epsilon=10.0) == col).all()
+    assert (split_evidence_colors(vals, col, epsilon=6.3, use_sqrt=False) == col).all()     # var = 6.0
+    assert (split_evidence_colors(vals, col, epsilon=5.9, use_sqrt=False) != col).any()
+    # three groups, k = 2: the nearest-centroid rule merges the two close ones
+    vals3 = np.array([0.0, 0.1, 5.0, 5.1, 0.05])
+    out3 = split_evidence_colors(vals3, np.zeros(5, dtype=np.int32), k=2, iteration=10)
+    assert out3[0] == out3[1] == out3[4] and out3[2] == out3[3] and out3[0] != out3[2]

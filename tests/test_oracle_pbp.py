@@ -105,3 +105,84 @@ def test_hlbp_oracle_matches_reference(golden_dir, name):
                                z['final_q'][gflat.var_hidden & gflat.var_cont], rtol=1e-9)
     got = o.belief_points(cl[hid], z['query_x'][hid])
     np.testing.assert_allclose(got, z['query_logb'][hid], rtol=1e-9, atol=1e-8)
+
+
+class OracleRefiner:
+    """lhvi.c2f.Refiner backed by the exact CPU colour refinement"""
+
+    def __init__(self, g):
+        self.gflat = flatten(g)
+        self.sym = np.array([1 if getattr(f.potential, 'symmetric', False) else 0 for f in self.gflat.factors])
+
+    def factors(self, rvc, fc):
+        return oracle.refine_factors(self.gflat, self.sym, rvc, fc)[0]
+
+    def rvs(self, fc, rvc):
+        return oracle.refine_rvs(self.gflat, fc, rvc)[0]
+
+
+class OracleEngine:
+    """lhvi.c2f engine backed by the CPU oracle (PbpOracle states)"""
+
+    def __init__(self, n, ep):
+        self.n, self.ep = n, ep
+
+    def make(self, flat):
+        return oracle.PbpOracle(flat, self.n, ep=self.ep, epbp=False, var_threshold=5)
+
+    get = staticmethod(getattr)
+    set = staticmethod(lambda st, name, value: setattr(st, name, np.ascontiguousarray(value)))
+    host = staticmethod(lambda a: a)
+    gather = staticmethod(lambda a, idx: np.ascontiguousarray(a[np.asarray(idx, dtype=np.int64)]))
+    init = staticmethod(lambda st: st.init())
+    v2f = staticmethod(lambda st: st.step_v2f())
+    proposal = staticmethod(lambda st: st.step_proposal())
+    f2v = staticmethod(lambda st: st.step_f2v())
+    install = staticmethod(lambda st, p: st.set_particles(p))
+
+
+def ground_edges(flat, ground_rv):
+    acc = {}
+    for f in ground_rv.nb:
+        fi = flat.fac_index[f.cluster]
+        pos = next(i for i, r in enumerate(f.nb) if r is ground_rv)
+        e = int(flat.edge_canon[flat.fac_ptr[fi] + pos])
+        acc[e] = acc.get(e, 0) + 1
+    return acc
+
+
+@pytest.mark.parametrize('name', ['hlbp_c2f_rgm', 'hlbp_c2f_rgm_simple'])
+def test_hlbp_c2f_oracle_matches_reference(golden_dir, name):
+    """HybridLBP.run(c2f=0) driven through lhvi.c2f with the CPU oracle as the engine vs the reference: partitions at
+    every draw (exact), proposals at every draw, final log-beliefs through the ground variables' factors"""
+    from lhvi import c2f
+    z, meta = load_npz(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    samples = z['samples']
+    q_at_draw = []
+
+    def draw(k, flat, q):
+        q_at_draw.append(q[np.searchsorted(np.sort(flat.rep_ground), flat.rep_ground)] if False else (flat.rep_ground.copy(), q.copy()))
+        return samples[k][flat.rep_ground]
+
+    st, flat, cg, rvc, fc, history = c2f.run_c2f(g, OracleEngine(meta['n'], meta['approx'] == 'EP'), OracleRefiner(g),
+                                                meta['iterations'], meta['c2f'], 2, 10, draw)
+    assert len(history) == z['draw_rv_labels'].shape[0]
+    for k, (r, f) in enumerate(history):
+        assert oracle.canonical_labels(r) == z['draw_rv_labels'][k].tolist(), 'rv partition at draw %d' % k
+        assert oracle.canonical_labels(f) == z['draw_f_labels'][k].tolist(), 'factor partition at draw %d' % k
+        # proposals per ground rv at the draw
+        cl = history[k][0]
+        want = z['draw_q'][k]
+        got = q_at_draw[k][1][cl]
+        m = ~np.isnan(want[:, 0])
+        np.testing.assert_allclose(got[m], want[m], rtol=1e-8, atol=1e-10, err_msg='q at draw %d' % k)
+    assert oracle.canonical_labels(rvc) == z['rv_label'].tolist() and oracle.canonical_labels(fc) == z['f_label'].tolist()
+    gflat = flatten(g)
+    hid = np.flatnonzero(gflat.var_hidden)
+    for i in hid:
+        acc = ground_edges(flat, rvs[i])
+        edges = np.array(list(acc))
+        vals = st.edge_points(edges, np.tile(z['query_x'][i], (edges.size, 1)))
+        got = (vals * np.array([acc[e] for e in acc], dtype=float)[:, None]).sum(axis=0)
+        np.testing.assert_allclose(got, z['query_logb'][i], rtol=1e-8, atol=1e-6)
