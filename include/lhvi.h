@@ -131,10 +131,16 @@ typedef struct lhvi_pbp {
     int32_t n_generic;
     int32_t generic_pts_log2;   /* ceil(log2(max output points of a generic edge)), clamped to [0, 6]: lanes per edge */
     const void* fast_desc;      /* [n_fast][LHVI_PBP_DESC_BYTES] from lhvi_pbp_describe, or NULL (built on the fly) */
-    /* edge-sharded runs only (all NULL on a single GPU): contributions of the variable's edges that live on other ranks */
-    const int32_t* bslot;       /* [V] row of a boundary variable in remote_m / remote_ph, -1 for interior variables */
-    const double* remote_m;     /* [nb][n] sum over remote edges of count * f2v[e][j] (particle part) */
-    const double* remote_ph;    /* [nb][2] sum over ALL ranks' edges (own included, fixed rank order) of count * (1/var, mu/var) */
+    /* edge-sharded runs only (all NULL on a single GPU).  A boundary variable (edges on several ranks) owns one row per
+     * peer rank in the exchange buffers; row r of the send buffer and row r of the receive buffer belong to the same
+     * (variable, peer) because both ends list their shared variables in ascending global id.  A row is n + 2 doubles:
+     * [sum over the sender's local edges of count * f2v[e][j], j < n | sum of count/var, sum of count*mu/var of its sites]. */
+    const int32_t* bslot;       /* [V] index of the variable in the boundary list, -1 for interior / observed variables */
+    const int32_t* brow_ptr;    /* [nb+1] CSR over exchange rows per boundary variable, rows in ascending peer rank */
+    const int32_t* brow_idx;    /* [rows] row ids (the same ids address the send and the receive buffer) */
+    const int32_t* brow_peer;   /* [rows] peer rank of each listed row */
+    const double* recv;         /* [rows][n+2] received rows of this sweep */
+    int32_t rank;               /* this rank (fixes the summation order of the proposals so that all replicas agree bit for bit) */
     const double* var_degree;   /* [V] global number of incoming messages (sum of counts over ALL ranks' edges) */
 } lhvi_pbp_t;
 
@@ -159,14 +165,13 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
 /* update_proposal (sites eta [E][2] in/out, q [V][2] in/out): EPBP.py:83-154; HLBP.py:100-171 */
 int lhvi_pbp_proposal(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* eta, double* q, void* stream);
 /* Sharded form of lhvi_pbp_proposal: `partial` updates the local sites and writes, per variable, the information-form sum
- * over its LOCAL edges ph[v] = (sum c/var, sum c*mu/var); after the boundary rows have been exchanged and summed into
- * s->remote_ph, `finish` forms q[v] from ph[v] (+ remote) -- together they equal lhvi_pbp_proposal on the whole graph. */
+ * over its LOCAL edges ph[v] = (sum c/var, sum c*mu/var); `boundary_pack` writes every boundary variable's row into each of
+ * its slots of the send buffer; after the all_to_all, lhvi_pbp_v2f reads the received rows through s->recv, and `finish`
+ * forms q[v] from ph[v] plus the received sums in rank order -- together they equal lhvi_pbp_proposal on the whole graph. */
 int lhvi_pbp_proposal_partial(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* eta, double* ph, void* stream);
 int lhvi_pbp_proposal_finish(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* ph, double* q, void* stream);
-/* out[i][0..n) = sum over the LOCAL edges of variable bvars[i] of count * f2v[e][j]; out[i][n..n+2) = ph[bvars[i]]:
- * the row a rank sends to the other owners of a boundary variable (one all_to_all per sweep). */
 int lhvi_pbp_boundary_pack(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, const double* ph, int32_t nb,
-                           const int32_t* bvars, double* out, void* stream);
+                           const int32_t* bvars, double* send, void* stream);
 /* initial_proposal: q=(0,5), sites (0, 5*deg): EPBP.py:72-81; HLBP.py:89-98 */
 int lhvi_pbp_init(const lhvi_graph_t* g, const lhvi_pbp_t* s, double* eta, double* q, double* f2v, double* v2f, void* stream);
 /* generate_sample with a counter-based device RNG keyed (seed, variable gid, iteration, j): EPBP.py:61-70.

@@ -126,9 +126,10 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp
         const double x = valid ? s.particles[(int64_t)v * n + j] : 0.0;
         const bool uq = valid && s.uniq[(int64_t)v * n + j];
         double total = 0.0;
-        if (s.bslot && valid) {                      // edges of this variable that live on other ranks
+        if (s.bslot && valid) {                      // edges of this variable that live on other ranks: received partial sums
             const int bs = s.bslot[v];
-            if (bs >= 0) total = s.remote_m[(int64_t)bs * n + j];
+            if (bs >= 0)
+                for (int r = s.brow_ptr[bs]; r < s.brow_ptr[bs + 1]; ++r) total += s.recv[(int64_t)s.brow_idx[r] * (n + 2) + j];
         }
 #pragma unroll
         for (int k = 0; k < V2F_CACHE; ++k)
@@ -658,38 +659,50 @@ __global__ void __launch_bounds__(BLOCK) pbp_proposal_finish_kernel(lhvi_graph_t
     if (!is_hidden(g.var_value[v]) || !g.dom_cont[g.var_dom[v]]) return;
     double ps = ph[2 * v], pm = ph[2 * v + 1];
     if (s.bslot) {
-        // boundary variable: remote_ph holds the COMPLETE sum over all ranks, accumulated in rank order by the host,
-        // so that every replica of the variable computes bit-identical q (and hence identical particles)
+        // boundary variable: add the ranks' information-form sums in ascending rank order (own sum at its own position),
+        // so that every replica of the variable computes bit-identical q and therefore draws identical particles
         const int bs = s.bslot[v];
-        if (bs >= 0) { ps = s.remote_ph[2 * bs]; pm = s.remote_ph[2 * bs + 1]; }
+        if (bs >= 0) {
+            const int W = s.n + 2;
+            const double own_s = ps, own_m = pm;
+            ps = 0.0; pm = 0.0;
+            bool own_done = false;
+            for (int r = s.brow_ptr[bs]; r < s.brow_ptr[bs + 1]; ++r) {
+                if (!own_done && s.brow_peer[r] > s.rank) { ps += own_s; pm += own_m; own_done = true; }
+                const double* row = s.recv + (int64_t)s.brow_idx[r] * W + s.n;
+                ps += row[0]; pm += row[1];
+            }
+            if (!own_done) { ps += own_s; pm += own_m; }
+        }
     }
     ps = 1.0 / ps;
     q[2 * v] = ps * pm; q[2 * v + 1] = ps;
 }
 
-// one wavefront per boundary variable: row = [sum_local c * f2v[e][j] for j < n | ph[v]]
+// one wavefront per boundary variable: row = [sum_local c * f2v[e][j] for j < n | ph[v]], written to each of the
+// variable's slots of the send buffer (one per peer rank that also owns edges of it)
 __global__ void __launch_bounds__(BLOCK) pbp_boundary_pack_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                                  const double* __restrict__ ph, int nb,
                                                                  const int32_t* __restrict__ bvars, double* __restrict__ out) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
     if (i >= nb) return;
     const int v = bvars[i];
     const int n = s.n, S = s.n + s.T, W = s.n + 2;
-    const int np = is_hidden(g.var_value[v]) ? s.np[v] : 0;
-    for (int j = lane; j < n; j += 64) {
-        double tot = 0.0;
-        if (j < np)
+    const int np = s.np[v];
+    const int r0 = s.brow_ptr[i], r1 = s.brow_ptr[i + 1];
+    for (int j = lane; j < W; j += 64) {
+        double val = 0.0;
+        if (j < np) {
             for (int k = g.var_ptr[v]; k < g.var_ptr[v + 1]; ++k) {
                 const int e = g.var_edge[k];
                 const double m = f2v[(int64_t)e * S + j];
-                tot += g.edge_count ? m * g.edge_count[e] : m;
+                val += g.edge_count ? m * g.edge_count[e] : m;
             }
-        out[(int64_t)i * W + j] = tot;
+        } else if (j >= n) val = ph[2 * v + (j - n)];
+        for (int r = r0; r < r1; ++r) out[(int64_t)s.brow_idx[r] * W + j] = val;
     }
-    if (lane < 2) out[(int64_t)i * W + n + lane] = ph[2 * v + lane];
 }
-
 
 // initial_proposal (EPBP:72-81; HLBP:89-98)
 __global__ void __launch_bounds__(BLOCK) pbp_init_kernel(lhvi_graph_t g, lhvi_pbp_t s, double* __restrict__ eta,
@@ -886,18 +899,18 @@ int lhvi_pbp_proposal_partial(const lhvi_graph_t* g, const lhvi_pbp_t* s, const 
 
 int lhvi_pbp_proposal_finish(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* ph, double* q, void* stream) {
     if (int rc = validate_pbp(g, s)) return rc;
-    if (!ph || !q || (s->bslot && !s->remote_ph)) return LHVI_E_ARG;
+    if (!ph || !q || (s->bslot && (!s->recv || !s->brow_ptr || !s->brow_idx || !s->brow_peer))) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
     hipLaunchKernelGGL(pbp_proposal_finish_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, as_stream(stream), *g, *s, ph, q);
     return check_launch();
 }
 
 int lhvi_pbp_boundary_pack(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, const double* ph, int32_t nb,
-                           const int32_t* bvars, double* out, void* stream) {
+                           const int32_t* bvars, double* out /* send buffer */, void* stream) {
     if (int rc = validate_pbp(g, s)) return rc;
     if (nb < 0) return LHVI_E_ARG;
     if (nb == 0) return LHVI_OK;
-    if (!f2v || !ph || !bvars || !out) return LHVI_E_ARG;
+    if (!f2v || !ph || !bvars || !out || !s->brow_ptr || !s->brow_idx) return LHVI_E_ARG;
     hipLaunchKernelGGL(pbp_boundary_pack_kernel, dim3(grid_for((int64_t)nb * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, ph,
                        nb, bvars, out);
     return check_launch();

@@ -94,25 +94,42 @@ class ShardPlan:
                                flat.fac_pot[self.f_lo:self.f_hi], [], flat.var_value[gids], flat.var_dom[gids], flat.domains)
         # the potential table is global and small: keep it whole so fac_pot stays valid
         self.flat.pot_kind, self.flat.pot_off, self.flat.pot_param = flat.pot_kind, flat.pot_off, flat.pot_param
-        # boundary bookkeeping: which ranks own edges of each variable
-        is_b = degree[gids] > local_degree[gids]
+        # boundary bookkeeping: which ranks own edges of each (hidden) variable; observed variables need no sums
+        is_b = (degree[gids] > local_degree[gids]) & np.isnan(flat.var_value[gids])
         self.bvars = np.flatnonzero(is_b).astype(np.int32)               # local ids, ascending gid
         self.bslot = np.full(gids.size, -1, dtype=np.int32)
         self.bslot[self.bvars] = np.arange(self.bvars.size, dtype=np.int32)
         bg = gids[self.bvars]
-        # owner sets of boundary variables, from the (variable, owner) incidence
         keys = np.unique(flat.edge_var.astype(np.int64) * world + edge_owner.astype(np.int64))
         pair_var, pair_owner = keys // world, keys % world
+        # exchange rows: peer-major, shared variables in ascending gid inside a peer block.  Both ends build the same
+        # order, so row r of my send buffer and row r of my receive buffer belong to the same (variable, peer).
         self.peer_rows = {}
+        row_bvar, row_peer = [], []
+        self.counts = []
         for s in range(world):
             if s == rank:
+                self.counts.append(0)
                 continue
             vs = pair_var[pair_owner == s]
             shared = np.intersect1d(bg, vs, assume_unique=True)          # ascending gid
-            self.peer_rows[s] = np.searchsorted(bg, shared).astype(np.int64)
+            rows = np.searchsorted(bg, shared).astype(np.int64)          # indices into bvars
+            self.peer_rows[s] = rows
+            row_bvar.append(rows)
+            row_peer.append(np.full(rows.size, s, dtype=np.int32))
+            self.counts.append(int(rows.size))
+        row_bvar = np.concatenate(row_bvar) if row_bvar else np.zeros(0, dtype=np.int64)
+        row_peer = np.concatenate(row_peer) if row_peer else np.zeros(0, dtype=np.int32)
+        self.n_rows = int(row_bvar.size)
+        # CSR boundary variable -> its rows, in ascending peer order (stable sort keeps the peer-major order)
+        order = np.argsort(row_bvar, kind='stable')
+        self.brow_idx = order.astype(np.int32)
+        self.brow_peer = row_peer[order].astype(np.int32)
+        self.brow_ptr = np.zeros(self.bvars.size + 1, dtype=np.int32)
+        np.cumsum(np.bincount(row_bvar, minlength=self.bvars.size), out=self.brow_ptr[1:])
 
     def send_counts(self):
-        return [0 if s == self.rank else int(self.peer_rows[s].size) for s in range(self.world)]
+        return list(self.counts)
 
 
 class LoopbackGroup:
@@ -140,9 +157,10 @@ class LoopbackGroup:
 class ShardedRunner:
     """One rank's part of the edge-sharded particle sweep (EPBP semantics).
 
-    Per sweep: [local sites + information-form partials] -> pack boundary rows -> ONE all_to_all -> accumulate the
-    remote rows -> v2f (with remote sums) -> proposal finish -> resample (Philox keyed by global id, so replicas of a
-    boundary variable draw identical particles without communicating) -> f2v (local).
+    Per sweep: [local sites + information-form partials] -> pack every boundary variable's row straight into its slots of
+    the peer-ordered send buffer -> ONE all_to_all -> v2f and proposal finish read the received rows in place (no
+    unpack pass) -> resample (Philox keyed by global id, so replicas of a boundary variable draw identical particles
+    without communicating) -> f2v (local).
     """
 
     def __init__(self, flat, n, seed, rank, world, proposal_approximation='simple', group=None):
@@ -161,19 +179,19 @@ class ShardedRunner:
         nb = int(plan.bvars.size)
         self.nb, self.W = nb, n + 2
         self.ph = torch.zeros(plan.flat.V, 2, dtype=torch.float64, device=dev)
-        self.rows = torch.zeros(max(nb, 1), self.W, dtype=torch.float64, device=dev)
-        self.remote = torch.zeros(max(nb, 1), self.W, dtype=torch.float64, device=dev)
-        self.remote_m = torch.zeros(max(nb, 1), n, dtype=torch.float64, device=dev)
-        self.remote_ph = torch.zeros(max(nb, 1), 2, dtype=torch.float64, device=dev)
-        self.peer_rows = {s: torch.from_numpy(r).to(dev) for s, r in plan.peer_rows.items()}
+        rows = max(plan.n_rows, 1)
+        self.send = torch.zeros(rows, self.W, dtype=torch.float64, device=dev)
+        self.recv = torch.zeros(rows, self.W, dtype=torch.float64, device=dev)
+        self.brow_ptr = _abi.to_dev(plan.brow_ptr)
+        self.brow_idx = _abi.to_dev(plan.brow_idx if plan.n_rows else np.zeros(1, dtype=np.int32))
+        self.brow_peer = _abi.to_dev(plan.brow_peer if plan.n_rows else np.zeros(1, dtype=np.int32))
         self.counts = plan.send_counts()
-        self._send_index = torch.cat([self.peer_rows[s] for s in range(world) if s != rank]) if world > 1 else \
-            torch.zeros(0, dtype=torch.int64, device=dev)
 
     def _struct(self):
         s = self.bp._struct()
         s.bslot, s.var_degree = _abi.ptr(self.bslot), _abi.ptr(self.var_degree)
-        s.remote_m, s.remote_ph = _abi.ptr(self.remote_m), _abi.ptr(self.remote_ph)
+        s.brow_ptr, s.brow_idx, s.brow_peer = _abi.ptr(self.brow_ptr), _abi.ptr(self.brow_idx), _abi.ptr(self.brow_peer)
+        s.recv, s.rank = _abi.ptr(self.recv), int(self.rank)
         return s
 
     def init(self):
@@ -188,36 +206,23 @@ class ShardedRunner:
         s = self._struct()
         _abi.check(l.lhvi_pbp_proposal_partial(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.eta), _abi.ptr(self.ph), st))
         _abi.check(l.lhvi_pbp_boundary_pack(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(self.ph), self.nb, _abi.ptr(self.bvars),
-                                            _abi.ptr(self.rows), st))
-        return self.rows.index_select(0, self._send_index) if self._send_index.numel() else self.rows[:0]
+                                            _abi.ptr(self.send), st))
+        return self.send[:self.plan.n_rows]
 
     def exchange(self, send):
-        import torch
         import torch.distributed as td
-        recv = torch.empty_like(send)          # symmetric: rows shared with s are sent to and received from s
-        td.all_to_all_single(recv, send, output_split_sizes=self.counts, input_split_sizes=self.counts)
+        recv = self.recv[:self.plan.n_rows]     # symmetric: the rows shared with rank s are sent to and received from s
+        splits = [c * self.W for c in self.counts]
+        td.all_to_all_single(recv.view(-1), send.reshape(-1), output_split_sizes=splits, input_split_sizes=splits)
         return recv
 
-    # -- phase 2: accumulate the peers' rows (fixed peer order -> deterministic), then the rest of the sweep -------
+    # -- phase 2: the rest of the sweep, reading the peers' rows straight from the receive buffer ---------------------
     def post(self, recv, f2v_events=None):
         bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
-        # remote_m: the OTHER ranks' particle-part sums.  remote_ph: the complete information-form sum of a boundary
-        # variable accumulated in rank order (own row at its turn), so every replica of the variable forms bit-identical
-        # q and therefore draws bit-identical particles.
-        n = bp.n
-        self.remote.zero_()
-        self.remote_ph.zero_()
-        off = 0
-        for s in range(self.world):
-            if s == self.rank:
-                self.remote_ph.add_(self.rows[:, n:])
-                continue
-            cnt = self.counts[s]
-            if cnt:
-                self.remote.index_add_(0, self.peer_rows[s], recv[off:off + cnt])
-                self.remote_ph.index_add_(0, self.peer_rows[s], recv[off:off + cnt, n:])
-            off += cnt
-        self.remote_m.copy_(self.remote[:, :n])
+        # the kernels read the received rows in place (v2f: particle-part sums; proposal_finish: information-form sums in
+        # rank order, so every replica of a boundary variable forms bit-identical q and draws bit-identical particles)
+        if recv.data_ptr() != self.recv.data_ptr():
+            self.recv[:recv.shape[0]].copy_(recv)
         s = self._struct()
         _abi.check(l.lhvi_pbp_v2f(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.v2f), st))
         _abi.check(l.lhvi_pbp_proposal_finish(bp.dg.g, s, _abi.ptr(self.ph), _abi.ptr(bp.q_dev), st))

@@ -1,0 +1,37 @@
+"""Rehearse the edge-sharded sweep for `world` ranks on ONE GPU (loopback exchange): checks that the plans build at full
+size and times each rank's pre / post phases (everything except the real all_to_all).  Tuning / validation aid."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
+import numpy as np, torch
+from lhvi import synth, dist
+
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+flat = synth.hybrid_mrf_flat(V=E // 4, deg=4, seed=0)
+group = dist.LoopbackGroup(world)
+t0 = time.perf_counter()
+runners = [dist.ShardedRunner(flat, n=64, seed=1, rank=r, world=world, group=group) for r in range(world)]
+print('plans + setup: %.1f s' % (time.perf_counter() - t0), flush=True)
+for r in runners:
+    r.init()
+torch.cuda.synchronize()
+nb = [r.nb for r in runners]
+sent = [r.plan.n_rows * r.W * 8 / 1e6 for r in runners]
+print('boundary vars per rank', nb[:3], '... send MB per rank', ['%.0f' % s for s in sent[:3]], 'per peer MB %.0f' % (sent[0] / max(world - 1, 1)))
+for it in range(3):
+    tp, tq = [], []
+    sends = []
+    for r in runners:
+        torch.cuda.synchronize(); t = time.perf_counter()
+        sends.append(r.pre())
+        torch.cuda.synchronize(); tp.append(time.perf_counter() - t)
+    for r, s in zip(runners, sends):
+        group.post(r.rank, s, r.counts)
+    for r in runners:
+        recv = group.collect(r.rank, r.W)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        r.post(recv)
+        torch.cuda.synchronize(); tq.append(time.perf_counter() - t)
+    print('sweep %d: per-rank pre %.2f ms, post %.2f ms (max over ranks %.2f / %.2f)' %
+          (it, 1e3 * np.mean(tp), 1e3 * np.mean(tq), 1e3 * max(tp), 1e3 * max(tq)), flush=True)

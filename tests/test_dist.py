@@ -30,7 +30,13 @@ def test_shard_plan_invariants(world):
         np.testing.assert_array_equal(np.isnan(p.flat.var_value), np.isnan(flat.var_value[p.var_gid]))
         owners[p.var_gid] += 1
         local_deg = np.diff(p.flat.var_ptr)
-        np.testing.assert_array_equal(local_deg < p.var_degree, p.bslot >= 0)
+        # boundary = hidden variables with edges on another rank (observed variables never need sums)
+        np.testing.assert_array_equal((local_deg < p.var_degree) & np.isnan(p.flat.var_value), p.bslot >= 0)
+        # every exchange row is listed exactly once, grouped per boundary variable in ascending peer order
+        assert sorted(p.brow_idx.tolist()) == list(range(p.n_rows)) and p.brow_ptr[-1] == p.n_rows
+        for b in range(0, p.bvars.size, max(1, p.bvars.size // 50)):
+            peers = p.brow_peer[p.brow_ptr[b]:p.brow_ptr[b + 1]]
+            assert (np.diff(peers) > 0).all() and p.rank not in peers.tolist()
     # both ends of every pair list the shared variables in the same (gid) order
     for r, p in enumerate(plans):
         for s, rows in p.peer_rows.items():
@@ -73,7 +79,8 @@ def _gloo_worker(rank, world, port, out):
     total[plan.bvars] += remote.numpy()
     want = np.zeros((flat.V, W))
     np.add.at(want, flat.edge_var, edge_val)
-    ok = np.allclose(total, want[plan.var_gid], rtol=1e-12, atol=1e-12)
+    hid = np.isnan(plan.flat.var_value)
+    ok = np.allclose(total[hid], want[plan.var_gid][hid], rtol=1e-12, atol=1e-12)
     out.put((rank, bool(ok), int(plan.bvars.size)))
     td.destroy_process_group()
 
