@@ -101,11 +101,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    # LHVI_DIST_BACKEND=gloo rehearses the multi-process path on a box with fewer GPUs than ranks (ranks then share
+    # devices and the exchange is staged through the host); the real runs use nccl = RCCL over xGMI, one rank per GPU
+    backend = os.environ.get('LHVI_DIST_BACKEND', 'nccl')
+    device_index = local_rank % max(torch.cuda.device_count(), 1) if backend == 'gloo' else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
         import torch.distributed as td
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        td.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            td.init_process_group('nccl', device_id=torch.device('cuda', device_index))
+        else:
+            td.init_process_group(backend)
 
     n, T = args.particles, args.grid
     deg = 4
@@ -138,7 +145,7 @@ def main():
         runner.sweep(f2v_events=ev[i])
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if os.environ.get('LHVI_DIST_BACKEND', 'nccl') == 'nccl' else 'cpu')
     if world > 1:
         import torch.distributed as td
         td.all_reduce(t, op=td.ReduceOp.MAX)

@@ -213,7 +213,14 @@ class ShardedRunner:
         import torch.distributed as td
         recv = self.recv[:self.plan.n_rows]     # symmetric: the rows shared with rank s are sent to and received from s
         splits = [c * self.W for c in self.counts]
-        td.all_to_all_single(recv.view(-1), send.reshape(-1), output_split_sizes=splits, input_split_sizes=splits)
+        if td.get_backend() == 'nccl':
+            td.all_to_all_single(recv.view(-1), send.reshape(-1), output_split_sizes=splits, input_split_sizes=splits)
+        else:
+            # rehearsal backend (gloo): same collective on host copies
+            h_send = send.reshape(-1).cpu()
+            h_recv = h_send.new_empty(h_send.shape)
+            td.all_to_all_single(h_recv, h_send, output_split_sizes=splits, input_split_sizes=splits)
+            recv.view(-1).copy_(h_recv)
         return recv
 
     # -- phase 2: the rest of the sweep, reading the peers' rows straight from the receive buffer ---------------------
