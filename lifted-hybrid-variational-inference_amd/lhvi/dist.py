@@ -59,30 +59,70 @@ class SingleRunner:
 # =================================================================================================
 # edge sharding
 # =================================================================================================
-class ShardPlan:
-    """Factor-partitioned shard of a ground ``FlatGraph`` for rank ``rank`` of ``world`` (pure NumPy, no GPU).
+def bfs_variable_order(flat):
+    """position of every variable in a breadth-first sweep of the factor graph (all components).  Cutting that order into
+    equal blocks gives shells whose variables mostly touch the neighbouring shells only: far fewer boundary variables, and
+    fewer peers per boundary variable, than cutting the (arbitrary) construction order of the factors."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import breadth_first_order
+    V = flat.V
+    # variable-variable adjacency through shared factors (first scope variable linked to every other: enough for BFS)
+    first = flat.edge_var[flat.fac_ptr[:-1][flat.edge_fac]]
+    rows, cols = first, flat.edge_var
+    keep = rows != cols
+    A = csr_matrix((np.ones(int(keep.sum()), dtype=np.int8), (rows[keep], cols[keep])), shape=(V, V))
+    A = A + A.T
+    pos = np.full(V, -1, dtype=np.int64)
+    nxt = 0
+    start = 0
+    while nxt < V:
+        while start < V and pos[start] >= 0:
+            start += 1
+        if start >= V:
+            break
+        order, _ = breadth_first_order(A, start, directed=False, return_predecessors=True)
+        order = order[pos[order] < 0]
+        pos[order] = nxt + np.arange(order.size)
+        nxt += order.size
+    return pos
 
-    * factors ``[F*rank/world, F*(rank+1)/world)`` with all their edges are local;
+
+class ShardPlan:
+    """Factor-partitioned shard of a ground ``FlatGraph`` for rank ``rank`` of ``world`` (pure NumPy/SciPy, no GPU).
+
+    * ``partition='bfs'`` (default): factors are ordered by the breadth-first position of their earliest scope variable and
+      cut into ``world`` equal blocks (locality-aware); ``'block'``: equal blocks of the construction order;
+    * the shard's factors (``fac_ids``, ascending global id) with all their edges (``edge_ids``) are local;
     * local variables = the variables those factors touch, renumbered in ascending global id (``var_gid``);
     * ``var_degree`` = a variable's degree in the WHOLE graph (site clamp / initial site of the proposal);
-    * a local variable is a *boundary* variable when some of its edges live on another rank; ``bvars`` lists them
-      (ascending gid) and ``peer_rows[s]`` = the rows of ``bvars`` shared with rank ``s`` (ascending gid on both sides,
+    * a local hidden variable is a *boundary* variable when some of its edges live on another rank; ``bvars`` lists them
+      (ascending gid) and ``peer_rows[s]`` = the entries of ``bvars`` shared with rank ``s`` (ascending gid on both sides,
       so the two ends of a pair agree on the order without communicating).
     """
 
-    def __init__(self, flat, rank, world):
+    def __init__(self, flat, rank, world, partition='bfs'):
         from .flat import build_flat
         if flat.lifted or (flat.edge_canon != np.arange(flat.E)).any():
             raise NotImplementedError('sharding expects a ground graph')
         self.rank, self.world = rank, world
         F = flat.F
-        bounds = (np.arange(world + 1, dtype=np.int64) * F) // world
-        self.f_lo, self.f_hi = int(bounds[rank]), int(bounds[rank + 1])
-        fac_owner = np.searchsorted(bounds, np.arange(F), side='right') - 1
+        if partition == 'bfs' and world > 1:
+            pos = bfs_variable_order(flat)
+            fpos = np.minimum.reduceat(pos[flat.edge_var], flat.fac_ptr[:-1]) if F else np.zeros(0, dtype=np.int64)
+            forder = np.argsort(fpos, kind='stable')
+            fac_owner = np.empty(F, dtype=np.int64)
+            fac_owner[forder] = (np.arange(F, dtype=np.int64) * world) // max(F, 1)
+        else:
+            fac_owner = (np.arange(F, dtype=np.int64) * world) // max(F, 1)
         edge_owner = fac_owner[flat.edge_fac]
-        e_lo, e_hi = int(flat.fac_ptr[self.f_lo]), int(flat.fac_ptr[self.f_hi])
-        self.e_lo, self.e_hi = e_lo, e_hi
-        local_edge_var = flat.edge_var[e_lo:e_hi]
+        self.fac_ids = np.flatnonzero(fac_owner == rank)
+        arity = np.diff(flat.fac_ptr)[self.fac_ids]
+        local_ptr = np.zeros(self.fac_ids.size + 1, dtype=np.int64)
+        np.cumsum(arity, out=local_ptr[1:])
+        # global edge ids of the shard, factor-major like the local numbering
+        self.edge_ids = (np.repeat(flat.fac_ptr[self.fac_ids].astype(np.int64) - local_ptr[:-1], arity) +
+                         np.arange(int(local_ptr[-1]), dtype=np.int64))
+        local_edge_var = flat.edge_var[self.edge_ids]
         gids = np.unique(local_edge_var)
         self.var_gid = gids.astype(np.int64)
         lid = np.full(flat.V, -1, dtype=np.int64)
@@ -90,8 +130,8 @@ class ShardPlan:
         degree = np.bincount(flat.edge_var, minlength=flat.V)
         local_degree = np.bincount(local_edge_var, minlength=flat.V)
         self.var_degree = degree[gids].astype(np.float64)
-        self.flat = build_flat(flat.fac_ptr[self.f_lo:self.f_hi + 1] - e_lo, lid[local_edge_var].astype(np.int32),
-                               flat.fac_pot[self.f_lo:self.f_hi], [], flat.var_value[gids], flat.var_dom[gids], flat.domains)
+        self.flat = build_flat(local_ptr.astype(np.int32), lid[local_edge_var].astype(np.int32),
+                               flat.fac_pot[self.fac_ids], [], flat.var_value[gids], flat.var_dom[gids], flat.domains)
         # the potential table is global and small: keep it whole so fac_pot stays valid
         self.flat.pot_kind, self.flat.pot_off, self.flat.pot_param = flat.pot_kind, flat.pot_off, flat.pot_param
         # boundary bookkeeping: which ranks own edges of each (hidden) variable; observed variables need no sums

@@ -21,11 +21,16 @@ def test_shard_plan_invariants(world):
     flat = synth.hybrid_mrf_flat(V=1500, deg=4, seed=2)
     plans = _plans(flat, world)
     assert sum(p.flat.E for p in plans) == flat.E and sum(p.flat.F for p in plans) == flat.F
+    assert sorted(np.concatenate([p.fac_ids for p in plans]).tolist()) == list(range(flat.F))     # a partition of the factors
+    assert max(p.flat.F for p in plans) - min(p.flat.F for p in plans) <= 1                       # balanced
+    # locality: the breadth-first cut has fewer exchange rows than cutting the construction order
+    from lhvi.dist import ShardPlan
+    assert sum(p.n_rows for p in plans) < sum(ShardPlan(flat, r, world, partition='block').n_rows for r in range(world))
     deg = np.bincount(flat.edge_var, minlength=flat.V)
     owners = np.zeros(flat.V, dtype=int)
     for p in plans:
         # local graph is the induced sub-incidence with consistent renumbering
-        np.testing.assert_array_equal(p.var_gid[p.flat.edge_var], flat.edge_var[p.e_lo:p.e_hi])
+        np.testing.assert_array_equal(p.var_gid[p.flat.edge_var], flat.edge_var[p.edge_ids])
         np.testing.assert_array_equal(p.var_degree, deg[p.var_gid])
         np.testing.assert_array_equal(np.isnan(p.flat.var_value), np.isnan(flat.var_value[p.var_gid]))
         owners[p.var_gid] += 1
@@ -59,7 +64,7 @@ def _gloo_worker(rank, world, port, out):
     W = 5
     rng = np.random.default_rng(0)
     edge_val = rng.normal(size=(flat.E, W))                     # same on every rank
-    local = edge_val[plan.e_lo:plan.e_hi]
+    local = edge_val[plan.edge_ids]
     part = np.zeros((plan.flat.V, W))
     np.add.at(part, plan.flat.edge_var, local)                  # per-variable partial sum over LOCAL edges
     rows = torch.from_numpy(part[plan.bvars])
@@ -140,8 +145,8 @@ def test_sharded_sweep_matches_single_gpu(world):
             np.testing.assert_allclose(r.bp.q_dev.cpu().numpy()[hid], q[plan.var_gid][hid], rtol=1e-11, atol=1e-13)
             he = hid[plan.flat.edge_var]
             # remote partial sums are added as a block: same values up to fp64 rounding of the summation order
-            np.testing.assert_allclose(r.bp.v2f.cpu().numpy()[he], v2f[plan.e_lo:plan.e_hi][he], rtol=1e-9, atol=1e-9)
-            np.testing.assert_allclose(r.bp.f2v.cpu().numpy()[he], f2v[plan.e_lo:plan.e_hi][he], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(r.bp.v2f.cpu().numpy()[he], v2f[plan.edge_ids][he], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(r.bp.f2v.cpu().numpy()[he], f2v[plan.edge_ids][he], rtol=1e-9, atol=1e-9)
         # replicas of a boundary variable hold bit-identical proposals and particles on every rank that owns it
         seen = {}
         for r in runners:
@@ -171,7 +176,7 @@ def _gpu_rank_worker(rank, world, port, out_dir):
         r.sweep()                      # pre -> all_to_all_single (gloo: staged through the host) -> post
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), gid=r.plan.var_gid, q=r.bp.q_dev.cpu().numpy(),
-             f2v=r.bp.f2v.cpu().numpy(), e_lo=r.plan.e_lo, e_hi=r.plan.e_hi)
+             f2v=r.bp.f2v.cpu().numpy(), edge_ids=r.plan.edge_ids)
     td.barrier()
     td.destroy_process_group()
 
@@ -207,5 +212,5 @@ def test_two_process_sharded_sweep_matches_single_gpu(tmp_path):
         z = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r))
         h = hid[z['gid']]
         np.testing.assert_allclose(z['q'][h], q[z['gid']][h], rtol=1e-10, atol=1e-12)
-        he = hid[flat.edge_var[int(z['e_lo']):int(z['e_hi'])]]
-        np.testing.assert_allclose(z['f2v'][he], f2v[int(z['e_lo']):int(z['e_hi'])][he], rtol=1e-9, atol=1e-8)
+        he = hid[flat.edge_var[z['edge_ids']]]
+        np.testing.assert_allclose(z['f2v'][he], f2v[z['edge_ids']][he], rtol=1e-9, atol=1e-8)
