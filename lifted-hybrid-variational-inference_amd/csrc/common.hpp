@@ -41,4 +41,41 @@ __device__ __forceinline__ void st2(double* p, int64_t i, double a, double b) {
     reinterpret_cast<double2*>(p)[i] = make_double2(a, b);
 }
 
+// ---- wavefront reductions on the DPP data path (no LDS crossbar round trips) --------------------------------------
+// The classic gfx9 sequence: two quad permutes, two row rotations, row_bcast:15, row_bcast:31 leave the total of the
+// wave in lane 63 (and the totals of lanes 0-31 / 32-63 in lanes 31 / 63 before the last step); v_readlane broadcasts.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+struct SumOp { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
+struct MaxOp { __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
+
+template <class Op>
+__device__ __forceinline__ double dpp_reduce_rows32(double v, Op op) {      // lanes 31 / 63 hold the half-wave results
+    v = op(dpp_move<0xb1>(v), v);      // quad_perm [1,0,3,2]
+    v = op(dpp_move<0x4e>(v), v);      // quad_perm [2,3,0,1]
+    v = op(dpp_move<0x124>(v), v);     // row_ror:4
+    v = op(dpp_move<0x128>(v), v);     // row_ror:8
+    v = op(dpp_move<0x142>(v), v);     // row_bcast:15
+    return v;
+}
+template <class Op>
+__device__ __forceinline__ double dpp_wave_reduce(double v, Op op) {        // every lane gets the wave-wide result
+    v = dpp_reduce_rows32(v, op);
+    v = op(dpp_move<0x143>(v), v);     // row_bcast:31
+    return readlane_f64(v, 63);
+}
+template <class Op>
+__device__ __forceinline__ double dpp_half_reduce(double v, Op op, int lane) {   // result of the lane's own 32-lane half
+    v = dpp_reduce_rows32(v, op);
+    const double a = readlane_f64(v, 31), b = readlane_f64(v, 63);
+    return lane < 32 ? a : b;
+}
+
 }  // namespace lhvi

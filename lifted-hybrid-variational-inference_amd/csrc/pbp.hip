@@ -19,16 +19,8 @@
 
 namespace lhvi {
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return dpp_wave_reduce(v, SumOp()); }
+__device__ __forceinline__ double wave_max(double v) { return dpp_wave_reduce(v, MaxOp()); }
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -140,6 +132,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp
             total += lifted ? m * g.edge_count[e] : m;
         }
         const double logw = valid ? log_importance(g, s, v, d, x, mu, sd, log_norm) : 0.0;
+        const int cnt1 = __builtin_popcountll(__ballot(uq));        // distinct particles: the same for every incident edge
         auto emit = [&](int e, double m) {
             // ground: sum over nb != f; lifted: own factor keeps count-1 copies (HLBP:182-191) -> total - m either way
             const double res = (total - m) + logw;
@@ -147,8 +140,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp
                 // log_message_balance over the distinct keys (EPBP:204-215)
                 const double tot = wave_sum(uq ? res : 0.0);
                 const double mx = wave_max(uq ? res : -__builtin_huge_val());
-                const int cnt = wave_sum_i(uq ? 1 : 0);
-                const double mean = tot / (double)cnt;
+                const double mean = tot / (double)cnt1;
                 const double shift = (mx - mean > s.max_log_value) ? mx - s.max_log_value : mean;
                 if (valid) v2f[(int64_t)e * n + j] = res - shift;
             } else if (valid) {
@@ -627,9 +619,8 @@ __global__ void __launch_bounds__(BLOCK) pbp_proposal_kernel(lhvi_graph_t g, lhv
             if (use_cav) w = w * norm_pdf_std(xg, c0, csd);
             z += w; a += w * xg; b += w * (xg * xg);
         }
-        for (int off = width >> 1; off > 0; off >>= 1) {
-            z += __shfl_xor(z, off); a += __shfl_xor(a, off); b += __shfl_xor(b, off);
-        }
+        if (groups == 2) { z = dpp_half_reduce(z, SumOp(), lane); a = dpp_half_reduce(a, SumOp(), lane); b = dpp_half_reduce(b, SumOp(), lane); }
+        else { z = wave_sum(z); a = wave_sum(a); b = wave_sum(b); }
         double mu = a / z;
         double sig = b / z - mu * mu;
         if (use_cav) { const double m0 = mu, m1 = sig; gdiv(m0, m1, c0, c1, mu, sig); }
