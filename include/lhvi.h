@@ -131,6 +131,9 @@ typedef struct lhvi_pbp {
     int32_t n_generic;
     int32_t generic_pts_log2;   /* ceil(log2(max output points of a generic edge)), clamped to [0, 6]: lanes per edge */
     const void* fast_desc;      /* [n_fast][LHVI_PBP_DESC_BYTES] from lhvi_pbp_describe, or NULL (built on the fly) */
+    const void* heavy_desc;     /* [n_heavy][LHVI_PBP_DESC_BYTES] descriptors of the edges served by the specialised kernel:
+                                 * class 1, constant x^2 coefficient (kind != HYBRID_QUADRATIC), nj <= 64, np + T <= 128; disjoint from fast_edges */
+    int32_t n_heavy;
     /* edge-sharded runs only (all NULL on a single GPU).  A boundary variable (edges on several ranks) owns one row per
      * peer rank in the exchange buffers; row r of the send buffer and row r of the receive buffer belong to the same
      * (variable, peer) because both ends list their shared variables in ascending global id.  A row is n + 2 doubles:
@@ -151,6 +154,10 @@ int lhvi_pbp_describe(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi
                       void* desc_out, void* stream);
 /* test hook: y[i] = the f2v kernel's exp(x[i]) */
 int lhvi_debug_exp(const double* x, double* y, int64_t n, void* stream);
+/* test hook: y[i] = exp(x[i] + c[i]) through the accumulating form the f2v term loop uses (c = the per-point constant) */
+int lhvi_debug_exp_acc(const double* x, const double* c, double* y, int64_t n, void* stream);
+/* test hook: y[i] = log(x[i]), x > 0; which = 0 the table-driven log of the f2v epilogue, 1 the series log */
+int lhvi_debug_log(const double* x, double* y, int64_t n, int32_t which, void* stream);
 
 /* edge_class[e]: 0 = no message (observed target / alias edge), 1|2 = quadratic-family (continuous | discrete target),
  * 3 = generic potential.  Static per (graph, potentials); the host turns it into the two work lists above. */

@@ -265,6 +265,69 @@ __device__ __forceinline__ void load_exp_table(double* __restrict__ tab) {
     __syncthreads();
 }
 
+// Accumulating form for sums  acc += exp(t + C)  where C does not change along the sum (the f2v term loop: C is the
+// output point's own constant).  C is split once into whole table steps kC and a remainder Cr, |Cr| <= step/2; kC rides
+// in the rounding constant (magic = 1.5*2^52 + kC, exact), so the low word of u is already kC + round(t/step) and the
+// per-term `+ C` disappears; exp(Cr) multiplies the finished sum.  The scaling by 2^(n >> 11) is applied to the table
+// entry, which lets the product and the accumulation share one fma: 10 fp64 + 3 integer operations per term.
+struct ExpShift { double magic, scale; };
+
+__device__ __forceinline__ ExpShift exp_shift(double C) {
+    const double MAGIC = 6755399441055744.0;
+    ExpShift o;
+    o.magic = fma(C, LHVI_EXP_INV_STEP, MAGIC);
+    const double kd = o.magic - MAGIC;
+    double r = fma(kd, -LHVI_EXP_STEP_HI, C);
+    r = fma(kd, -LHVI_EXP_STEP_LO, r);
+    double p = fma(r, 1.6666666666666666667e-1, 0.5);
+    p = fma(p, r, 1.0);
+    o.scale = fma(p, r, 1.0);
+    return o;
+}
+
+__device__ __forceinline__ double exp_accumulate(double acc, double t, double magic, const double* __restrict__ tab) {
+    // u = t / step + magic in the three-address form: `magic` stays live for the whole loop, and the compiler's choice
+    // (v_fmac on a copy of it) costs a 64-bit move per term
+    double u;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(u) : "v"(t), "s"((double)LHVI_EXP_INV_STEP), "v"(magic));
+    const int nn = __double2loint(u);
+    const double kd = u - magic;
+    // one-constant reduction: RN(step) is off by 2^-55 relative, i.e. |t| * 3e-17 in r -- below the rounding of t itself
+    // (t = a + b x carries |t| * 1.1e-16), so the second Cody-Waite step of exp_core would buy nothing here
+    const double r = fma(kd, -LHVI_EXP_STEP_HI, t);
+    double p = fma(r, 1.6666666666666666667e-1, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return fma(ldexp(tab[nn & (EXP_TAB_N - 1)], nn >> LHVI_EXP_TABLE_BITS), p, acc);
+}
+
+// log(x), x > 0 (denormals and +inf included), for the one-log-per-output-point epilogues: x = m 2^e, m in [0.5, 1) cut
+// into 128 slices with midpoints c_i; table (1/c_i, ln c_i) in LDS; r = m / c_i - 1, |r| <= 2^-8, log1p(r) to degree 7.
+// ~20 VALU operations and one 16-byte LDS gather against ~95 operations for the ocml routine.  Absolute error
+// < 2.5e-16 for |log x| < 1 and <= 2 ulp beyond (tests/test_gpu_pbp.py::test_device_log_accuracy); the cancellation
+// next to x = 1 is not compensated -- log-messages are used additively.
+constexpr int LOG_TAB_N = 1 << LHVI_LOG_TABLE_BITS;
+struct LogRec { double inv_c, log_c; };
+
+__device__ __forceinline__ void load_log_table(LogRec* __restrict__ tab) {       // caller synchronises the block
+    for (int i = threadIdx.x; i < LOG_TAB_N; i += blockDim.x) { tab[i].inv_c = LOG_TAB[2 * i]; tab[i].log_c = LOG_TAB[2 * i + 1]; }
+}
+
+__device__ __forceinline__ double log_table(double x, const LogRec* __restrict__ tab) {
+    const int e = __builtin_amdgcn_frexp_exp(x);
+    const double m = __builtin_amdgcn_frexp_mant(x);
+    const LogRec c = tab[(__double2hiint(m) >> (20 - LHVI_LOG_TABLE_BITS)) & (LOG_TAB_N - 1)];
+    const double r = fma(m, c.inv_c, -1.0);
+    double q = fma(r, LHVI_SCONST(1.0 / 7.0), LHVI_SCONST(-1.0 / 6.0));
+    q = fma(q, r, LHVI_SCONST(1.0 / 5.0));
+    q = fma(q, r, -0.25);
+    q = fma(q, r, LHVI_SCONST(1.0 / 3.0));
+    q = fma(q, r, -0.5);
+    const double l = fma(r * r, q, r);
+    const double y = fma((double)e, LHVI_SCONST(LHVI_LN2), c.log_c + l);
+    return x == __builtin_huge_val() ? x : y;
+}
+
 // Edge classes of the f -> v half sweep.  FAST edges have a term of the form
 //     log phi + m_j = a_j + b_j * X1 + k_j * X2 + C        (j = partner particle, X1/X2/C = per output point)
 //   (1) continuous target, log phi quadratic in it (Gaussian / Quadratic / LinearGaussian / XY / HybridQuadratic with
@@ -347,14 +410,14 @@ enum { MODE_CONST = 0, MODE_VARK = 1, MODE_DISC = 2 };
 struct AB { double a, b; };
 
 template <int MODE>
-__device__ __forceinline__ double fast_term(const AB* __restrict__ sh, const double* __restrict__ shk, const double* __restrict__ tab,
-                                            int j, double X1, double X2, double C) {
+__device__ __forceinline__ double fast_term(double acc, const AB* __restrict__ sh, const double* __restrict__ shk,
+                                            const double* __restrict__ tab, int j, double X1, double X2, double magic) {
     const AB r = sh[j];
     double t;
-    if (MODE == MODE_CONST) t = fma(r.b, X1, r.a) + C;                 // C = k * x^2
+    if (MODE == MODE_CONST) t = fma(r.b, X1, r.a);                     // + C = k * x^2 through `magic`
     else if (MODE == MODE_VARK) t = fma(shk[j], X2, fma(r.b, X1, r.a));
-    else t = fma(r.b, fma(r.b, X2, X1), r.a) + C;
-    return exp_core(t, tab);
+    else t = fma(r.b, fma(r.b, X2, X1), r.a);
+    return exp_accumulate(acc, t, magic, tab);
 }
 
 // every lane walks `jn` consecutive records starting at its own base (full rounds: the same base for all lanes; the
@@ -364,42 +427,46 @@ template <int MODE>
 __device__ __forceinline__ double fast_accumulate_uniform(const AB* __restrict__ sh, const double* __restrict__ shk,
                                                           const double* __restrict__ tab, int jn_, double X1, double X2, double C) {
     const int jn = __builtin_amdgcn_readfirstlane(jn_);
+    const ExpShift sft = exp_shift(C);
     double acc0 = 0.0, acc1 = 0.0;
     int j = 0;
     for (; j + 2 <= jn; j += 2) {
-        acc0 += fast_term<MODE>(sh, shk, tab, j, X1, X2, C);
-        acc1 += fast_term<MODE>(sh, shk, tab, j + 1, X1, X2, C);
+        acc0 = fast_term<MODE>(acc0, sh, shk, tab, j, X1, X2, sft.magic);
+        acc1 = fast_term<MODE>(acc1, sh, shk, tab, j + 1, X1, X2, sft.magic);
     }
-    if (j < jn) acc0 += fast_term<MODE>(sh, shk, tab, j, X1, X2, C);
-    return acc0 + acc1;
+    if (j < jn) acc0 = fast_term<MODE>(acc0, sh, shk, tab, j, X1, X2, sft.magic);
+    return (acc0 + acc1) * sft.scale;
 }
 
 // FAST edges: persistent kernel, one wavefront per edge at a time (each wave strides over the work list).
 // Partner coefficients are staged in wave-private LDS in tiles of 64; each lane owns one output point per round and
 // accumulates sum_j exp(.).  A final partial round splits the partner range over idle lanes and folds the partial
 // sums with shuffles, so n + T = 96 points on 64 lanes still keep every lane busy.
-#ifndef LHVI_FAST_WAVES
-#define LHVI_FAST_WAVES 4
-#endif
-__global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
+// HEAVY = true is the compile-time specialisation for the bulk of the work: continuous target, constant x^2 coefficient
+// (continuous x continuous quadratic-family potential), at most 64 partner particles.  Dropping the other modes lets the
+// register allocator fit more waves per SIMD, which is what hides the per-edge load latency behind other waves' term loops.
+template <bool HEAVY>
+__global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
                                                             const double* __restrict__ v2f, double* __restrict__ f2v) {
     __shared__ AB sh_all[BLOCK / WAVE][WAVE];
     __shared__ double shk_all[BLOCK / WAVE][WAVE];
     __shared__ double sh_tab[EXP_TAB_N];
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    load_log_table(sh_log);
     load_exp_table(sh_tab);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     AB* sh = sh_all[wid];
     double* shk = shk_all[wid];
-    const FastDesc* __restrict__ descs = reinterpret_cast<const FastDesc*>(s.fast_desc);
-    const int nitems = s.fast_edges ? s.n_fast : g.E;
+    const FastDesc* __restrict__ descs = reinterpret_cast<const FastDesc*>(HEAVY ? s.heavy_desc : s.fast_desc);
+    const int nitems = HEAVY ? s.n_heavy : (s.fast_edges ? s.n_fast : g.E);
     const int nwaves = gridDim.x * (BLOCK / WAVE);
     const int n = s.n, S = s.n + s.T;
     for (int item = blockIdx.x * (BLOCK / WAVE) + wid; item < nitems; item += nwaves) {
         FastDesc d;
-        if (descs) d = descs[item];                       // wave-uniform address: scalar loads
+        if (HEAVY || descs) d = descs[item];              // wave-uniform address: scalar loads
         else d = make_fast_desc(g, pots, s, s.fast_edges ? s.fast_edges[item] : item);
-        if (d.cls != EDGE_FAST_CONT && d.cls != EDGE_FAST_DISC) continue;
+        if (!HEAVY && d.cls != EDGE_FAST_CONT && d.cls != EDGE_FAST_DISC) continue;
         const double* par = pots.param + d.par_off;
         const int np = d.np, npts = d.np + d.T, nj = d.nj;
         const bool partner_hidden = is_hidden(d.pval);
@@ -422,7 +489,8 @@ __global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lh
         }
 
         // x^2 coefficient: constant per edge unless the partner is the discrete argument of a HybridQuadratic
-        const int mode = d.cls == EDGE_FAST_DISC ? MODE_DISC : (d.kind == LHVI_POT_HYBRID_QUADRATIC ? MODE_VARK : MODE_CONST);
+        const int mode = HEAVY ? MODE_CONST
+                               : (d.cls == EDGE_FAST_DISC ? MODE_DISC : (d.kind == LHVI_POT_HYBRID_QUADRATIC ? MODE_VARK : MODE_CONST));
         double kconst = 0.0;
         if (mode == MODE_CONST) { Quad2 q; quad2_of(d.kind, par, 0, q); kconst = d.pos == 0 ? q.a00 : q.a11; }
         auto stage = [&](int j0, int jn, double y, double m) {
@@ -434,7 +502,7 @@ __global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lh
                 r.a = -800.0; r.b = 0.0;
                 double kk = 0.0;
                 if (lane < jn) {
-                    if (d.cls == EDGE_FAST_CONT) {
+                    if (HEAVY || d.cls == EDGE_FAST_CONT) {
                         Quad2 q;
                         quad2_of(d.kind, par, (d.kind == LHVI_POT_HYBRID_QUADRATIC) ? (int)y : 0, q);
                         if (d.pos == 0) { r.a = (q.a11 * y + q.b1) * y + q.c + m; r.b = q.axy * y + q.b0; kk = q.a00; }
@@ -446,7 +514,7 @@ __global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lh
             }
             LHVI_WAVE_SYNC();
         };
-        const bool single_tile = nj <= 64;
+        const bool single_tile = HEAVY || nj <= 64;
         if (single_tile) stage(0, nj, y0, m0);             // staged once per edge, reused by every round
 
         for (int p0 = 0; p0 < npts; p0 += 64) {
@@ -462,7 +530,7 @@ __global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lh
             else if (valid) xv = p < np ? s.particles[(int64_t)d.tv * n + p] : g.dom_val[d.gb + p - np];
             double X1 = 0.0, X2 = 0.0, C = 0.0;
             if (valid) {
-                if (d.cls == EDGE_FAST_CONT) { X1 = xv; X2 = xv * xv; C = kconst * X2; }
+                if (HEAVY || d.cls == EDGE_FAST_CONT) { X1 = xv; X2 = xv * xv; C = kconst * X2; }
                 else {
                     const int nst = (int)par[2];
                     const int st = (int)xv;                                  // HybridQuadratic indexes by the state value
@@ -486,8 +554,105 @@ __global__ void __launch_bounds__(BLOCK, LHVI_FAST_WAVES) pbp_f2v_fast_kernel(lh
                 else acc += fast_accumulate_uniform<MODE_DISC>(base, basek, sh_tab, chunk, X1, X2, C);
             }
             for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
-            if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log(acc) : -700.0;
+            if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
         }
+    }
+}
+
+// HEAVY edges = the bulk of the work: continuous target, constant x^2 coefficient (continuous x continuous
+// quadratic-family potential, or an observed partner), nj <= 64 partner particles, at most 128 output points.  Same
+// arithmetic as the general kernel above in MODE_CONST, but (a) only this mode, which fits 6+ waves per SIMD, and
+// (b) software-pipelined: while edge k is in its term loops the loads of edge k+1 are already in flight (its descriptor
+// was fetched one edge earlier still), so a wave never sits out a memory round trip between two term loops.
+struct HeavyData { double y, m, x0, x1; };
+
+__device__ __forceinline__ int round_log2_width(int rem) {      // 64 lanes for a full round, else next pow2 >= rem
+    int lw = 6;
+    if (rem <= 32) { lw = 0; while ((1 << lw) < rem) ++lw; }
+    return lw;
+}
+
+__device__ __forceinline__ HeavyData heavy_fetch(const FastDesc& d, const lhvi_graph_t& g, const lhvi_pbp_t& s,
+                                                 const double* __restrict__ v2f, int lane) {
+    HeavyData h;
+    const int n = s.n, np = d.np, npts = d.np + d.T;
+    h.y = d.pval; h.m = 0.0; h.x0 = 0.0; h.x1 = 0.0;
+    if (is_hidden(d.pval) && lane < d.nj) { h.y = s.old_particles[(int64_t)d.pv * n + lane]; h.m = v2f[(int64_t)d.pce * n + lane]; }
+    {
+        const int pl = lane & ((1 << round_log2_width(npts)) - 1);
+        if (pl < npts) h.x0 = pl < np ? s.particles[(int64_t)d.tv * n + pl] : g.dom_val[d.gb + pl - np];
+    }
+    if (npts > 64) {
+        const int rem = npts - 64, pl = lane & ((1 << round_log2_width(rem)) - 1), pp = 64 + pl;
+        if (pl < rem) h.x1 = pp < np ? s.particles[(int64_t)d.tv * n + pp] : g.dom_val[d.gb + pp - np];
+    }
+    return h;
+}
+
+__global__ void __launch_bounds__(BLOCK) pbp_f2v_heavy_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
+                                                             const double* __restrict__ v2f, double* __restrict__ f2v) {
+    __shared__ AB sh_all[BLOCK / WAVE][WAVE];
+    __shared__ double sh_tab[EXP_TAB_N];
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    load_log_table(sh_log);
+    load_exp_table(sh_tab);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    AB* sh = sh_all[wid];
+    const FastDesc* __restrict__ descs = reinterpret_cast<const FastDesc*>(s.heavy_desc);
+    const int nitems = s.n_heavy, last = nitems - 1;
+    const int nwaves = gridDim.x * (BLOCK / WAVE);
+    const int n = s.n, S = s.n + s.T;
+    int item = blockIdx.x * (BLOCK / WAVE) + wid;
+    if (item >= nitems) return;
+    // descriptor pipeline: `d` = what the arithmetic of the current edge needs (7 words), `dn` = full descriptor of the
+    // next edge (its loads are issued at the top of the iteration), reloaded for the edge after that as soon as those
+    // loads are out.  Keeping two full descriptors instead of three leaves the scalar registers for the constants.
+    struct { int32_t e, pos, kind, nj, np, T, par_off; } d, dnc;
+    FastDesc dn = descs[item];
+    HeavyData h = heavy_fetch(dn, g, s, v2f, lane);
+    d.e = dn.e; d.pos = dn.pos; d.kind = dn.kind; d.nj = dn.nj; d.np = dn.np; d.T = dn.T; d.par_off = dn.par_off;
+    dn = descs[min(item + nwaves, last)];
+    for (; item < nitems; item += nwaves) {
+        HeavyData hn = h;
+        if (item + nwaves < nitems) hn = heavy_fetch(dn, g, s, v2f, lane);          // next edge's loads go out first
+        dnc.e = dn.e; dnc.pos = dn.pos; dnc.kind = dn.kind; dnc.nj = dn.nj; dnc.np = dn.np; dnc.T = dn.T; dnc.par_off = dn.par_off;
+        dn = descs[min(item + 2 * nwaves, last)];
+
+        const double* par = pots.param + d.par_off;
+        const int np = d.np, npts = d.np + d.T, nj = d.nj;
+        double* out = f2v + (int64_t)d.e * S;
+        Quad2 q;
+        quad2_of(d.kind, par, 0, q);
+        const double kconst = d.pos == 0 ? q.a00 : q.a11;
+        LHVI_WAVE_SYNC();
+        {
+            AB r;
+            r.a = -800.0; r.b = 0.0;                       // padding: exp(-800) underflows to exactly 0
+            if (lane < nj) {
+                const double y = h.y;
+                if (d.pos == 0) { r.a = (q.a11 * y + q.b1) * y + q.c + h.m; r.b = q.axy * y + q.b0; }
+                else            { r.a = (q.a00 * y + q.b0) * y + q.c + h.m; r.b = q.axy * y + q.b1; }
+            }
+            sh[lane] = r;
+        }
+        LHVI_WAVE_SYNC();
+#pragma nounroll
+        for (int r = 0; r < 2; ++r) {
+            const int rem = npts - 64 * r;
+            if (rem <= 0) break;
+            const int lw = round_log2_width(rem);
+            const int width = 1 << lw, split = 64 >> lw, sub = lane >> lw, pl = lane & (width - 1);
+            const int p = 64 * r + pl;
+            const bool valid = pl < rem;
+            const double xv = r == 0 ? h.x0 : h.x1;
+            const double X1 = valid ? xv : 0.0, C = kconst * X1 * X1;
+            const int chunk = (s.flags & 16u) ? 0 : (nj + split - 1) >> (6 - lw);   // flag 16: tuning aid, skips the term loop
+            double acc = fast_accumulate_uniform<MODE_CONST>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
+            for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+            if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
+        }
+        d = dnc; h = hn;
     }
 }
 
@@ -497,6 +662,27 @@ __global__ void __launch_bounds__(BLOCK) debug_exp_kernel(const double* __restri
     load_exp_table(sh_tab);
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n) y[i] = exp_core(x[i], sh_tab);
+}
+
+// test hook: y[i] = log_pos(x[i])
+__global__ void __launch_bounds__(BLOCK) debug_log_kernel(const double* __restrict__ x, double* __restrict__ y, int64_t n, int which) {
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    load_log_table(sh_log);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) y[i] = which == 0 ? log_table(x[i], sh_log) : log_pos(x[i]);
+}
+
+// test hook: y[i] = exp(x[i] + c[i]) through the accumulating form of the f2v term loop
+__global__ void __launch_bounds__(BLOCK) debug_exp_acc_kernel(const double* __restrict__ x, const double* __restrict__ c,
+                                                             double* __restrict__ y, int64_t n) {
+    __shared__ double sh_tab[EXP_TAB_N];
+    load_exp_table(sh_tab);
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) {
+        const ExpShift sft = exp_shift(c[i]);
+        y[i] = exp_accumulate(0.0, x[i], sft.magic, sh_tab) * sft.scale;
+    }
 }
 
 __global__ void __launch_bounds__(BLOCK) pbp_classify_kernel(lhvi_graph_t g, lhvi_pots_t pots, uint8_t* __restrict__ cls) {
@@ -841,6 +1027,20 @@ int lhvi_debug_exp(const double* x, double* y, int64_t n, void* stream) {
     return check_launch();
 }
 
+int lhvi_debug_log(const double* x, double* y, int64_t n, int32_t which, void* stream) {
+    if (!x || !y || n < 0 || which < 0 || which > 1) return LHVI_E_ARG;
+    if (n == 0) return LHVI_OK;
+    hipLaunchKernelGGL(debug_log_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, as_stream(stream), x, y, n, which);
+    return check_launch();
+}
+
+int lhvi_debug_exp_acc(const double* x, const double* c, double* y, int64_t n, void* stream) {
+    if (!x || !c || !y || n < 0) return LHVI_E_ARG;
+    if (n == 0) return LHVI_OK;
+    hipLaunchKernelGGL(debug_exp_acc_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, as_stream(stream), x, c, y, n);
+    return check_launch();
+}
+
 int lhvi_pbp_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* v2f, void* stream) {
     if (int rc = validate_pbp(g, s)) return rc;
     if (!f2v || !v2f || !s->uniq || !s->q) return LHVI_E_ARG;
@@ -856,10 +1056,17 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     // persistent grids sized from the measured residency: CUs x resident workgroups per CU, every wave strides over its list
     const int nfast = s->fast_edges ? s->n_fast : g->E, ngen = s->generic_edges ? s->n_generic : g->E;
     static const int cus = device_cus();
-    static const int fast_per_cu = blocks_per_cu((const void*)pbp_f2v_fast_kernel);
+    static const int fast_per_cu = blocks_per_cu((const void*)pbp_f2v_fast_kernel<false>);
+    static const int heavy_per_cu = blocks_per_cu((const void*)pbp_f2v_heavy_kernel);
     static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel);
-    if (!(s->flags & LHVI_PBP_SKIP_FAST) && nfast > 0)
-        hipLaunchKernelGGL(pbp_f2v_fast_kernel, dim3(min((nfast + 3) / 4, cus * fast_per_cu)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, *s, v2f, f2v);
+    if (!(s->flags & LHVI_PBP_SKIP_FAST)) {
+        if (s->heavy_desc && s->n_heavy > 0)
+            hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(min((s->n_heavy + 3) / 4, cus * heavy_per_cu)), dim3(BLOCK), 0, as_stream(stream),
+                               *g, *pots, *s, v2f, f2v);
+        if (nfast > 0)
+            hipLaunchKernelGGL(pbp_f2v_fast_kernel<false>, dim3(min((nfast + 3) / 4, cus * fast_per_cu)), dim3(BLOCK), 0, as_stream(stream),
+                               *g, *pots, *s, v2f, f2v);
+    }
     if (!(s->flags & LHVI_PBP_SKIP_GENERIC) && ngen > 0) {
         int pts_log2 = s->generic_edges ? s->generic_pts_log2 : 6;
         if (pts_log2 < 0 || pts_log2 > 6) pts_log2 = 6;

@@ -45,7 +45,7 @@ class PbpStruct(C.Structure):
         ('particles', C.c_void_p), ('old_particles', C.c_void_p), ('np', C.c_void_p), ('uniq', C.c_void_p),
         ('q', C.c_void_p),
         ('fast_edges', C.c_void_p), ('n_fast', C.c_int32), ('generic_edges', C.c_void_p), ('n_generic', C.c_int32),
-        ('generic_pts_log2', C.c_int32), ('fast_desc', C.c_void_p),
+        ('generic_pts_log2', C.c_int32), ('fast_desc', C.c_void_p), ('heavy_desc', C.c_void_p), ('n_heavy', C.c_int32),
         ('bslot', C.c_void_p), ('brow_ptr', C.c_void_p), ('brow_idx', C.c_void_p), ('brow_peer', C.c_void_p),
         ('recv', C.c_void_p), ('rank', C.c_int32), ('var_degree', C.c_void_p),
     ]
@@ -82,6 +82,8 @@ SIGNATURES = {
     'lhvi_pbp_classify': (C.c_int, [_G, _P, _vp, _vp]),
     'lhvi_pbp_describe': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _vp]),
     'lhvi_debug_exp': (C.c_int, [_vp, _vp, _i64, _vp]),
+    'lhvi_debug_log': (C.c_int, [_vp, _vp, _i64, C.c_int32, _vp]),
+    'lhvi_debug_exp_acc': (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     'lhvi_pbp_v2f': (C.c_int, [_G, _S, _vp, _vp, _vp]),
     'lhvi_pbp_f2v': (C.c_int, [_G, _P, _S, _vp, _vp, _vp]),
     'lhvi_pbp_proposal': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp]),

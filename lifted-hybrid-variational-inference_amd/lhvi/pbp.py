@@ -72,13 +72,22 @@ class _ParticleSweep:
         tv = flat.edge_var[ge]
         pts = self.np_host[tv] + np.where(flat.var_cont[tv], flat.var_nstates[tv], 0) if ge.size else np.zeros(0, dtype=int)
         self.generic_pts_log2 = int(min(6, max(0, int(np.ceil(np.log2(max(int(pts.max()), 1)))) if ge.size else 6)))
-        self.fast_desc = None
+        self.fast_desc = self.heavy_desc = None
+        self.n_heavy = 0
         nf = int(self.fast_edges.numel())
         if nf:
             desc = torch.empty(nf * _abi.PBP_DESC_BYTES, dtype=torch.uint8, device=dg.device)
             _abi.check(_abi.lib().lhvi_pbp_describe(dg.g, dg.p, self._struct(), _abi.ptr(self.fast_edges), nf,
                                                     _abi.ptr(desc), _abi.stream_ptr()))
-            self.fast_desc = desc
+            # split off the edges the specialised kernel serves (descriptor words: 4 = class, 6 = potential kind, 7 = nj, 8 = np, 9 = T)
+            words = desc.view(torch.int32).view(nf, _abi.PBP_DESC_BYTES // 4)
+            heavy = (words[:, 4] == 1) & (words[:, 6] != 4) & (words[:, 7] <= 64) & (words[:, 8] + words[:, 9] <= 128)
+            rows = desc.view(nf, _abi.PBP_DESC_BYTES)
+            self.heavy_desc = rows[heavy].contiguous()
+            self.n_heavy = int(self.heavy_desc.shape[0])
+            self.fast_desc = rows[~heavy].contiguous()
+            self.fast_edges = self.fast_edges[~heavy].contiguous()
+            self._fast_list = self.fast_edges if self.fast_edges.numel() else pad
 
     def _struct(self):
         s = _abi.PbpStruct()
@@ -90,6 +99,7 @@ class _ParticleSweep:
         s.generic_edges, s.n_generic = _abi.ptr(self._generic_list), int(self.generic_edges.numel())
         s.generic_pts_log2 = int(getattr(self, 'generic_pts_log2', 6))
         s.fast_desc = _abi.ptr(getattr(self, 'fast_desc', None))
+        s.heavy_desc, s.n_heavy = _abi.ptr(getattr(self, 'heavy_desc', None)), int(getattr(self, 'n_heavy', 0))
         return s
 
     # ---- sampling ----------------------------------------------------------------------------

@@ -180,6 +180,48 @@ def test_device_exp_accuracy(api):
     assert (y[x < -760] == 0).all() and np.isinf(y[x > 709.9]).all()
 
 
+def test_device_log_accuracy(api):
+    """the f2v epilogue's table-driven log: <= 2 ulp away from 1 and < 2.5e-16 absolute next to it, from the denormals to
+    the top of the range; the series log (which = 1): <= 2 ulp everywhere"""
+    import torch
+    rng = np.random.default_rng(1)
+    x = np.concatenate([np.exp(rng.uniform(-744, 709, 300000)), rng.uniform(0.5, 2.0, 200000), 1.0 + rng.uniform(-1e-6, 1e-6, 10000),
+                        np.array([1.0, 0.5, 2.0, np.sqrt(0.5), np.sqrt(2.0), 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, np.inf])])
+    xd = api.to_dev(x)
+    want = np.log(x)
+    fin = np.isfinite(want)
+    for which in (0, 1):
+        yd = torch.empty_like(xd)
+        api.check(api.lib().lhvi_debug_log(api.ptr(xd), api.ptr(yd), x.size, which, api.stream_ptr()))
+        y = yd.cpu().numpy()
+        scale = np.abs(want[fin]) if which == 1 else np.maximum(np.abs(want[fin]), 1.0)
+        scale = np.where(scale == 0, 1.0, scale)
+        ulp = np.abs(y[fin] - want[fin]) / np.spacing(scale)
+        assert ulp.max() <= (2.0 if which == 1 else 2.25), (which, ulp.max(), x[fin][ulp.argmax()])
+        assert abs(y[x == 1.0][0]) <= (0.0 if which == 1 else 2.5e-16) and np.isinf(y[-1])
+
+
+def test_device_exp_accumulate_accuracy(api):
+    """the term loop's exp(t + C): C folded into the rounding constant (exactly), one-constant range reduction of t.
+    Relative error <= 6e-16 + 3.8e-17 |t| -- less than the rounding that t = a + b x already carries (1.1e-16 |t|)"""
+    import torch
+    rng = np.random.default_rng(2)
+    t = np.concatenate([rng.uniform(-700, 50, 200000), rng.uniform(-20, 20, 200000), np.array([-800.0, -1e4, 0.0])])
+    c = np.concatenate([rng.uniform(-600, 30, 200000), rng.uniform(-20, 20, 200000), np.array([0.0, 0.0, 0.0])])
+    keep = (t + c < 700)
+    t, c = t[keep], c[keep]
+    td, cd = api.to_dev(t), api.to_dev(c)
+    yd = torch.empty_like(td)
+    api.check(api.lib().lhvi_debug_exp_acc(api.ptr(td), api.ptr(cd), api.ptr(yd), t.size, api.stream_ptr()))
+    y = yd.cpu().numpy()
+    want = np.exp(np.longdouble(t) + np.longdouble(c)).astype(np.float64)
+    fin = want > 1e-300
+    rel = np.abs(y[fin] - want[fin]) / want[fin]
+    bound = 6e-16 + 3.8e-17 * np.abs(t[fin])          # 2 ulp of the table/polynomial + |t| * (step - RN(step)) / step
+    assert (rel <= bound).all(), (rel / bound).max()
+    assert (y[t + c < -760] == 0).all()
+
+
 @pytest.mark.parametrize('name', ['hlbp_c2f_rgm', 'hlbp_c2f_rgm_simple'])
 def test_hlbp_coarse_to_fine_matches_reference(api, golden_dir, name):
     """c2f=0: coarse start, per-sweep refinement with message inheritance; partitions and proposals at every draw and the
