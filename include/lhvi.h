@@ -147,7 +147,7 @@ typedef struct lhvi_pbp {
     const double* var_degree;   /* [V] global number of incoming messages (sum of counts over ALL ranks' edges) */
 } lhvi_pbp_t;
 
-#define LHVI_PBP_DESC_BYTES 64
+#define LHVI_PBP_DESC_BYTES 128
 /* static per-edge descriptors of the fast work list (targets, partners, particle counts, potential rows): lets the
  * persistent f2v kernel fetch an edge with scalar loads.  Must be rebuilt when np / the graph / the potentials change. */
 int lhvi_pbp_describe(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const int32_t* edges, int32_t count,

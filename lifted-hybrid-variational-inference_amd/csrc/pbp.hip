@@ -366,8 +366,12 @@ struct FastDesc {
     int32_t np, T, gb, par_off;    // target particle count, target grid size, grid base in dom_val, offset into pots.param
     double pval;                   // partner evidence value (NaN = hidden)
     int32_t pad[2];
+    // class 1 with a constant x^2 coefficient (kind != HYBRID_QUADRATIC): the potential resolved for this edge's target
+    // position, log phi(x, y) = kx x^2 + (ay y + by) y + c + (axy y + bx) x with x = target, y = partner
+    double ay, by, c, axy, bx, kx;
+    double pad2[2];
 };
-static_assert(sizeof(FastDesc) == 64, "FastDesc is part of the ABI (LHVI_PBP_DESC_BYTES)");
+static_assert(sizeof(FastDesc) == LHVI_PBP_DESC_BYTES, "FastDesc is part of the ABI (LHVI_PBP_DESC_BYTES)");
 
 __device__ __forceinline__ FastDesc make_fast_desc(const lhvi_graph_t& g, const lhvi_pots_t& pots, const lhvi_pbp_t& s, int e) {
     FastDesc d;
@@ -389,6 +393,13 @@ __device__ __forceinline__ FastDesc make_fast_desc(const lhvi_graph_t& g, const 
     d.gb = g.dom_ptr[dom];
     d.T = (d.cls == EDGE_FAST_CONT) ? g.dom_ptr[dom + 1] - d.gb : 0;
     d.pad[0] = d.pad[1] = 0;
+    d.ay = d.by = d.c = d.axy = d.bx = d.kx = d.pad2[0] = d.pad2[1] = 0.0;
+    Quad2 q;
+    if (d.cls == EDGE_FAST_CONT && d.kind != LHVI_POT_HYBRID_QUADRATIC && quad2_of(d.kind, pots.param + d.par_off, 0, q)) {
+        if (d.pos == 0) { d.ay = q.a11; d.by = q.b1; d.axy = q.axy; d.bx = q.b0; d.kx = q.a00; }
+        else            { d.ay = q.a00; d.by = q.b0; d.axy = q.axy; d.bx = q.b1; d.kx = q.a11; }
+        d.c = q.c;
+    }
     return d;
 }
 
@@ -422,14 +433,24 @@ __device__ __forceinline__ double fast_term(double acc, const AB* __restrict__ s
 
 // every lane walks `jn` consecutive records starting at its own base (full rounds: the same base for all lanes; the
 // last partial round: one base per lane group) -> scalar loop control, LDS addresses with immediate offsets, two
-// independent exp chains per iteration (four bought nothing at >= 4 waves/SIMD and cost a wave of occupancy)
-template <int MODE>
+// (or four) independent exp chains per iteration
+template <int MODE, int UNROLL = 2>
 __device__ __forceinline__ double fast_accumulate_uniform(const AB* __restrict__ sh, const double* __restrict__ shk,
                                                           const double* __restrict__ tab, int jn_, double X1, double X2, double C) {
     const int jn = __builtin_amdgcn_readfirstlane(jn_);
     const ExpShift sft = exp_shift(C);
     double acc0 = 0.0, acc1 = 0.0;
     int j = 0;
+    if (UNROLL == 4) {                  // four chains: fewer LDS round trips per term; worth its registers in the heavy kernel only
+        double acc2 = 0.0, acc3 = 0.0;
+        for (; j + 4 <= jn; j += 4) {
+            acc0 = fast_term<MODE>(acc0, sh, shk, tab, j, X1, X2, sft.magic);
+            acc1 = fast_term<MODE>(acc1, sh, shk, tab, j + 1, X1, X2, sft.magic);
+            acc2 = fast_term<MODE>(acc2, sh, shk, tab, j + 2, X1, X2, sft.magic);
+            acc3 = fast_term<MODE>(acc3, sh, shk, tab, j + 3, X1, X2, sft.magic);
+        }
+        acc0 += acc2; acc1 += acc3;
+    }
     for (; j + 2 <= jn; j += 2) {
         acc0 = fast_term<MODE>(acc0, sh, shk, tab, j, X1, X2, sft.magic);
         acc1 = fast_term<MODE>(acc1, sh, shk, tab, j + 1, X1, X2, sft.magic);
@@ -589,8 +610,9 @@ __device__ __forceinline__ HeavyData heavy_fetch(const FastDesc& d, const lhvi_g
     return h;
 }
 
-__global__ void __launch_bounds__(BLOCK) pbp_f2v_heavy_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
-                                                             const double* __restrict__ v2f, double* __restrict__ f2v) {
+__global__ void __launch_bounds__(BLOCK) pbp_f2v_heavy_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
+                                                             double* __restrict__ f2v, const FastDesc* __restrict__ descs,
+                                                             int nitems) {
     __shared__ AB sh_all[BLOCK / WAVE][WAVE];
     __shared__ double sh_tab[EXP_TAB_N];
     __shared__ LogRec sh_log[LOG_TAB_N];
@@ -599,44 +621,41 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_heavy_kernel(lhvi_graph_t g, lh
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     AB* sh = sh_all[wid];
-    const FastDesc* __restrict__ descs = reinterpret_cast<const FastDesc*>(s.heavy_desc);
-    const int nitems = s.n_heavy, last = nitems - 1;
+    // (descs is a kernel argument of its own so that its restrict qualifier holds and the descriptors come through the
+    // scalar cache: s_load does not take part in vmcnt, which the prefetched vector loads rely on)
+    const int last = nitems - 1;
     const int nwaves = gridDim.x * (BLOCK / WAVE);
     const int n = s.n, S = s.n + s.T;
     int item = blockIdx.x * (BLOCK / WAVE) + wid;
     if (item >= nitems) return;
-    // descriptor pipeline: `d` = what the arithmetic of the current edge needs (7 words), `dn` = full descriptor of the
-    // next edge (its loads are issued at the top of the iteration), reloaded for the edge after that as soon as those
-    // loads are out.  Keeping two full descriptors instead of three leaves the scalar registers for the constants.
-    struct { int32_t e, pos, kind, nj, np, T, par_off; } d, dnc;
+    // pipeline: the loads of edge k+1 are issued as soon as edge k has been staged into LDS (its registers are free
+    // then, so nothing has to be rotated) and stay in flight through the term loops of edge k; `dn` is the full
+    // descriptor of edge k+1, fetched one edge ahead, `d` the seven words the arithmetic of edge k needs
+    struct { int32_t e, nj, np, T; double ay, by, c, axy, bx, kx; } d;
     FastDesc dn = descs[item];
     HeavyData h = heavy_fetch(dn, g, s, v2f, lane);
-    d.e = dn.e; d.pos = dn.pos; d.kind = dn.kind; d.nj = dn.nj; d.np = dn.np; d.T = dn.T; d.par_off = dn.par_off;
-    dn = descs[min(item + nwaves, last)];
-    for (; item < nitems; item += nwaves) {
-        HeavyData hn = h;
-        if (item + nwaves < nitems) hn = heavy_fetch(dn, g, s, v2f, lane);          // next edge's loads go out first
-        dnc.e = dn.e; dnc.pos = dn.pos; dnc.kind = dn.kind; dnc.nj = dn.nj; dnc.np = dn.np; dnc.T = dn.T; dnc.par_off = dn.par_off;
-        dn = descs[min(item + 2 * nwaves, last)];
-
-        const double* par = pots.param + d.par_off;
+    for (;;) {
+        d.e = dn.e; d.nj = dn.nj; d.np = dn.np; d.T = dn.T;
+        d.ay = dn.ay; d.by = dn.by; d.c = dn.c; d.axy = dn.axy; d.bx = dn.bx; d.kx = dn.kx;
+        const bool more = item + nwaves < nitems;
+        dn = descs[__builtin_amdgcn_readfirstlane(min(item + nwaves, last))];
         const int np = d.np, npts = d.np + d.T, nj = d.nj;
         double* out = f2v + (int64_t)d.e * S;
-        Quad2 q;
-        quad2_of(d.kind, par, 0, q);
-        const double kconst = d.pos == 0 ? q.a00 : q.a11;
+        const double kconst = d.kx;
         LHVI_WAVE_SYNC();
         {
             AB r;
             r.a = -800.0; r.b = 0.0;                       // padding: exp(-800) underflows to exactly 0
             if (lane < nj) {
                 const double y = h.y;
-                if (d.pos == 0) { r.a = (q.a11 * y + q.b1) * y + q.c + h.m; r.b = q.axy * y + q.b0; }
-                else            { r.a = (q.a00 * y + q.b0) * y + q.c + h.m; r.b = q.axy * y + q.b1; }
+                r.a = (d.ay * y + d.by) * y + d.c + h.m;
+                r.b = d.axy * y + d.bx;
             }
             sh[lane] = r;
         }
         LHVI_WAVE_SYNC();
+        const double x0 = h.x0, x1 = h.x1;
+        if (more) h = heavy_fetch(dn, g, s, v2f, lane);
 #pragma nounroll
         for (int r = 0; r < 2; ++r) {
             const int rem = npts - 64 * r;
@@ -645,14 +664,15 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_heavy_kernel(lhvi_graph_t g, lh
             const int width = 1 << lw, split = 64 >> lw, sub = lane >> lw, pl = lane & (width - 1);
             const int p = 64 * r + pl;
             const bool valid = pl < rem;
-            const double xv = r == 0 ? h.x0 : h.x1;
+            const double xv = r == 0 ? x0 : x1;
             const double X1 = valid ? xv : 0.0, C = kconst * X1 * X1;
             const int chunk = (s.flags & 16u) ? 0 : (nj + split - 1) >> (6 - lw);   // flag 16: tuning aid, skips the term loop
-            double acc = fast_accumulate_uniform<MODE_CONST>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
+            double acc = fast_accumulate_uniform<MODE_CONST, 4>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
             for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
             if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
         }
-        d = dnc; h = hn;
+        if (!more) break;
+        item += nwaves;
     }
 }
 
@@ -907,7 +927,45 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
-__device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t gid, uint32_t j, uint32_t iteration) {
+// sqrt(x), x > 0 normal: v_rsq_f64 seed (about 24 good bits) + one coupled Newton step + a residual correction
+__device__ __forceinline__ double sqrt_pos(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    return fma(fma(-g, g, x), h, g);
+}
+
+// cos(2 pi t), t in [0, 1): fold to w = distance to the nearest half turn's quarter, |2 pi w| <= pi/2, even series to a^22
+// (remainder < 2e-17); the argument reduction is exact because t is
+__device__ __forceinline__ double cos_turns(double t) {
+    const double tt = fabs(t - rint(t));                        // [0, 0.5]
+    const bool flip = tt > 0.25;
+    const double w = flip ? 0.5 - tt : tt;                      // [0, 0.25]
+    const double a = w * 6.283185307179586477;
+    const double z = a * a;
+    double p = LHVI_SCONST(-1.0 / 1124000727777607680000.0);    // -1/22!
+    p = fma(p, z, LHVI_SCONST(1.0 / 2432902008176640000.0));    //  1/20!
+    p = fma(p, z, LHVI_SCONST(-1.0 / 6402373705728000.0));      // -1/18!
+    p = fma(p, z, LHVI_SCONST(1.0 / 20922789888000.0));         //  1/16!
+    p = fma(p, z, LHVI_SCONST(-1.0 / 87178291200.0));           // -1/14!
+    p = fma(p, z, LHVI_SCONST(1.0 / 479001600.0));              //  1/12!
+    p = fma(p, z, LHVI_SCONST(-1.0 / 3628800.0));               // -1/10!
+    p = fma(p, z, LHVI_SCONST(1.0 / 40320.0));                  //  1/8!
+    p = fma(p, z, LHVI_SCONST(-1.0 / 720.0));                   // -1/6!
+    p = fma(p, z, LHVI_SCONST(1.0 / 24.0));                     //  1/4!
+    p = fma(p, z, -0.5);
+    p = fma(p, z, 1.0);
+    return flip ? -p : p;
+}
+
+// standard normal draw for (variable gid, particle j, iteration): Box-Muller on two 53-bit uniforms of one Philox block.
+// log / sqrt / cos are the short routines above (absolute error < 1e-15 on z): a sampler needs reproducibility -- every
+// rank runs this same code, so replicas of a boundary variable still draw identical particles -- not the last ulp.
+// `logtab` = LDS copy of the log table (load_log_table), or nullptr for the table-free series
+__device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t gid, uint32_t j, uint32_t iteration,
+                                                const LogRec* __restrict__ logtab) {
     uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), j, iteration};
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -915,7 +973,8 @@ __device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t gid, uin
     const uint64_t r0 = ((uint64_t)c[0] << 32) | c[1], r1 = ((uint64_t)c[2] << 32) | c[3];
     const double u1 = ((double)(r0 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
     const double u2 = ((double)(r1 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
-    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    const double l = logtab ? log_table(u1, logtab) : log_pos(u1);
+    return sqrt_pos(-2.0 * l) * cos_turns(u2);
 }
 
 // generate_sample (EPBP:61-70): clip(normal(q.mu, sqrt(q.var)), lo, hi); discrete rvs: the domain states
@@ -928,7 +987,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_kernel(lhvi_graph_t g, lhv
     if (j >= s.np[v]) return;
     const int d = g.var_dom[v];
     if (!g.dom_cont[d]) { out[i] = g.dom_val[g.dom_ptr[d] + j]; return; }
-    const double z = philox_normal(seed, gid ? (uint64_t)gid[v] : (uint64_t)v, (uint32_t)j, iteration);
+    const double z = philox_normal(seed, gid ? (uint64_t)gid[v] : (uint64_t)v, (uint32_t)j, iteration, nullptr);
     const double x = s.q[2 * v] + sqrt(s.q[2 * v + 1]) * z;
     out[i] = fmin(fmax(x, g.dom_lo[d]), g.dom_hi[d]);
 }
@@ -951,29 +1010,48 @@ static int blocks_per_cu(const void* kernel) {
 __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g, lhvi_pbp_t s, const int64_t* __restrict__ gid,
                                                                  uint64_t seed, uint32_t iteration, double* __restrict__ out,
                                                                  uint8_t* __restrict__ uniq) {
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    load_log_table(sh_log);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
-    if (v >= g.V) return;
     const int n = s.n;
-    const int cnt = s.np[v];
-    const int d = g.var_dom[v];
-    double x = 0.0;
-    if (lane < cnt) {
-        if (!g.dom_cont[d]) x = g.dom_val[g.dom_ptr[d] + lane];
-        else {
-            const double z = philox_normal(seed, gid ? (uint64_t)gid[v] : (uint64_t)v, (uint32_t)lane, iteration);
-            x = fmin(fmax(s.q[2 * v] + sqrt(s.q[2 * v + 1]) * z, g.dom_lo[d]), g.dom_hi[d]);
+    const int nwaves = gridDim.x * (BLOCK / WAVE);
+    // persistent waves (the table is loaded once per block, not once per four variables)
+    for (int v = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)); v < g.V; v += nwaves) {
+        const int cnt = s.np[v];
+        const int d = g.var_dom[v];
+        double x = 0.0;
+        if (lane < cnt) {
+            if (!g.dom_cont[d]) x = g.dom_val[g.dom_ptr[d] + lane];
+            else {
+                const double z = philox_normal(seed, gid ? (uint64_t)gid[v] : (uint64_t)v, (uint32_t)lane, iteration, sh_log);
+                // + 0.0: no -0, so that bitwise equality below is numeric equality
+                x = fmin(fmax(s.q[2 * v] + sqrt_pos(s.q[2 * v + 1]) * z, g.dom_lo[d]), g.dom_hi[d]) + 0.0;
+            }
+            out[(int64_t)v * n + lane] = x;
         }
-        out[(int64_t)v * n + lane] = x;
+        // first-occurrence mask.  Pass 1 compares the low words only (a readlane and a 32-bit compare per particle, the
+        // lane masks live in scalar registers); two different draws agree there with probability 2^-32, so the exact
+        // 64-bit pass runs only for a wave that has candidates -- in practice the ones with particles clipped to a bound
+        const int xlo = __double2loint(x), xhi = __double2hiint(x);
+        const uint64_t live = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1);
+        uint64_t dup = 0;
+        for (int k = 0; k < cnt - 1; ++k) {
+            const int klo = __builtin_amdgcn_readlane(xlo, k);
+            dup |= __ballot(xlo == klo) & (~1ull << k);              // lanes above k
+        }
+        dup &= live;
+        if (dup) {
+            dup = 0;
+            for (int k = 0; k < cnt - 1; ++k) {
+                const int klo = __builtin_amdgcn_readlane(xlo, k), khi = __builtin_amdgcn_readlane(xhi, k);
+                dup |= __ballot(xlo == klo && xhi == khi) & (~1ull << k);
+            }
+            dup &= live;
+        }
+        const int u = (lane < cnt) && !((dup >> lane) & 1);
+        if (lane < n) uniq[(int64_t)v * n + lane] = (uint8_t)u;
     }
-    const int xlo = __double2loint(x), xhi = __double2hiint(x);
-    int u = lane < cnt;
-    for (int k = 0; k < cnt - 1; ++k) {
-        const int klo = __builtin_amdgcn_readlane(xlo, k), khi = __builtin_amdgcn_readlane(xhi, k);
-        const double xk = __hiloint2double(khi, klo);
-        if (k < lane && xk == x) u = 0;
-    }
-    if (lane < n) uniq[(int64_t)v * n + lane] = (uint8_t)u;
 }
 
 static int validate_pbp(const lhvi_graph_t* g, const lhvi_pbp_t* s) {
@@ -1062,7 +1140,7 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     if (!(s->flags & LHVI_PBP_SKIP_FAST)) {
         if (s->heavy_desc && s->n_heavy > 0)
             hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(min((s->n_heavy + 3) / 4, cus * heavy_per_cu)), dim3(BLOCK), 0, as_stream(stream),
-                               *g, *pots, *s, v2f, f2v);
+                               *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy);
         if (nfast > 0)
             hipLaunchKernelGGL(pbp_f2v_fast_kernel<false>, dim3(min((nfast + 3) / 4, cus * fast_per_cu)), dim3(BLOCK), 0, as_stream(stream),
                                *g, *pots, *s, v2f, f2v);
@@ -1157,8 +1235,10 @@ int lhvi_pbp_resample_uniq(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int
         if (int rc = lhvi_pbp_resample(g, s, var_gid, seed, iteration, particles_out, stream)) return rc;
         return lhvi_pbp_uniq(g, s->n, particles_out, s->np, uniq_out, stream);
     }
-    hipLaunchKernelGGL(pbp_resample_uniq_kernel, dim3(grid_for((int64_t)g->V * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s,
-                       var_gid, seed, iteration, particles_out, uniq_out);
+    static const int cus = device_cus();
+    const int64_t want = ((int64_t)g->V + BLOCK / WAVE - 1) / (BLOCK / WAVE);
+    hipLaunchKernelGGL(pbp_resample_uniq_kernel, dim3((unsigned)(want < (int64_t)cus * 8 ? want : (int64_t)cus * 8)), dim3(BLOCK), 0,
+                       as_stream(stream), *g, *s, var_gid, seed, iteration, particles_out, uniq_out);
     return check_launch();
 }
 

@@ -62,7 +62,7 @@ PBP_EP = 1
 PBP_EPBP_DISCRETE = 2
 PBP_SKIP_FAST = 4
 PBP_SKIP_GENERIC = 8
-PBP_DESC_BYTES = 64
+PBP_DESC_BYTES = 128
 
 _G, _P, _S, _VI = C.POINTER(GraphStruct), C.POINTER(PotsStruct), C.POINTER(PbpStruct), C.POINTER(ViStruct)
 _vp, _i32, _i64, _u32, _u64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double, C.c_size_t

@@ -9,8 +9,8 @@ from lhvi.pbp import EPBP
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 reps = 5
-fd = float(os.environ.get('FRAC_DISC', 0.2)); ev = float(os.environ.get('EVID', 0.1))
-flat = synth.hybrid_mrf_flat(V=E // 4, deg=4, seed=0, frac_discrete=fd, evidence_ratio=ev)
+fd = float(os.environ.get('FRAC_DISC', 0.2)); ev = float(os.environ.get('EVID', 0.1)); T = int(os.environ.get('GRID', 32))
+flat = synth.hybrid_mrf_flat(V=E // 4, deg=4, seed=0, frac_discrete=fd, evidence_ratio=ev, T=T)
 bp = EPBP(None, n=n, proposal_approximation='simple', sampler='device', seed=1)
 bp._setup(None, flat=flat)
 run = dist.SingleRunner(bp)
