@@ -57,7 +57,8 @@ def cpu_baseline(n, T, seconds_target=15.0):
     workload: same generator, smaller V; all host cores through OpenMP on the f2v half."""
     from lhvi import synth
     from oracle import oracle
-    cores = os.cpu_count() or 1
+    # a one-GPU box owns a 16-core share of the host; more OpenMP threads than that only oversubscribe it
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 16)
     os.environ.setdefault('OMP_NUM_THREADS', str(cores))
     V = 10000
     flat = synth.hybrid_mrf_flat(V=V, deg=4, seed=123, T=T)
@@ -157,12 +158,16 @@ def main():
         sweeps_per_s = args.steps / elapsed
         bytes_e = algorithmic_bytes_per_edge(n, T)
         E_local = runner.local_edges()
-        f2v_bytes = bytes_e['f2v'] * E_local
+        # dominant kernel = pbp_f2v_heavy_kernel (continuous target, continuous or observed partner): its edges read the
+        # partner's particles + message (16n B), the target's points (8(n+T) B) and write n+T log-messages -- the f2v figure
+        # of DESIGN.md section 4 plus the target points, per edge of ITS work list
+        heavy_edges, terms = runner.heavy_stats()
+        f2v_bytes = (bytes_e['f2v'] + 8 * (n + T)) * heavy_edges
         f2v_gbs = f2v_bytes / (f2v_ms * 1e-3) / 1e9
         hidden_frac = runner.work_fraction()
-        # fp64 work of the dominant kernel: (n+T)*n_partner joint terms per edge, ~30 flop each
-        terms = runner.f2v_joint_terms()
-        f2v_tflops = terms * 30.0 / (f2v_ms * 1e-3) / 1e12
+        # fp64 work: 16 flop per (output point, partner particle) term -- 7 fma, 1 add, 1 ldexp
+        FLOP_PER_TERM = 16.0
+        f2v_tflops = terms * FLOP_PER_TERM / (f2v_ms * 1e-3) / 1e12
         out = {
             'metric': 'lbp_sweeps_per_sec_10M_edge_hybrid_mrf', 'value': sweeps_per_s, 'unit': 'sweeps/s',
             'edge_messages_per_sec': 2.0 * E_total * sweeps_per_s,
@@ -171,14 +176,15 @@ def main():
             'config': {'workload': 'cfg4x10 random hybrid pairwise MRF, EPBP particle sweep', 'edges': E_total,
                        'variables': V, 'particles': n, 'integral_points': T, 'proposal': 'simple',
                        'sharding': 'single GPU' if world == 1 else 'factor-partitioned edge shards, 1 all_to_all/sweep'},
-            'roofline': {'bound': 'hbm', 'kernel': 'pbp_f2v_fast_kernel', 'achieved': f2v_gbs, 'peak': HBM_PEAK_GBS,
+            'roofline': {'bound': 'hbm', 'kernel': 'pbp_f2v_heavy_kernel', 'achieved': f2v_gbs, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': f2v_gbs / HBM_PEAK_GBS,
-                         'traffic': measured_traffic('pbp_f2v_fast_kernel') if world == 1 and args.edges == 10_000_000 else None,
-                         'kernel_ms': f2v_ms, 'algorithmic_bytes_per_launch': f2v_bytes,
-                         'note': 'f2v is fp64-VALU bound (arithmetic intensity ~140 flop/B); see fp64_valu',
+                         'traffic': measured_traffic('pbp_f2v_heavy_kernel') if world == 1 and args.edges == 10_000_000 else None,
+                         'kernel_ms': f2v_ms, 'algorithmic_bytes_per_launch': f2v_bytes, 'edges_per_launch': heavy_edges,
+                         'note': 'the kernel is bound by fp64 VALU issue (9 fp64 + 3 int32 instructions per term, no FMA-only '
+                                 'stream) and LDS (2 reads per term), not by HBM; see fp64_valu and DESIGN.md section 5',
                          'fp64_valu': {'achieved': f2v_tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                        'frac': f2v_tflops / FP64_PEAK_TFLOPS, 'joint_terms_per_launch': terms,
-                                       'flop_per_term': 30},
+                                       'flop_per_term': FLOP_PER_TERM},
                          'sweep_hbm': {'achieved': bytes_e['sweep'] * E_local / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
                                        'unit': 'GB/s', 'frac': bytes_e['sweep'] * E_local / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             'hidden_edge_fraction': hidden_frac,

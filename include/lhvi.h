@@ -110,8 +110,12 @@ int lhvi_gabp_marginals(const lhvi_graph_t* g, const double* f2v, double* mu_var
 
 #define LHVI_PBP_EP 1u            /* proposal_approximation == 'EP' (else 'simple') */
 #define LHVI_PBP_EPBP_DISCRETE 2u /* EPBP applies importance weights to discrete rvs too (EPBP.py:157) */
-#define LHVI_PBP_SKIP_FAST 4u     /* lhvi_pbp_f2v: do not launch the quadratic-family kernel (profiling aid) */
+#define LHVI_PBP_SKIP_FAST 4u     /* lhvi_pbp_f2v: launch neither quadratic-family kernel (profiling aid) */
 #define LHVI_PBP_SKIP_GENERIC 8u  /* lhvi_pbp_f2v: do not launch the generic-potential kernel (profiling aid) */
+#define LHVI_PBP_SKIP_TERMS 16u   /* lhvi_pbp_f2v: the quadratic-family kernels skip their term loops -- results are
+                                   * meaningless; isolates the per-edge load/store cost when tuning */
+#define LHVI_PBP_SKIP_HEAVY 32u   /* lhvi_pbp_f2v: do not launch the continuous x continuous (heavy_desc) kernel (profiling aid) */
+#define LHVI_PBP_SKIP_LIGHT 64u   /* lhvi_pbp_f2v: do not launch the kernel of the remaining fast edges (profiling aid) */
 
 typedef struct lhvi_pbp {
     int32_t n;                  /* particle slots per variable */

@@ -82,6 +82,23 @@ __device__ __forceinline__ double dpp_half_reduce(double v, Op op, int lane) {  
 // s = (m - 1)/(m + 1), |s| <= 0.1716, odd series through s^19 (next term < 3e-17 relative).  ~35 fp64 operations against
 // ~95 for the ocml routine (which carries double-double intermediates for < 1 ulp); measured max error 2 ulp
 // (tests/test_gpu_pbp.py::test_device_log_accuracy).  Used where a kernel takes one log per output point.
+// sqrt(x), x > 0 normal: v_rsq_f64 seed (about 24 good bits) + one coupled Newton step + a residual correction
+__device__ __forceinline__ double sqrt_pos(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    return fma(fma(-g, g, x), h, g);
+}
+
+// 1 / x for finite normal x != 0: v_rcp_f64 seed + two Newton steps (< 1 ulp); for divisors shared by many divisions
+__device__ __forceinline__ double rcp_newton(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
 // A double constant materialised in a scalar register pair right where it is used.  Left to itself the compiler keeps
 // every fp64 literal of a polynomial in a VGPR pair for the whole kernel (v_fmac wants its addend in a VGPR), which
 // costs the persistent kernels a wave of occupancy; scalar moves are free next to fp64 VALU work.

@@ -37,7 +37,7 @@ __device__ __forceinline__ double norm_pdf_std(double x, double mu, double sig) 
 // log(1 / max(N(x; mu, sd), 1e-200)); with N = exp(-u^2/2) / (2.5066 sd) that is min(u^2/2 + log(2.5066 sd), -log 1e-200),
 // which needs one division per particle instead of exp + two divisions + log (log_sd_term is per variable).
 __device__ __forceinline__ double log_importance(const lhvi_graph_t& g, const lhvi_pbp_t& s, int v, int d, double x,
-                                                 double mu, double sd, double log_norm) {
+                                                 double mu, double rsd /* 1 / sd */, double log_norm) {
     const double LOG_1E200 = 460.51701859880916;       // -log(1e-200)
     if (g.dom_cont[d]) {
         if (x == g.dom_lo[d] || x == g.dom_hi[d]) return -LOG_1E200;
@@ -47,7 +47,7 @@ __device__ __forceinline__ double log_importance(const lhvi_graph_t& g, const lh
         const int ns = g.dom_ptr[d + 1] - b;
         if (x == g.dom_val[b] || (ns > 1 && x == g.dom_val[b + 1])) return -LOG_1E200;
     }
-    const double u = (x - mu) / sd;
+    const double u = (x - mu) * rsd;
     return fmin(u * u * 0.5 + log_norm, LOG_1E200);
 }
 
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_uniq_wave_kernel(int V, int n, cons
 // variable has four 512-byte rows in flight per wave instead of one.
 constexpr int V2F_CACHE = 8;
 
-__global__ void __launch_bounds__(BLOCK) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                        double* __restrict__ v2f) {
     const int lane = threadIdx.x & 63;
     const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp
     const int d = g.var_dom[v];
     const bool lifted = g.edge_count != nullptr;
     const int nchunk = (np + 63) / 64;
-    const double mu = s.q[2 * v], sd = sqrt(s.q[2 * v + 1]);
+    const double mu = s.q[2 * v], sd = sqrt(s.q[2 * v + 1]), rsd = 1.0 / sd;
     const double log_norm = log(2.506628274631 * sd);
     for (int c = 0; c < nchunk; ++c) {
         const int j = c * 64 + lane;
@@ -131,8 +131,9 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp
             const double m = valid ? f2v[(int64_t)e * S + j] : 0.0;
             total += lifted ? m * g.edge_count[e] : m;
         }
-        const double logw = valid ? log_importance(g, s, v, d, x, mu, sd, log_norm) : 0.0;
+        const double logw = valid ? log_importance(g, s, v, d, x, mu, rsd, log_norm) : 0.0;
         const int cnt1 = __builtin_popcountll(__ballot(uq));        // distinct particles: the same for every incident edge
+        const double rcnt = rcp_newton((double)cnt1);
         auto emit = [&](int e, double m) {
             // ground: sum over nb != f; lifted: own factor keeps count-1 copies (HLBP:182-191) -> total - m either way
             const double res = (total - m) + logw;
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp
                 // log_message_balance over the distinct keys (EPBP:204-215)
                 const double tot = wave_sum(uq ? res : 0.0);
                 const double mx = wave_max(uq ? res : -__builtin_huge_val());
-                const double mean = tot / (double)cnt1;
+                const double mean = tot * rcnt;
                 const double shift = (mx - mean > s.max_log_value) ? mx - s.max_log_value : mean;
                 if (valid) v2f[(int64_t)e * n + j] = res - shift;
             } else if (valid) {
@@ -248,13 +249,13 @@ __device__ double f2v_point_generic(const lhvi_graph_t& g, const lhvi_pots_t& po
 constexpr int EXP_TAB_N = 1 << LHVI_EXP_TABLE_BITS;
 
 __device__ __forceinline__ double exp_core(double t, const double* __restrict__ tab /* LDS copy of EXP_TAB */) {
-    const double MAGIC = 6755399441055744.0;                 // 1.5 * 2^52
-    const double u = fma(t, LHVI_EXP_INV_STEP, MAGIC);
+    const double MAGIC = LHVI_SCONST(6755399441055744.0);   // 1.5 * 2^52
+    const double u = fma(t, LHVI_SCONST(LHVI_EXP_INV_STEP), MAGIC);
     const int nn = __double2loint(u);
     const double kd = u - MAGIC;
-    double r = fma(kd, -LHVI_EXP_STEP_HI, t);
-    r = fma(kd, -LHVI_EXP_STEP_LO, r);
-    double p = fma(r, 1.6666666666666666667e-1, 0.5);
+    double r = fma(kd, LHVI_SCONST(-LHVI_EXP_STEP_HI), t);
+    r = fma(kd, LHVI_SCONST(-LHVI_EXP_STEP_LO), r);
+    double p = fma(r, LHVI_SCONST(1.6666666666666666667e-1), 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return ldexp(tab[nn & (EXP_TAB_N - 1)] * p, nn >> LHVI_EXP_TABLE_BITS);
@@ -559,7 +560,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
                 }
             }
             double acc = 0.0;
-            for (int j0 = 0; j0 < ((s.flags & 16u) ? 0 : nj); j0 += 64) {     // flag 16: tuning aid, skips the term loop
+            for (int j0 = 0; j0 < ((s.flags & LHVI_PBP_SKIP_TERMS) ? 0 : nj); j0 += 64) {     // flag 16: tuning aid, skips the term loop
                 const int jn = min(64, nj - j0);
                 if (!single_tile) {
                     double y = d.pval, m = 0.0;
@@ -666,7 +667,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_heavy_kernel(lhvi_graph_t g, lh
             const bool valid = pl < rem;
             const double xv = r == 0 ? x0 : x1;
             const double X1 = valid ? xv : 0.0, C = kconst * X1 * X1;
-            const int chunk = (s.flags & 16u) ? 0 : (nj + split - 1) >> (6 - lw);   // flag 16: tuning aid, skips the term loop
+            const int chunk = (s.flags & LHVI_PBP_SKIP_TERMS) ? 0 : (nj + split - 1) >> (6 - lw);   // flag 16: tuning aid, skips the term loop
             double acc = fast_accumulate_uniform<MODE_CONST, 4>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
             for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
             if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
@@ -927,16 +928,6 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
-// sqrt(x), x > 0 normal: v_rsq_f64 seed (about 24 good bits) + one coupled Newton step + a residual correction
-__device__ __forceinline__ double sqrt_pos(double x) {
-    const double r = __builtin_amdgcn_rsq(x);
-    double g = x * r, h = 0.5 * r;
-    const double e = fma(-h, g, 0.5);
-    g = fma(g, e, g);
-    h = fma(h, e, h);
-    return fma(fma(-g, g, x), h, g);
-}
-
 // cos(2 pi t), t in [0, 1): fold to w = distance to the nearest half turn's quarter, |2 pi w| <= pi/2, even series to a^22
 // (remainder < 2e-17); the argument reduction is exact because t is
 __device__ __forceinline__ double cos_turns(double t) {
@@ -999,6 +990,13 @@ static int device_cus() {
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 }
 
+// grid of a wave-per-item persistent kernel: enough blocks for `per_cu` per CU, never more than the items need
+static unsigned persistent_grid(int64_t items, int per_cu) {
+    static const int cus = device_cus();
+    const int64_t want = (items + BLOCK / WAVE - 1) / (BLOCK / WAVE), cap = (int64_t)cus * per_cu;
+    return (unsigned)(want < cap ? want : cap);
+}
+
 static int blocks_per_cu(const void* kernel) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
@@ -1036,11 +1034,23 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
         const int xlo = __double2loint(x), xhi = __double2hiint(x);
         const uint64_t live = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1);
         uint64_t dup = 0;
-        for (int k = 0; k < cnt - 1; ++k) {
-            const int klo = __builtin_amdgcn_readlane(xlo, k);
-            dup |= __ballot(xlo == klo) & (~1ull << k);              // lanes above k
+        if (cnt == 64) {
+            // full wave: unrolled, four instructions per particle.  `xm` is the low word with the lanes <= k overwritten
+            // by a poison value, so the comparison needs no lane mask; a poison hit can only add a false candidate
+            int xm = xlo;
+#pragma unroll
+            for (int k = 0; k < 63; ++k) {
+                const int klo = __builtin_amdgcn_readlane(xlo, k);
+                asm("v_writelane_b32 %0, -1, %1" : "+v"(xm) : "n"(k));
+                dup |= __ballot(xm == klo);
+            }
+        } else {
+            for (int k = 0; k < cnt - 1; ++k) {
+                const int klo = __builtin_amdgcn_readlane(xlo, k);
+                dup |= __ballot(xlo == klo) & (~1ull << k);              // lanes above k
+            }
+            dup &= live;
         }
-        dup &= live;
         if (dup) {
             dup = 0;
             for (int k = 0; k < cnt - 1; ++k) {
@@ -1138,10 +1148,10 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     static const int heavy_per_cu = blocks_per_cu((const void*)pbp_f2v_heavy_kernel);
     static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel);
     if (!(s->flags & LHVI_PBP_SKIP_FAST)) {
-        if (s->heavy_desc && s->n_heavy > 0)
+        if (s->heavy_desc && s->n_heavy > 0 && !(s->flags & LHVI_PBP_SKIP_HEAVY))
             hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(min((s->n_heavy + 3) / 4, cus * heavy_per_cu)), dim3(BLOCK), 0, as_stream(stream),
                                *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy);
-        if (nfast > 0)
+        if (nfast > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
             hipLaunchKernelGGL(pbp_f2v_fast_kernel<false>, dim3(min((nfast + 3) / 4, cus * fast_per_cu)), dim3(BLOCK), 0, as_stream(stream),
                                *g, *pots, *s, v2f, f2v);
     }
@@ -1235,9 +1245,7 @@ int lhvi_pbp_resample_uniq(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int
         if (int rc = lhvi_pbp_resample(g, s, var_gid, seed, iteration, particles_out, stream)) return rc;
         return lhvi_pbp_uniq(g, s->n, particles_out, s->np, uniq_out, stream);
     }
-    static const int cus = device_cus();
-    const int64_t want = ((int64_t)g->V + BLOCK / WAVE - 1) / (BLOCK / WAVE);
-    hipLaunchKernelGGL(pbp_resample_uniq_kernel, dim3((unsigned)(want < (int64_t)cus * 8 ? want : (int64_t)cus * 8)), dim3(BLOCK), 0,
+    hipLaunchKernelGGL(pbp_resample_uniq_kernel, dim3(persistent_grid(g->V, 8)), dim3(BLOCK), 0,
                        as_stream(stream), *g, *s, var_gid, seed, iteration, particles_out, uniq_out);
     return check_launch();
 }

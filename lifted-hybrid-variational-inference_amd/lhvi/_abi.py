@@ -62,6 +62,9 @@ PBP_EP = 1
 PBP_EPBP_DISCRETE = 2
 PBP_SKIP_FAST = 4
 PBP_SKIP_GENERIC = 8
+PBP_SKIP_TERMS = 16
+PBP_SKIP_HEAVY = 32
+PBP_SKIP_LIGHT = 64
 PBP_DESC_BYTES = 128
 
 _G, _P, _S, _VI = C.POINTER(GraphStruct), C.POINTER(PotsStruct), C.POINTER(PbpStruct), C.POINTER(ViStruct)

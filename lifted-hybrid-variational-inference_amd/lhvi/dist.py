@@ -55,6 +55,10 @@ class SingleRunner:
     def f2v_joint_terms(self):
         return joint_terms(self.bp.flat, self.bp.np_host)
 
+    def heavy_stats(self):
+        """(edges, joint terms) of the continuous x continuous kernel's work list"""
+        return self.bp.n_heavy, self.bp.heavy_terms
+
 
 # =================================================================================================
 # edge sharding
@@ -275,12 +279,15 @@ class ShardedRunner:
         _abi.check(l.lhvi_pbp_proposal_finish(bp.dg.g, s, _abi.ptr(self.ph), _abi.ptr(bp.q_dev), st))
         bp._generate_sample()
         s = self._struct()
-        if f2v_events:
-            s.flags |= _abi.PBP_SKIP_GENERIC
+        if f2v_events:          # the dominant kernel alone between the events, then the other two
+            base = s.flags
+            s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_LIGHT
             f2v_events[0].record()
             _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
             f2v_events[1].record()
-            s.flags = (s.flags & ~_abi.PBP_SKIP_GENERIC) | _abi.PBP_SKIP_FAST
+            s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_HEAVY
+            _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
+            s.flags = base | _abi.PBP_SKIP_FAST
             _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
         else:
             _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
@@ -299,3 +306,6 @@ class ShardedRunner:
 
     def f2v_joint_terms(self):
         return joint_terms(self.plan.flat, self.bp.np_host)
+
+    def heavy_stats(self):
+        return self.bp.n_heavy, self.bp.heavy_terms

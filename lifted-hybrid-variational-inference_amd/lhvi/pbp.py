@@ -74,6 +74,7 @@ class _ParticleSweep:
         self.generic_pts_log2 = int(min(6, max(0, int(np.ceil(np.log2(max(int(pts.max()), 1)))) if ge.size else 6)))
         self.fast_desc = self.heavy_desc = None
         self.n_heavy = 0
+        self.heavy_terms = 0
         nf = int(self.fast_edges.numel())
         if nf:
             desc = torch.empty(nf * _abi.PBP_DESC_BYTES, dtype=torch.uint8, device=dg.device)
@@ -85,6 +86,9 @@ class _ParticleSweep:
             rows = desc.view(nf, _abi.PBP_DESC_BYTES)
             self.heavy_desc = rows[heavy].contiguous()
             self.n_heavy = int(self.heavy_desc.shape[0])
+            # (output point, partner particle) terms of the heavy kernel: sum over its edges of (np + T) * nj
+            hw = words[heavy].to(torch.int64)
+            self.heavy_terms = int(((hw[:, 8] + hw[:, 9]) * hw[:, 7]).sum().item())
             self.fast_desc = rows[~heavy].contiguous()
             self.fast_edges = self.fast_edges[~heavy].contiguous()
             self._fast_list = self.fast_edges if self.fast_edges.numel() else pad
@@ -165,13 +169,16 @@ class _ParticleSweep:
             _abi.check(l.lhvi_pbp_proposal(g, self._struct(), _abi.ptr(self.f2v), _abi.ptr(self.eta),
                                            _abi.ptr(self.q_dev), st))
             self._generate_sample()
-            if f2v_events:      # time the dominant (quadratic-family) kernel alone: two calls, one kernel each
+            if f2v_events:      # time the dominant (continuous x continuous) kernel alone: three calls, one kernel each
                 s = self._struct()
-                s.flags |= _abi.PBP_SKIP_GENERIC
+                base = s.flags
+                s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_LIGHT
                 f2v_events[0].record()
                 _abi.check(l.lhvi_pbp_f2v(g, p, s, _abi.ptr(self.v2f), _abi.ptr(self.f2v), st))
                 f2v_events[1].record()
-                s.flags = (s.flags & ~_abi.PBP_SKIP_GENERIC) | _abi.PBP_SKIP_FAST
+                s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_HEAVY
+                _abi.check(l.lhvi_pbp_f2v(g, p, s, _abi.ptr(self.v2f), _abi.ptr(self.f2v), st))
+                s.flags = base | _abi.PBP_SKIP_FAST
                 _abi.check(l.lhvi_pbp_f2v(g, p, s, _abi.ptr(self.v2f), _abi.ptr(self.f2v), st))
             else:
                 _abi.check(l.lhvi_pbp_f2v(g, p, self._struct(), _abi.ptr(self.v2f), _abi.ptr(self.f2v), st))

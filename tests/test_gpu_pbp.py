@@ -163,6 +163,35 @@ def test_device_sampler_statistics(api):
     assert (runs[0] == runs[1]).all()
 
 
+@pytest.mark.parametrize('n', [64, 48])
+def test_device_sampler_first_occurrence_mask(api, n):
+    """fused draw + mask against the stand-alone exact mask kernel: wide proposals on a narrow domain clip most draws to
+    the bounds (many exact duplicates), tight ones none; n = 48 takes the partial-wave path"""
+    import torch
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    flat = synth.hybrid_mrf_flat(V=3000, deg=4, seed=2)
+    bp = EPBP(None, n=n, proposal_approximation='simple', sampler='device', seed=5)
+    bp._setup(None, flat=flat)
+    _init(api, bp)
+    q = bp.q_dev.cpu().numpy()
+    rng = np.random.default_rng(0)
+    q[:, 0] = rng.uniform(-12, 12, flat.V)
+    q[:, 1] = np.where(rng.random(flat.V) < 0.5, 400.0, 0.01)
+    bp.q_dev.copy_(api.to_dev(q))
+    bp._generate_sample()
+    fused = bp.uniq.cpu().numpy().copy()
+    P = bp.particles.cpu().numpy()
+    exact = torch.zeros_like(bp.uniq)
+    api.check(api.lib().lhvi_pbp_uniq(bp.dg.g, n, api.ptr(bp.particles), api.ptr(bp.np_dev), api.ptr(exact), api.stream_ptr()))
+    exact = exact.cpu().numpy()
+    np.testing.assert_array_equal(fused, exact)
+    cont = np.flatnonzero(flat.var_hidden & flat.var_cont)
+    first = np.array([[P[v, j] not in P[v, :j] for j in range(n)] for v in cont[:300]])
+    np.testing.assert_array_equal(exact.reshape(flat.V, -1)[cont[:300], :n].astype(bool), first)
+    assert (~first).sum() > 1000            # the duplicates are really there
+
+
 def test_device_exp_accuracy(api):
     """the f2v kernel's table-driven exp stays within 2 ulp of libm over the whole log-message range"""
     import torch
