@@ -66,6 +66,13 @@ __device__ __forceinline__ double dpp_reduce_rows32(double v, Op op) {      // l
     return v;
 }
 template <class Op>
+__device__ __forceinline__ double dpp_row_reduce(double v, Op op) {         // every lane gets its 16-lane row's result
+    v = op(dpp_move<0xb1>(v), v);
+    v = op(dpp_move<0x4e>(v), v);
+    v = op(dpp_move<0x124>(v), v);
+    return op(dpp_move<0x128>(v), v);
+}
+template <class Op>
 __device__ __forceinline__ double dpp_wave_reduce(double v, Op op) {        // every lane gets the wave-wide result
     v = dpp_reduce_rows32(v, op);
     v = op(dpp_move<0x143>(v), v);     // row_bcast:31

@@ -469,7 +469,9 @@ __device__ __forceinline__ double fast_accumulate_uniform(const AB* __restrict__
 // register allocator fit more waves per SIMD, which is what hides the per-edge load latency behind other waves' term loops.
 template <bool HEAVY>
 __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
-                                                            const double* __restrict__ v2f, double* __restrict__ f2v) {
+                                                            const double* __restrict__ v2f, double* __restrict__ f2v,
+                                                            const FastDesc* __restrict__ descs,
+                                                            const double* __restrict__ param) {
     __shared__ AB sh_all[BLOCK / WAVE][WAVE];
     __shared__ double shk_all[BLOCK / WAVE][WAVE];
     __shared__ double sh_tab[EXP_TAB_N];
@@ -480,7 +482,6 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
     const int lane = threadIdx.x & 63;
     AB* sh = sh_all[wid];
     double* shk = shk_all[wid];
-    const FastDesc* __restrict__ descs = reinterpret_cast<const FastDesc*>(HEAVY ? s.heavy_desc : s.fast_desc);
     const int nitems = HEAVY ? s.n_heavy : (s.fast_edges ? s.n_fast : g.E);
     const int nwaves = gridDim.x * (BLOCK / WAVE);
     const int n = s.n, S = s.n + s.T;
@@ -489,7 +490,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
         if (HEAVY || descs) d = descs[item];              // wave-uniform address: scalar loads
         else d = make_fast_desc(g, pots, s, s.fast_edges ? s.fast_edges[item] : item);
         if (!HEAVY && d.cls != EDGE_FAST_CONT && d.cls != EDGE_FAST_DISC) continue;
-        const double* par = pots.param + d.par_off;
+        const double* __restrict__ par = param + d.par_off;
         const int np = d.np, npts = d.np + d.T, nj = d.nj;
         const bool partner_hidden = is_hidden(d.pval);
         double* out = f2v + (int64_t)d.e * S;
@@ -785,11 +786,11 @@ __device__ __forceinline__ void gdiv(double a0, double a1, double b0, double b1,
 }
 
 // update_proposal (EPBP:83-154; HLBP:100-171): one wavefront per continuous hidden variable.  With T <= 32 integral
-// points the wave works on two incident edges at once (lanes 0-31 / 32-63), otherwise on one; the T-point moments are
-// shuffle reductions inside the lane group.  Each group accumulates the information-form sum of its edges; the groups
+// points the wave works on four incident edges at once (16 lanes each), with T <= 64 on two, otherwise on one; the
+// T-point moments are DPP reductions inside the lane group.  Each group accumulates the information-form sum of its edges; the groups
 // are folded at the end (summation order differs from the reference's edge order by rounding only).
 // ph_out != nullptr: sharded mode -- write the local information-form sums instead of q (lhvi_pbp_proposal_partial)
-__global__ void __launch_bounds__(BLOCK) pbp_proposal_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) pbp_proposal_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                             double* __restrict__ eta, double* __restrict__ q,
                                                             double* __restrict__ ph_out) {
     const int lane = threadIdx.x & 63;
@@ -805,8 +806,10 @@ __global__ void __launch_bounds__(BLOCK) pbp_proposal_kernel(lhvi_graph_t g, lhv
     else for (int k = lo; k < hi; ++k) total += g.edge_count ? g.edge_count[g.var_edge[k]] : 1.0;
     const double min_sig = total * s.var_threshold;
     const double q0 = s.q[2 * v], q1 = s.q[2 * v + 1];
-    const int groups = T <= 32 ? 2 : 1;
-    const int width = 64 / groups;
+    // lane groups of 16 / 32 / 64 lanes, one incident edge per group and pass: with T <= 32 integral points a degree-4
+    // variable is done in one pass (two points per lane) and the moment sums are 4-step row reductions
+    const int width = T <= 32 ? 16 : (T <= 64 ? 32 : 64);
+    const int groups = 64 / width;
     const int grp = lane / width, tl = lane % width;
     double pm = 0.0, ps = 0.0;
     for (int k0 = lo; k0 < hi; k0 += groups) {
@@ -826,10 +829,12 @@ __global__ void __launch_bounds__(BLOCK) pbp_proposal_kernel(lhvi_graph_t g, lhv
             if (use_cav) w = w * norm_pdf_std(xg, c0, csd);
             z += w; a += w * xg; b += w * (xg * xg);
         }
-        if (groups == 2) { z = dpp_half_reduce(z, SumOp(), lane); a = dpp_half_reduce(a, SumOp(), lane); b = dpp_half_reduce(b, SumOp(), lane); }
+        if (width == 16) { z = dpp_row_reduce(z, SumOp()); a = dpp_row_reduce(a, SumOp()); b = dpp_row_reduce(b, SumOp()); }
+        else if (width == 32) { z = dpp_half_reduce(z, SumOp(), lane); a = dpp_half_reduce(a, SumOp(), lane); b = dpp_half_reduce(b, SumOp(), lane); }
         else { z = wave_sum(z); a = wave_sum(a); b = wave_sum(b); }
-        double mu = a / z;
-        double sig = b / z - mu * mu;
+        const double rz = rcp_newton(z);                  // z = 0 (every weight underflowed) -> nan -> the test below fails
+        double mu = a * rz;
+        double sig = b * rz - mu * mu;
         if (use_cav) { const double m0 = mu, m1 = sig; gdiv(m0, m1, c0, c1, mu, sig); }
         if (0.0 < sig && sig < __builtin_huge_val()) {
             sig = fmax(sig, min_sig);
@@ -838,12 +843,12 @@ __global__ void __launch_bounds__(BLOCK) pbp_proposal_kernel(lhvi_graph_t g, lhv
             mu = b0; sig = b1;
         }
         if (live) {
-            const double p = 1.0 / sig;
+            const double p = rcp_newton(sig);
             if (g.edge_count) { const double c = g.edge_count[e]; ps += p * c; pm += p * mu * c; }
             else { ps += p; pm += p * mu; }
         }
     }
-    if (groups == 2) { ps += __shfl_xor(ps, 32); pm += __shfl_xor(pm, 32); }
+    for (int off = width; off < 64; off <<= 1) { ps += __shfl_xor(ps, off); pm += __shfl_xor(pm, off); }
     if (ph_out) { if (lane == 0) { ph_out[2 * v] = ps; ph_out[2 * v + 1] = pm; } return; }
     ps = 1.0 / ps;
     if (lane == 0) { q[2 * v] = ps * pm; q[2 * v + 1] = ps; }
@@ -1153,7 +1158,7 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
                                *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy);
         if (nfast > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
             hipLaunchKernelGGL(pbp_f2v_fast_kernel<false>, dim3(min((nfast + 3) / 4, cus * fast_per_cu)), dim3(BLOCK), 0, as_stream(stream),
-                               *g, *pots, *s, v2f, f2v);
+                               *g, *pots, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->fast_desc), pots->param);
     }
     if (!(s->flags & LHVI_PBP_SKIP_GENERIC) && ngen > 0) {
         int pts_log2 = s->generic_edges ? s->generic_pts_log2 : 6;

@@ -37,6 +37,10 @@ tot += timed('proposal', lambda: _abi.check(l.lhvi_pbp_proposal(g, s, _abi.ptr(b
 tot += timed('resample+uniq', lambda: _abi.check(l.lhvi_pbp_resample_uniq(g, s, None, 1, 3, _abi.ptr(bp.particles), _abi.ptr(bp.uniq), st)))
 sf = bp._struct(); sf.flags |= _abi.PBP_SKIP_GENERIC
 tot += timed('f2v fast', lambda: _abi.check(l.lhvi_pbp_f2v(g, p, sf, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st)))
+sh = bp._struct(); sh.flags |= _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_LIGHT
+timed('  f2v heavy', lambda: _abi.check(l.lhvi_pbp_f2v(g, p, sh, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st)))
+sl = bp._struct(); sl.flags |= _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_HEAVY
+timed('  f2v light', lambda: _abi.check(l.lhvi_pbp_f2v(g, p, sl, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st)))
 sn = bp._struct(); sn.flags |= _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_TERMS
 timed('f2v fast (no term loop)', lambda: _abi.check(l.lhvi_pbp_f2v(g, p, sn, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st)))
 sg = bp._struct(); sg.flags |= _abi.PBP_SKIP_FAST
