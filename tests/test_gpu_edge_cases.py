@@ -106,28 +106,30 @@ def test_high_degree_hub_matches_oracle(api):
     np.testing.assert_allclose(mv.cpu().numpy(), omv, rtol=1e-11, atol=1e-12)
 
 
-def test_particle_counts_other_than_64(api):
-    """n = 5 (tiny), n = 100 (> one wavefront: chunked v2f, tiled f2v staging, generic uniq) vs the oracle"""
+@pytest.mark.parametrize('n,T', [(5, 20), (100, 20), (50, 32), (64, 64), (64, 70), (33, 7), (64, 0)])
+def test_particle_counts_and_grid_sizes(api, n, T):
+    """shapes around the kernels' fast paths, against the oracle: n = 5 (tiny), n = 100 (> one wavefront: chunked v2f,
+    tiled f2v staging, generic uniq), n = 50 (the reference's default), n + T = 128 (two full rounds, the heavy kernel's
+    limit), n + T = 134 (three rounds, general kernel), odd sizes, and no integral points at all"""
     from lhvi import synth
     from lhvi.pbp import EPBP
     from oracle import oracle
-    flat = synth.hybrid_mrf_flat(V=400, deg=4, seed=9, T=20)
-    for n in (5, 100):
-        bp = EPBP(None, n=n, proposal_approximation='simple', sampler='device', seed=n)
-        bp._setup(None, flat=flat)
-        l, st = api.lib(), api.stream_ptr()
-        api.check(l.lhvi_pbp_init(bp.dg.g, bp._struct(), api.ptr(bp.eta), api.ptr(bp.q_dev), api.ptr(bp.f2v), api.ptr(bp.v2f), st))
-        bp._generate_sample()
-        o = oracle.PbpOracle(flat, n, ep=False, epbp=True, var_threshold=3)
-        o.init()
-        o.set_particles(bp.particles.cpu().numpy())
-        assert (o.uniq == bp.uniq.cpu().numpy()).all()
-        hid_e = flat.var_hidden[flat.edge_var]
-        for _ in range(2):
-            bp.sweep(last=False)
-            o.step_v2f(); o.step_proposal(); o.set_particles(bp.particles.cpu().numpy()); o.step_f2v()
-            np.testing.assert_allclose(bp.v2f.cpu().numpy()[hid_e], o.v2f[hid_e], rtol=1e-9, atol=1e-7)
-            np.testing.assert_allclose(bp.f2v.cpu().numpy()[hid_e], o.f2v[hid_e], rtol=1e-9, atol=1e-7)
+    flat = synth.hybrid_mrf_flat(V=400, deg=4, seed=9, T=T)
+    bp = EPBP(None, n=n, proposal_approximation='simple', sampler='device', seed=n)
+    bp._setup(None, flat=flat)
+    l, st = api.lib(), api.stream_ptr()
+    api.check(l.lhvi_pbp_init(bp.dg.g, bp._struct(), api.ptr(bp.eta), api.ptr(bp.q_dev), api.ptr(bp.f2v), api.ptr(bp.v2f), st))
+    bp._generate_sample()
+    o = oracle.PbpOracle(flat, n, ep=False, epbp=True, var_threshold=3)
+    o.init()
+    o.set_particles(bp.particles.cpu().numpy())
+    assert (o.uniq == bp.uniq.cpu().numpy()).all()
+    hid_e = flat.var_hidden[flat.edge_var]
+    for _ in range(2):
+        bp.sweep(last=False)
+        o.step_v2f(); o.step_proposal(); o.set_particles(bp.particles.cpu().numpy()); o.step_f2v()
+        np.testing.assert_allclose(bp.v2f.cpu().numpy()[hid_e], o.v2f[hid_e], rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(bp.f2v.cpu().numpy()[hid_e], o.f2v[hid_e], rtol=1e-9, atol=1e-7)
 
 
 def test_argument_validation_returns_codes(api):
