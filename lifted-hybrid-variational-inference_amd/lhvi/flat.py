@@ -84,8 +84,11 @@ def flatten(g, require_device_potentials=False):
 
     ``require_device_potentials``: raise if a potential has no device encoding (particle BP and VI
     evaluate potentials on the GPU; Gaussian BP only needs the closed-form kinds and maps anything
-    else to the vacuous message like the reference does, ``GaBP.py:138``).
+    else to the vacuous message like the reference does, ``GaBP.py:138``).  A ``FlatGraph`` (e.g. from
+    ``RelationalGraph.ground_flat`` or ``build_flat``) is passed through unchanged.
     """
+    if isinstance(g, FlatGraph):
+        return g
     rvs = list(g.rvs)
     factors = list(g.factors)
     var_index = {rv: i for i, rv in enumerate(rvs)}

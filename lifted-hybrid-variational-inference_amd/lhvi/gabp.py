@@ -63,8 +63,14 @@ class _GaussianSweep:
         self._message = value
 
     def _params(self, rv_flat):
-        i = self.flat.var_index[rv_flat]
+        # an int is a variable index of a flat graph (RelationalGraph.ground_flat / build_flat have no rv objects)
+        i = int(rv_flat) if isinstance(rv_flat, (int, np.integer)) else self.flat.var_index[rv_flat]
         return float(self._mu_var[i, 0]), float(self._mu_var[i, 1])
+
+    @property
+    def mu_var(self):
+        """(V, 2) array of the marginals' (mean, variance), variable-index order (extension: batched get_belief_params)"""
+        return self._mu_var
 
 
 def _message_dict(flat, f2v, v2f):

@@ -112,3 +112,31 @@ def test_color_refinement_large_random_vs_oracle(api):
     orv, of = oracle.color_passing(flat, sym, rv0, f0)
     assert oracle.canonical_labels(rv_color) == oracle.canonical_labels(orv)
     assert oracle.canonical_labels(f_color) == oracle.canonical_labels(of)
+
+
+def test_flat_grounded_rgm_matches_object_path(api):
+    """RelationalGraph.ground_flat -> GaBP on the arrays, against ground_graph -> GaBP on the objects (different rv /
+    factor order because the object path keeps sets; same marginals)"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_host_api import _rgm_relational
+    from lhvi.gabp import GaBP
+    rng = np.random.default_rng(3)
+    rel_o, rel_f = _rgm_relational(40, 25), _rgm_relational(40, 25)
+    g, table = rel_o.ground_graph()
+    keys_all = list(table)
+    ev = {keys_all[i]: float(rng.uniform(-30, 30)) for i in rng.choice(len(keys_all), 60, replace=False)}
+    rel_o.add_evidence(ev)
+    bo = GaBP(g)
+    bo.run(15)
+    flat, keys = rel_f.ground_flat(ev)
+    bf = GaBP(flat)
+    bf.run(15)
+    checked = 0
+    for key, rv in table.items():
+        if rv.value is None:
+            mo = bo.get_belief_params(rv)
+            mf = bf.mu_var[keys.var_id(key)]
+            np.testing.assert_allclose(mf, mo, rtol=1e-10, atol=1e-12)
+            checked += 1
+    assert checked == len(keys_all) - 60
