@@ -156,6 +156,17 @@ typedef struct lhvi_pbp {
  * persistent f2v kernel fetch an edge with scalar loads.  Must be rebuilt when np / the graph / the potentials change. */
 int lhvi_pbp_describe(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const int32_t* edges, int32_t count,
                       void* desc_out, void* stream);
+/* Batched queries (extension; EPBP.belief_rv EPBP:196-202 for every variable at once).  Tabulate the messages at n query
+ * points per variable by running lhvi_pbp_f2v with s->particles = the query points [V][n] and s->old_particles = the
+ * current sample into a scratch f2v buffer, then
+ *   lhvi_pbp_var_sum      out[v][j] = sum over the variable's edges of count * f2v[e][j]   (the log-belief at point j)
+ *   lhvi_pbp_domain_grid  x[v][:] = uniform n-point grid on the domain (discrete: the states)
+ *   lhvi_pbp_refine_grid  best[v] / best_val[v] = argmax point and value of logb[v][:]; x[v][:] := uniform grid on the
+ *                         bracket around it (one step of the batched MAP search, EPBP.map EPBP:377-394 uses fminbound) */
+int lhvi_pbp_var_sum(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* out, void* stream);
+int lhvi_pbp_domain_grid(const lhvi_graph_t* g, const lhvi_pbp_t* s, double* x, void* stream);
+int lhvi_pbp_refine_grid(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* logb, double* x, double* best, double* best_val,
+                         void* stream);
 /* test hook: y[i] = the f2v kernel's exp(x[i]) */
 int lhvi_debug_exp(const double* x, double* y, int64_t n, void* stream);
 /* test hook: y[i] = exp(x[i] + c[i]) through the accumulating form the f2v term loop uses (c = the per-point constant) */

@@ -907,6 +907,65 @@ __global__ void __launch_bounds__(BLOCK) pbp_boundary_pack_kernel(lhvi_graph_t g
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batched queries.  belief_rv(x) = sum over the variable's factors of message_f_to_rv(x)
+// (EPBP:196-202): lhvi_pbp_f2v run with the query points in the place of the target particles tabulates every message
+// at n points per variable; this kernel adds the rows up per variable (count-weighted on a lifted graph).
+__global__ void __launch_bounds__(BLOCK) pbp_var_sum_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
+                                                           double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int n = s.n, S = s.n + s.T;
+    if (i >= (int64_t)g.V * n) return;
+    const int v = (int)(i / n), j = (int)(i % n);
+    double acc = 0.0;
+    if (is_hidden(g.var_value[v]) && j < s.np[v])
+        for (int k = g.var_ptr[v]; k < g.var_ptr[v + 1]; ++k) {
+            const int e = g.var_edge[k];
+            const double m = f2v[(int64_t)e * S + j];
+            acc += g.edge_count ? m * g.edge_count[e] : m;
+        }
+    out[i] = acc;
+}
+
+// One step of the batched MAP search: per continuous hidden variable, the best of its n tabulated points and a new
+// uniform grid of n points on the bracket around it [x_(i-1), x_(i+1)] (clamped to the previous grid's ends).
+// Discrete variables keep their states as points; best[v] = the argmax point, best_val[v] = its log-belief.
+__global__ void __launch_bounds__(BLOCK) pbp_refine_grid_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ logb,
+                                                               double* __restrict__ x, double* __restrict__ best,
+                                                               double* __restrict__ best_val) {
+    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v >= g.V) return;
+    const int n = s.n;
+    if (!is_hidden(g.var_value[v])) { best[v] = g.var_value[v]; best_val[v] = 0.0; return; }
+    const int cnt = s.np[v];
+    double* xr = x + (int64_t)v * n;
+    const double* br = logb + (int64_t)v * n;
+    int arg = 0;
+    for (int j = 1; j < cnt; ++j)
+        if (br[j] > br[arg]) arg = j;                      // first maximum, like the reference's argmax over a list
+    best[v] = xr[arg];
+    best_val[v] = br[arg];
+    if (!g.dom_cont[g.var_dom[v]] || cnt < 3) return;
+    const double lo = xr[arg > 0 ? arg - 1 : 0], hi = xr[arg < cnt - 1 ? arg + 1 : cnt - 1];
+    const double step = (hi - lo) / (double)(cnt - 1);
+    for (int j = 0; j < cnt; ++j) xr[j] = j == cnt - 1 ? hi : lo + step * j;
+}
+
+// uniform n-point grid on every continuous hidden variable's domain (discrete: the states), the start of the search
+__global__ void __launch_bounds__(BLOCK) pbp_domain_grid_kernel(lhvi_graph_t g, lhvi_pbp_t s, double* __restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int n = s.n;
+    if (i >= (int64_t)g.V * n) return;
+    const int v = (int)(i / n), j = (int)(i % n);
+    const int d = g.var_dom[v], cnt = s.np[v];
+    double val = 0.0;
+    if (is_hidden(g.var_value[v]) && j < cnt) {
+        if (g.dom_cont[d]) val = j == cnt - 1 ? g.dom_hi[d] : g.dom_lo[d] + (g.dom_hi[d] - g.dom_lo[d]) / (double)(cnt - 1) * j;
+        else val = g.dom_val[g.dom_ptr[d] + j];
+    }
+    x[i] = val;
+}
+
 // initial_proposal (EPBP:72-81; HLBP:89-98)
 __global__ void __launch_bounds__(BLOCK) pbp_init_kernel(lhvi_graph_t g, lhvi_pbp_t s, double* __restrict__ eta,
                                                         double* __restrict__ q) {
@@ -1252,6 +1311,31 @@ int lhvi_pbp_resample_uniq(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int
     }
     hipLaunchKernelGGL(pbp_resample_uniq_kernel, dim3(persistent_grid(g->V, 8)), dim3(BLOCK), 0,
                        as_stream(stream), *g, *s, var_gid, seed, iteration, particles_out, uniq_out);
+    return check_launch();
+}
+
+int lhvi_pbp_var_sum(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* out, void* stream) {
+    if (int rc = validate_pbp(g, s)) return rc;
+    if (!f2v || !out) return LHVI_E_ARG;
+    if (g->V == 0) return LHVI_OK;
+    hipLaunchKernelGGL(pbp_var_sum_kernel, dim3(grid_for((int64_t)g->V * s->n)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, out);
+    return check_launch();
+}
+
+int lhvi_pbp_domain_grid(const lhvi_graph_t* g, const lhvi_pbp_t* s, double* x, void* stream) {
+    if (int rc = validate_pbp(g, s)) return rc;
+    if (!x || !g->dom_lo || !g->dom_hi || !g->dom_val) return LHVI_E_ARG;
+    if (g->V == 0) return LHVI_OK;
+    hipLaunchKernelGGL(pbp_domain_grid_kernel, dim3(grid_for((int64_t)g->V * s->n)), dim3(BLOCK), 0, as_stream(stream), *g, *s, x);
+    return check_launch();
+}
+
+int lhvi_pbp_refine_grid(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* logb, double* x, double* best, double* best_val,
+                         void* stream) {
+    if (int rc = validate_pbp(g, s)) return rc;
+    if (!logb || !x || !best || !best_val) return LHVI_E_ARG;
+    if (g->V == 0) return LHVI_OK;
+    hipLaunchKernelGGL(pbp_refine_grid_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, as_stream(stream), *g, *s, logb, x, best, best_val);
     return check_launch();
 }
 

@@ -84,6 +84,9 @@ SIGNATURES = {
     'lhvi_pbp_uniq': (C.c_int, [_G, _i32, _vp, _vp, _vp, _vp]),
     'lhvi_pbp_classify': (C.c_int, [_G, _P, _vp, _vp]),
     'lhvi_pbp_describe': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _vp]),
+    'lhvi_pbp_var_sum': (C.c_int, [_G, _S, _vp, _vp, _vp]),
+    'lhvi_pbp_domain_grid': (C.c_int, [_G, _S, _vp, _vp]),
+    'lhvi_pbp_refine_grid': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp, _vp]),
     'lhvi_debug_exp': (C.c_int, [_vp, _vp, _i64, _vp]),
     'lhvi_debug_log': (C.c_int, [_vp, _vp, _i64, C.c_int32, _vp]),
     'lhvi_debug_exp_acc': (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

@@ -73,6 +73,24 @@ def test_epbp_matches_reference_golden(api, golden_dir, name):
     for i, x0, want in z['belief']:
         # "marginals within 1e-5 of the CPU reference" (BASELINE.json north_star)
         assert bp.belief(x0, rvs[int(i)]) == pytest.approx(want, rel=1e-5, abs=1e-7)
+    # batched queries: every variable in one f2v launch -- the recorded log-beliefs again, and the reference's MAPs
+    k = z['query_x'].shape[1]
+    xq = bp.particles.cpu().numpy().copy()                 # discrete rows keep their states
+    for i in hid:
+        if flat.var_cont[i]:
+            xq[i] = np.resize(z['query_x'][i], n)
+    allb = bp.belief_rv_all(xq).cpu().numpy()
+    chid = [i for i in hid if flat.var_cont[i]]
+    np.testing.assert_allclose(allb[chid][:, :min(k, n)], z['query_logb'][chid][:, :min(k, n)], rtol=1e-9, atol=1e-7)
+    mp, mval = bp.map_all(steps=6 if n >= 32 else 9)
+    for i in hid:
+        want = z['map'][i]
+        if flat.var_cont[i]:
+            # same mode as fminbound unless the belief is multi-modal: accept a better optimum, never a worse one
+            ref_val = float(bp._belief_rv_points(i, [want])[0])
+            assert mp[i] == pytest.approx(want, abs=2e-4) or mval[i] >= ref_val - 1e-9
+        else:
+            assert mp[i] == want
 
 
 @pytest.mark.parametrize('name', HLBP_CASES)
