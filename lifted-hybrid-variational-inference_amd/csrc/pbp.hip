@@ -464,10 +464,8 @@ __device__ __forceinline__ double fast_accumulate_uniform(const AB* __restrict__
 // Partner coefficients are staged in wave-private LDS in tiles of 64; each lane owns one output point per round and
 // accumulates sum_j exp(.).  A final partial round splits the partner range over idle lanes and folds the partial
 // sums with shuffles, so n + T = 96 points on 64 lanes still keep every lane busy.
-// HEAVY = true is the compile-time specialisation for the bulk of the work: continuous target, constant x^2 coefficient
-// (continuous x continuous quadratic-family potential), at most 64 partner particles.  Dropping the other modes lets the
-// register allocator fit more waves per SIMD, which is what hides the per-edge load latency behind other waves' term loops.
-template <bool HEAVY>
+// This kernel serves every fast edge the heavy kernel below does not take (per-state x^2 coefficient, discrete target,
+// more than 64 partner particles or more than 128 output points): few terms per edge, general in every respect.
 __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
                                                             const double* __restrict__ v2f, double* __restrict__ f2v,
                                                             const FastDesc* __restrict__ descs,
@@ -482,14 +480,14 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
     const int lane = threadIdx.x & 63;
     AB* sh = sh_all[wid];
     double* shk = shk_all[wid];
-    const int nitems = HEAVY ? s.n_heavy : (s.fast_edges ? s.n_fast : g.E);
+    const int nitems = s.fast_edges ? s.n_fast : g.E;
     const int nwaves = gridDim.x * (BLOCK / WAVE);
     const int n = s.n, S = s.n + s.T;
     for (int item = blockIdx.x * (BLOCK / WAVE) + wid; item < nitems; item += nwaves) {
         FastDesc d;
-        if (HEAVY || descs) d = descs[item];              // wave-uniform address: scalar loads
+        if (descs) d = descs[item];                       // wave-uniform address: scalar loads
         else d = make_fast_desc(g, pots, s, s.fast_edges ? s.fast_edges[item] : item);
-        if (!HEAVY && d.cls != EDGE_FAST_CONT && d.cls != EDGE_FAST_DISC) continue;
+        if (d.cls != EDGE_FAST_CONT && d.cls != EDGE_FAST_DISC) continue;
         const double* __restrict__ par = param + d.par_off;
         const int np = d.np, npts = d.np + d.T, nj = d.nj;
         const bool partner_hidden = is_hidden(d.pval);
@@ -512,8 +510,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
         }
 
         // x^2 coefficient: constant per edge unless the partner is the discrete argument of a HybridQuadratic
-        const int mode = HEAVY ? MODE_CONST
-                               : (d.cls == EDGE_FAST_DISC ? MODE_DISC : (d.kind == LHVI_POT_HYBRID_QUADRATIC ? MODE_VARK : MODE_CONST));
+        const int mode = d.cls == EDGE_FAST_DISC ? MODE_DISC : (d.kind == LHVI_POT_HYBRID_QUADRATIC ? MODE_VARK : MODE_CONST);
         double kconst = 0.0;
         if (mode == MODE_CONST) { Quad2 q; quad2_of(d.kind, par, 0, q); kconst = d.pos == 0 ? q.a00 : q.a11; }
         auto stage = [&](int j0, int jn, double y, double m) {
@@ -525,7 +522,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
                 r.a = -800.0; r.b = 0.0;
                 double kk = 0.0;
                 if (lane < jn) {
-                    if (HEAVY || d.cls == EDGE_FAST_CONT) {
+                    if (d.cls == EDGE_FAST_CONT) {
                         Quad2 q;
                         quad2_of(d.kind, par, (d.kind == LHVI_POT_HYBRID_QUADRATIC) ? (int)y : 0, q);
                         if (d.pos == 0) { r.a = (q.a11 * y + q.b1) * y + q.c + m; r.b = q.axy * y + q.b0; kk = q.a00; }
@@ -537,7 +534,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
             }
             LHVI_WAVE_SYNC();
         };
-        const bool single_tile = HEAVY || nj <= 64;
+        const bool single_tile = nj <= 64;
         if (single_tile) stage(0, nj, y0, m0);             // staged once per edge, reused by every round
 
         for (int p0 = 0; p0 < npts; p0 += 64) {
@@ -553,7 +550,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
             else if (valid) xv = p < np ? s.particles[(int64_t)d.tv * n + p] : g.dom_val[d.gb + p - np];
             double X1 = 0.0, X2 = 0.0, C = 0.0;
             if (valid) {
-                if (HEAVY || d.cls == EDGE_FAST_CONT) { X1 = xv; X2 = xv * xv; C = kconst * X2; }
+                if (d.cls == EDGE_FAST_CONT) { X1 = xv; X2 = xv * xv; C = kconst * X2; }
                 else {
                     const int nst = (int)par[2];
                     const int st = (int)xv;                                  // HybridQuadratic indexes by the state value
@@ -1208,7 +1205,7 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     // persistent grids sized from the measured residency: CUs x resident workgroups per CU, every wave strides over its list
     const int nfast = s->fast_edges ? s->n_fast : g->E, ngen = s->generic_edges ? s->n_generic : g->E;
     static const int cus = device_cus();
-    static const int fast_per_cu = blocks_per_cu((const void*)pbp_f2v_fast_kernel<false>);
+    static const int fast_per_cu = blocks_per_cu((const void*)pbp_f2v_fast_kernel);
     static const int heavy_per_cu = blocks_per_cu((const void*)pbp_f2v_heavy_kernel);
     static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel);
     if (!(s->flags & LHVI_PBP_SKIP_FAST)) {
@@ -1216,7 +1213,7 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
             hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(min((s->n_heavy + 3) / 4, cus * heavy_per_cu)), dim3(BLOCK), 0, as_stream(stream),
                                *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy);
         if (nfast > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
-            hipLaunchKernelGGL(pbp_f2v_fast_kernel<false>, dim3(min((nfast + 3) / 4, cus * fast_per_cu)), dim3(BLOCK), 0, as_stream(stream),
+            hipLaunchKernelGGL(pbp_f2v_fast_kernel, dim3(min((nfast + 3) / 4, cus * fast_per_cu)), dim3(BLOCK), 0, as_stream(stream),
                                *g, *pots, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->fast_desc), pots->param);
     }
     if (!(s->flags & LHVI_PBP_SKIP_GENERIC) && ngen > 0) {
