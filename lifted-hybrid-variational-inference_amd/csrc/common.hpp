@@ -112,7 +112,7 @@ __device__ __forceinline__ double rcp_newton(double x) {
 template <unsigned long long BITS>
 __device__ __forceinline__ double scalar_const() {
     int lo, hi;
-    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"((int)(BITS & 0xffffffffull)), "i"((int)(BITS >> 32)));
+    asm("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"((int)(BITS & 0xffffffffull)), "i"((int)(BITS >> 32)));
     return __hiloint2double(hi, lo);
 }
 #define LHVI_SCONST(x) scalar_const<__builtin_bit_cast(unsigned long long, (double)(x))>()

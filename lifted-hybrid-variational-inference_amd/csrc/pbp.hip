@@ -1066,13 +1066,18 @@ static int blocks_per_cu(const void* kernel) {
 
 // generate_sample + the first-occurrence mask in one pass (n <= 64): one wavefront per variable, lane = particle;
 // the row never leaves registers and is broadcast lane by lane with v_readlane (exact equality test, like the dict keys)
+constexpr int UNIQ_HASH_BITS = 14;
+
 __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g, lhvi_pbp_t s, const int64_t* __restrict__ gid,
                                                                  uint64_t seed, uint32_t iteration, double* __restrict__ out,
                                                                  uint8_t* __restrict__ uniq) {
     __shared__ LogRec sh_log[LOG_TAB_N];
+    __shared__ uint32_t sh_bits[BLOCK / WAVE][1 << (UNIQ_HASH_BITS - 5)];
     load_log_table(sh_log);
+    for (int i = threadIdx.x; i < (BLOCK / WAVE) << (UNIQ_HASH_BITS - 5); i += BLOCK) (&sh_bits[0][0])[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    uint32_t* bits = sh_bits[threadIdx.x >> 6];
     const int n = s.n;
     const int nwaves = gridDim.x * (BLOCK / WAVE);
     // persistent waves (the table is loaded once per block, not once per four variables)
@@ -1089,29 +1094,22 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
             }
             out[(int64_t)v * n + lane] = x;
         }
-        // first-occurrence mask.  Pass 1 compares the low words only (a readlane and a 32-bit compare per particle, the
-        // lane masks live in scalar registers); two different draws agree there with probability 2^-32, so the exact
-        // 64-bit pass runs only for a wave that has candidates -- in practice the ones with particles clipped to a bound
+        // first-occurrence mask.  Pass 1 only asks "can two live particles be equal at all?": every lane sets the bit its
+        // low word hashes to in a wave-private 16 Kbit LDS bitset with a returning atomic OR; equal particles always
+        // meet in the same bit, different ones do with probability 64^2 / 2 / 16384 = 12 % per variable (a false alarm
+        // costs the exact pass, nothing else).  The exact pass compares the 64-bit patterns particle by particle and
+        // in practice runs for the variables with draws clipped to a bound.  Each lane clears its own word afterwards.
         const int xlo = __double2loint(x), xhi = __double2hiint(x);
         const uint64_t live = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1);
-        uint64_t dup = 0;
-        if (cnt == 64) {
-            // full wave: unrolled, four instructions per particle.  `xm` is the low word with the lanes <= k overwritten
-            // by a poison value, so the comparison needs no lane mask; a poison hit can only add a false candidate
-            int xm = xlo;
-#pragma unroll
-            for (int k = 0; k < 63; ++k) {
-                const int klo = __builtin_amdgcn_readlane(xlo, k);
-                asm("v_writelane_b32 %0, -1, %1" : "+v"(xm) : "n"(k));
-                dup |= __ballot(xm == klo);
-            }
-        } else {
-            for (int k = 0; k < cnt - 1; ++k) {
-                const int klo = __builtin_amdgcn_readlane(xlo, k);
-                dup |= __ballot(xlo == klo) & (~1ull << k);              // lanes above k
-            }
-            dup &= live;
-        }
+        const uint32_t hsh = ((uint32_t)xlo * 0x9E3779B1u) >> (32 - UNIQ_HASH_BITS);
+        uint32_t* word = bits + (hsh >> 5);
+        const uint32_t bit = 1u << (hsh & 31);
+        uint32_t old = 0;
+        if (lane < cnt) old = atomicOr(word, bit);
+        uint64_t dup = __ballot(lane < cnt && (old & bit));
+        LHVI_WAVE_SYNC();
+        if (lane < cnt) *word = 0;
+        LHVI_WAVE_SYNC();
         if (dup) {
             dup = 0;
             for (int k = 0; k < cnt - 1; ++k) {
