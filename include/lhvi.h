@@ -115,7 +115,8 @@ int lhvi_gabp_marginals(const lhvi_graph_t* g, const double* f2v, double* mu_var
 #define LHVI_PBP_SKIP_TERMS 16u   /* lhvi_pbp_f2v: the quadratic-family kernels skip their term loops -- results are
                                    * meaningless; isolates the per-edge load/store cost when tuning */
 #define LHVI_PBP_SKIP_HEAVY 32u   /* lhvi_pbp_f2v: do not launch the continuous x continuous (heavy_desc) kernel (profiling aid) */
-#define LHVI_PBP_SKIP_LIGHT 64u   /* lhvi_pbp_f2v: do not launch the kernel of the remaining fast edges (profiling aid) */
+#define LHVI_PBP_SKIP_LIGHT 64u   /* lhvi_pbp_f2v: do not launch the kernels of the remaining fast edges (light_desc and fast_edges;
+                                   * profiling aid) */
 
 typedef struct lhvi_pbp {
     int32_t n;                  /* particle slots per variable */
@@ -138,6 +139,9 @@ typedef struct lhvi_pbp {
     const void* heavy_desc;     /* [n_heavy][LHVI_PBP_DESC_BYTES] descriptors of the edges served by the specialised kernel:
                                  * class 1, constant x^2 coefficient (kind != HYBRID_QUADRATIC), nj <= 64, np + T <= 128; disjoint from fast_edges */
     int32_t n_heavy;
+    const void* light_desc;     /* [n_light] descriptors with word 14 != 0: HybridQuadratic edges with a binary (or observed)
+                                 * discrete side, served by their own kernel; disjoint from fast_edges and heavy_desc */
+    int32_t n_light;
     /* edge-sharded runs only (all NULL on a single GPU).  A boundary variable (edges on several ranks) owns one row per
      * peer rank in the exchange buffers; row r of the send buffer and row r of the receive buffer belong to the same
      * (variable, peer) because both ends list their shared variables in ascending global id.  A row is n + 2 doubles:

@@ -401,6 +401,31 @@ __device__ __forceinline__ FastDesc make_fast_desc(const lhvi_graph_t& g, const 
         else            { d.ay = q.a00; d.by = q.b0; d.axy = q.axy; d.bx = q.b1; d.kx = q.a11; }
         d.c = q.c;
     }
+    // HybridQuadratic(1 discrete, 1 continuous) edges whose discrete side has at most two points (binary variables,
+    // or an observed discrete partner): log phi = A_s x^2 + b_s x + c_s per discrete point s, resolved here as
+    // (A_0, b_0, c_0, A_1, b_1, c_1) for the light kernel.  pad[0]: 1 = continuous target / discrete partner,
+    // 2 = discrete target / continuous partner, 0 = not a light edge
+    if (d.kind == LHVI_POT_HYBRID_QUADRATIC && (d.cls == EDGE_FAST_CONT || d.cls == EDGE_FAST_DISC)) {
+        const double* par = pots.param + d.par_off;
+        const int nst = (int)par[2];
+        const bool cont_target = d.cls == EDGE_FAST_CONT;
+        const int dv = cont_target ? d.pv : d.tv;                 // the discrete variable of the factor
+        const int npt = cont_target ? d.nj : d.np;
+        const bool ok = npt <= 2 && (cont_target ? d.np + d.T <= 128 : (d.nj <= 64 && d.T == 0));
+        if (ok) {
+            double* co = &d.ay;
+            for (int k = 0; k < 2; ++k) {
+                int st = 0;
+                if (k < npt) {
+                    const double val = is_hidden(g.var_value[dv]) ? g.dom_val[g.dom_ptr[g.var_dom[dv]] + k] : g.var_value[dv];
+                    st = (int)val;
+                }
+                st = st < 0 ? 0 : (st >= nst ? nst - 1 : st);
+                co[3 * k] = par[3 + st]; co[3 * k + 1] = par[3 + nst + st]; co[3 * k + 2] = par[3 + 2 * nst + st];
+            }
+            d.pad[0] = cont_target ? 1 : 2;
+        }
+    }
     return d;
 }
 
@@ -669,6 +694,86 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_heavy_kernel(lhvi_graph_t g, lh
             double acc = fast_accumulate_uniform<MODE_CONST, 4>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
             for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
             if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
+        }
+        if (!more) break;
+        item += nwaves;
+    }
+}
+
+// LIGHT edges: HybridQuadratic(1 discrete, 1 continuous) with a binary (or observed) discrete side -- the edges between
+// the continuous and the binary variables of the benchmark.  A handful of terms per output point, so the general
+// kernel's staging / splitting / shuffling is all overhead; here nothing goes through LDS but the two tables:
+//   type 1 (continuous target):  lane = output point, log sum_s exp(A_s x^2 + b_s x + c_s + m_s), s = partner states
+//   type 2 (discrete target):    lane = partner particle j, one wave reduction per target state p of
+//                                exp(A_p y_j^2 + b_p y_j + c_p + m_j)
+// Same software pipeline as the heavy kernel (descriptor one edge ahead, vector loads in flight during the arithmetic).
+struct LightData { double a, b; };      // type 1: own points of round 0 / 1;  type 2: partner particle and its message
+
+__device__ __forceinline__ LightData light_fetch(const FastDesc& d, const lhvi_graph_t& g, const lhvi_pbp_t& s,
+                                                 const double* __restrict__ v2f, int lane) {
+    LightData h;
+    h.a = 0.0; h.b = 0.0;
+    const int n = s.n;
+    if (d.pad[0] == 1) {
+        const int np = d.np, npts = d.np + d.T;
+        if (lane < npts) h.a = lane < np ? s.particles[(int64_t)d.tv * n + lane] : g.dom_val[d.gb + lane - np];
+        const int pp = 64 + lane;
+        if (pp < npts) h.b = pp < np ? s.particles[(int64_t)d.tv * n + pp] : g.dom_val[d.gb + pp - np];
+    } else if (lane < d.nj) {
+        h.a = d.pval;
+        if (is_hidden(d.pval)) { h.a = s.old_particles[(int64_t)d.pv * n + lane]; h.b = v2f[(int64_t)d.pce * n + lane]; }
+    }
+    return h;
+}
+
+__global__ void __launch_bounds__(BLOCK) pbp_f2v_light_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
+                                                             double* __restrict__ f2v, const FastDesc* __restrict__ descs,
+                                                             int nitems) {
+    __shared__ double sh_tab[EXP_TAB_N];
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    load_log_table(sh_log);
+    load_exp_table(sh_tab);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int last = nitems - 1;
+    const int nwaves = gridDim.x * (BLOCK / WAVE);
+    const int n = s.n, S = s.n + s.T;
+    int item = blockIdx.x * (BLOCK / WAVE) + wid;
+    if (item >= nitems) return;
+    struct { int32_t e, type, nj, np, T, pce; double pval, A0, b0, c0, A1, b1, c1; } d;
+    FastDesc dn = descs[item];
+    LightData h = light_fetch(dn, g, s, v2f, lane);
+    for (;;) {
+        d.e = dn.e; d.type = dn.pad[0]; d.nj = dn.nj; d.np = dn.np; d.T = dn.T; d.pce = dn.pce; d.pval = dn.pval;
+        d.A0 = dn.ay; d.b0 = dn.by; d.c0 = dn.c; d.A1 = dn.axy; d.b1 = dn.bx; d.c1 = dn.kx;
+        const bool more = item + nwaves < nitems;
+        dn = descs[__builtin_amdgcn_readfirstlane(min(item + nwaves, last))];
+        double* out = f2v + (int64_t)d.e * S;
+        const LightData cur = h;
+        if (d.type == 1) {
+            // messages of the (at most two) partner states: wave-uniform values
+            double m0 = 0.0, m1 = 0.0;
+            if (is_hidden(d.pval)) { m0 = v2f[(int64_t)d.pce * n]; if (d.nj > 1) m1 = v2f[(int64_t)d.pce * n + 1]; }
+            if (more) h = light_fetch(dn, g, s, v2f, lane);
+            const int npts = d.np + d.T;
+#pragma nounroll
+            for (int r = 0; r < 2; ++r) {
+                const int p = 64 * r + lane;
+                if (64 * r >= npts) break;
+                const double x = r == 0 ? cur.a : cur.b;
+                double acc = exp_core(fma(x, fma(x, d.A0, d.b0), d.c0 + m0), sh_tab);
+                if (d.nj > 1) acc += exp_core(fma(x, fma(x, d.A1, d.b1), d.c1 + m1), sh_tab);
+                if (p < npts) out[p < d.np ? p : n + (p - d.np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
+            }
+        } else {
+            if (more) h = light_fetch(dn, g, s, v2f, lane);
+            const double y = cur.a, m = cur.b;
+            double res = wave_sum(lane < d.nj ? exp_core(fma(y, fma(y, d.A0, d.b0), d.c0 + m), sh_tab) : 0.0);
+            if (d.np > 1) {
+                const double sum1 = wave_sum(lane < d.nj ? exp_core(fma(y, fma(y, d.A1, d.b1), d.c1 + m), sh_tab) : 0.0);
+                if (lane == 1) res = sum1;
+            }
+            if (lane < d.np) out[lane] = res > 0.0 ? log_table(res, sh_log) : -700.0;
         }
         if (!more) break;
         item += nwaves;
@@ -1205,11 +1310,15 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     static const int cus = device_cus();
     static const int fast_per_cu = blocks_per_cu((const void*)pbp_f2v_fast_kernel);
     static const int heavy_per_cu = blocks_per_cu((const void*)pbp_f2v_heavy_kernel);
+    static const int light_per_cu = blocks_per_cu((const void*)pbp_f2v_light_kernel);
     static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel);
     if (!(s->flags & LHVI_PBP_SKIP_FAST)) {
         if (s->heavy_desc && s->n_heavy > 0 && !(s->flags & LHVI_PBP_SKIP_HEAVY))
             hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(min((s->n_heavy + 3) / 4, cus * heavy_per_cu)), dim3(BLOCK), 0, as_stream(stream),
                                *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy);
+        if (s->light_desc && s->n_light > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
+            hipLaunchKernelGGL(pbp_f2v_light_kernel, dim3(min((s->n_light + 3) / 4, cus * light_per_cu)), dim3(BLOCK), 0, as_stream(stream),
+                               *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->light_desc), s->n_light);
         if (nfast > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
             hipLaunchKernelGGL(pbp_f2v_fast_kernel, dim3(min((nfast + 3) / 4, cus * fast_per_cu)), dim3(BLOCK), 0, as_stream(stream),
                                *g, *pots, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->fast_desc), pots->param);

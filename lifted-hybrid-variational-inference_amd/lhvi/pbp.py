@@ -72,8 +72,8 @@ class _ParticleSweep:
         tv = flat.edge_var[ge]
         pts = self.np_host[tv] + np.where(flat.var_cont[tv], flat.var_nstates[tv], 0) if ge.size else np.zeros(0, dtype=int)
         self.generic_pts_log2 = int(min(6, max(0, int(np.ceil(np.log2(max(int(pts.max()), 1)))) if ge.size else 6)))
-        self.fast_desc = self.heavy_desc = None
-        self.n_heavy = 0
+        self.fast_desc = self.heavy_desc = self.light_desc = None
+        self.n_heavy = self.n_light = 0
         self.heavy_terms = 0
         nf = int(self.fast_edges.numel())
         if nf:
@@ -89,8 +89,12 @@ class _ParticleSweep:
             # (output point, partner particle) terms of the heavy kernel: sum over its edges of (np + T) * nj
             hw = words[heavy].to(torch.int64)
             self.heavy_terms = int(((hw[:, 8] + hw[:, 9]) * hw[:, 7]).sum().item())
-            self.fast_desc = rows[~heavy].contiguous()
-            self.fast_edges = self.fast_edges[~heavy].contiguous()
+            light = ~heavy & (words[:, 14] != 0)          # word 14: set by lhvi_pbp_describe for the light kernel's edges
+            self.light_desc = rows[light].contiguous()
+            self.n_light = int(self.light_desc.shape[0])
+            rest = ~heavy & ~light
+            self.fast_desc = rows[rest].contiguous()
+            self.fast_edges = self.fast_edges[rest].contiguous()
             self._fast_list = self.fast_edges if self.fast_edges.numel() else pad
 
     def _struct(self):
@@ -104,6 +108,7 @@ class _ParticleSweep:
         s.generic_pts_log2 = int(getattr(self, 'generic_pts_log2', 6))
         s.fast_desc = _abi.ptr(getattr(self, 'fast_desc', None))
         s.heavy_desc, s.n_heavy = _abi.ptr(getattr(self, 'heavy_desc', None)), int(getattr(self, 'n_heavy', 0))
+        s.light_desc, s.n_light = _abi.ptr(getattr(self, 'light_desc', None)), int(getattr(self, 'n_light', 0))
         return s
 
     # ---- sampling ----------------------------------------------------------------------------
