@@ -156,8 +156,16 @@ typedef struct lhvi_pbp {
 } lhvi_pbp_t;
 
 #define LHVI_PBP_DESC_BYTES 128
-/* static per-edge descriptors of the fast work list (targets, partners, particle counts, potential rows): lets the
- * persistent f2v kernel fetch an edge with scalar loads.  Must be rebuilt when np / the graph / the potentials change. */
+/* static per-edge descriptors of the fast work list: lets the persistent f2v kernels fetch everything about an edge with
+ * scalar loads.  Must be rebuilt when np / the graph / the potentials change.  Layout (32-bit words unless noted):
+ *   0 edge   1 target variable   2 partner variable   3 partner's canonical edge   4 class (lhvi_pbp_classify)
+ *   5 target position   6 potential kind   7 nj = partner particle count (1 = observed)   8 np = target particle count
+ *   9 T = target integral points   10 grid base in dom_val   11 offset into pots.param   12-13 partner value (double,
+ *   NaN = hidden)   14 light-kernel type (0 none, 1 continuous target / discrete partner, 2 discrete target /
+ *   continuous partner)   15 reserved   16-27 six doubles: the potential resolved for this edge -- class 1 with a constant
+ *   x^2 coefficient: log phi = kx x^2 + (ay y + by) y + c + (axy y + bx) x as (ay, by, c, axy, bx, kx), x = target;
+ *   light edges: (A_0, b_0, c_0, A_1, b_1, c_1) of the discrete side's two points   28-31 reserved.
+ * The host builds heavy_desc / light_desc / fast_desc by splitting the rows on words 4, 6, 7, 8 + 9 and 14. */
 int lhvi_pbp_describe(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const int32_t* edges, int32_t count,
                       void* desc_out, void* stream);
 /* Batched queries (extension; EPBP.belief_rv EPBP:196-202 for every variable at once).  Tabulate the messages at n query
