@@ -74,6 +74,9 @@ typedef struct lhvi_graph {
     const double* dom_hi;       /* [D] */
     const int32_t* dom_ptr;     /* [D+1] into dom_val */
     const double* dom_val;      /* discrete: the states; continuous: the integral points */
+    /* optional denormalised copies that turn random gathers of the Gaussian sweep into contiguous reads (NULL = gather) */
+    const double* edge_value;   /* [E] var_value[edge_var[e]] */
+    const int32_t* slot_var;    /* [nnz] variable of CSR slot k (the v with var_ptr[v] <= k < var_ptr[v+1]) */
 } lhvi_graph_t;
 
 /* Potential table: one row per distinct (potential object, scope domains). */

@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(BLOCK) gabp_v2f_kernel(lhvi_graph_t g, const d
     int k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= g.nnz) return;
     const int e = g.var_edge[k];
-    const int v = g.edge_var[e];
+    const int v = g.slot_var ? g.slot_var[k] : g.edge_var[e];      // contiguous copy instead of a gather through e
     if (!is_hidden(g.var_value[v])) {          // observed rv sends nothing (returns None)
         st2(v2f, e, NAN, NAN);
         return;
@@ -115,8 +115,8 @@ __global__ void __launch_bounds__(BLOCK) gabp_f2v_kernel(lhvi_graph_t g, lhvi_po
     int e = blockIdx.x * BLOCK + threadIdx.x;
     if (e >= g.E) return;
     if (canon(g.edge_canon, e) != e) return;     // alias of a repeated cluster: the canonical edge owns the message
-    const int v = g.edge_var[e];
-    if (!is_hidden(g.var_value[v])) return;       // message to an observed rv is never produced (GaBP.py:39-40)
+    // message to an observed rv is never produced (GaBP.py:39-40); edge_value = the variable's value, per edge
+    if (!is_hidden(g.edge_value ? g.edge_value[e] : g.var_value[g.edge_var[e]])) return;
     const int f = g.edge_fac[e];
     const int base = g.fac_ptr[f];
     const int arity = g.fac_ptr[f + 1] - base;
@@ -128,8 +128,7 @@ __global__ void __launch_bounds__(BLOCK) gabp_f2v_kernel(lhvi_graph_t g, lhvi_po
     double u = 0.0, s = 0.0, y = 0.0;
     if (arity == 2) {
         const int pe = base + (1 - pos);
-        const int pv = g.edge_var[pe];
-        y = g.var_value[pv];
+        y = g.edge_value ? g.edge_value[pe] : g.var_value[g.edge_var[pe]];
         partner_hidden = is_hidden(y);
         if (partner_hidden) {
             const double2 m = ld2(v2f, canon(g.edge_canon, pe));

@@ -30,7 +30,7 @@ class GraphStruct(C.Structure):
         ('var_value', C.c_void_p), ('var_dom', C.c_void_p), ('var_mult', C.c_void_p), ('fac_mult', C.c_void_p),
         ('D', C.c_int32),
         ('dom_cont', C.c_void_p), ('dom_lo', C.c_void_p), ('dom_hi', C.c_void_p), ('dom_ptr', C.c_void_p),
-        ('dom_val', C.c_void_p),
+        ('dom_val', C.c_void_p), ('edge_value', C.c_void_p), ('slot_var', C.c_void_p),
     ]
 
 
@@ -191,6 +191,10 @@ class DeviceGraph:
                      'dom_val'):
             setattr(g, name, ptr(t[name]))
         g.D = int(flat.dom_cont.size)
+        # denormalised copies for the Gaussian sweep (contiguous instead of gathered)
+        t['edge_value'] = to_dev(np.ascontiguousarray(flat.var_value[flat.edge_var]), device) if flat.E else None
+        t['slot_var'] = to_dev(np.repeat(np.arange(flat.V, dtype=np.int32), np.diff(flat.var_ptr)), device) if flat.var_edge.size else None
+        g.edge_value, g.slot_var = ptr(t['edge_value']), ptr(t['slot_var'])
         self.g = g
         p = PotsStruct()
         p.P = int(flat.pot_kind.size)
