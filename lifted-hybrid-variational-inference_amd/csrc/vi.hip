@@ -7,8 +7,9 @@
 //                      F = log(phi + 1e-100) - log(b_f + 1e-100), per-edge gradient partials
 //   vi_gather_kernel   thread per (variable, k): sums its edges' partials in rv.nb order (no atomics -> deterministic),
 //                      softmax-Jacobian projection of the category gradient
-//   vi_weights_kernel  one workgroup: g_w and the free energy from the per-variable / per-factor expectations
-// fp64-VALU bound and tiny after lifting; written for clarity, not tuned.
+//   vi_factor_cc_kernel the same for pairwise factors over continuous / observed variables (the bulk of a Gaussian model)
+//   vi_weights_*       g_w and the free energy: two-stage reduction of the per-variable / per-factor expectations
+// fp64-VALU bound and tiny after lifting.
 #include "common.hpp"
 #include "potential.hpp"
 
@@ -84,8 +85,11 @@ __global__ void __launch_bounds__(BLOCK) vi_var_kernel(lhvi_graph_t g, lhvi_vi_t
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= (int64_t)g.V * p.K) return;
     const int v = (int)(i / p.K), k = (int)(i % p.K);
-    double N = 0.0;
-    for (int j = g.var_ptr[v]; j < g.var_ptr[v + 1]; ++j) N += g.edge_count ? g.edge_count[g.var_edge[j]] : 1.0;
+    double N = (double)(g.var_ptr[v + 1] - g.var_ptr[v]);          // ground graph: the degree (sum of ones is exact)
+    if (g.edge_count) {
+        N = 0.0;
+        for (int j = g.var_ptr[v]; j < g.var_ptr[v + 1]; ++j) N += g.edge_count[g.var_edge[j]];
+    }
     const double Mv = g.var_mult ? g.var_mult[v] : 1.0;
     const bool hid = is_hidden(g.var_value[v]);
     const bool cont = v_cont(g, v);
@@ -159,11 +163,96 @@ __device__ double pinned_expectation(const lhvi_graph_t& g, const lhvi_pots_t& p
 }
 
 // ---- factor terms ------------------------------------------------------------------------------------------
+// Pairwise factors whose two (distinct) variables are continuous or observed -- every factor of the Gaussian relational
+// models -- take the kernel below: same arithmetic in the same order as the general kernel, minus the mixed-radix
+// machinery for arity <= 6 and discrete axes (which costs the general kernel 256 VGPRs and a wave of occupancy).
+__device__ __forceinline__ bool vi_is_cc(const lhvi_graph_t& g, const lhvi_pots_t& pots, int f) {
+    const int base = g.fac_ptr[f];
+    if (g.fac_ptr[f + 1] - base != 2) return false;
+    const int kind = pots.kind[g.fac_pot[f]];
+    if (kind != LHVI_POT_GAUSSIAN && kind != LHVI_POT_QUADRATIC && kind != LHVI_POT_LINEAR_GAUSSIAN && kind != LHVI_POT_XY) return false;
+    const int v0 = g.edge_var[base], v1 = g.edge_var[base + 1];
+    if (v0 == v1) return false;
+    return (!is_hidden(g.var_value[v0]) || v_cont(g, v0)) && (!is_hidden(g.var_value[v1]) || v_cont(g, v1));
+}
+
+// log phi(x0, x1) for the four kinds above: the same expressions, in the same order, as pot_eval (potential.hpp)
+__device__ __forceinline__ double pot_log_cc(int kind, const double* __restrict__ par, double x0, double x1) {
+    if (kind == LHVI_POT_GAUSSIAN) {           // n = 2: mu = par[1..2], P = par[3..6] row-major
+        const double d0 = x0 - par[1], d1 = x1 - par[2];
+        double q = 0.0;
+        q += (0.0 + d0 * par[3] + d1 * par[5]) * d0;
+        q += (0.0 + d0 * par[4] + d1 * par[6]) * d1;
+        return -0.5 * q;
+    }
+    if (kind == LHVI_POT_QUADRATIC) {          // A = par[1..4], b = par[5..6], c = par[7]
+        double res = 0.0;
+        res += x0 * (0.0 + par[1] * x0 + par[2] * x1);
+        res += x1 * (0.0 + par[3] * x0 + par[4] * x1);
+        res += par[5] * x0;
+        res += par[6] * x1;
+        return res + par[7];
+    }
+    if (kind == LHVI_POT_LINEAR_GAUSSIAN) { const double d = x1 - par[0] * x0; return -(d * d) * 0.5 / par[1]; }
+    return -par[0] * x0 * x1 * 0.5 / par[1];   // XY
+}
+
+__global__ void __launch_bounds__(BLOCK) vi_factor_cc_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
+                                                            double* __restrict__ pe_c, double* __restrict__ pe_d) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= (int64_t)g.F * p.K) return;
+    const int f = (int)(i / p.K), k = (int)(i % p.K);
+    if (!vi_is_cc(g, pots, f)) return;
+    const int base = g.fac_ptr[f];
+    const int v0 = g.edge_var[base], v1 = g.edge_var[base + 1];
+    const double val0 = g.var_value[v0], val1 = g.var_value[v1];
+    const bool h0 = is_hidden(val0), h1 = is_hidden(val1);
+    const double* e0 = p.eta_c + ((int64_t)v0 * p.K + k) * 2;
+    const double* e1 = p.eta_c + ((int64_t)v1 * p.K + k) * 2;
+    const double mu0 = e0[0], var0 = e0[1], mu1 = e1[0], var1 = e1[1];
+    const double s0 = h0 ? sqrt(2 * var0) : 0.0, s1 = h1 ? sqrt(2 * var1) : 0.0;
+    const int n0 = h0 ? p.T : 1, n1 = h1 ? p.T : 1;
+    const int pot = g.fac_pot[f];
+    const int kind = pots.kind[pot];
+    const double* par = pots.param + pots.off[pot];
+    double E = 0.0, Em0 = 0.0, Ev0 = 0.0, Em1 = 0.0, Ev1 = 0.0;
+    for (int t0 = 0; t0 < n0; ++t0) {
+        const double x0 = h0 ? s0 * p.gh_x[t0] + mu0 : val0, w0 = h0 ? p.gh_w[t0] : 1.0;
+        for (int t1 = 0; t1 < n1; ++t1) {
+            const double x1 = h1 ? s1 * p.gh_x[t1] + mu1 : val1, w1 = h1 ? p.gh_w[t1] : 1.0;
+            const double w = 1.0 * w0 * w1;
+            const double phi = exp(pot_log_cc(kind, par, x0, x1));
+            double b = 0.0;                                   // rvs_belief: the mixture at (x0, x1), evidence agrees by construction
+            for (int kk = 0; kk < p.K; ++kk) {
+                double t = p.w[kk];
+                if (h0) { const double* e = p.eta_c + ((int64_t)v0 * p.K + kk) * 2; t *= norm_pdf_var(x0, e[0], e[1]); }
+                if (h1) { const double* e = p.eta_c + ((int64_t)v1 * p.K + kk) * 2; t *= norm_pdf_var(x1, e[0], e[1]); }
+                b += t;
+            }
+            const double F = log(phi + 1e-100) - log(b + 1e-100);
+            E += w * F;
+            if (h0) { Em0 += w * (F * (x0 - mu0)); Ev0 += w * (F * ((x0 - mu0) * (x0 - mu0) - var0)); }
+            if (h1) { Em1 += w * (F * (x1 - mu1)); Ev1 += w * (F * ((x1 - mu1) * (x1 - mu1) - var1)); }
+        }
+    }
+    ef[i] = (g.fac_mult ? g.fac_mult[f] : 1.0) * E;
+    const double c0 = g.edge_count ? g.edge_count[base] : 1.0, c1 = g.edge_count ? g.edge_count[base + 1] : 1.0;
+    double* o0 = pe_c + ((int64_t)base * p.K + k) * 2;
+    double* o1 = pe_c + ((int64_t)(base + 1) * p.K + k) * 2;
+    o0[0] = h0 ? c0 * Em0 / var0 : 0.0; o0[1] = h0 ? c0 * Ev0 / (2 * var0 * var0) : 0.0;
+    o1[0] = h1 ? c1 * Em1 / var1 : 0.0; o1[1] = h1 ? c1 * Ev1 / (2 * var1 * var1) : 0.0;
+    for (int d = 0; d < p.Dmax; ++d) {
+        pe_d[((int64_t)base * p.K + k) * p.Dmax + d] = 0.0;
+        pe_d[((int64_t)(base + 1) * p.K + k) * p.Dmax + d] = 0.0;
+    }
+}
+
 __global__ void __launch_bounds__(BLOCK) vi_factor_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
                                                          double* __restrict__ pe_c, double* __restrict__ pe_d) {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= (int64_t)g.F * p.K) return;
     const int f = (int)(i / p.K), k = (int)(i % p.K);
+    if (vi_is_cc(g, pots, f)) return;                      // served by vi_factor_cc_kernel
     const int base = g.fac_ptr[f], arity = g.fac_ptr[f + 1] - base;
     int vars[LHVI_MAX_ARITY], len[LHVI_MAX_ARITY], it[LHVI_MAX_ARITY], idx[LHVI_MAX_ARITY];
     double x[LHVI_MAX_ARITY], wt[LHVI_MAX_ARITY], Em[LHVI_MAX_ARITY], Ev[LHVI_MAX_ARITY];
@@ -227,6 +316,9 @@ __global__ void __launch_bounds__(BLOCK) vi_factor_kernel(lhvi_graph_t g, lhvi_p
 }
 
 // ---- gather per variable + projection ----------------------------------------------------------------------
+// thread per (variable, k) up to VI_HUB_DEGREE incident edges; a wavefront per (variable, k) beyond (the template
+// variables of a relational model touch thousands of factors: one thread walking them serialises the whole launch)
+constexpr int VI_HUB_DEGREE = 64;
 __global__ void __launch_bounds__(BLOCK) vi_gather_kernel(lhvi_graph_t g, lhvi_vi_t p, const double* __restrict__ pe_c,
                                                          const double* __restrict__ pe_d, double* __restrict__ g_c,
                                                          double* __restrict__ g_d) {
@@ -234,6 +326,7 @@ __global__ void __launch_bounds__(BLOCK) vi_gather_kernel(lhvi_graph_t g, lhvi_v
     if (i >= (int64_t)g.V * p.K) return;
     const int v = (int)(i / p.K), k = (int)(i % p.K);
     if (!is_hidden(g.var_value[v])) return;
+    if (g.var_ptr[v + 1] - g.var_ptr[v] > VI_HUB_DEGREE) return;          // hubs: vi_gather_hub_kernel
     if (v_cont(g, v)) {
         double a = g_c[i * 2], b = g_c[i * 2 + 1];
         for (int j = g.var_ptr[v]; j < g.var_ptr[v + 1]; ++j) {
@@ -257,16 +350,72 @@ __global__ void __launch_bounds__(BLOCK) vi_gather_kernel(lhvi_graph_t g, lhvi_v
     }
 }
 
-// ---- mixture-weight gradient and free energy (one workgroup; fixed summation order) -------------------------
-__global__ void __launch_bounds__(BLOCK) vi_weights_kernel(int64_t nv, int64_t nf, lhvi_vi_t p, const double* __restrict__ rvterm,
-                                                          const double* __restrict__ ef, double* __restrict__ g_w,
-                                                          double* __restrict__ fe) {
+__global__ void __launch_bounds__(BLOCK) vi_gather_hub_kernel(lhvi_graph_t g, lhvi_vi_t p, const double* __restrict__ pe_c,
+                                                             const double* __restrict__ pe_d, double* __restrict__ g_c,
+                                                             double* __restrict__ g_d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (i >= (int64_t)g.V * p.K) return;
+    const int v = (int)(i / p.K), k = (int)(i % p.K);
+    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    if (hi - lo <= VI_HUB_DEGREE || !is_hidden(g.var_value[v])) return;
+    if (v_cont(g, v)) {
+        double a = 0.0, b = 0.0;
+        for (int j = lo + lane; j < hi; j += 64) {
+            const int e = g.var_edge[j];
+            a += pe_c[((int64_t)e * p.K + k) * 2];
+            b += pe_c[((int64_t)e * p.K + k) * 2 + 1];
+        }
+        a = dpp_wave_reduce(a, SumOp()); b = dpp_wave_reduce(b, SumOp());
+        if (lane == 0) { g_c[i * 2] -= a; g_c[i * 2 + 1] -= b; }
+    } else {
+        const int D = v_nstates(g, v);
+        double* row = g_d + i * p.Dmax;
+        const double* eta = p.eta_d + i * p.Dmax;
+        double s = 0.0;
+        for (int d = 0; d < D; ++d) {
+            double acc = 0.0;
+            for (int j = lo + lane; j < hi; j += 64) acc += pe_d[((int64_t)g.var_edge[j] * p.K + k) * p.Dmax + d];
+            acc = row[d] - dpp_wave_reduce(acc, SumOp());
+            if (lane == 0) row[d] = acc;
+            s += acc * eta[d];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane == 0) for (int d = 0; d < D; ++d) row[d] = eta[d] * (row[d] - s);
+    }
+}
+
+// ---- mixture-weight gradient and free energy: two-stage reduction in a fixed order (deterministic) ------------
+// stage 1: block b sums a contiguous slice of the concatenated (rvterm | ef) rows for every k -> partial[b][k]
+constexpr int VI_RED_BLOCKS = 512;
+__global__ void __launch_bounds__(BLOCK) vi_weights_partial_kernel(int64_t nv, int64_t nf, lhvi_vi_t p, const double* __restrict__ rvterm,
+                                                                  const double* __restrict__ ef, double* __restrict__ partial) {
+    __shared__ double red[BLOCK];
+    const int64_t n = nv + nf;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (int k = 0; k < p.K; ++k) {
+        double acc = 0.0;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += BLOCK) acc += i < nv ? rvterm[i * p.K + k] : ef[(i - nv) * p.K + k];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = BLOCK / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * p.K + k] = red[0];
+        __syncthreads();
+    }
+}
+
+// stage 2: one workgroup folds the partials (ascending block order) and applies the softmax-Jacobian projection
+__global__ void __launch_bounds__(BLOCK) vi_weights_kernel(int nblocks, lhvi_vi_t p, const double* __restrict__ partial,
+                                                          double* __restrict__ g_w, double* __restrict__ fe) {
     __shared__ double red[BLOCK];
     __shared__ double gw[64];
     for (int k = 0; k < p.K; ++k) {
         double acc = 0.0;
-        for (int64_t i = threadIdx.x; i < nv; i += BLOCK) acc += rvterm[i * p.K + k];
-        for (int64_t i = threadIdx.x; i < nf; i += BLOCK) acc += ef[i * p.K + k];
+        for (int i = threadIdx.x; i < nblocks; i += BLOCK) acc += partial[(int64_t)i * p.K + k];
         red[threadIdx.x] = acc;
         __syncthreads();
         for (int s = BLOCK / 2; s > 0; s >>= 1) {
@@ -319,7 +468,7 @@ size_t lhvi_vi_workspace_bytes(const lhvi_graph_t* g, const lhvi_vi_t* p) {
     if (!g || !p) return 0;
     const size_t K = (size_t)p->K, D = (size_t)p->Dmax;
     return align256((size_t)g->V * K * 8) + align256((size_t)g->F * K * 8) + align256((size_t)g->E * K * 16) +
-           align256((size_t)g->E * K * D * 8) + 256;
+           align256((size_t)g->E * K * D * 8) + align256((size_t)VI_RED_BLOCKS * K * 8) + 256;
 }
 
 int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t* p, double* g_w, double* g_c, double* g_d,
@@ -334,14 +483,23 @@ int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t
     double* rvterm = (double*)base; base += align256((size_t)g->V * K * 8);
     double* ef = (double*)base; base += align256((size_t)g->F * K * 8);
     double* pe_c = (double*)base; base += align256((size_t)g->E * K * 16);
-    double* pe_d = (double*)base;
+    double* pe_d = (double*)base; base += align256((size_t)g->E * K * (size_t)p->Dmax * 8);
+    double* partial = (double*)base;
     if (g->V > 0)
         hipLaunchKernelGGL(vi_var_kernel, dim3(grid_for((int64_t)g->V * p->K)), dim3(BLOCK), 0, st, *g, *p, rvterm, g_c, g_d);
-    if (g->F > 0)
+    if (g->F > 0) {
+        hipLaunchKernelGGL(vi_factor_cc_kernel, dim3(grid_for((int64_t)g->F * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d);
         hipLaunchKernelGGL(vi_factor_kernel, dim3(grid_for((int64_t)g->F * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d);
+    }
     if (g->V > 0)
+    {
         hipLaunchKernelGGL(vi_gather_kernel, dim3(grid_for((int64_t)g->V * p->K)), dim3(BLOCK), 0, st, *g, *p, pe_c, pe_d, g_c, g_d);
-    hipLaunchKernelGGL(vi_weights_kernel, dim3(1), dim3(BLOCK), 0, st, (int64_t)g->V, (int64_t)g->F, *p, rvterm, ef, g_w, fe);
+        hipLaunchKernelGGL(vi_gather_hub_kernel, dim3(grid_for((int64_t)g->V * p->K * WAVE)), dim3(BLOCK), 0, st, *g, *p, pe_c, pe_d, g_c, g_d);
+    }
+    const int64_t nred = (int64_t)g->V + g->F;
+    const int nblocks = (int)(nred < VI_RED_BLOCKS ? (nred > 0 ? nred : 1) : VI_RED_BLOCKS);
+    hipLaunchKernelGGL(vi_weights_partial_kernel, dim3(nblocks), dim3(BLOCK), 0, st, (int64_t)g->V, (int64_t)g->F, *p, rvterm, ef, partial);
+    hipLaunchKernelGGL(vi_weights_kernel, dim3(1), dim3(BLOCK), 0, st, nblocks, *p, partial, g_w, fe);
     return check_launch();
 }
 

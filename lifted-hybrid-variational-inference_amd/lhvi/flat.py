@@ -53,18 +53,30 @@ class FlatGraph:
     domains: list = field(repr=False, default_factory=list)
 
     # ---- derived helpers -------------------------------------------------------------------
+    # The three per-variable views below are cached per source array object (callers index them inside loops; evaluating
+    # an O(V) expression per access made such loops quadratic).  Replace `var_value` / `var_dom` wholesale to change
+    # them, as all code here does -- in-place edits would not be seen.
+    def _cached(self, name, sources, fn):
+        cache = self.__dict__.setdefault('_view_cache', {})
+        hit = cache.get(name)
+        if hit is None or any(a is not b for a, b in zip(hit[0], sources)):
+            hit = (tuple(sources), fn())
+            cache[name] = hit
+        return hit[1]
+
     @property
     def var_hidden(self):
-        return np.isnan(self.var_value)
+        return self._cached('hidden', (self.var_value,), lambda: np.isnan(self.var_value))
 
     @property
     def var_cont(self):
-        return self.dom_cont[self.var_dom].astype(bool)
+        return self._cached('cont', (self.dom_cont, self.var_dom), lambda: self.dom_cont[self.var_dom].astype(bool))
 
     @property
     def var_nstates(self):
         """number of tabulation points a domain owns: states (discrete) or grid points (continuous)"""
-        return (self.dom_ptr[1:] - self.dom_ptr[:-1])[self.var_dom]
+        return self._cached('nstates', (self.dom_ptr, self.var_dom),
+                            lambda: (self.dom_ptr[1:] - self.dom_ptr[:-1])[self.var_dom])
 
     def edge_of(self, f, rv):
         """canonical edge id of the (factor object, variable object) pair"""

@@ -111,14 +111,18 @@ class _Variational:
         flat, K = self.flat, self.K
         eta_c = np.ones((flat.V, K, 2))
         tau_d = np.zeros((flat.V, K, self.Dmax))
-        for v in range(flat.V):
-            if not flat.var_hidden[v]:
-                continue
-            if flat.var_cont[v]:
-                eta_c[v, :, 0] = np.random.rand(K) * 3 - 1.5
-            else:
-                D = int(flat.var_nstates[v])
-                tau_d[v, :, :D] = np.random.rand(K, D) * 10
+        hidden, cont, nst = flat.var_hidden, flat.var_cont, flat.var_nstates      # (properties: evaluate once)
+        if not (hidden & ~cont).any():
+            # continuous variables only: one call draws the same stream as rand(K) per variable in order
+            idx = np.flatnonzero(hidden)
+            eta_c[idx, :, 0] = np.random.rand(idx.size, K) * 3 - 1.5
+        else:
+            for v in np.flatnonzero(hidden):
+                if cont[v]:
+                    eta_c[v, :, 0] = np.random.rand(K) * 3 - 1.5
+                else:
+                    D = int(nst[v])
+                    tau_d[v, :, :D] = np.random.rand(K, D) * 10
         self._upload_params(np.zeros(K), eta_c, tau_d)
 
     # ---- gradient / free energy -------------------------------------------------------------------
