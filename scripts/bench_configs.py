@@ -7,7 +7,7 @@ import numpy as np, torch
 from lhvi import _abi, synth, lifting
 from lhvi.flat import flatten
 
-which = sys.argv[1:] or ['gauss', 'cfg2', 'cfg3', 'cfg5']
+which = sys.argv[1:] or ['gauss', 'cfg2', 'cfg3', 'cfg5', 'vi_ground']
 
 
 def ev_time(fn, reps=5):
@@ -142,3 +142,15 @@ if 'cfg5' in which:
     out(config='cfg5 RGM 10M ground edges -> colour refinement -> LVI K=2 T=3', ground_edges=flat.E,
         rv_clusters=int(rvc.max()) + 1, f_clusters=int(fc.max()) + 1, lifted_edges=lflat.E, colour_refinement_s=t_ref,
         lift_flat_host_s=t_lift, adam_iterations_per_s=20 / dt, fe_start=fe0, fe_after_20=vi.free_energy())
+
+if 'vi_ground' in which:
+    # the variational step on a GROUND graph: RGM template C=1000, B=500 (1.0 M pairwise Gaussian factors), K=2, T=3
+    from lhvi.vi import VarInference
+    flat, sym, rv0, f0 = synth.rgm_flat(C=1000, B=500, n_values=0, evidence_ratio=0.1, seed=0)
+    vi = VarInference(None, 2, 3)
+    vi._setup_flat(flat)
+    np.random.seed(0)
+    vi.init_param()
+    t = ev_time(vi._grad)
+    out(config='ground VI gradient + free energy, RGM C=1000 B=500, K=2 T=3', factors=int(flat.F), edges=int(flat.E), grad_ms=t,
+        factors_per_s=flat.F / (t * 1e-3), quadrature_nodes_per_s=flat.F * 2 * 9 / (t * 1e-3))
