@@ -71,17 +71,46 @@ __global__ void __launch_bounds__(BLOCK) rv_sig_init_kernel(int V, const int32_t
     idx[v] = (uint32_t)v;
 }
 
-// one thread per variable-CSR slot: add the incident factor's colour mix into the variable's fingerprints
+// Add the incident factors' colour mixes into the variable's two fingerprints.  Integer sums commute, so any order
+// gives the same bits: a thread walks the CSR row of a variable with up to HUB_DEGREE edges, a wavefront shares the row
+// of a hub (template variables of relational models have thousands of edges).  No atomics: 20 M 64-bit atomic adds on
+// a 10 M-edge graph cost 3 ms per round, the segmented sums 0.3.
+constexpr int HUB_DEGREE = 64;
+
+__device__ __forceinline__ void sig_terms(const lhvi_graph_t& g, const int32_t* __restrict__ f_color, uint64_t seed, int k,
+                                          uint64_t& a, uint64_t& b) {
+    const uint64_t c = (uint64_t)(uint32_t)f_color[g.edge_fac[g.var_edge[k]]];
+    a += mix64(c ^ seed ^ SEED1);
+    b += mix64((c + 0x7Full) * 0xC2B2AE3D27D4EB4Full + seed);
+}
+
 __global__ void __launch_bounds__(BLOCK) rv_sig_accum_kernel(lhvi_graph_t g, const int32_t* __restrict__ f_color,
                                                             uint64_t seed, uint64_t* __restrict__ h1,
                                                             uint64_t* __restrict__ h2) {
-    int k = blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= g.nnz) return;
-    const int e = g.var_edge[k];
-    const int v = g.edge_var[e];
-    const uint64_t c = (uint64_t)(uint32_t)f_color[g.edge_fac[e]];
-    atomicAdd(reinterpret_cast<unsigned long long*>(h1 + v), (unsigned long long)mix64(c ^ seed ^ SEED1));
-    atomicAdd(reinterpret_cast<unsigned long long*>(h2 + v), (unsigned long long)mix64((c + 0x7Full) * 0xC2B2AE3D27D4EB4Full + seed));
+    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v >= g.V) return;
+    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    if (hi - lo > HUB_DEGREE) return;
+    uint64_t a = 0, b = 0;
+    for (int k = lo; k < hi; ++k) sig_terms(g, f_color, seed, k, a, b);
+    h1[v] += a; h2[v] += b;
+}
+
+__global__ void __launch_bounds__(BLOCK) rv_sig_accum_hub_kernel(lhvi_graph_t g, const int32_t* __restrict__ f_color,
+                                                                uint64_t seed, uint64_t* __restrict__ h1,
+                                                                uint64_t* __restrict__ h2) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (v >= g.V) return;
+    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    if (hi - lo <= HUB_DEGREE) return;
+    uint64_t a = 0, b = 0;
+    for (int k = lo + lane; k < hi; k += 64) sig_terms(g, f_color, seed, k, a, b);
+    for (int off = 32; off > 0; off >>= 1) {
+        a += ((uint64_t)(uint32_t)__shfl_xor((int)(a >> 32), off) << 32) | (uint32_t)__shfl_xor((int)a, off);
+        b += ((uint64_t)(uint32_t)__shfl_xor((int)(b >> 32), off) << 32) | (uint32_t)__shfl_xor((int)b, off);
+    }
+    if (lane == 0) { h1[v] += a; h2[v] += b; }
 }
 
 __global__ void __launch_bounds__(BLOCK) flag_kernel(int n, const uint64_t* __restrict__ key_sorted,
@@ -195,7 +224,10 @@ int lhvi_color_refine_rvs(const lhvi_graph_t* g, const int32_t* f_color, const i
     const uint64_t seed = 0;
     hipLaunchKernelGGL(rv_sig_init_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, st, g->V, rv_color, seed, w.h1, w.h2, w.idx);
     if (g->nnz > 0)
-        hipLaunchKernelGGL(rv_sig_accum_kernel, dim3(grid_for(g->nnz)), dim3(BLOCK), 0, st, *g, f_color, seed, w.h1, w.h2);
+    {
+        hipLaunchKernelGGL(rv_sig_accum_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, st, *g, f_color, seed, w.h1, w.h2);
+        hipLaunchKernelGGL(rv_sig_accum_hub_kernel, dim3(grid_for((int64_t)g->V * 64)), dim3(BLOCK), 0, st, *g, f_color, seed, w.h1, w.h2);
+    }
     if (int rc = check_launch()) return rc;
     return rank_and_scatter(w, g->V, rv_color_out, n_colors_out, st);
 }

@@ -421,11 +421,12 @@ def lift_flat(flat, rv_color, f_color):
         potentials=flat.potentials, domains=flat.domains)
 
 
-def refine_flat(flat, symmetric, rv_color, f_color, max_rounds=1000):
+def refine_flat(flat, symmetric, rv_color, f_color, max_rounds=1000, dg=None, stats=None):
     """Colour passing on flat arrays entirely on the device (the large-graph path: no Python objects).
-    Same loop as ``CompressedGraph.run``: factor half-round, rv half-round, until #rv colours is stable."""
+    Same loop as ``CompressedGraph.run``: factor half-round, rv half-round, until #rv colours is stable.
+    ``dg``: an already uploaded ``DeviceGraph`` of ``flat``; ``stats``: dict that receives the number of rounds."""
     torch = _abi.require_gpu()
-    dg = _abi.DeviceGraph(flat)
+    dg = dg or _abi.DeviceGraph(flat)
     l = _abi.lib()
     ws_bytes = int(l.lhvi_color_workspace_bytes(dg.g))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dg.device)
@@ -449,4 +450,6 @@ def refine_flat(flat, symmetric, rv_color, f_color, max_rounds=1000):
         if collision:
             raise _abi.LhviError('colour refinement fingerprint collision')
         rounds += 1
+    if stats is not None:
+        stats['rounds'] = rounds
     return rvc.cpu().numpy(), fc.cpu().numpy()
