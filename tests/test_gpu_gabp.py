@@ -104,10 +104,12 @@ def test_galbp_matches_reference_golden(api, golden_dir, name):
 
 
 def test_color_refinement_large_random_vs_oracle(api):
-    """colour passing on a graph with structure (RGM template) at a size the python oracle still finishes"""
+    """colour passing on a graph with structure (RGM template) at a size the python oracle still finishes; the template
+    variables have 90 / 71 incident factors, i.e. they take the wavefront-per-row path of the fingerprint sums"""
     from lhvi import synth, lifting, _abi
     from oracle import oracle
-    flat, sym, rv0, f0 = synth.rgm_flat(C=40, B=25, n_values=4, evidence_ratio=0.2, seed=1)
+    flat, sym, rv0, f0 = synth.rgm_flat(C=90, B=70, n_values=4, evidence_ratio=0.2, seed=1)
+    assert np.diff(flat.var_ptr).max() > 64
     rv_color, f_color = lifting.refine_flat(flat, sym, rv0, f0)
     orv, of = oracle.color_passing(flat, sym, rv0, f0)
     assert oracle.canonical_labels(rv_color) == oracle.canonical_labels(orv)
