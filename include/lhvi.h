@@ -77,7 +77,15 @@ typedef struct lhvi_graph {
     /* optional denormalised copies that turn random gathers of the Gaussian sweep into contiguous reads (NULL = gather) */
     const double* edge_value;   /* [E] var_value[edge_var[e]] */
     const int32_t* slot_var;    /* [nnz] variable of CSR slot k (the v with var_ptr[v] <= k < var_ptr[v+1]) */
+    /* optional: the variables with more than LHVI_HUB_DEGREE incident edges (template variables of relational models).
+     * Kernels that walk a variable's CSR row give these a wavefront each; without the list (NULL) the hub kernels
+     * scan all V variables for them (colour refinement, variational gather) or the row is walked by one thread
+     * (Gaussian v2f / marginals, which keep the reference's summation order up to 512 edges and use the list beyond:
+     * direct O(deg^2) leave-one-out sums). */
+    const int32_t* hub_vars;    /* [n_hubs] ascending variable ids */
+    int32_t n_hubs;
 } lhvi_graph_t;
+#define LHVI_HUB_DEGREE 64
 
 /* Potential table: one row per distinct (potential object, scope domains). */
 typedef struct lhvi_pots {

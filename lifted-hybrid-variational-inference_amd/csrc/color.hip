@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(BLOCK) rv_sig_init_kernel(int V, const int32_t
 // gives the same bits: a thread walks the CSR row of a variable with up to HUB_DEGREE edges, a wavefront shares the row
 // of a hub (template variables of relational models have thousands of edges).  No atomics: 20 M 64-bit atomic adds on
 // a 10 M-edge graph cost 3 ms per round, the segmented sums 0.3.
-constexpr int HUB_DEGREE = 64;
+constexpr int HUB_DEGREE = LHVI_HUB_DEGREE;
 
 __device__ __forceinline__ void sig_terms(const lhvi_graph_t& g, const int32_t* __restrict__ f_color, uint64_t seed, int k,
                                           uint64_t& a, uint64_t& b) {
@@ -100,8 +100,9 @@ __global__ void __launch_bounds__(BLOCK) rv_sig_accum_hub_kernel(lhvi_graph_t g,
                                                                 uint64_t seed, uint64_t* __restrict__ h1,
                                                                 uint64_t* __restrict__ h2) {
     const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    if (v >= g.V) return;
+    const int i = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (i >= (g.hub_vars ? g.n_hubs : g.V)) return;
+    const int v = g.hub_vars ? g.hub_vars[i] : i;          // without a hub list: scan every variable
     const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
     if (hi - lo <= HUB_DEGREE) return;
     uint64_t a = 0, b = 0;
@@ -226,7 +227,9 @@ int lhvi_color_refine_rvs(const lhvi_graph_t* g, const int32_t* f_color, const i
     if (g->nnz > 0)
     {
         hipLaunchKernelGGL(rv_sig_accum_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, st, *g, f_color, seed, w.h1, w.h2);
-        hipLaunchKernelGGL(rv_sig_accum_hub_kernel, dim3(grid_for((int64_t)g->V * 64)), dim3(BLOCK), 0, st, *g, f_color, seed, w.h1, w.h2);
+        const int64_t nh = g->hub_vars ? g->n_hubs : g->V;
+        if (nh > 0)
+            hipLaunchKernelGGL(rv_sig_accum_hub_kernel, dim3(grid_for(nh * 64)), dim3(BLOCK), 0, st, *g, f_color, seed, w.h1, w.h2);
     }
     if (int rc = check_launch()) return rc;
     return rank_and_scatter(w, g->V, rv_color_out, n_colors_out, st);

@@ -22,6 +22,11 @@ __global__ void __launch_bounds__(BLOCK) gabp_init_kernel(int64_t n2, double* __
 // variable sit in adjacent lanes and walk the same d incoming messages, so after the first touch the
 // reads are same-address broadcasts out of L1.  Leave-one-out is a direct sum (no total-minus-own
 // cancellation), in rv.nb order like GaBP.py:23-29 / GaLBP.py:24-34.
+// The Gaussian sweep keeps the reference's summation order (bit-identical messages on the fixtures) for every variable
+// with up to GABP_HUB_DEGREE incident factors and only switches to wave-parallel sums beyond, where the direct
+// leave-one-out sum is quadratic in the degree.
+constexpr int GABP_HUB_DEGREE = 512;
+
 __global__ void __launch_bounds__(BLOCK) gabp_v2f_kernel(lhvi_graph_t g, const double* __restrict__ f2v,
                                                         double* __restrict__ v2f) {
     int k = blockIdx.x * BLOCK + threadIdx.x;
@@ -33,6 +38,7 @@ __global__ void __launch_bounds__(BLOCK) gabp_v2f_kernel(lhvi_graph_t g, const d
         return;
     }
     const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    if (g.hub_vars && hi - lo > GABP_HUB_DEGREE) return;   // hubs: gabp_v2f_hub_kernel (the direct sum is O(deg^2))
     double H = 0.0, P = 0.0;
     for (int j = lo; j < hi; ++j) {
         const int ej = g.var_edge[j];
@@ -55,6 +61,42 @@ __global__ void __launch_bounds__(BLOCK) gabp_v2f_kernel(lhvi_graph_t g, const d
     }
     const double var = 1.0 / P;
     st2(v2f, e, var * H, var);
+}
+
+// Variables with more than GABP_HUB_DEGREE incident factors (the template variables of a relational model): one wavefront
+// per variable forms the information-form total once and every slot subtracts one copy of its own factor's term
+// ("total minus own": O(deg) instead of O(deg^2); costs a relative error of ~deg * 1e-16 in the hub's messages, which
+// the direct sum of the low-degree path avoids).
+__global__ void __launch_bounds__(BLOCK) gabp_v2f_hub_kernel(lhvi_graph_t g, const double* __restrict__ f2v,
+                                                            double* __restrict__ v2f) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (i >= g.n_hubs) return;
+    const int v = g.hub_vars[i];
+    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    if (hi - lo <= GABP_HUB_DEGREE) return;
+    if (!is_hidden(g.var_value[v])) {
+        for (int k = lo + lane; k < hi; k += 64) st2(v2f, g.var_edge[k], NAN, NAN);
+        return;
+    }
+    double H = 0.0, P = 0.0;
+    for (int k = lo + lane; k < hi; k += 64) {
+        const int e = g.var_edge[k];
+        const double c = g.edge_count ? g.edge_count[e] : 1.0;
+        const double2 m = ld2(f2v, e);
+        if (m.y != m.y) H -= m.x * c;
+        else { const double p = 1.0 / m.y; H += p * m.x * c; P += p * c; }
+    }
+    H = dpp_wave_reduce(H, SumOp()); P = dpp_wave_reduce(P, SumOp());
+    for (int k = lo + lane; k < hi; k += 64) {
+        const int e = g.var_edge[k];
+        const double2 m = ld2(f2v, e);
+        double h = H, p = P;
+        if (m.y != m.y) h += m.x;                                  // take one copy of the own term back out
+        else { const double q = 1.0 / m.y; h -= q * m.x; p -= q; }
+        const double var = 1.0 / p;
+        st2(v2f, e, var * h, var);
+    }
 }
 
 // closed forms of GaBP.message_f_to_rv (GaBP.py:37-138).  (u, s): partner's v->f message when the
@@ -146,6 +188,7 @@ __global__ void __launch_bounds__(BLOCK) gabp_marginal_kernel(lhvi_graph_t g, co
     if (v >= g.V) return;
     const double val = g.var_value[v];
     if (!is_hidden(val)) { st2(out, v, val, 0.0); return; }
+    if (g.hub_vars && g.var_ptr[v + 1] - g.var_ptr[v] > GABP_HUB_DEGREE) return;      // gabp_marginal_hub_kernel
     double H = 0.0, P = 0.0;
     for (int j = g.var_ptr[v]; j < g.var_ptr[v + 1]; ++j) {
         const int ej = g.var_edge[j];
@@ -161,6 +204,27 @@ __global__ void __launch_bounds__(BLOCK) gabp_marginal_kernel(lhvi_graph_t g, co
     }
     const double var = 1.0 / P;
     st2(out, v, var * H, var);
+}
+
+__global__ void __launch_bounds__(BLOCK) gabp_marginal_hub_kernel(lhvi_graph_t g, const double* __restrict__ f2v,
+                                                                 double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (i >= g.n_hubs) return;
+    const int v = g.hub_vars[i];
+    if (g.var_ptr[v + 1] - g.var_ptr[v] <= GABP_HUB_DEGREE) return;
+    if (!is_hidden(g.var_value[v])) return;                 // written by the thread-per-variable kernel
+    double H = 0.0, P = 0.0;
+    for (int j = g.var_ptr[v] + lane; j < g.var_ptr[v + 1]; j += 64) {
+        const int ej = g.var_edge[j];
+        const double c = g.edge_count ? g.edge_count[ej] : 1.0;
+        const double2 m = ld2(f2v, ej);
+        if (m.y != m.y) H -= m.x * c;
+        else { const double p = 1.0 / m.y; H += p * m.x * c; P += p * c; }
+    }
+    H = dpp_wave_reduce(H, SumOp()); P = dpp_wave_reduce(P, SumOp());
+    const double var = 1.0 / P;
+    if (lane == 0) st2(out, v, var * H, var);
 }
 
 static int validate(const lhvi_graph_t* g) {
@@ -190,6 +254,8 @@ int lhvi_gabp_v2f(const lhvi_graph_t* g, const double* f2v, double* v2f, void* s
     if (g->nnz == 0) return LHVI_OK;
     if (!f2v || !v2f) return LHVI_E_ARG;
     hipLaunchKernelGGL(gabp_v2f_kernel, dim3(grid_for(g->nnz)), dim3(BLOCK), 0, as_stream(stream), *g, f2v, v2f);
+    if (g->hub_vars && g->n_hubs > 0)
+        hipLaunchKernelGGL(gabp_v2f_hub_kernel, dim3(grid_for((int64_t)g->n_hubs * 64)), dim3(BLOCK), 0, as_stream(stream), *g, f2v, v2f);
     return check_launch();
 }
 
@@ -218,6 +284,8 @@ int lhvi_gabp_marginals(const lhvi_graph_t* g, const double* f2v, double* mu_var
     if (g->V == 0) return LHVI_OK;
     if (!f2v || !mu_var) return LHVI_E_ARG;
     hipLaunchKernelGGL(gabp_marginal_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, as_stream(stream), *g, f2v, mu_var);
+    if (g->hub_vars && g->n_hubs > 0)
+        hipLaunchKernelGGL(gabp_marginal_hub_kernel, dim3(grid_for((int64_t)g->n_hubs * 64)), dim3(BLOCK), 0, as_stream(stream), *g, f2v, mu_var);
     return check_launch();
 }
 

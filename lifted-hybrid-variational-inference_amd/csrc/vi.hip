@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(BLOCK) vi_factor_kernel(lhvi_graph_t g, lhvi_p
 // ---- gather per variable + projection ----------------------------------------------------------------------
 // thread per (variable, k) up to VI_HUB_DEGREE incident edges; a wavefront per (variable, k) beyond (the template
 // variables of a relational model touch thousands of factors: one thread walking them serialises the whole launch)
-constexpr int VI_HUB_DEGREE = 64;
+constexpr int VI_HUB_DEGREE = LHVI_HUB_DEGREE;
 __global__ void __launch_bounds__(BLOCK) vi_gather_kernel(lhvi_graph_t g, lhvi_vi_t p, const double* __restrict__ pe_c,
                                                          const double* __restrict__ pe_d, double* __restrict__ g_c,
                                                          double* __restrict__ g_d) {
@@ -354,9 +354,10 @@ __global__ void __launch_bounds__(BLOCK) vi_gather_hub_kernel(lhvi_graph_t g, lh
                                                              const double* __restrict__ pe_d, double* __restrict__ g_c,
                                                              double* __restrict__ g_d) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
-    if (i >= (int64_t)g.V * p.K) return;
-    const int v = (int)(i / p.K), k = (int)(i % p.K);
+    const int64_t w = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (w >= (int64_t)(g.hub_vars ? g.n_hubs : g.V) * p.K) return;
+    const int v = g.hub_vars ? g.hub_vars[w / p.K] : (int)(w / p.K), k = (int)(w % p.K);
+    const int64_t i = (int64_t)v * p.K + k;
     const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
     if (hi - lo <= VI_HUB_DEGREE || !is_hidden(g.var_value[v])) return;
     if (v_cont(g, v)) {
@@ -494,7 +495,9 @@ int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t
     if (g->V > 0)
     {
         hipLaunchKernelGGL(vi_gather_kernel, dim3(grid_for((int64_t)g->V * p->K)), dim3(BLOCK), 0, st, *g, *p, pe_c, pe_d, g_c, g_d);
-        hipLaunchKernelGGL(vi_gather_hub_kernel, dim3(grid_for((int64_t)g->V * p->K * WAVE)), dim3(BLOCK), 0, st, *g, *p, pe_c, pe_d, g_c, g_d);
+        const int64_t nh = g->hub_vars ? g->n_hubs : g->V;
+        if (nh > 0)
+            hipLaunchKernelGGL(vi_gather_hub_kernel, dim3(grid_for(nh * p->K * WAVE)), dim3(BLOCK), 0, st, *g, *p, pe_c, pe_d, g_c, g_d);
     }
     const int64_t nred = (int64_t)g->V + g->F;
     const int nblocks = (int)(nred < VI_RED_BLOCKS ? (nred > 0 ? nred : 1) : VI_RED_BLOCKS);

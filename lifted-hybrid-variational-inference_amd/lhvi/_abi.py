@@ -31,6 +31,7 @@ class GraphStruct(C.Structure):
         ('D', C.c_int32),
         ('dom_cont', C.c_void_p), ('dom_lo', C.c_void_p), ('dom_hi', C.c_void_p), ('dom_ptr', C.c_void_p),
         ('dom_val', C.c_void_p), ('edge_value', C.c_void_p), ('slot_var', C.c_void_p),
+        ('hub_vars', C.c_void_p), ('n_hubs', C.c_int32),
     ]
 
 
@@ -66,6 +67,7 @@ PBP_SKIP_TERMS = 16
 PBP_SKIP_HEAVY = 32
 PBP_SKIP_LIGHT = 64
 PBP_DESC_BYTES = 128
+HUB_DEGREE = 64              # LHVI_HUB_DEGREE
 
 _G, _P, _S, _VI = C.POINTER(GraphStruct), C.POINTER(PotsStruct), C.POINTER(PbpStruct), C.POINTER(ViStruct)
 _vp, _i32, _i64, _u32, _u64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double, C.c_size_t
@@ -195,6 +197,9 @@ class DeviceGraph:
         t['edge_value'] = to_dev(np.ascontiguousarray(flat.var_value[flat.edge_var]), device) if flat.E else None
         t['slot_var'] = to_dev(np.repeat(np.arange(flat.V, dtype=np.int32), np.diff(flat.var_ptr)), device) if flat.var_edge.size else None
         g.edge_value, g.slot_var = ptr(t['edge_value']), ptr(t['slot_var'])
+        hubs = np.flatnonzero(np.diff(flat.var_ptr) > HUB_DEGREE).astype(np.int32)
+        t['hub_vars'] = to_dev(hubs if hubs.size else np.zeros(1, dtype=np.int32), device)   # non-NULL even when empty
+        g.hub_vars, g.n_hubs = ptr(t['hub_vars']), int(hubs.size)
         self.g = g
         p = PotsStruct()
         p.P = int(flat.pot_kind.size)

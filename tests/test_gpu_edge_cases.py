@@ -142,3 +142,31 @@ def test_argument_validation_returns_codes(api):
     assert l.lhvi_adam_step(None, None, None, None, 0, 1, 0.1, 0.9, 0.999, 1e-8, 0, 0.0, None) == 0
     assert l.lhvi_softmax_rows(None, None, 4, 0, 0, None) == -1
     assert l.lhvi_strerror(-3) == b'unsupported configuration'
+
+
+def test_gaussian_hub_above_the_direct_sum_threshold(api):
+    """a star with 700 pairwise neighbours: the hub takes the wave-parallel total-minus-own path of the Gaussian sweep
+    (beyond 512 edges the reference-order direct sum is quadratic in the degree); marginals against the oracle"""
+    from lhvi.flat import build_flat
+    from lhvi.graph import Domain
+    from lhvi import potentials as P
+    from oracle import oracle
+    D = 700
+    dom = Domain((-10, 10), continuous=True, integral_points=np.linspace(-10, 10, 8))
+    edge_var = np.stack([np.zeros(D, dtype=np.int32), np.arange(1, D + 1, dtype=np.int32)], axis=1).ravel()
+    edge_var = np.concatenate([edge_var, np.arange(D + 1, dtype=np.int32)])
+    fac_ptr = np.concatenate([np.arange(0, 2 * D + 1, 2), 2 * D + np.arange(1, D + 2)]).astype(np.int32)
+    specs = [(P.POT_LINEAR_GAUSSIAN, [0.7, 2.0]), (P.POT_X2, [1.0, 4.0])]
+    fac_pot = np.concatenate([np.zeros(D), np.ones(D + 1)]).astype(np.int32)
+    value = np.full(D + 1, np.nan)
+    value[5::7] = 1.0
+    flat = build_flat(fac_ptr, edge_var, fac_pot, specs, value, np.zeros(D + 1, dtype=np.int32), [dom])
+    assert np.diff(flat.var_ptr).max() > 512
+    dg = api.DeviceGraph(flat)
+    assert dg.g.n_hubs == 1
+    f2v, v2f, mv = dg.empty(flat.E, 2), dg.empty(flat.E, 2), dg.empty(flat.V, 2)
+    l, st = api.lib(), api.stream_ptr()
+    api.check(l.lhvi_gabp_run(dg.g, dg.p, api.ptr(f2v), api.ptr(v2f), 6, st))
+    api.check(l.lhvi_gabp_marginals(dg.g, api.ptr(f2v), api.ptr(mv), st))
+    _, _, omv = oracle.gabp_run(flat, 6)
+    np.testing.assert_allclose(mv.cpu().numpy(), omv, rtol=1e-10, atol=1e-12)
