@@ -140,9 +140,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
             if (nchunk == 1) {
                 // log_message_balance over the distinct keys (EPBP:204-215)
                 const double tot = wave_sum(uq ? res : 0.0);
-                const double mx = wave_max(uq ? res : -__builtin_huge_val());
                 const double mean = tot * rcnt;
-                const double shift = (mx - mean > s.max_log_value) ? mx - s.max_log_value : mean;
+                double shift = mean;
+                // max - mean > max_log_value  <=>  some distinct particle exceeds mean + max_log_value: one ballot
+                // decides, and the max reduction runs only in that (rare) case
+                if (__ballot(uq && (res - mean > s.max_log_value)))
+                    shift = wave_max(uq ? res : -__builtin_huge_val()) - s.max_log_value;
                 if (valid) v2f[(int64_t)e * n + j] = res - shift;
             } else if (valid) {
                 v2f[(int64_t)e * n + j] = res;       // balanced below once every chunk is written
