@@ -104,8 +104,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
     const int d = g.var_dom[v];
     const bool lifted = g.edge_count != nullptr;
     const int nchunk = (np + 63) / 64;
-    const double mu = s.q[2 * v], sd = sqrt(s.q[2 * v + 1]), rsd = 1.0 / sd;
-    const double log_norm = log(2.506628274631 * sd);
+    // per-variable constants through the short routines (a few ulp from the libm ones; same value in every lane)
+    const double mu = s.q[2 * v], sd = sqrt_pos(s.q[2 * v + 1]), rsd = rcp_newton(sd);
+    const double log_norm = log_pos(2.506628274631 * sd);
     for (int c = 0; c < nchunk; ++c) {
         const int j = c * 64 + lane;
         const bool valid = j < np;
