@@ -291,3 +291,31 @@ def test_flat_grounding_matches_reference_grounding(golden_dir):
         got = sorted([pf_of_pot[int(flat.fac_pot[f])], [list(keys.key_of(v)) for v in flat.edge_var[flat.fac_ptr[f]:flat.fac_ptr[f + 1]]]]
                      for f in range(flat.F))
         assert got == want['factors']
+
+
+@pytest.mark.parametrize('n,T,missing', [(4, 5, 0.3), (3, 2, 0.0), (5, 7, 0.6), (2, 1, 0.0)])
+def test_kalman_flat_builder_equals_object_builder(n, T, missing):
+    """KalmanFilter.grounded_flat against grounded_graph + flatten: same variables, same factors in the same order, the
+    same (kind, parameters) behind every factor (the flat builder deduplicates potentials by value)"""
+    rng = np.random.default_rng(n * 10 + T)
+    A = rng.normal(size=(n, n)) * (rng.random((n, n)) < 0.7)
+    Cm = np.diag(rng.uniform(0.5, 1.5, n))
+    data = rng.normal(size=(n, max(T, 1)))
+    data[rng.random(data.shape) < missing] = kalman.MISSING
+    data[:, 0] = rng.normal(size=n)
+    dom = G.Domain((-20, 20), continuous=True, integral_points=np.linspace(-20, 20, 8))
+    kf = kalman.KalmanFilter(dom, A, 0.7, Cm, 0.4)
+    g, table = kf.grounded_graph(T, data)
+    fo = flatten(g)
+    ff, sid = kf.grounded_flat(T, data)
+    assert (fo.V, fo.F, fo.E) == (ff.V, ff.F, ff.E)
+    for name in ('fac_ptr', 'edge_var', 'var_ptr', 'var_edge', 'var_dom'):
+        np.testing.assert_array_equal(getattr(fo, name), getattr(ff, name), err_msg=name)
+    np.testing.assert_array_equal(np.nan_to_num(fo.var_value, nan=-1e9), np.nan_to_num(ff.var_value, nan=-1e9))
+    for f in range(fo.F):
+        po, pf = fo.fac_pot[f], ff.fac_pot[f]
+        assert fo.pot_kind[po] == ff.pot_kind[pf]
+        np.testing.assert_array_equal(fo.pot_param[fo.pot_off[po]:fo.pot_off[po + 1]], ff.pot_param[ff.pot_off[pf]:ff.pot_off[pf + 1]])
+    for t in range(T):
+        for i in range(n):
+            assert fo.rvs[sid[t, i]] is table[t][i]
