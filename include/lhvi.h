@@ -115,6 +115,12 @@ int lhvi_gabp_run(const lhvi_graph_t* g, const lhvi_pots_t* pots, double* f2v, d
  * GaBP.get_belief_params GaBP.py:187-200, GaLBP.map GaLBP.py:201-217 */
 int lhvi_gabp_marginals(const lhvi_graph_t* g, const double* f2v, double* mu_var, void* stream);
 
+/* utils.log_likelihood (utils.py:6-15) of a full assignment x [V] on flat arrays: out[0] = -sum_f log phi_f(x_scope),
+ * or -inf when some factor is 0 at x (the reference's convention).  Discrete arguments are matched to their states. */
+size_t lhvi_log_likelihood_workspace_bytes(const lhvi_graph_t* g);
+int lhvi_log_likelihood(const lhvi_graph_t* g, const lhvi_pots_t* pots, const double* x, double* out, void* ws, size_t ws_bytes,
+                        void* stream);
+
 /* ---- Particle BP (EPBPLogVersion.py / HybridLBPLogVersion.py) -----------------------------------
  * Log messages are tabulated per edge: f2v [E][n+T] (first n = at the variable's particles, next T = at
  * the variable's integral points), v2f [E][n]. */

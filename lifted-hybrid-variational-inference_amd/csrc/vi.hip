@@ -434,6 +434,53 @@ __global__ void __launch_bounds__(BLOCK) vi_weights_kernel(int nblocks, lhvi_vi_
     }
 }
 
+// ---- utils.log_likelihood (utils.py:6-15) on flat arrays: -sum_f log phi_f(x), -inf as soon as a factor vanishes ------
+__global__ void __launch_bounds__(BLOCK) loglik_factor_kernel(lhvi_graph_t g, lhvi_pots_t pots, const double* __restrict__ x,
+                                                             double* __restrict__ term) {
+    const int f = blockIdx.x * BLOCK + threadIdx.x;
+    if (f >= g.F) return;
+    const int base = g.fac_ptr[f], arity = g.fac_ptr[f + 1] - base;
+    double xs[LHVI_MAX_ARITY];
+    int idx[LHVI_MAX_ARITY];
+#pragma unroll
+    for (int a = 0; a < LHVI_MAX_ARITY; ++a) {
+        xs[a] = 0.0; idx[a] = 0;
+        if (a < arity) { const int v = g.edge_var[base + a]; xs[a] = x[v]; idx[a] = vi_state_index(g, v, xs[a]); }
+    }
+    const int pot = g.fac_pot[f];
+    const double phi = pot_value(pots.kind[pot], pots.param + pots.off[pot], xs, idx);
+    term[f] = phi == 0.0 ? -__builtin_huge_val() : log(phi);
+}
+
+__global__ void __launch_bounds__(BLOCK) loglik_partial_kernel(int64_t n, const double* __restrict__ term, double* __restrict__ partial) {
+    __shared__ double red[BLOCK];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    double acc = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += BLOCK) acc += term[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = BLOCK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(BLOCK) loglik_final_kernel(int nblocks, const double* __restrict__ partial, double* __restrict__ out) {
+    __shared__ double red[BLOCK];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += BLOCK) acc += partial[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = BLOCK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    // a vanishing factor makes the sum -inf; the reference then returns -inf (not +inf) -- keep its sign convention
+    if (threadIdx.x == 0) out[0] = red[0] == -__builtin_huge_val() ? -__builtin_huge_val() : -red[0];
+}
+
 __global__ void __launch_bounds__(BLOCK) adam_kernel(double* __restrict__ theta, double* __restrict__ m, double* __restrict__ s,
                                                     const double* __restrict__ grad, int64_t count, double c1, double c2, double lr,
                                                     double b1, double b2, double eps, int clip_stride, double clip_min) {
@@ -503,6 +550,25 @@ int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t
     const int nblocks = (int)(nred < VI_RED_BLOCKS ? (nred > 0 ? nred : 1) : VI_RED_BLOCKS);
     hipLaunchKernelGGL(vi_weights_partial_kernel, dim3(nblocks), dim3(BLOCK), 0, st, (int64_t)g->V, (int64_t)g->F, *p, rvterm, ef, partial);
     hipLaunchKernelGGL(vi_weights_kernel, dim3(1), dim3(BLOCK), 0, st, nblocks, *p, partial, g_w, fe);
+    return check_launch();
+}
+
+size_t lhvi_log_likelihood_workspace_bytes(const lhvi_graph_t* g) {
+    return g ? align256((size_t)g->F * 8) + align256((size_t)VI_RED_BLOCKS * 8) + 256 : 0;
+}
+
+int lhvi_log_likelihood(const lhvi_graph_t* g, const lhvi_pots_t* pots, const double* x, double* out, void* ws, size_t ws_bytes,
+                        void* stream) {
+    if (!g || !pots || !x || !out || !ws) return LHVI_E_ARG;
+    if (ws_bytes < lhvi_log_likelihood_workspace_bytes(g)) return LHVI_E_ARG;
+    hipStream_t st = as_stream(stream);
+    double* term = (double*)ws;
+    double* partial = (double*)((char*)ws + align256((size_t)g->F * 8));
+    const int nblocks = g->F < VI_RED_BLOCKS ? (g->F > 0 ? g->F : 1) : VI_RED_BLOCKS;
+    if (g->F > 0)
+        hipLaunchKernelGGL(loglik_factor_kernel, dim3(grid_for(g->F)), dim3(BLOCK), 0, st, *g, *pots, x, term);
+    hipLaunchKernelGGL(loglik_partial_kernel, dim3(nblocks), dim3(BLOCK), 0, st, (int64_t)g->F, term, partial);
+    hipLaunchKernelGGL(loglik_final_kernel, dim3(1), dim3(BLOCK), 0, st, nblocks, partial, out);
     return check_launch();
 }
 

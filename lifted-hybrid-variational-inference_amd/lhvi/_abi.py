@@ -86,6 +86,8 @@ SIGNATURES = {
     'lhvi_pbp_uniq': (C.c_int, [_G, _i32, _vp, _vp, _vp, _vp]),
     'lhvi_pbp_classify': (C.c_int, [_G, _P, _vp, _vp]),
     'lhvi_pbp_describe': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _vp]),
+    'lhvi_log_likelihood_workspace_bytes': (C.c_size_t, [_G]),
+    'lhvi_log_likelihood': (C.c_int, [_G, _P, _vp, _vp, _vp, C.c_size_t, _vp]),
     'lhvi_pbp_var_sum': (C.c_int, [_G, _S, _vp, _vp, _vp]),
     'lhvi_pbp_domain_grid': (C.c_int, [_G, _S, _vp, _vp]),
     'lhvi_pbp_refine_grid': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp, _vp]),
