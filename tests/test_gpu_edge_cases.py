@@ -170,3 +170,29 @@ def test_gaussian_hub_above_the_direct_sum_threshold(api):
     api.check(l.lhvi_gabp_marginals(dg.g, api.ptr(f2v), api.ptr(mv), st))
     _, _, omv = oracle.gabp_run(flat, 6)
     np.testing.assert_allclose(mv.cpu().numpy(), omv, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize('frac_discrete,evidence', [(0.0, 0.0), (0.5, 0.5), (0.9, 0.2), (1.0, 0.1)])
+def test_graph_compositions_against_oracle(api, frac_discrete, evidence):
+    """all-continuous (heavy kernel only), half discrete with heavy evidence (light kernel, observed partners on both
+    sides), almost all discrete and all discrete (generic table kernel only): two sweeps against the oracle"""
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    from oracle import oracle
+    flat = synth.hybrid_mrf_flat(V=600, deg=4, seed=21, frac_discrete=frac_discrete, evidence_ratio=evidence, T=16)
+    n = 32
+    bp = EPBP(None, n=n, proposal_approximation='EP', sampler='device', seed=3)
+    bp._setup(None, flat=flat)
+    l, st = api.lib(), api.stream_ptr()
+    api.check(l.lhvi_pbp_init(bp.dg.g, bp._struct(), api.ptr(bp.eta), api.ptr(bp.q_dev), api.ptr(bp.f2v), api.ptr(bp.v2f), st))
+    bp._generate_sample()
+    o = oracle.PbpOracle(flat, n, ep=True, epbp=True, var_threshold=3)
+    o.init()
+    o.set_particles(bp.particles.cpu().numpy())
+    hid_e = flat.var_hidden[flat.edge_var]
+    for _ in range(2):
+        bp.sweep(last=False)
+        o.step_v2f(); o.step_proposal(); o.set_particles(bp.particles.cpu().numpy()); o.step_f2v()
+        np.testing.assert_allclose(bp.v2f.cpu().numpy()[hid_e], o.v2f[hid_e], rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(bp.f2v.cpu().numpy()[hid_e], o.f2v[hid_e], rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(bp.q_dev.cpu().numpy()[flat.var_hidden], o.q[flat.var_hidden], rtol=1e-9, atol=1e-10)
