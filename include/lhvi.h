@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LHVI_ABI_VERSION 1
+#define LHVI_ABI_VERSION 2   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */

@@ -66,6 +66,7 @@ PBP_SKIP_GENERIC = 8
 PBP_SKIP_TERMS = 16
 PBP_SKIP_HEAVY = 32
 PBP_SKIP_LIGHT = 64
+ABI_VERSION = 2             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
 PBP_DESC_BYTES = 128
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE
 
@@ -133,7 +134,7 @@ def lib():
                 MISSING.append(name)        # build() and tests/test_abi.py require this list to be empty
                 continue
             fn.restype, fn.argtypes = res, args
-        if handle.lhvi_version() != 1:
+        if handle.lhvi_version() != ABI_VERSION:
             raise LhviError('liblhvi.so ABI version mismatch')
         _lib = handle
     return _lib
