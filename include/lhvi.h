@@ -161,13 +161,15 @@ typedef struct lhvi_pbp {
     int32_t n_light;
     /* edge-sharded runs only (all NULL on a single GPU).  A boundary variable (edges on several ranks) owns one row per
      * peer rank in the exchange buffers; row r of the send buffer and row r of the receive buffer belong to the same
-     * (variable, peer) because both ends list their shared variables in ascending global id.  A row is n + 2 doubles:
-     * [sum over the sender's local edges of count * f2v[e][j], j < n | sum of count/var, sum of count*mu/var of its sites]. */
+     * (variable, peer) because both ends list their shared variables in ascending global id.  A row of a continuous
+     * variable is n + 2 doubles: [sum over the sender's local edges of count * f2v[e][j], j < n | sum of count/var, sum of
+     * count*mu/var of its sites]; a row of a discrete variable is np doubles (the sums at its states; it has no proposal).
+     * Rows are packed back to back, peer-major; brow_off gives each row's element offset in either buffer. */
     const int32_t* bslot;       /* [V] index of the variable in the boundary list, -1 for interior / observed variables */
     const int32_t* brow_ptr;    /* [nb+1] CSR over exchange rows per boundary variable, rows in ascending peer rank */
-    const int32_t* brow_idx;    /* [rows] row ids (the same ids address the send and the receive buffer) */
+    const int64_t* brow_off;    /* [rows] element offset of the row (the same offsets address the send and the receive buffer) */
     const int32_t* brow_peer;   /* [rows] peer rank of each listed row */
-    const double* recv;         /* [rows][n+2] received rows of this sweep */
+    const double* recv;         /* received rows of this sweep, packed like the send buffer */
     int32_t rank;               /* this rank (fixes the summation order of the proposals so that all replicas agree bit for bit) */
     const double* var_degree;   /* [V] global number of incoming messages (sum of counts over ALL ranks' edges) */
 } lhvi_pbp_t;

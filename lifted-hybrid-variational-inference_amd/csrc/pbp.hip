@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
         if (s.bslot && valid) {                      // edges of this variable that live on other ranks: received partial sums
             const int bs = s.bslot[v];
             if (bs >= 0)
-                for (int r = s.brow_ptr[bs]; r < s.brow_ptr[bs + 1]; ++r) total += s.recv[(int64_t)s.brow_idx[r] * (n + 2) + j];
+                for (int r = s.brow_ptr[bs]; r < s.brow_ptr[bs + 1]; ++r) total += s.recv[s.brow_off[r] + j];
         }
 #pragma unroll
         for (int k = 0; k < V2F_CACHE; ++k)
@@ -972,13 +972,12 @@ __global__ void __launch_bounds__(BLOCK) pbp_proposal_finish_kernel(lhvi_graph_t
         // so that every replica of the variable computes bit-identical q and therefore draws identical particles
         const int bs = s.bslot[v];
         if (bs >= 0) {
-            const int W = s.n + 2;
             const double own_s = ps, own_m = pm;
             ps = 0.0; pm = 0.0;
             bool own_done = false;
             for (int r = s.brow_ptr[bs]; r < s.brow_ptr[bs + 1]; ++r) {
                 if (!own_done && s.brow_peer[r] > s.rank) { ps += own_s; pm += own_m; own_done = true; }
-                const double* row = s.recv + (int64_t)s.brow_idx[r] * W + s.n;
+                const double* row = s.recv + s.brow_off[r] + s.n;       // continuous variable: [n sums | 2 site sums]
                 ps += row[0]; pm += row[1];
             }
             if (!own_done) { ps += own_s; pm += own_m; }
@@ -997,9 +996,12 @@ __global__ void __launch_bounds__(BLOCK) pbp_boundary_pack_kernel(lhvi_graph_t g
     const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
     if (i >= nb) return;
     const int v = bvars[i];
-    const int n = s.n, S = s.n + s.T, W = s.n + 2;
+    const int n = s.n, S = s.n + s.T;
     const int np = s.np[v];
     const int r0 = s.brow_ptr[i], r1 = s.brow_ptr[i + 1];
+    // row width: n + 2 for a continuous variable (particle sums | site sums), np for a discrete one (its states only;
+    // discrete variables have no proposal to exchange)
+    const int W = g.dom_cont[g.var_dom[v]] ? n + 2 : np;
     for (int j = lane; j < W; j += 64) {
         double val = 0.0;
         if (j < np) {
@@ -1009,7 +1011,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_boundary_pack_kernel(lhvi_graph_t g
                 val += g.edge_count ? m * g.edge_count[e] : m;
             }
         } else if (j >= n) val = ph[2 * v + (j - n)];
-        for (int r = r0; r < r1; ++r) out[(int64_t)s.brow_idx[r] * W + j] = val;
+        for (int r = r0; r < r1; ++r) out[s.brow_off[r] + j] = val;
     }
 }
 
@@ -1357,7 +1359,7 @@ int lhvi_pbp_proposal_partial(const lhvi_graph_t* g, const lhvi_pbp_t* s, const 
 
 int lhvi_pbp_proposal_finish(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* ph, double* q, void* stream) {
     if (int rc = validate_pbp(g, s)) return rc;
-    if (!ph || !q || (s->bslot && (!s->recv || !s->brow_ptr || !s->brow_idx || !s->brow_peer))) return LHVI_E_ARG;
+    if (!ph || !q || (s->bslot && (!s->recv || !s->brow_ptr || !s->brow_off || !s->brow_peer))) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
     hipLaunchKernelGGL(pbp_proposal_finish_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, as_stream(stream), *g, *s, ph, q);
     return check_launch();
@@ -1368,7 +1370,7 @@ int lhvi_pbp_boundary_pack(const lhvi_graph_t* g, const lhvi_pbp_t* s, const dou
     if (int rc = validate_pbp(g, s)) return rc;
     if (nb < 0) return LHVI_E_ARG;
     if (nb == 0) return LHVI_OK;
-    if (!f2v || !ph || !bvars || !out || !s->brow_ptr || !s->brow_idx) return LHVI_E_ARG;
+    if (!f2v || !ph || !bvars || !out || !s->brow_ptr || !s->brow_off) return LHVI_E_ARG;
     hipLaunchKernelGGL(pbp_boundary_pack_kernel, dim3(grid_for((int64_t)nb * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, ph,
                        nb, bvars, out);
     return check_launch();

@@ -47,7 +47,7 @@ class PbpStruct(C.Structure):
         ('q', C.c_void_p),
         ('fast_edges', C.c_void_p), ('n_fast', C.c_int32), ('generic_edges', C.c_void_p), ('n_generic', C.c_int32),
         ('generic_pts_log2', C.c_int32), ('fast_desc', C.c_void_p), ('heavy_desc', C.c_void_p), ('n_heavy', C.c_int32), ('light_desc', C.c_void_p), ('n_light', C.c_int32),
-        ('bslot', C.c_void_p), ('brow_ptr', C.c_void_p), ('brow_idx', C.c_void_p), ('brow_peer', C.c_void_p),
+        ('bslot', C.c_void_p), ('brow_ptr', C.c_void_p), ('brow_off', C.c_void_p), ('brow_peer', C.c_void_p),
         ('recv', C.c_void_p), ('rank', C.c_int32), ('var_degree', C.c_void_p),
     ]
 

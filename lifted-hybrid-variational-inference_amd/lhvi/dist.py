@@ -223,18 +223,28 @@ class ShardedRunner:
         nb = int(plan.bvars.size)
         self.nb, self.W = nb, n + 2
         self.ph = torch.zeros(plan.flat.V, 2, dtype=torch.float64, device=dev)
-        rows = max(plan.n_rows, 1)
-        self.send = torch.zeros(rows, self.W, dtype=torch.float64, device=dev)
-        self.recv = torch.zeros(rows, self.W, dtype=torch.float64, device=dev)
+        # exchange rows, packed back to back in peer-major order: n + 2 doubles for a continuous boundary variable, its
+        # np states for a discrete one (nothing else of a discrete variable is exchanged)
+        lf = plan.flat
+        bcont = lf.var_cont[plan.bvars]
+        bwidth = np.where(bcont, n + 2, bp.np_host[plan.bvars]).astype(np.int64)
+        row_bvar = np.concatenate([plan.peer_rows[s] for s in range(world) if s != rank]) if plan.n_rows else np.zeros(0, np.int64)
+        row_width = bwidth[row_bvar]
+        row_off = np.concatenate([[0], np.cumsum(row_width)]).astype(np.int64)
+        self.n_elems = int(row_off[-1])
+        self.send = torch.zeros(max(self.n_elems, 1), dtype=torch.float64, device=dev)
+        self.recv = torch.zeros(max(self.n_elems, 1), dtype=torch.float64, device=dev)
         self.brow_ptr = _abi.to_dev(plan.brow_ptr)
-        self.brow_idx = _abi.to_dev(plan.brow_idx if plan.n_rows else np.zeros(1, dtype=np.int32))
+        self.brow_off = _abi.to_dev(row_off[:-1][plan.brow_idx] if plan.n_rows else np.zeros(1, dtype=np.int64))
         self.brow_peer = _abi.to_dev(plan.brow_peer if plan.n_rows else np.zeros(1, dtype=np.int32))
-        self.counts = plan.send_counts()
+        # elements per peer (what the all_to_all splits by); rows per peer stay in plan.counts
+        ends = np.cumsum([c for c in plan.counts])
+        self.counts = [int(row_off[e] - row_off[e - c]) for e, c in zip(ends, plan.counts)]
 
     def _struct(self):
         s = self.bp._struct()
         s.bslot, s.var_degree = _abi.ptr(self.bslot), _abi.ptr(self.var_degree)
-        s.brow_ptr, s.brow_idx, s.brow_peer = _abi.ptr(self.brow_ptr), _abi.ptr(self.brow_idx), _abi.ptr(self.brow_peer)
+        s.brow_ptr, s.brow_off, s.brow_peer = _abi.ptr(self.brow_ptr), _abi.ptr(self.brow_off), _abi.ptr(self.brow_peer)
         s.recv, s.rank = _abi.ptr(self.recv), int(self.rank)
         return s
 
@@ -251,12 +261,12 @@ class ShardedRunner:
         _abi.check(l.lhvi_pbp_proposal_partial(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.eta), _abi.ptr(self.ph), st))
         _abi.check(l.lhvi_pbp_boundary_pack(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(self.ph), self.nb, _abi.ptr(self.bvars),
                                             _abi.ptr(self.send), st))
-        return self.send[:self.plan.n_rows]
+        return self.send[:self.n_elems]
 
     def exchange(self, send):
         import torch.distributed as td
-        recv = self.recv[:self.plan.n_rows]     # symmetric: the rows shared with rank s are sent to and received from s
-        splits = [c * self.W for c in self.counts]
+        recv = self.recv[:self.n_elems]         # symmetric: the rows shared with rank s are sent to and received from s
+        splits = list(self.counts)
         if td.get_backend() == 'nccl':
             td.all_to_all_single(recv.view(-1), send.reshape(-1), output_split_sizes=splits, input_split_sizes=splits)
         else:

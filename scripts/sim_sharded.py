@@ -17,7 +17,7 @@ for r in runners:
     r.init()
 torch.cuda.synchronize()
 nb = [r.nb for r in runners]
-sent = [r.plan.n_rows * r.W * 8 / 1e6 for r in runners]
+sent = [r.n_elems * 8 / 1e6 for r in runners]
 print('boundary vars per rank', nb[:3], '... send MB per rank', ['%.0f' % s for s in sent[:3]], 'per peer MB %.0f' % (sent[0] / max(world - 1, 1)))
 for it in range(3):
     tp, tq = [], []
