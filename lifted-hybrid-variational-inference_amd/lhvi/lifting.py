@@ -136,6 +136,32 @@ def initial_colors(g, is_split_cont_evidence=True):
     return rv_color, f_color
 
 
+def initial_colors_flat(flat, is_split_cont_evidence=True):
+    """``initial_colors`` for a ``FlatGraph`` without rv / factor objects (``ground_flat``, ``build_flat``), vectorised:
+    variables by (domain id, hidden) / (domain id, evidence value), factors by their row of the potential table -- plus the
+    per-factor ``symmetric`` flags ``refine_flat`` wants.  ``flat.potentials`` (kept by ``ground_flat``) supplies
+    ``symmetric`` and the potentials' own ``__eq__`` where they define one; otherwise table rows are distinct potentials."""
+    hidden = flat.var_hidden
+    dom = flat.var_dom.astype(np.int64)
+    val = np.where(hidden, 0.0, flat.var_value)
+    if not is_split_cont_evidence:
+        val = np.where(flat.var_cont, 0.0, val)
+    keys = np.stack([dom.astype(np.float64), (~hidden).astype(np.float64), val], axis=1)
+    _, first, inv = np.unique(keys, axis=0, return_index=True, return_inverse=True)
+    order = np.argsort(np.argsort(first))                  # colours numbered in order of first appearance, like the dict
+    rv_color = order[inv.ravel()].astype(np.int32)
+    pots = list(getattr(flat, 'potentials', []) or [])
+    row_color = np.arange(int(flat.pot_kind.size), dtype=np.int32)
+    sym_row = np.zeros(int(flat.pot_kind.size), dtype=np.uint8)
+    if len(pots) == flat.pot_kind.size:
+        table = {}
+        for i, p in enumerate(pots):
+            row_color[i] = table.setdefault(p, len(table))
+            sym_row[i] = 1 if getattr(p, 'symmetric', False) else 0
+    f_color = row_color[flat.fac_pot].astype(np.int32)
+    return rv_color, f_color, sym_row[flat.fac_pot]
+
+
 def split_evidence_colors(values, rv_color, k=2, iteration=10, epsilon=0.0, use_sqrt=True):
     """``SuperRV.split_by_evidence`` (``CompressedGraphWithObs.py:78-130``) applied to every evidence cluster whose
     spread exceeds ``epsilon`` -- ``sqrt(variance) > epsilon`` in ``CompressedGraph.split_evidence`` (CGWO:236-247),
