@@ -16,6 +16,7 @@
 //                        update rule, Gaussian product.
 #include "common.hpp"
 #include "potential.hpp"
+#include "fastmath.hpp"
 
 namespace lhvi {
 
@@ -240,97 +241,6 @@ __device__ double f2v_point_generic(const lhvi_graph_t& g, const lhvi_pots_t& po
         if (a < 0) break;
     }
     return res > 0.0 ? log(res) : -700.0;
-}
-
-// exp for the f2v inner loop (argument = log phi + log message).  Table-driven: t = n * (ln2/2048) + r with
-// |r| <= ln2/4096, exp(t) = 2^(n >> 11) * 2^((n & 2047)/2048) * exp(r).  The 2048-entry table of correctly rounded
-// 2^(j/2048) (16 KB) lives in LDS, exp(r) is the cubic Taylor polynomial (remainder r^4/24 < 4e-17), and the rounding to
-// the nearest multiple uses the 1.5*2^52 magic constant so that the integer n sits in the low word of the same register.
-// 12 fp64 operations per call against 22 for the ocml routine; measured max error 2 ulp
-// (tests/test_gpu_pbp.py::test_device_exp_accuracy).  Valid for |t| < 2^31 * ln2/2048 ~ 7e5; anything below -745
-// underflows to 0 through ldexp, overflow saturates to +inf.
-#include "exp_table.inc"
-constexpr int EXP_TAB_N = 1 << LHVI_EXP_TABLE_BITS;
-
-__device__ __forceinline__ double exp_core(double t, const double* __restrict__ tab /* LDS copy of EXP_TAB */) {
-    const double MAGIC = LHVI_SCONST(6755399441055744.0);   // 1.5 * 2^52
-    const double u = fma(t, LHVI_SCONST(LHVI_EXP_INV_STEP), MAGIC);
-    const int nn = __double2loint(u);
-    const double kd = u - MAGIC;
-    double r = fma(kd, LHVI_SCONST(-LHVI_EXP_STEP_HI), t);
-    r = fma(kd, LHVI_SCONST(-LHVI_EXP_STEP_LO), r);
-    double p = fma(r, LHVI_SCONST(1.6666666666666666667e-1), 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(tab[nn & (EXP_TAB_N - 1)] * p, nn >> LHVI_EXP_TABLE_BITS);
-}
-
-__device__ __forceinline__ void load_exp_table(double* __restrict__ tab) {
-    for (int i = threadIdx.x; i < EXP_TAB_N; i += blockDim.x) tab[i] = EXP_TAB[i];
-    __syncthreads();
-}
-
-// Accumulating form for sums  acc += exp(t + C)  where C does not change along the sum (the f2v term loop: C is the
-// output point's own constant).  C is split once into whole table steps kC and a remainder Cr, |Cr| <= step/2; kC rides
-// in the rounding constant (magic = 1.5*2^52 + kC, exact), so the low word of u is already kC + round(t/step) and the
-// per-term `+ C` disappears; exp(Cr) multiplies the finished sum.  The scaling by 2^(n >> 11) is applied to the table
-// entry, which lets the product and the accumulation share one fma: 10 fp64 + 3 integer operations per term.
-struct ExpShift { double magic, scale; };
-
-__device__ __forceinline__ ExpShift exp_shift(double C) {
-    const double MAGIC = 6755399441055744.0;
-    ExpShift o;
-    o.magic = fma(C, LHVI_EXP_INV_STEP, MAGIC);
-    const double kd = o.magic - MAGIC;
-    double r = fma(kd, -LHVI_EXP_STEP_HI, C);
-    r = fma(kd, -LHVI_EXP_STEP_LO, r);
-    double p = fma(r, 1.6666666666666666667e-1, 0.5);
-    p = fma(p, r, 1.0);
-    o.scale = fma(p, r, 1.0);
-    return o;
-}
-
-__device__ __forceinline__ double exp_accumulate(double acc, double t, double magic, const double* __restrict__ tab) {
-    // u = t / step + magic in the three-address form: `magic` stays live for the whole loop, and the compiler's choice
-    // (v_fmac on a copy of it) costs a 64-bit move per term
-    double u;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(u) : "v"(t), "s"((double)LHVI_EXP_INV_STEP), "v"(magic));
-    const int nn = __double2loint(u);
-    const double kd = u - magic;
-    // one-constant reduction: RN(step) is off by 2^-55 relative, i.e. |t| * 3e-17 in r -- below the rounding of t itself
-    // (t = a + b x carries |t| * 1.1e-16), so the second Cody-Waite step of exp_core would buy nothing here
-    const double r = fma(kd, -LHVI_EXP_STEP_HI, t);
-    double p = fma(r, 1.6666666666666666667e-1, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return fma(ldexp(tab[nn & (EXP_TAB_N - 1)], nn >> LHVI_EXP_TABLE_BITS), p, acc);
-}
-
-// log(x), x > 0 (denormals and +inf included), for the one-log-per-output-point epilogues: x = m 2^e, m in [0.5, 1) cut
-// into 128 slices with midpoints c_i; table (1/c_i, ln c_i) in LDS; r = m / c_i - 1, |r| <= 2^-8, log1p(r) to degree 7.
-// ~20 VALU operations and one 16-byte LDS gather against ~95 operations for the ocml routine.  Absolute error
-// < 2.5e-16 for |log x| < 1 and <= 2 ulp beyond (tests/test_gpu_pbp.py::test_device_log_accuracy); the cancellation
-// next to x = 1 is not compensated -- log-messages are used additively.
-constexpr int LOG_TAB_N = 1 << LHVI_LOG_TABLE_BITS;
-struct LogRec { double inv_c, log_c; };
-
-__device__ __forceinline__ void load_log_table(LogRec* __restrict__ tab) {       // caller synchronises the block
-    for (int i = threadIdx.x; i < LOG_TAB_N; i += blockDim.x) { tab[i].inv_c = LOG_TAB[2 * i]; tab[i].log_c = LOG_TAB[2 * i + 1]; }
-}
-
-__device__ __forceinline__ double log_table(double x, const LogRec* __restrict__ tab) {
-    const int e = __builtin_amdgcn_frexp_exp(x);
-    const double m = __builtin_amdgcn_frexp_mant(x);
-    const LogRec c = tab[(__double2hiint(m) >> (20 - LHVI_LOG_TABLE_BITS)) & (LOG_TAB_N - 1)];
-    const double r = fma(m, c.inv_c, -1.0);
-    double q = fma(r, LHVI_SCONST(1.0 / 7.0), LHVI_SCONST(-1.0 / 6.0));
-    q = fma(q, r, LHVI_SCONST(1.0 / 5.0));
-    q = fma(q, r, -0.25);
-    q = fma(q, r, LHVI_SCONST(1.0 / 3.0));
-    q = fma(q, r, -0.5);
-    const double l = fma(r * r, q, r);
-    const double y = fma((double)e, LHVI_SCONST(LHVI_LN2), c.log_c + l);
-    return x == __builtin_huge_val() ? x : y;
 }
 
 // Edge classes of the f -> v half sweep.  FAST edges have a term of the form

@@ -12,6 +12,7 @@
 // fp64-VALU bound and tiny after lifting.
 #include "common.hpp"
 #include "potential.hpp"
+#include "fastmath.hpp"
 
 namespace lhvi {
 
@@ -197,10 +198,14 @@ __device__ __forceinline__ double pot_log_cc(int kind, const double* __restrict_
     return -par[0] * x0 * x1 * 0.5 / par[1];   // XY
 }
 
-__global__ void __launch_bounds__(BLOCK) vi_factor_cc_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
-                                                            double* __restrict__ pe_c, double* __restrict__ pe_d) {
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= (int64_t)g.F * p.K) return;
+__device__ __forceinline__ double norm_pdf_var_fast(double x, double mu, double var, const double* __restrict__ tab) {
+    const double u = x - mu;
+    return exp_core(-u * u * 0.5 / var, tab) / (2.506628274631 * var);
+}
+
+__device__ __forceinline__ void vi_factor_cc(const lhvi_graph_t& g, const lhvi_pots_t& pots, const lhvi_vi_t& p, double* __restrict__ ef,
+                                             double* __restrict__ pe_c, double* __restrict__ pe_d, int64_t i,
+                                             const double* __restrict__ sh_tab, const LogRec* __restrict__ sh_log) {
     const int f = (int)(i / p.K), k = (int)(i % p.K);
     if (!vi_is_cc(g, pots, f)) return;
     const int base = g.fac_ptr[f];
@@ -221,15 +226,15 @@ __global__ void __launch_bounds__(BLOCK) vi_factor_cc_kernel(lhvi_graph_t g, lhv
         for (int t1 = 0; t1 < n1; ++t1) {
             const double x1 = h1 ? s1 * p.gh_x[t1] + mu1 : val1, w1 = h1 ? p.gh_w[t1] : 1.0;
             const double w = 1.0 * w0 * w1;
-            const double phi = exp(pot_log_cc(kind, par, x0, x1));
+            const double phi = exp_core(pot_log_cc(kind, par, x0, x1), sh_tab);
             double b = 0.0;                                   // rvs_belief: the mixture at (x0, x1), evidence agrees by construction
             for (int kk = 0; kk < p.K; ++kk) {
                 double t = p.w[kk];
-                if (h0) { const double* e = p.eta_c + ((int64_t)v0 * p.K + kk) * 2; t *= norm_pdf_var(x0, e[0], e[1]); }
-                if (h1) { const double* e = p.eta_c + ((int64_t)v1 * p.K + kk) * 2; t *= norm_pdf_var(x1, e[0], e[1]); }
+                if (h0) { const double* e = p.eta_c + ((int64_t)v0 * p.K + kk) * 2; t *= norm_pdf_var_fast(x0, e[0], e[1], sh_tab); }
+                if (h1) { const double* e = p.eta_c + ((int64_t)v1 * p.K + kk) * 2; t *= norm_pdf_var_fast(x1, e[0], e[1], sh_tab); }
                 b += t;
             }
-            const double F = log(phi + 1e-100) - log(b + 1e-100);
+            const double F = log_table(phi + 1e-100, sh_log) - log_table(b + 1e-100, sh_log);
             E += w * F;
             if (h0) { Em0 += w * (F * (x0 - mu0)); Ev0 += w * (F * ((x0 - mu0) * (x0 - mu0) - var0)); }
             if (h1) { Em1 += w * (F * (x1 - mu1)); Ev1 += w * (F * ((x1 - mu1) * (x1 - mu1) - var1)); }
@@ -246,6 +251,19 @@ __global__ void __launch_bounds__(BLOCK) vi_factor_cc_kernel(lhvi_graph_t g, lhv
         pe_d[((int64_t)(base + 1) * p.K + k) * p.Dmax + d] = 0.0;
     }
 }
+
+__global__ void __launch_bounds__(BLOCK) vi_factor_cc_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
+                                                            double* __restrict__ pe_c, double* __restrict__ pe_d) {
+    // grid-stride over (factor, k): the exp / log tables are copied into LDS once per block; the ~9 transcendental
+    // evaluations per quadrature node then cost ~12 and ~20 instructions instead of ocml's ~25 and ~95
+    __shared__ double sh_tab[EXP_TAB_N];
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    load_log_table(sh_log);
+    load_exp_table(sh_tab);
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < (int64_t)g.F * p.K; i += (int64_t)gridDim.x * BLOCK)
+        vi_factor_cc(g, pots, p, ef, pe_c, pe_d, i, sh_tab, sh_log);
+}
+
 
 __global__ void __launch_bounds__(BLOCK) vi_factor_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
                                                          double* __restrict__ pe_c, double* __restrict__ pe_d) {
@@ -536,7 +554,10 @@ int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t
     if (g->V > 0)
         hipLaunchKernelGGL(vi_var_kernel, dim3(grid_for((int64_t)g->V * p->K)), dim3(BLOCK), 0, st, *g, *p, rvterm, g_c, g_d);
     if (g->F > 0) {
-        hipLaunchKernelGGL(vi_factor_cc_kernel, dim3(grid_for((int64_t)g->F * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d);
+        {
+            const int64_t want = ((int64_t)g->F * p->K + BLOCK - 1) / BLOCK;
+            hipLaunchKernelGGL(vi_factor_cc_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d);
+        }
         hipLaunchKernelGGL(vi_factor_kernel, dim3(grid_for((int64_t)g->F * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d);
     }
     if (g->V > 0)
