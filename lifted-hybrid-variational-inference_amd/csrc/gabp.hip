@@ -8,7 +8,6 @@
 // Floating point: contraction is disabled in this file so a*b+c is rounded twice like CPython does;
 // sums run in rv.nb order.  That makes the ground sweep bit-identical to the reference on the fixtures.
 #include "common.hpp"
-#include <hip/hip_cooperative_groups.h>
 
 #pragma clang fp contract(off)
 
@@ -28,8 +27,10 @@ __global__ void __launch_bounds__(BLOCK) gabp_init_kernel(int64_t n2, double* __
 // leave-one-out sum is quadratic in the degree.
 constexpr int GABP_HUB_DEGREE = 512;
 
-template <bool SKIP_HUBS>
-__device__ __forceinline__ void gabp_v2f_slot(const lhvi_graph_t& g, const double* f2v, double* v2f, int k) {
+__global__ void __launch_bounds__(BLOCK) gabp_v2f_kernel(lhvi_graph_t g, const double* __restrict__ f2v,
+                                                        double* __restrict__ v2f) {
+    int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= g.nnz) return;
     const int e = g.var_edge[k];
     const int v = g.slot_var ? g.slot_var[k] : g.edge_var[e];      // contiguous copy instead of a gather through e
     if (!is_hidden(g.var_value[v])) {          // observed rv sends nothing (returns None)
@@ -37,7 +38,7 @@ __device__ __forceinline__ void gabp_v2f_slot(const lhvi_graph_t& g, const doubl
         return;
     }
     const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
-    if (SKIP_HUBS && g.hub_vars && hi - lo > GABP_HUB_DEGREE) return;   // hubs: gabp_v2f_hub_kernel (the direct sum is O(deg^2))
+    if (g.hub_vars && hi - lo > GABP_HUB_DEGREE) return;   // hubs: gabp_v2f_hub_kernel (the direct sum is O(deg^2))
     double H = 0.0, P = 0.0;
     for (int j = lo; j < hi; ++j) {
         const int ej = g.var_edge[j];
@@ -60,12 +61,6 @@ __device__ __forceinline__ void gabp_v2f_slot(const lhvi_graph_t& g, const doubl
     }
     const double var = 1.0 / P;
     st2(v2f, e, var * H, var);
-}
-
-__global__ void __launch_bounds__(BLOCK) gabp_v2f_kernel(lhvi_graph_t g, const double* __restrict__ f2v,
-                                                        double* __restrict__ v2f) {
-    const int k = blockIdx.x * BLOCK + threadIdx.x;
-    if (k < g.nnz) gabp_v2f_slot<true>(g, f2v, v2f, k);
 }
 
 // Variables with more than GABP_HUB_DEGREE incident factors (the template variables of a relational model): one wavefront
@@ -157,7 +152,10 @@ __device__ __forceinline__ double2 f2v_closed_form(int kind, const double* __res
 
 // One thread per edge (factor-major, so a factor's two edges are adjacent lanes and the partner's
 // message is a neighbouring 16-byte load).
-__device__ __forceinline__ void gabp_f2v_edge(const lhvi_graph_t& g, const lhvi_pots_t& pots, const double* v2f, double* f2v, int e) {
+__global__ void __launch_bounds__(BLOCK) gabp_f2v_kernel(lhvi_graph_t g, lhvi_pots_t pots,
+                                                        const double* __restrict__ v2f, double* __restrict__ f2v) {
+    int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= g.E) return;
     if (canon(g.edge_canon, e) != e) return;     // alias of a repeated cluster: the canonical edge owns the message
     // message to an observed rv is never produced (GaBP.py:39-40); edge_value = the variable's value, per edge
     if (!is_hidden(g.edge_value ? g.edge_value[e] : g.var_value[g.edge_var[e]])) return;
@@ -181,31 +179,6 @@ __device__ __forceinline__ void gabp_f2v_edge(const lhvi_graph_t& g, const lhvi_
     }
     const double2 out = f2v_closed_form(kind, par, arity, pos, partner_hidden, u, s, y);
     st2(f2v, e, out.x, out.y);
-}
-
-__global__ void __launch_bounds__(BLOCK) gabp_f2v_kernel(lhvi_graph_t g, lhvi_pots_t pots,
-                                                        const double* __restrict__ v2f, double* __restrict__ f2v) {
-    const int e = blockIdx.x * BLOCK + threadIdx.x;
-    if (e < g.E) gabp_f2v_edge(g, pots, v2f, f2v, e);
-}
-
-// All sweeps of GaBP.run in ONE cooperative launch (small graphs are launch-bound: 20 sweeps of a 20 k-edge graph are 40
-// launches of ~5 us of work each).  Grid-wide barriers separate the half sweeps; every thread reaches every barrier.
-// Same per-slot / per-edge code as the two kernels above, direct sums for every variable -> identical bits.
-__global__ void __launch_bounds__(BLOCK) gabp_run_coop_kernel(lhvi_graph_t g, lhvi_pots_t pots, double* f2v, double* v2f,
-                                                             int iterations) {
-    cooperative_groups::grid_group grid = cooperative_groups::this_grid();
-    const int64_t tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x, nthreads = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = tid; i < g.E; i += nthreads) { st2(f2v, i, 0.0, 1.0); st2(v2f, i, 0.0, 1.0); }
-    grid.sync();
-    for (int it = 0; it < iterations; ++it) {
-        for (int64_t k = tid; k < g.nnz; k += nthreads) gabp_v2f_slot<false>(g, f2v, v2f, (int)k);
-        grid.sync();
-        if (it < iterations - 1) {
-            for (int64_t e = tid; e < g.E; e += nthreads) gabp_f2v_edge(g, pots, v2f, f2v, (int)e);
-            grid.sync();
-        }
-    }
 }
 
 // Per-variable product of all incoming messages (GaBP.py:187-200, GaLBP.py:201-217).
@@ -295,41 +268,8 @@ int lhvi_gabp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const double* 
     return check_launch();
 }
 
-// graphs up to this many CSR slots run all their sweeps in one cooperative launch (beyond, a sweep is long enough for the
-// launches not to matter, and hubs want their own kernel)
-static const int64_t GABP_COOP_MAX_SLOTS = 1 << 20;
-
-static bool gabp_run_cooperative(const lhvi_graph_t* g, const lhvi_pots_t* pots, double* f2v, double* v2f, int iterations,
-                                 hipStream_t st) {
-    static int max_blocks = -1;
-    if (max_blocks < 0) {
-        int dev = 0, coop = 0, per_cu = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess ||
-            !coop || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gabp_run_coop_kernel, BLOCK, 0) != hipSuccess || per_cu < 1)
-            max_blocks = 0;
-        else
-            max_blocks = per_cu * prop.multiProcessorCount;
-    }
-    if (max_blocks == 0) return false;
-    const int64_t work = g->nnz > g->E ? g->nnz : g->E;
-    int64_t blocks = (work + BLOCK - 1) / BLOCK;
-    if (blocks > max_blocks) blocks = max_blocks;
-    if (blocks < 1) blocks = 1;
-    lhvi_graph_t gg = *g;
-    lhvi_pots_t pp = *pots;
-    void* args[] = {&gg, &pp, &f2v, &v2f, &iterations};
-    return hipLaunchCooperativeKernel((const void*)gabp_run_coop_kernel, dim3((unsigned)blocks), dim3(BLOCK), args, 0, st) == hipSuccess;
-}
-
 int lhvi_gabp_run(const lhvi_graph_t* g, const lhvi_pots_t* pots, double* f2v, double* v2f, int iterations, void* stream) {
     if (iterations < 0) return LHVI_E_ARG;
-    if (int rc = validate(g)) return rc;
-    if (g->E > 0 && g->nnz <= GABP_COOP_MAX_SLOTS && f2v && v2f && pots && (g->F == 0 || (pots->kind && pots->off))) {
-        if (gabp_run_cooperative(g, pots, f2v, v2f, iterations, as_stream(stream))) return check_launch();
-        (void)hipGetLastError();            // cooperative launch unavailable: fall through to one launch per half sweep
-    }
     if (int rc = lhvi_gabp_init(g, f2v, v2f, stream)) return rc;
     for (int i = 0; i < iterations; ++i) {
         if (int rc = lhvi_gabp_v2f(g, f2v, v2f, stream)) return rc;
