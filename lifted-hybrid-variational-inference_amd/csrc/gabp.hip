@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(BLOCK) gabp_init_kernel(int64_t n2, double* __
 // with up to GABP_HUB_DEGREE incident factors and only switches to wave-parallel sums beyond, where the direct
 // leave-one-out sum is quadratic in the degree.
 constexpr int GABP_HUB_DEGREE = 512;
+constexpr int GABP_BATCH = 4;            // messages in flight per thread while it walks a variable's row
 
 __global__ void __launch_bounds__(BLOCK) gabp_v2f_kernel(lhvi_graph_t g, const double* __restrict__ f2v,
                                                         double* __restrict__ v2f) {
@@ -40,23 +41,38 @@ __global__ void __launch_bounds__(BLOCK) gabp_v2f_kernel(lhvi_graph_t g, const d
     const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
     if (g.hub_vars && hi - lo > GABP_HUB_DEGREE) return;   // hubs: gabp_v2f_hub_kernel (the direct sum is O(deg^2))
     double H = 0.0, P = 0.0;
-    for (int j = lo; j < hi; ++j) {
-        const int ej = g.var_edge[j];
-        double c;
-        if (g.edge_count) {                     // lifted: own factor enters count-1 times
-            c = g.edge_count[ej];
-            if (j == k) c -= 1.0;
-        } else {
-            if (j == k) continue;               // ground: own factor skipped
-            c = 1.0;
+    // GABP_BATCH messages are fetched before any of them is used (the loads are independent, the sums are not: they stay in
+    // rv.nb order); a long row is a chain of L2 round trips otherwise
+    for (int j0 = lo; j0 < hi; j0 += GABP_BATCH) {
+        int ej[GABP_BATCH];
+        double2 mm[GABP_BATCH];
+        double cc[GABP_BATCH];
+#pragma unroll
+        for (int i = 0; i < GABP_BATCH; ++i) {
+            const int j = j0 + i < hi ? j0 + i : hi - 1;
+            ej[i] = g.var_edge[j];
         }
-        const double2 m = ld2(f2v, ej);
-        if (m.y != m.y) {                       // var is None: linear term only
-            H -= g.edge_count ? m.x * c : m.x;
-        } else {
-            const double p = 1.0 / m.y;
-            if (g.edge_count) { H += p * m.x * c; P += p * c; }
-            else              { H += p * m.x;     P += p; }
+#pragma unroll
+        for (int i = 0; i < GABP_BATCH; ++i) {
+            mm[i] = ld2(f2v, ej[i]);
+            cc[i] = g.edge_count ? g.edge_count[ej[i]] : 1.0;
+        }
+#pragma unroll
+        for (int i = 0; i < GABP_BATCH; ++i) {
+            const int j = j0 + i;
+            if (j >= hi) break;
+            double c = cc[i];
+            if (g.edge_count) {                 // lifted: own factor enters count-1 times
+                if (j == k) c -= 1.0;
+            } else if (j == k) continue;        // ground: own factor skipped
+            const double2 m = mm[i];
+            if (m.y != m.y) {                   // var is None: linear term only
+                H -= g.edge_count ? m.x * c : m.x;
+            } else {
+                const double p = 1.0 / m.y;
+                if (g.edge_count) { H += p * m.x * c; P += p * c; }
+                else              { H += p * m.x;     P += p; }
+            }
         }
     }
     const double var = 1.0 / P;
