@@ -169,7 +169,8 @@ def main():
         FLOP_PER_TERM = 16.0
         f2v_tflops = terms * FLOP_PER_TERM / (f2v_ms * 1e-3) / 1e12
         out = {
-            'metric': 'lbp_sweeps_per_sec_10M_edge_hybrid_mrf', 'value': sweeps_per_s, 'unit': 'sweeps/s',
+            'metric': 'lbp_sweeps_per_sec_10M_edge_hybrid_mrf' if args.edges == 10_000_000
+                      else 'lbp_sweeps_per_sec_%d_edge_hybrid_mrf' % args.edges, 'value': sweeps_per_s, 'unit': 'sweeps/s',
             'edge_messages_per_sec': 2.0 * E_total * sweeps_per_s,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
