@@ -271,11 +271,13 @@ class _ParticleSweep:
     def belief_rv_all(self, x):
         """log-beliefs ``belief_rv`` (EPBP:196-202) of EVERY variable at ``x[v, :]`` (n points per variable; a device
         tensor or array of shape (V, n)): one f2v launch with the query points in the place of the target particles
-        tabulates all messages, one pass adds them up per variable.  Ground graphs (a lifted query walks the ground
-        variable's factors, HLBP:313-317).  Returns a (V, n) device tensor; rows of observed variables are 0."""
+        tabulates all messages, one pass adds them up per variable (count-weighted on a lifted graph with a stable
+        partition: rows are clusters then).  Returns a (V, n) device tensor; rows of observed variables are 0."""
         torch = _abi.require_gpu()
-        if self.flat.lifted:
-            raise NotImplementedError('batched queries are defined on a ground graph')
+        if self.flat.lifted and not getattr(self, '_stable_partition', False):
+            # a lifted query walks the GROUND variable's factors (HLBP:313-317); that equals the count-weighted sum over
+            # the cluster's edges only when the partition is stable (run with c2f = -1)
+            raise NotImplementedError('batched queries on a lifted graph need a stable partition (run(c2f=-1))')
         l, st = _abi.lib(), _abi.stream_ptr()
         xq = x if torch.is_tensor(x) else _abi.to_dev(np.ascontiguousarray(x, dtype=np.float64))
         assert tuple(xq.shape) == (self.flat.V, self.n) and xq.is_contiguous()
@@ -439,6 +441,7 @@ class HybridLBP(_ParticleSweep):
         k-means while their variance exceeds a shrinking threshold, rv / factor clusters are refined once per sweep and
         every new cluster inherits the messages, sites, proposal and particles of the cluster it came from."""
         self.query_cache = dict()
+        self._stable_partition = False
         if c2f == -1:
             self.g.init_cluster(True)
             prev = -1
@@ -449,6 +452,7 @@ class HybridLBP(_ParticleSweep):
             self._setup(self.g)
             self._run_sweeps(iteration)
             self.g.split_factors()                          # HLBP:536 (a no-op on a stable partition)
+            self._stable_partition = True
             return
         from . import c2f as _c2f
         engine = _DeviceEngine(self)

@@ -120,6 +120,16 @@ def test_hlbp_matches_reference_golden(api, golden_dir, name):
     for i in hid[:6]:
         assert bp.map(rvs[i]) == pytest.approx(z['map'][i], abs=1e-4)
         assert bp.belief(z['query_x'][i][2], rvs[i]) == pytest.approx(z['belief_mid'][i], rel=1e-5, abs=1e-7)
+    # batched queries on the lifted graph (stable partition): one row per cluster
+    flat = bp.flat
+    mp, mval = bp.map_all(steps=9 if meta['n'] < 32 else 6)
+    for i in hid:
+        c = flat.var_index[rvs[i].cluster]
+        if rvs[i].domain.continuous:
+            ref_val = bp.belief_rv_query(float(z["map"][i]), rvs[i])
+            assert mp[c] == pytest.approx(z['map'][i], abs=2e-4) or mval[c] >= ref_val - 1e-9
+        else:
+            assert mp[c] == z['map'][i]
 
 
 def test_epbp_host_sampler_reproduces_reference_stream(api, golden_dir):
