@@ -214,3 +214,49 @@ def test_two_process_sharded_sweep_matches_single_gpu(tmp_path):
         np.testing.assert_allclose(z['q'][h], q[z['gid']][h], rtol=1e-10, atol=1e-12)
         he = hid[flat.edge_var[z['edge_ids']]]
         np.testing.assert_allclose(z['f2v'][he], f2v[z['edge_ids']][he], rtol=1e-9, atol=1e-8)
+
+
+def _rccl_self_worker(port, out):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
+    import torch
+    import torch.distributed as td
+    from lhvi import synth, dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    td.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    flat = synth.hybrid_mrf_flat(V=600, deg=4, seed=8)
+    runner = dist.ShardedRunner(flat, n=64, seed=3, rank=0, world=1)
+    runner.init()
+    # the exchange call of a real run, on a fabricated row block addressed to this rank itself
+    k = 5 * (64 + 2)
+    runner.n_elems, runner.counts = k, [k]
+    runner.send = torch.arange(k, dtype=torch.float64, device='cuda')
+    runner.recv = torch.zeros(k, dtype=torch.float64, device='cuda')
+    got = runner.exchange(runner.send[:k])
+    td.barrier()
+    t = torch.tensor([1.5], dtype=torch.float64, device='cuda')
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(got, runner.send)) and float(t.item()) == 1.5
+    td.destroy_process_group()
+    with open(out, 'w') as f:
+        f.write('ok' if ok else 'mismatch')
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_call_path(tmp_path):
+    """the RCCL (backend 'nccl') calls of the multi-GPU run -- init with a device id, all_to_all_single with split lists on
+    fp64 device buffers, barrier, max all-reduce -- on the one GPU a test box has (world size 1, rank 0 <-> rank 0)"""
+    import torch.multiprocessing as mp
+    from lhvi import _abi
+    _abi.require_gpu()
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out = os.path.join(str(tmp_path), 'rccl.txt')
+    p = mp.get_context('spawn').Process(target=_rccl_self_worker, args=(port, out))
+    p.start()
+    p.join(timeout=300)
+    assert p.exitcode == 0
+    assert open(out).read() == 'ok'
