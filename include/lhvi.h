@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define LHVI_ABI_VERSION 2   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors */
+#define LHVI_ABI_VERSION 3   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
+                              * 3: lhvi_pbp_t gained var_lo / var_hi */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -172,6 +173,10 @@ typedef struct lhvi_pbp {
     const double* recv;         /* received rows of this sweep, packed like the send buffer */
     int32_t rank;               /* this rank (fixes the summation order of the proposals so that all replicas agree bit for bit) */
     const double* var_degree;   /* [V] global number of incoming messages (sum of counts over ALL ranks' edges) */
+    /* variable range of the per-variable entry points (lhvi_pbp_v2f, _proposal, _proposal_partial, _proposal_finish,
+     * _resample_uniq): they work on [var_lo, var_hi) when var_hi > var_lo, on every variable when both are 0.  A sharded
+     * run numbers its interior variables first and sweeps them while the boundary rows are in flight. */
+    int32_t var_lo, var_hi;
 } lhvi_pbp_t;
 
 #define LHVI_PBP_DESC_BYTES 128

@@ -28,6 +28,10 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 
+// variable range of the per-variable kernels: [var_lo, var_hi) when set, else every variable
+__host__ __device__ __forceinline__ int var_first(const lhvi_pbp_t& s) { return s.var_hi > s.var_lo ? s.var_lo : 0; }
+__host__ __device__ __forceinline__ int var_limit(const lhvi_graph_t& g, const lhvi_pbp_t& s) { return s.var_hi > s.var_lo ? s.var_hi : g.V; }
+
 // EPBP.norm_pdf (EPBPLogVersion.py:49-53): sig is a standard deviation
 __device__ __forceinline__ double norm_pdf_std(double x, double mu, double sig) {
     const double u = (x - mu) / sig;
@@ -95,8 +99,8 @@ constexpr int V2F_CACHE = 8;
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                        double* __restrict__ v2f) {
     const int lane = threadIdx.x & 63;
-    const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
-    if (v >= g.V) return;
+    const int v = __builtin_amdgcn_readfirstlane(var_first(s) + blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+    if (v >= var_limit(g, s)) return;
     if (!is_hidden(g.var_value[v])) return;
     const int n = s.n, S = s.n + s.T;
     const int np = s.np[v];
@@ -810,8 +814,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8
                                                             double* __restrict__ eta, double* __restrict__ q,
                                                             double* __restrict__ ph_out) {
     const int lane = threadIdx.x & 63;
-    const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
-    if (v >= g.V) return;
+    const int v = __builtin_amdgcn_readfirstlane(var_first(s) + blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+    if (v >= var_limit(g, s)) return;
     const int d = g.var_dom[v];
     if (!is_hidden(g.var_value[v]) || !g.dom_cont[d]) return;
     const int n = s.n, S = s.n + s.T;
@@ -873,8 +877,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8
 // q[v] from the local information-form sums plus the other ranks' (lhvi_pbp_proposal_finish)
 __global__ void __launch_bounds__(BLOCK) pbp_proposal_finish_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ ph,
                                                                    double* __restrict__ q) {
-    const int v = blockIdx.x * BLOCK + threadIdx.x;
-    if (v >= g.V) return;
+    const int v = var_first(s) + blockIdx.x * BLOCK + threadIdx.x;
+    if (v >= var_limit(g, s)) return;
     if (!is_hidden(g.var_value[v]) || !g.dom_cont[g.var_dom[v]]) return;
     double ps = ph[2 * v], pm = ph[2 * v + 1];
     if (s.bslot) {
@@ -1102,7 +1106,8 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
     const int n = s.n;
     const int nwaves = gridDim.x * (BLOCK / WAVE);
     // persistent waves (the table is loaded once per block, not once per four variables)
-    for (int v = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)); v < g.V; v += nwaves) {
+    const int vend = var_limit(g, s);
+    for (int v = __builtin_amdgcn_readfirstlane(var_first(s) + blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)); v < vend; v += nwaves) {
         const int cnt = s.np[v];
         const int d = g.var_dom[v];
         double x = 0.0;
@@ -1149,6 +1154,7 @@ static int validate_pbp(const lhvi_graph_t* g, const lhvi_pbp_t* s) {
     if (g->V < 0 || g->E < 0 || s->n <= 0 || s->T < 0) return LHVI_E_ARG;
     if (g->V > 0 && (!g->var_ptr || !g->var_edge || !g->var_value || !g->var_dom || !g->dom_cont || !g->dom_ptr ||
                      !s->particles || !s->np)) return LHVI_E_ARG;
+    if (s->var_hi > s->var_lo ? (s->var_lo < 0 || s->var_hi > g->V) : (s->var_lo != 0 || s->var_hi != 0)) return LHVI_E_ARG;
     return LHVI_OK;
 }
 
@@ -1213,7 +1219,8 @@ int lhvi_pbp_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, 
     if (int rc = validate_pbp(g, s)) return rc;
     if (!f2v || !v2f || !s->uniq || !s->q) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
-    hipLaunchKernelGGL(pbp_v2f_kernel, dim3(grid_for((int64_t)g->V * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, v2f);
+    hipLaunchKernelGGL(pbp_v2f_kernel, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0, as_stream(stream),
+                       *g, *s, f2v, v2f);
     return check_launch();
 }
 
@@ -1253,8 +1260,8 @@ int lhvi_pbp_proposal(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* 
     if (int rc = validate_pbp(g, s)) return rc;
     if (!f2v || !eta || !q) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
-    hipLaunchKernelGGL(pbp_proposal_kernel, dim3(grid_for((int64_t)g->V * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, eta, q,
-                       (double*)nullptr);
+    hipLaunchKernelGGL(pbp_proposal_kernel, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0,
+                       as_stream(stream), *g, *s, f2v, eta, q, (double*)nullptr);
     return check_launch();
 }
 
@@ -1262,8 +1269,8 @@ int lhvi_pbp_proposal_partial(const lhvi_graph_t* g, const lhvi_pbp_t* s, const 
     if (int rc = validate_pbp(g, s)) return rc;
     if (!f2v || !eta || !ph || !s->q) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
-    hipLaunchKernelGGL(pbp_proposal_kernel, dim3(grid_for((int64_t)g->V * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, eta,
-                       (double*)nullptr, ph);
+    hipLaunchKernelGGL(pbp_proposal_kernel, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0,
+                       as_stream(stream), *g, *s, f2v, eta, (double*)nullptr, ph);
     return check_launch();
 }
 
@@ -1271,7 +1278,8 @@ int lhvi_pbp_proposal_finish(const lhvi_graph_t* g, const lhvi_pbp_t* s, const d
     if (int rc = validate_pbp(g, s)) return rc;
     if (!ph || !q || (s->bslot && (!s->recv || !s->brow_ptr || !s->brow_off || !s->brow_peer))) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
-    hipLaunchKernelGGL(pbp_proposal_finish_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, as_stream(stream), *g, *s, ph, q);
+    hipLaunchKernelGGL(pbp_proposal_finish_kernel, dim3(grid_for(var_limit(*g, *s) - var_first(*s))), dim3(BLOCK), 0, as_stream(stream),
+                       *g, *s, ph, q);
     return check_launch();
 }
 
@@ -1325,11 +1333,12 @@ int lhvi_pbp_resample_uniq(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int
     if (int rc = validate_pbp(g, s)) return rc;
     if (!particles_out || !uniq_out || !s->q) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
-    if (s->n > WAVE) {            // general n: two passes
+    if (s->n > WAVE) {            // general n: two passes over every variable
+        if (s->var_hi > s->var_lo) return LHVI_E_ARG;
         if (int rc = lhvi_pbp_resample(g, s, var_gid, seed, iteration, particles_out, stream)) return rc;
         return lhvi_pbp_uniq(g, s->n, particles_out, s->np, uniq_out, stream);
     }
-    hipLaunchKernelGGL(pbp_resample_uniq_kernel, dim3(persistent_grid(g->V, 8)), dim3(BLOCK), 0,
+    hipLaunchKernelGGL(pbp_resample_uniq_kernel, dim3(persistent_grid(var_limit(*g, *s) - var_first(*s), 8)), dim3(BLOCK), 0,
                        as_stream(stream), *g, *s, var_gid, seed, iteration, particles_out, uniq_out);
     return check_launch();
 }

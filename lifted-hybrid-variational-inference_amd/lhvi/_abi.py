@@ -49,6 +49,7 @@ class PbpStruct(C.Structure):
         ('generic_pts_log2', C.c_int32), ('fast_desc', C.c_void_p), ('heavy_desc', C.c_void_p), ('n_heavy', C.c_int32), ('light_desc', C.c_void_p), ('n_light', C.c_int32),
         ('bslot', C.c_void_p), ('brow_ptr', C.c_void_p), ('brow_off', C.c_void_p), ('brow_peer', C.c_void_p),
         ('recv', C.c_void_p), ('rank', C.c_int32), ('var_degree', C.c_void_p),
+        ('var_lo', C.c_int32), ('var_hi', C.c_int32),
     ]
 
 
@@ -66,7 +67,7 @@ PBP_SKIP_GENERIC = 8
 PBP_SKIP_TERMS = 16
 PBP_SKIP_HEAVY = 32
 PBP_SKIP_LIGHT = 64
-ABI_VERSION = 2             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
+ABI_VERSION = 3             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
 PBP_DESC_BYTES = 128
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE
 

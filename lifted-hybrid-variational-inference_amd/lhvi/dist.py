@@ -97,7 +97,9 @@ class ShardPlan:
     * ``partition='bfs'`` (default): factors are ordered by the breadth-first position of their earliest scope variable and
       cut into ``world`` equal blocks (locality-aware); ``'block'``: equal blocks of the construction order;
     * the shard's factors (``fac_ids``, ascending global id) with all their edges (``edge_ids``) are local;
-    * local variables = the variables those factors touch, renumbered in ascending global id (``var_gid``);
+    * local variables = the variables those factors touch (``var_gid``): the ``n_interior`` interior ones first, then the
+      boundary ones, ascending global id inside each block; ``edge_boundary[e]`` = 1 when the edge's factor touches a
+      boundary variable;
     * ``var_degree`` = a variable's degree in the WHOLE graph (site clamp / initial site of the proposal);
     * a local hidden variable is a *boundary* variable when some of its edges live on another rank; ``bvars`` lists them
       (ascending gid) and ``peer_rows[s]`` = the entries of ``bvars`` shared with rank ``s`` (ascending gid on both sides,
@@ -128,19 +130,28 @@ class ShardPlan:
                          np.arange(int(local_ptr[-1]), dtype=np.int64))
         local_edge_var = flat.edge_var[self.edge_ids]
         gids = np.unique(local_edge_var)
+        degree = np.bincount(flat.edge_var, minlength=flat.V)
+        local_degree = np.bincount(local_edge_var, minlength=flat.V)
+        # boundary = hidden variable with edges on another rank (observed variables need no sums).  Local numbering: the
+        # interior variables first, then the boundary ones, ascending global id inside each block -- the per-variable
+        # kernels can then sweep [0, n_interior) while the boundary rows are in flight
+        is_b = (degree[gids] > local_degree[gids]) & np.isnan(flat.var_value[gids])
+        gids = gids[np.argsort(is_b, kind='stable')]
+        self.n_interior = int((~is_b).sum())
         self.var_gid = gids.astype(np.int64)
         lid = np.full(flat.V, -1, dtype=np.int64)
         lid[gids] = np.arange(gids.size)
-        degree = np.bincount(flat.edge_var, minlength=flat.V)
-        local_degree = np.bincount(local_edge_var, minlength=flat.V)
         self.var_degree = degree[gids].astype(np.float64)
         self.flat = build_flat(local_ptr.astype(np.int32), lid[local_edge_var].astype(np.int32),
                                flat.fac_pot[self.fac_ids], [], flat.var_value[gids], flat.var_dom[gids], flat.domains)
         # the potential table is global and small: keep it whole so fac_pot stays valid
         self.flat.pot_kind, self.flat.pot_off, self.flat.pot_param = flat.pot_kind, flat.pot_off, flat.pot_param
-        # boundary bookkeeping: which ranks own edges of each (hidden) variable; observed variables need no sums
-        is_b = (degree[gids] > local_degree[gids]) & np.isnan(flat.var_value[gids])
-        self.bvars = np.flatnonzero(is_b).astype(np.int32)               # local ids, ascending gid
+        # boundary bookkeeping: which ranks own edges of each boundary variable
+        is_b = np.arange(gids.size) >= self.n_interior
+        self.bvars = np.flatnonzero(is_b).astype(np.int32)               # local ids = [n_interior, V), ascending gid
+        # an edge is interior when its factor touches no boundary variable: its message needs nothing from the exchange
+        fac_b = np.maximum.reduceat(is_b[self.flat.edge_var].astype(np.int8), local_ptr[:-1]) if self.fac_ids.size else np.zeros(0, np.int8)
+        self.edge_boundary = np.repeat(fac_b, arity).astype(np.int32)
         self.bslot = np.full(gids.size, -1, dtype=np.int32)
         self.bslot[self.bvars] = np.arange(self.bvars.size, dtype=np.int32)
         bg = gids[self.bvars]
@@ -201,19 +212,22 @@ class LoopbackGroup:
 class ShardedRunner:
     """One rank's part of the edge-sharded particle sweep (EPBP semantics).
 
-    Per sweep: [local sites + information-form partials] -> pack every boundary variable's row straight into its slots of
-    the peer-ordered send buffer -> ONE all_to_all -> v2f and proposal finish read the received rows in place (no
-    unpack pass) -> resample (Philox keyed by global id, so replicas of a boundary variable draw identical particles
-    without communicating) -> f2v (local).
+    Per sweep: local sites + information-form partials of the BOUNDARY variables -> their rows packed straight into the
+    peer-ordered send buffer -> ONE all_to_all, started asynchronously -> while it is in flight, the whole sweep of the
+    interior part (partials, v2f, proposal, resample of the interior variables; f2v of the edges whose factor touches no
+    boundary variable) -> wait -> the boundary part: v2f and proposal finish read the received rows in place (no unpack
+    pass), resample (Philox keyed by global id, so replicas of a boundary variable draw identical particles without
+    communicating), f2v of the remaining edges.  The two parts are variable ranges ([0, n_interior) and [n_interior, V)
+    of the plan's numbering) and prefixes / suffixes of the f2v work lists, so no kernel needs an index list.
     """
 
-    def __init__(self, flat, n, seed, rank, world, proposal_approximation='simple', group=None):
+    def __init__(self, flat, n, seed, rank, world, proposal_approximation='simple', group=None, overlap=True):
         import torch
         from .pbp import EPBP
         self.plan = plan = ShardPlan(flat, rank, world)
         self.rank, self.world, self.group = rank, world, group
         bp = EPBP(None, n=n, proposal_approximation=proposal_approximation, sampler='device', seed=seed)
-        bp._setup(None, flat=plan.flat)
+        bp._setup(None, flat=plan.flat, edge_key=plan.edge_boundary)
         self.bp = bp
         dev = bp.dg.device
         bp.var_gid = _abi.to_dev(plan.var_gid)
@@ -222,6 +236,10 @@ class ShardedRunner:
         self.bvars = _abi.to_dev(plan.bvars)
         nb = int(plan.bvars.size)
         self.nb, self.W = nb, n + 2
+        self.n_int = int(plan.n_interior)
+        # two-part schedule: needs both parts non-empty and the fused resample kernel (n <= 64), which takes a range
+        self.overlap = bool(overlap) and world > 1 and nb > 0 and self.n_int > 0 and n <= 64
+        self.f2v_extra = []                 # event pairs around the second heavy-kernel launch of a sweep (bench)
         self.ph = torch.zeros(plan.flat.V, 2, dtype=torch.float64, device=dev)
         # exchange rows, packed back to back in peer-major order: n + 2 doubles for a continuous boundary variable, its
         # np states for a discrete one (nothing else of a discrete variable is exchanged)
@@ -241,11 +259,35 @@ class ShardedRunner:
         ends = np.cumsum([c for c in plan.counts])
         self.counts = [int(row_off[e] - row_off[e - c]) for e, c in zip(ends, plan.counts)]
 
-    def _struct(self):
+    def _struct(self, part=None):
+        """`part`: None = everything, 0 = interior variables, 1 = boundary variables (variable range only)"""
         s = self.bp._struct()
         s.bslot, s.var_degree = _abi.ptr(self.bslot), _abi.ptr(self.var_degree)
         s.brow_ptr, s.brow_off, s.brow_peer = _abi.ptr(self.brow_ptr), _abi.ptr(self.brow_off), _abi.ptr(self.brow_peer)
         s.recv, s.rank = _abi.ptr(self.recv), int(self.rank)
+        if part is not None:
+            s.var_lo, s.var_hi = (0, self.n_int) if part == 0 else (self.n_int, self.plan.flat.V)
+        return s
+
+    def _edge_part(self, s, part):
+        """restrict the f2v work lists of `s` to the interior prefix (part 0) or the boundary suffix (part 1)"""
+        bp, pc = self.bp, self.bp.part_counts
+
+        def cut(total, first):
+            return (0, first) if part == 0 else (first, total - first)
+        D = _abi.PBP_DESC_BYTES
+        off, cnt = cut(bp.n_heavy, pc['heavy'])
+        s.heavy_desc, s.n_heavy = (bp.heavy_desc.data_ptr() + off * D if cnt else None), cnt
+        off, cnt = cut(bp.n_light, pc['light'])
+        s.light_desc, s.n_light = (bp.light_desc.data_ptr() + off * D if cnt else None), cnt
+        off, cnt = cut(int(bp.fast_edges.numel()), pc['fast'])
+        if cnt:
+            s.fast_edges, s.fast_desc = bp.fast_edges.data_ptr() + 4 * off, bp.fast_desc.data_ptr() + off * D
+        s.n_fast = cnt                       # 0 with a non-null list pointer = nothing to do
+        off, cnt = cut(int(bp.generic_edges.numel()), pc['generic'])
+        if cnt:
+            s.generic_edges = bp.generic_edges.data_ptr() + 4 * off
+        s.n_generic = cnt
         return s
 
     def init(self):
@@ -255,40 +297,36 @@ class ShardedRunner:
         bp._generate_sample()
 
     # -- phase 1: everything that must precede the exchange -----------------------------------------
-    def pre(self):
+    def pre(self, part=None):
+        """site updates + information-form partials (of one part), boundary rows packed into the send buffer"""
         bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
-        s = self._struct()
+        s = self._struct(part)
         _abi.check(l.lhvi_pbp_proposal_partial(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.eta), _abi.ptr(self.ph), st))
-        _abi.check(l.lhvi_pbp_boundary_pack(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(self.ph), self.nb, _abi.ptr(self.bvars),
-                                            _abi.ptr(self.send), st))
+        if part != 0:
+            _abi.check(l.lhvi_pbp_boundary_pack(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(self.ph), self.nb, _abi.ptr(self.bvars),
+                                                _abi.ptr(self.send), st))
         return self.send[:self.n_elems]
 
-    def exchange(self, send):
+    def exchange(self, send, async_op=False):
+        """the one collective of a sweep; returns the receive buffer (and the work handle when `async_op`)"""
         import torch.distributed as td
         recv = self.recv[:self.n_elems]         # symmetric: the rows shared with rank s are sent to and received from s
         splits = list(self.counts)
+        work = None
         if td.get_backend() == 'nccl':
-            td.all_to_all_single(recv.view(-1), send.reshape(-1), output_split_sizes=splits, input_split_sizes=splits)
+            work = td.all_to_all_single(recv.view(-1), send.reshape(-1), output_split_sizes=splits, input_split_sizes=splits,
+                                        async_op=async_op)
         else:
             # rehearsal backend (gloo): same collective on host copies
             h_send = send.reshape(-1).cpu()
             h_recv = h_send.new_empty(h_send.shape)
             td.all_to_all_single(h_recv, h_send, output_split_sizes=splits, input_split_sizes=splits)
             recv.view(-1).copy_(h_recv)
-        return recv
+        return (recv, work) if async_op else recv
 
     # -- phase 2: the rest of the sweep, reading the peers' rows straight from the receive buffer ---------------------
-    def post(self, recv, f2v_events=None):
+    def _f2v(self, s, f2v_events=None):
         bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
-        # the kernels read the received rows in place (v2f: particle-part sums; proposal_finish: information-form sums in
-        # rank order, so every replica of a boundary variable forms bit-identical q and draws bit-identical particles)
-        if recv.data_ptr() != self.recv.data_ptr():
-            self.recv[:recv.shape[0]].copy_(recv)
-        s = self._struct()
-        _abi.check(l.lhvi_pbp_v2f(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.v2f), st))
-        _abi.check(l.lhvi_pbp_proposal_finish(bp.dg.g, s, _abi.ptr(self.ph), _abi.ptr(bp.q_dev), st))
-        bp._generate_sample()
-        s = self._struct()
         if f2v_events:          # the dominant kernel alone between the events, then the other two
             base = s.flags
             s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_LIGHT
@@ -299,13 +337,70 @@ class ShardedRunner:
             _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
             s.flags = base | _abi.PBP_SKIP_FAST
             _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
+            s.flags = base
         else:
             _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
 
+    def post(self, recv, f2v_events=None):
+        """plain schedule: everything after the exchange, over all variables and edges"""
+        bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
+        # the kernels read the received rows in place (v2f: particle-part sums; proposal_finish: information-form sums in
+        # rank order, so every replica of a boundary variable forms bit-identical q and draws bit-identical particles)
+        if recv.data_ptr() != self.recv.data_ptr():
+            self.recv[:recv.shape[0]].copy_(recv)
+        s = self._struct()
+        _abi.check(l.lhvi_pbp_v2f(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.v2f), st))
+        _abi.check(l.lhvi_pbp_proposal_finish(bp.dg.g, s, _abi.ptr(self.ph), _abi.ptr(bp.q_dev), st))
+        bp._generate_sample()
+        self._f2v(self._struct(), f2v_events)
+
+    def _var_part(self, part, swapped):
+        """v2f, proposal and new particles of one variable range.  `swapped`: the particle buffers were already exchanged
+        for this sweep (by the other part), so the sample v2f weighs is in `old_particles`"""
+        bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
+        s = self._struct(part)
+        if swapped:
+            s.particles = _abi.ptr(bp.old_particles)
+        _abi.check(l.lhvi_pbp_v2f(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.v2f), st))
+        _abi.check(l.lhvi_pbp_proposal_finish(bp.dg.g, s, _abi.ptr(self.ph), _abi.ptr(bp.q_dev), st))
+        if not swapped:
+            bp.old_particles, bp.particles = bp.particles, bp.old_particles
+            bp._draws += 1
+            bp._views = {}
+        s = self._struct(part)
+        _abi.check(l.lhvi_pbp_resample_uniq(bp.dg.g, s, _abi.ptr(bp.var_gid), int(bp.seed), int(bp._draws - 1),
+                                            _abi.ptr(bp.particles), _abi.ptr(bp.uniq), st))
+
+    def interior(self, f2v_events=None):
+        """the part of the sweep that needs nothing from the peers"""
+        self.pre(part=0)
+        self._var_part(0, swapped=False)
+        self._f2v(self._edge_part(self._struct(), 0), f2v_events)
+
+    def boundary(self, recv, f2v_events=None):
+        """the rest, once the peers' rows have arrived (after `interior`)"""
+        if recv.data_ptr() != self.recv.data_ptr():
+            self.recv[:recv.shape[0]].copy_(recv)
+        self._var_part(1, swapped=True)
+        self._f2v(self._edge_part(self._struct(), 1), f2v_events)
+
     def sweep(self, f2v_events=None):
-        send = self.pre()
-        recv = self.exchange(send) if self.world > 1 else send
-        self.post(recv, f2v_events)
+        if not self.overlap:
+            send = self.pre()
+            recv = self.exchange(send) if self.world > 1 else send
+            self.post(recv, f2v_events)
+            return
+        import torch
+        send = self.pre(part=1)                             # boundary rows first: the exchange starts as early as it can
+        recv, work = self.exchange(send, async_op=True)
+        extra = None
+        if f2v_events:
+            extra = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.f2v_extra.append(extra)
+        self.interior(extra)
+        if work is not None:
+            work.wait()                                     # the compute stream waits for the collective
+        self.boundary(recv, f2v_events)
 
     def local_edges(self):
         return self.plan.flat.E

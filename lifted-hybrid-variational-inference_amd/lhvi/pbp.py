@@ -32,7 +32,9 @@ class _ParticleSweep:
     verbose = False
 
     # ---- set-up ------------------------------------------------------------------------------
-    def _setup(self, graph_like, flat=None):
+    def _setup(self, graph_like, flat=None, edge_key=None):
+        """`edge_key` (sharded runs): 0 / 1 per edge; every f2v work list is ordered key-0 edges first and ``part_counts``
+        gives the length of that first part per list (heavy, light, fast, generic)"""
         flat = flat if flat is not None else flatten(graph_like, require_device_potentials=True)
         self.flat = flat
         self.dg = dg = _abi.DeviceGraph(flat)
@@ -64,6 +66,15 @@ class _ParticleSweep:
         cls = cls[:flat.E]
         self.fast_edges = torch.nonzero((cls == 1) | (cls == 2)).flatten().to(torch.int32)
         self.generic_edges = torch.nonzero(cls == 3).flatten().to(torch.int32)
+        key_dev = None
+        if edge_key is not None:
+            key_dev = _abi.to_dev(np.ascontiguousarray(edge_key, dtype=np.int32))
+            self.fast_edges = self.fast_edges[torch.sort(key_dev[self.fast_edges.long()], stable=True).indices].contiguous()
+            self.generic_edges = self.generic_edges[torch.sort(key_dev[self.generic_edges.long()], stable=True).indices].contiguous()
+
+        def first_part(edges):      # entries of an (ordered) edge list with key 0
+            return int((key_dev[edges.long()] == 0).sum().item()) if key_dev is not None and edges.numel() else 0
+        self.part_counts = {'heavy': 0, 'light': 0, 'fast': 0, 'generic': first_part(self.generic_edges)}
         pad = torch.zeros(1, dtype=torch.int32, device=dg.device)       # keeps the pointers non-null when a list is empty
         self._fast_list = self.fast_edges if self.fast_edges.numel() else pad
         self._generic_list = self.generic_edges if self.generic_edges.numel() else pad
@@ -94,8 +105,11 @@ class _ParticleSweep:
             self.n_light = int(self.light_desc.shape[0])
             rest = ~heavy & ~light
             self.fast_desc = rows[rest].contiguous()
-            self.fast_edges = self.fast_edges[rest].contiguous()
+            all_fast = self.fast_edges
+            self.fast_edges = all_fast[rest].contiguous()
             self._fast_list = self.fast_edges if self.fast_edges.numel() else pad
+            self.part_counts.update(heavy=first_part(all_fast[heavy]), light=first_part(all_fast[light]),
+                                    fast=first_part(self.fast_edges))
 
     def _struct(self):
         s = _abi.PbpStruct()
@@ -307,6 +321,83 @@ class _ParticleSweep:
             logb = self.belief_rv_all(x)
             _abi.check(l.lhvi_pbp_refine_grid(self.dg.g, s, _abi.ptr(logb), _abi.ptr(x), _abi.ptr(best), _abi.ptr(val), st))
         return best.cpu().numpy(), val.cpu().numpy()
+
+    def _per_var(self, a):
+        torch = _abi.require_gpu()
+        t = torch.as_tensor(np.broadcast_to(np.asarray(a, dtype=np.float64), (self.flat.V,)).copy()) if not torch.is_tensor(a) else a
+        return t.to(self.particles.device, torch.float64)
+
+    def log_area_all(self, a, b, npts=20, shift=None):
+        """``log_area`` (EPBP:291-308, HLBP:318-341) of every continuous hidden variable at once: trapezoid of
+        exp(belief_rv - shift) on linspace(a[v], b[v], npts), shift = ``log_message_balance`` of the tabulated values
+        unless given.  `a`, `b`: scalars or arrays / tensors of length V.  Returns device tensors
+        (area [V], shift [V]); rows of discrete and observed variables are NaN."""
+        torch = _abi.require_gpu()
+        if npts < 2:
+            raise ValueError('npts must be at least 2')
+        a, b = self._per_var(a), self._per_var(b)
+        n = self.n
+        x = torch.empty(self.flat.V, n, dtype=torch.float64, device=a.device)
+        _abi.check(_abi.lib().lhvi_pbp_domain_grid(self.dg.g, self._struct(), _abi.ptr(x), _abi.stream_ptr()))
+        cont = _abi.to_dev(self.flat.var_hidden & self.flat.var_cont)
+        step = (b - a) / (npts - 1)                                   # numpy.linspace: start + i * step, last point = stop
+        lin = torch.arange(npts, dtype=torch.float64, device=a.device)[None, :] * step[:, None] + a[:, None]
+        lin[:, npts - 1] = b
+        y = torch.empty_like(lin)
+        for c in range(0, npts, n):                                   # n query points per variable and pass
+            w = min(n, npts - c)
+            x[:, :w] = torch.where(cont[:, None], lin[:, c:c + w], x[:, :w])
+            y[:, c:c + w] = self.belief_rv_all(x)[:, :w]
+        if shift is None:
+            mean, mx = y.mean(dim=1), y.max(dim=1).values
+            shift = torch.where(mx - mean > self.max_log_value, mx - self.max_log_value, mean)
+        w = torch.exp(y - shift[:, None])
+        area = (w[:, :-1] + w[:, 1:]).sum(dim=1) * (lin[:, 1] - lin[:, 0]) * 0.5
+        nan = torch.full_like(area, float('nan'))
+        return torch.where(cont, area, nan), torch.where(cont, shift, nan)
+
+    def belief_all(self, x):
+        """normalised beliefs of EVERY variable (``HybridLBP.belief`` HLBP:343-382 for all of them at once; for EPBP the
+        same 20-point trapezoid normaliser in the place of ``scipy.integrate.quad``).  `x`: (V, m) query points, m <= n.
+        Continuous hidden rows: exp(belief_rv(x) - shift) / area over the domain; discrete hidden rows: the normalised
+        beliefs of the variable's states in columns [0, #states) (x is ignored there); observed rows: 1 where x equals
+        the value.  Returns a (V, m) device tensor."""
+        torch = _abi.require_gpu()
+        flat = self.flat
+        xq = x if torch.is_tensor(x) else _abi.to_dev(np.ascontiguousarray(x, dtype=np.float64))
+        xq = xq.reshape(flat.V, -1)
+        m = xq.shape[1]
+        if m > self.n:
+            raise ValueError('at most n query points per variable')
+        lo = np.where(flat.var_cont, flat.dom_lo[flat.var_dom], 0.0)
+        hi = np.where(flat.var_cont, flat.dom_hi[flat.var_dom], 1.0)
+        z, shift = self.log_area_all(lo, hi, 20)
+        grid = torch.empty(flat.V, self.n, dtype=torch.float64, device=xq.device)
+        _abi.check(_abi.lib().lhvi_pbp_domain_grid(self.dg.g, self._struct(), _abi.ptr(grid), _abi.stream_ptr()))
+        cont = _abi.to_dev(flat.var_hidden & flat.var_cont)
+        grid[:, :m] = torch.where(cont[:, None], xq, grid[:, :m])     # discrete rows keep their states
+        logb = self.belief_rv_all(grid)
+        out = torch.exp(logb[:, :m] - shift[:, None] - torch.log(z)[:, None])
+        disc = _abi.to_dev(flat.var_hidden & ~flat.var_cont)
+        if bool(disc.any()):
+            nst = _abi.to_dev(self.np_host.astype(np.int64))
+            live = torch.arange(self.n, device=xq.device)[None, :] < nst[:, None]
+            w = torch.where(live, torch.exp(logb), torch.zeros_like(logb))
+            w = w / w.sum(dim=1, keepdim=True)
+            out = torch.where(disc[:, None], w[:, :m], out)
+        obs = _abi.to_dev(~flat.var_hidden)
+        val = _abi.to_dev(np.nan_to_num(flat.var_value, nan=0.0))
+        return torch.where(obs[:, None], (xq == val[:, None]).to(torch.float64), out)
+
+    def probability_all(self, a, b):
+        """``probability(a, b, rv)`` (EPBP:356-375, HLBP:384-403) of every continuous hidden variable at once: 5-point
+        trapezoid on [a[v], b[v]] over the 20-point one on the domain.  Returns a device tensor [V] (NaN elsewhere)."""
+        flat = self.flat
+        lo = np.where(flat.var_cont, flat.dom_lo[flat.var_dom], 0.0)
+        hi = np.where(flat.var_cont, flat.dom_hi[flat.var_dom], 1.0)
+        z, shift = self.log_area_all(lo, hi, 20)
+        num, _ = self.log_area_all(a, b, 5, shift=shift)
+        return num / z
 
     def log_message_balance(self, message):
         """EPBP.log_message_balance (EPBP:204-215) on a host dict (used by log_area)"""

@@ -31,6 +31,19 @@ t0 = time.perf_counter()
 mp, mv = bp.map_all(steps=5)
 torch.cuda.synchronize()
 t_map = time.perf_counter() - t0
+# normalised beliefs at 8 points per variable (20-point trapezoid normaliser) and interval probabilities
+lo = flat.dom_lo[flat.var_dom]
+bp.probability_all(lo + 1.0, lo + 3.0); torch.cuda.synchronize()
+t0 = time.perf_counter()
+ball = bp.belief_all(x[:, :8].contiguous())
+torch.cuda.synchronize()
+t_bel = time.perf_counter() - t0
+t0 = time.perf_counter()
+pall = bp.probability_all(lo + 1.0, lo + 3.0)
+torch.cuda.synchronize()
+t_prob = time.perf_counter() - t0
+cont = torch.from_numpy(flat.var_hidden & flat.var_cont).to(pall.device)
+assert bool(torch.isfinite(pall[cont]).all()) and bool(((pall[cont] >= 0) & (pall[cont] <= 1.0 + 1e-9)).all())
 # per-variable path (what EPBP.belief_rv / map do for one rv): 64 points of one variable per launch
 vs = np.flatnonzero(flat.var_hidden & flat.var_cont)[:200]
 t0 = time.perf_counter()
@@ -40,6 +53,7 @@ t_one = (time.perf_counter() - t0) / len(vs)
 out = {'edges': flat.E, 'variables': flat.V, 'hidden_variables': hidden, 'points_per_variable': n,
        'belief_rv_all_ms': round(1e3 * t_all, 2), 'log_belief_points_per_s': round(hidden * n / t_all),
        'map_all_5_steps_ms': round(1e3 * t_map, 1), 'maps_per_s': round(hidden / t_map),
+       'belief_all_8_points_ms': round(1e3 * t_bel, 1), 'probability_all_ms': round(1e3 * t_prob, 1),
        'per_variable_query_ms': round(1e3 * t_one, 3), 'per_variable_path_for_all_s': round(t_one * hidden, 1),
        'speedup_vs_per_variable': round(t_one * hidden / t_all)}
 print(json.dumps(out))

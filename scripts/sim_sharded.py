@@ -1,5 +1,6 @@
 """Rehearse the edge-sharded sweep for `world` ranks on ONE GPU (loopback exchange): checks that the plans build at full
-size and times each rank's pre / post phases (everything except the real all_to_all).  Tuning / validation aid."""
+size and times each rank's three phases -- boundary pack, interior part (overlaps the exchange), boundary part -- i.e. everything
+except the real all_to_all.  Tuning / validation aid."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
@@ -19,19 +20,30 @@ torch.cuda.synchronize()
 nb = [r.nb for r in runners]
 sent = [r.n_elems * 8 / 1e6 for r in runners]
 print('boundary vars per rank', nb[:3], '... send MB per rank', ['%.0f' % s for s in sent[:3]], 'per peer MB %.0f' % (sent[0] / max(world - 1, 1)))
+print('interior variables per rank: %s of %s' % ([r.n_int for r in runners[:3]], [r.plan.flat.V for r in runners[:3]]),
+      'interior heavy edges: %s of %s' % ([r.bp.part_counts['heavy'] for r in runners[:3]], [r.bp.n_heavy for r in runners[:3]]))
+
+
+def timed(fn):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize()
+    return out, time.perf_counter() - t
+
+
 for it in range(3):
-    tp, tq = [], []
+    tp, ti, tb = [], [], []
     sends = []
     for r in runners:
-        torch.cuda.synchronize(); t = time.perf_counter()
-        sends.append(r.pre())
-        torch.cuda.synchronize(); tp.append(time.perf_counter() - t)
+        send, t = timed(lambda: r.pre(part=1))          # boundary partials + pack: precedes the exchange
+        sends.append(send); tp.append(t)
     for r, s in zip(runners, sends):
         group.post(r.rank, s, r.counts)
     for r in runners:
+        ti.append(timed(r.interior)[1])                 # runs while the rows are in flight
+    for r in runners:
         recv = group.collect(r.rank, r.W)
-        torch.cuda.synchronize(); t = time.perf_counter()
-        r.post(recv)
-        torch.cuda.synchronize(); tq.append(time.perf_counter() - t)
-    print('sweep %d: per-rank pre %.2f ms, post %.2f ms (max over ranks %.2f / %.2f)' %
-          (it, 1e3 * np.mean(tp), 1e3 * np.mean(tq), 1e3 * max(tp), 1e3 * max(tq)), flush=True)
+        tb.append(timed(lambda: r.boundary(recv))[1])
+    print('sweep %d: per-rank pack %.2f ms, interior %.2f ms, boundary %.2f ms (max over ranks %.2f / %.2f / %.2f; slowest rank total %.2f)' %
+          (it, 1e3 * np.mean(tp), 1e3 * np.mean(ti), 1e3 * np.mean(tb), 1e3 * max(tp), 1e3 * max(ti), 1e3 * max(tb),
+           1e3 * max(a + b + c for a, b, c in zip(tp, ti, tb))), flush=True)

@@ -109,9 +109,10 @@ def test_boundary_exchange_gloo_world2():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('world', [2, 3])
-def test_sharded_sweep_matches_single_gpu(world):
-    """simulate `world` ranks in one process (loopback exchange): messages and proposals equal the unsharded sweep"""
+@pytest.mark.parametrize('world,two_part', [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_sweep_matches_single_gpu(world, two_part):
+    """simulate `world` ranks in one process (loopback exchange): messages and proposals equal the unsharded sweep, with
+    the plain schedule (everything after the exchange) and the two-part one (interior part while the rows are in flight)"""
     import torch
     from lhvi import synth, dist, _abi
     from lhvi.pbp import EPBP
@@ -128,11 +129,18 @@ def test_sharded_sweep_matches_single_gpu(world):
         r.init()
     for it in range(3):
         single.sweep()
-        sends = [r.pre() for r in runners]
+        sends = [r.pre(part=1) if two_part else r.pre() for r in runners]
         for r, s in zip(runners, sends):
             group.post(r.rank, s, r.counts)
-        for r in runners:
-            r.post(group.collect(r.rank, r.W))
+        if two_part:
+            assert all(r.overlap for r in runners)
+            for r in runners:
+                r.interior()
+            for r in runners:
+                r.boundary(group.collect(r.rank, r.W))
+        else:
+            for r in runners:
+                r.post(group.collect(r.rank, r.W))
         q = bp.q_dev.cpu().numpy()
         f2v = bp.f2v.cpu().numpy()
         v2f = bp.v2f.cpu().numpy()

@@ -91,6 +91,19 @@ def test_epbp_matches_reference_golden(api, golden_dir, name):
             assert mp[i] == pytest.approx(want, abs=2e-4) or mval[i] >= ref_val - 1e-9
         else:
             assert mp[i] == want
+    # batched interval probabilities (5-point over 20-point trapezoid, EPBP:356-375) against the per-variable query
+    lo = flat.dom_lo[flat.var_dom]
+    pall = bp.probability_all(lo + 0.5, lo + 2.0).cpu().numpy()
+    for i in chid[:8]:
+        assert pall[i] == pytest.approx(bp.probability(lo[i] + 0.5, lo[i] + 2.0, rvs[i]), rel=1e-10)
+    assert np.isnan(pall[[i for i in range(flat.V) if i not in chid]]).all()
+    # discrete rows of belief_all: normalised over the states, like EPBP.belief
+    ball = bp.belief_all(np.zeros((flat.V, 2))).cpu().numpy()
+    for i in hid:
+        if not flat.var_cont[i]:
+            vals = list(rvs[i].domain.values)
+            for k in range(min(2, len(vals))):
+                assert ball[i, k] == pytest.approx(bp.belief(vals[k], rvs[i]), rel=1e-10)
 
 
 @pytest.mark.parametrize('name', HLBP_CASES)
@@ -130,6 +143,23 @@ def test_hlbp_matches_reference_golden(api, golden_dir, name):
             assert mp[c] == pytest.approx(z['map'][i], abs=2e-4) or mval[c] >= ref_val - 1e-9
         else:
             assert mp[c] == z['map'][i]
+    # batched normalised beliefs / interval probabilities: the per-variable queries for every cluster at once
+    first = {}
+    for i in hid:
+        first.setdefault(flat.var_index[rvs[i].cluster], i)
+    xq = np.zeros((flat.V, 1))
+    for c, i in first.items():
+        xq[c, 0] = z['query_x'][i][2]
+    ball = bp.belief_all(xq).cpu().numpy()
+    lo = np.array([rv.domain.values[0] for rv in flat.rvs], dtype=float)
+    pall = bp.probability_all(lo + 0.25, lo + 1.5).cpu().numpy()
+    for c, i in first.items():
+        if rvs[i].domain.continuous:
+            assert ball[c, 0] == pytest.approx(z['belief_mid'][i], rel=1e-5, abs=1e-7)
+            assert ball[c, 0] == pytest.approx(bp.belief(z['query_x'][i][2], rvs[i]), rel=1e-10)
+            assert pall[c] == pytest.approx(bp.probability(lo[c] + 0.25, lo[c] + 1.5, rvs[i]), rel=1e-10)
+        else:
+            assert ball[c, 0] == pytest.approx(bp.belief(rvs[i].domain.values[0], rvs[i]), rel=1e-10)
 
 
 def test_epbp_host_sampler_reproduces_reference_stream(api, golden_dir):
