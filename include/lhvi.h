@@ -135,6 +135,8 @@ int lhvi_log_likelihood(const lhvi_graph_t* g, const lhvi_pots_t* pots, const do
 #define LHVI_PBP_SKIP_HEAVY 32u   /* lhvi_pbp_f2v: do not launch the continuous x continuous (heavy_desc) kernel (profiling aid) */
 #define LHVI_PBP_SKIP_LIGHT 64u   /* lhvi_pbp_f2v: do not launch the kernels of the remaining fast edges (light_desc and fast_edges;
                                    * profiling aid) */
+#define LHVI_PBP_NO_GRID 128u    /* lhvi_pbp_f2v: integral points always by the direct form (one exponential per term), never by the
+                                   * uniform-grid recurrence (testing / profiling aid) */
 
 typedef struct lhvi_pbp {
     int32_t n;                  /* particle slots per variable */
@@ -186,9 +188,9 @@ typedef struct lhvi_pbp {
  *   5 target position   6 potential kind   7 nj = partner particle count (1 = observed)   8 np = target particle count
  *   9 T = target integral points   10 grid base in dom_val   11 offset into pots.param   12-13 partner value (double,
  *   NaN = hidden)   14 light-kernel type (0 none, 1 continuous target / discrete partner, 2 discrete target /
- *   continuous partner)   15 reserved   16-27 six doubles: the potential resolved for this edge -- class 1 with a constant
+ *   continuous partner)   15 1 = the target's integral points are a uniform grid (x_t = x0 + t h to a few ulp)   16-27 six doubles: the potential resolved for this edge -- class 1 with a constant
  *   x^2 coefficient: log phi = kx x^2 + (ay y + by) y + c + (axy y + bx) x as (ay, by, c, axy, bx, kx), x = target;
- *   light edges: (A_0, b_0, c_0, A_1, b_1, c_1) of the discrete side's two points   28-31 reserved.
+ *   light edges: (A_0, b_0, c_0, A_1, b_1, c_1) of the discrete side's two points   28-31 two doubles (x0, h) of a uniform grid.
  * The host builds heavy_desc / light_desc / fast_desc by splitting the rows on words 4, 6, 7, 8 + 9 and 14. */
 int lhvi_pbp_describe(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const int32_t* edges, int32_t count,
                       void* desc_out, void* stream);

@@ -284,11 +284,11 @@ struct FastDesc {
     int32_t cls, pos, kind, nj;    // edge class, target position, potential kind, partner particle count (1 = observed)
     int32_t np, T, gb, par_off;    // target particle count, target grid size, grid base in dom_val, offset into pots.param
     double pval;                   // partner evidence value (NaN = hidden)
-    int32_t pad[2];
+    int32_t pad[2];                // [0] light-kernel type, [1] 1 = the target's integral points are a uniform grid
     // class 1 with a constant x^2 coefficient (kind != HYBRID_QUADRATIC): the potential resolved for this edge's target
     // position, log phi(x, y) = kx x^2 + (ay y + by) y + c + (axy y + bx) x with x = target, y = partner
     double ay, by, c, axy, bx, kx;
-    double pad2[2];
+    double pad2[2];                // uniform grid: first point and spacing (x_t = x0 + t h)
 };
 static_assert(sizeof(FastDesc) == LHVI_PBP_DESC_BYTES, "FastDesc is part of the ABI (LHVI_PBP_DESC_BYTES)");
 
@@ -313,6 +313,16 @@ __device__ __forceinline__ FastDesc make_fast_desc(const lhvi_graph_t& g, const 
     d.T = (d.cls == EDGE_FAST_CONT) ? g.dom_ptr[dom + 1] - d.gb : 0;
     d.pad[0] = d.pad[1] = 0;
     d.ay = d.by = d.c = d.axy = d.bx = d.kx = d.pad2[0] = d.pad2[1] = 0.0;
+    // uniform integral-point grid (the reference's Domain default is a linspace): x_t = x0 + t h to a few ulp.  The heavy
+    // kernel then tabulates exp(a + b x_t) along t by multiplication instead of one exponential per point
+    if (d.cls == EDGE_FAST_CONT && d.T >= 2) {
+        const double x0 = g.dom_val[d.gb], xl = g.dom_val[d.gb + d.T - 1];
+        const double h = (xl - x0) / (double)(d.T - 1);
+        const double tol = 1.8e-15 * fmax(fabs(x0), fabs(xl));
+        bool uniform = h > 0.0 && h < __builtin_huge_val();
+        for (int t = 0; t < d.T && uniform; ++t) uniform = fabs(g.dom_val[d.gb + t] - fma((double)t, h, x0)) <= tol;
+        if (uniform) { d.pad[1] = 1; d.pad2[0] = x0; d.pad2[1] = h; }
+    }
     Quad2 q;
     if (d.cls == EDGE_FAST_CONT && d.kind != LHVI_POT_HYBRID_QUADRATIC && quad2_of(d.kind, pots.param + d.par_off, 0, q)) {
         if (d.pos == 0) { d.ay = q.a11; d.by = q.b1; d.axy = q.axy; d.bx = q.b0; d.kx = q.a00; }
@@ -529,6 +539,63 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
 // was fetched one edge earlier still), so a wave never sits out a memory round trip between two term loops.
 struct HeavyData { double y, m, x0, x1; };
 
+// ---- integral points on a uniform grid: sum_j exp(a_j + b_j x_t) for t < 32 with lane = partner particle j ------------
+// G_{t+1,j} = G_{t,j} * exp(b_j h) replaces the exponential per (t, j) by one multiplication; the sums over j are then a
+// reduce-scatter over the lanes that leaves S_t in the lanes owning t.  One fold per lane-id bit: x is the value kept by
+// the lanes whose bit is 0, y by the others, and the result is own + partner's copy of the kept value.  Bits 5 and 4:
+// v_permlane32_swap / v_permlane16_swap (gfx950; a swap per dword moves both values, no selects); bits 3 and 2:
+// bank-masked DPP row rotations / shifts; bits 1 and 0: quad permutes.
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_into(double old, double src) {     // enabled banks take src[permuted], the rest keep old
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xf, BANK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xf, BANK, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double fold_bit5(double x, double y) {
+    auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double fold_bit4(double x, double y) {
+    auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double fold_bit3(double x, double y) {        // lane ^ 8 = row_ror:8; bit 3 set = banks 2, 3
+    return dpp_into<0x128, 0x3>(y, x) + dpp_into<0x128, 0xc>(x, y);
+}
+__device__ __forceinline__ double fold_bit2(double x, double y) {        // lane ^ 4: row_shl:4 into banks 0, 2; row_shr:4 into banks 1, 3
+    return dpp_into<0x104, 0x5>(y, x) + dpp_into<0x114, 0xa>(x, y);
+}
+__device__ __forceinline__ double fold_bit1(double x, double y, bool bit1) {      // lane ^ 2 = quad_perm [2,3,0,1]
+    const double send = bit1 ? x : y, keep = bit1 ? y : x;
+    return keep + dpp_move<0x4e>(send);
+}
+__device__ __forceinline__ double fold_bit0(double x) { return x + dpp_move<0xb1>(x); }   // lane ^ 1 = quad_perm [1,0,3,2]
+
+// the point whose sum a lane holds after the six folds of 4 batches of 8 consecutive points
+__device__ __forceinline__ int grid_owned_point(int lane) {
+    return 8 * (2 * ((lane >> 1) & 1) + ((lane >> 2) & 1)) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
+}
+
+// g = this lane's G at the first of 32 consecutive grid points (advanced by 32 steps on return), q = its ratio
+__device__ __forceinline__ double grid_sums32(double& g, double q, int lane) {
+    double z[4];
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) {
+        double v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = g; g *= q; }
+        const double u0 = fold_bit4(fold_bit5(v[0], v[1]), fold_bit5(v[2], v[3]));
+        const double u1 = fold_bit4(fold_bit5(v[4], v[5]), fold_bit5(v[6], v[7]));
+        z[bt] = fold_bit3(u0, u1);
+    }
+    return fold_bit0(fold_bit1(fold_bit2(z[0], z[1]), fold_bit2(z[2], z[3]), (lane >> 1) & 1));
+}
+constexpr int GRID_MIN_NJ = 24;         // fewer partner particles: the direct loop is cheaper than 32 multiplications + 6 folds
+constexpr double GRID_MAX_EXPONENT = 600.0;
+__device__ __forceinline__ bool grid_eligible(int uniform_grid, int nj, int T) { return uniform_grid && nj >= GRID_MIN_NJ && T <= 64; }
+
 __device__ __forceinline__ int round_log2_width(int rem) {      // 64 lanes for a full round, else next pow2 >= rem
     int lw = 6;
     if (rem <= 32) { lw = 0; while ((1 << lw) < rem) ++lw; }
@@ -538,7 +605,8 @@ __device__ __forceinline__ int round_log2_width(int rem) {      // 64 lanes for 
 __device__ __forceinline__ HeavyData heavy_fetch(const FastDesc& d, const lhvi_graph_t& g, const lhvi_pbp_t& s,
                                                  const double* __restrict__ v2f, int lane) {
     HeavyData h;
-    const int n = s.n, np = d.np, npts = d.np + d.T;
+    // edges whose integral points go through the grid recurrence (or its fallback) fetch their particles only
+    const int n = s.n, np = d.np, npts = grid_eligible(d.pad[1], d.nj, d.T) ? d.np : d.np + d.T;
     h.y = d.pval; h.m = 0.0; h.x0 = 0.0; h.x1 = 0.0;
     if (is_hidden(d.pval) && lane < d.nj) { h.y = s.old_particles[(int64_t)d.pv * n + lane]; h.m = v2f[(int64_t)d.pce * n + lane]; }
     {
@@ -573,31 +641,67 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_heavy_kernel(lhvi_graph_t g, lh
     // pipeline: the loads of edge k+1 are issued as soon as edge k has been staged into LDS (its registers are free
     // then, so nothing has to be rotated) and stay in flight through the term loops of edge k; `dn` is the full
     // descriptor of edge k+1, fetched one edge ahead, `d` the seven words the arithmetic of edge k needs
-    struct { int32_t e, nj, np, T; double ay, by, c, axy, bx, kx; } d;
+    struct { int32_t e, nj, np, T, gb, grid; double ay, by, c, axy, bx, kx, gx0, gh; } d;
     FastDesc dn = descs[item];
     HeavyData h = heavy_fetch(dn, g, s, v2f, lane);
     for (;;) {
-        d.e = dn.e; d.nj = dn.nj; d.np = dn.np; d.T = dn.T;
-        d.ay = dn.ay; d.by = dn.by; d.c = dn.c; d.axy = dn.axy; d.bx = dn.bx; d.kx = dn.kx;
+        d.e = dn.e; d.nj = dn.nj; d.np = dn.np; d.T = dn.T; d.gb = dn.gb; d.grid = dn.pad[1];
+        d.ay = dn.ay; d.by = dn.by; d.c = dn.c; d.axy = dn.axy; d.bx = dn.bx; d.kx = dn.kx; d.gx0 = dn.pad2[0]; d.gh = dn.pad2[1];
         const bool more = item + nwaves < nitems;
         dn = descs[__builtin_amdgcn_readfirstlane(min(item + nwaves, last))];
-        const int np = d.np, npts = d.np + d.T, nj = d.nj;
+        const int np = d.np, nj = d.nj;
         double* out = f2v + (int64_t)d.e * S;
         const double kconst = d.kx;
+        // integral points by recurrence along the uniform grid (below) when every exponent a_j + b_j x + kx x^2 stays far
+        // inside the double range over the whole grid (then neither form under- or overflows and they agree to rounding)
+        const bool eligible = grid_eligible(d.grid, nj, d.T);
+        bool grid_path = eligible && !(s.flags & (LHVI_PBP_SKIP_TERMS | LHVI_PBP_NO_GRID));
+        AB mine;
+        mine.a = -800.0; mine.b = 0.0;                     // padding: exp(-800) underflows to exactly 0
         LHVI_WAVE_SYNC();
         {
-            AB r;
-            r.a = -800.0; r.b = 0.0;                       // padding: exp(-800) underflows to exactly 0
             if (lane < nj) {
                 const double y = h.y;
-                r.a = (d.ay * y + d.by) * y + d.c + h.m;
-                r.b = d.axy * y + d.bx;
+                mine.a = (d.ay * y + d.by) * y + d.c + h.m;
+                mine.b = d.axy * y + d.bx;
             }
-            sh[lane] = r;
+            sh[lane] = mine;
         }
         LHVI_WAVE_SYNC();
+        if (grid_path) {
+            const double X = fmax(fabs(d.gx0), fabs(fma((double)(d.T - 1), d.gh, d.gx0)));
+            const double bound = fma(fabs(mine.b) + fabs(kconst) * X, X, fabs(mine.a));
+            grid_path = __ballot(lane < nj && !(bound < GRID_MAX_EXPONENT)) == 0;
+        }
+        const int npts = eligible ? np : np + d.T;          // eligible: the integral points are handled after the particle rounds
         const double x0 = h.x0, x1 = h.x1;
         if (more) h = heavy_fetch(dn, g, s, v2f, lane);
+        if (grid_path) {
+            double gv = exp_core(fma(mine.b, d.gx0, mine.a), sh_tab);
+            const double q = exp_core(mine.b * d.gh, sh_tab);
+            for (int t0 = 0; t0 < d.T; t0 += 32) {
+                const double sum = grid_sums32(gv, q, lane);
+                const int t = t0 + grid_owned_point(lane);
+                if (t < d.T && !(lane & 1)) {
+                    const double xt = fma((double)t, d.gh, d.gx0);
+                    out[n + t] = sum > 0.0 ? fma(kconst * xt, xt, log_table(sum, sh_log)) : -700.0;
+                }
+            }
+        } else if (eligible) {
+            // an exponent too close to the double range somewhere on the grid: the direct form, points fetched here
+#pragma nounroll
+            for (int t0 = 0; t0 < d.T; t0 += 64) {
+                const int rem = d.T - t0;
+                const int lw = round_log2_width(rem);
+                const int width = 1 << lw, split = 64 >> lw, sub = lane >> lw, pl = lane & (width - 1);
+                const bool valid = pl < rem;
+                const double X1 = valid ? g.dom_val[d.gb + t0 + pl] : 0.0, C = kconst * X1 * X1;
+                const int chunk = (s.flags & LHVI_PBP_SKIP_TERMS) ? 0 : (nj + split - 1) >> (6 - lw);
+                double acc = fast_accumulate_uniform<MODE_CONST, 4>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
+                for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+                if (valid && sub == 0) out[n + t0 + pl] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
+            }
+        }
 #pragma nounroll
         for (int r = 0; r < 2; ++r) {
             const int rem = npts - 64 * r;

@@ -204,6 +204,60 @@ def test_pbp_sweep_matches_oracle_on_random_hybrid_mrf(api):
         np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-8)
 
 
+def _with_domain(flat, dom):
+    """`flat` with its first (continuous) domain replaced"""
+    from lhvi.flat import build_flat
+    specs = [(int(k), flat.pot_param[int(o):int(o2)].tolist()) for k, o, o2 in zip(flat.pot_kind, flat.pot_off[:-1], flat.pot_off[1:])]
+    lo, hi = dom.values
+    return build_flat(flat.fac_ptr, flat.edge_var, flat.fac_pot, specs, np.clip(flat.var_value, lo, hi), flat.var_dom,
+                      [dom, flat.domains[1]])
+
+
+@pytest.mark.parametrize('grid', ['uniform', 'uneven', 'T48', 'wide'])
+def test_integral_points_by_grid_recurrence_match_the_direct_form(api, grid):
+    """the heavy f2v kernel tabulates exp(a_j + b_j x_t) along a uniform integral-point grid by multiplication and
+    reduce-scatters the sums over the lanes; LHVI_PBP_NO_GRID forces one exponential per term.  Same messages to 1e-12
+    (uniform grids of 32 and 48 points), identical ones where the recurrence may not run: a grid that is not uniform,
+    or exponents too close to the double range (domain [-40, 40]: the guard sends those edges through the direct form)."""
+    import torch
+    from lhvi import synth, _abi
+    from lhvi.graph import Domain
+    from lhvi.pbp import EPBP
+    lo, hi = (-40.0, 40.0) if grid == 'wide' else (-10.0, 10.0)
+    pts = np.linspace(lo, hi, 48 if grid == 'T48' else 32)
+    if grid == 'uneven':
+        pts = np.sign(pts) * np.abs(pts) ** 1.3 / 10 ** 0.3
+    flat = _with_domain(synth.hybrid_mrf_flat(V=3000, deg=4, seed=11, frac_discrete=0.1),
+                        Domain((lo, hi), continuous=True, integral_points=pts))
+    bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=2)
+    bp._setup(None, flat=flat)
+    _init(api, bp)
+    for _ in range(2):
+        bp.sweep(last=False)
+    l, st = api.lib(), api.stream_ptr()
+    s = bp._struct()
+    api.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, api.ptr(bp.v2f), api.ptr(bp.f2v), st))
+    with_grid = bp.f2v.clone()
+    s.flags |= _abi.PBP_NO_GRID
+    api.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, api.ptr(bp.v2f), api.ptr(bp.f2v), st))
+    words = bp.heavy_desc.view(torch.int32).view(-1, 32).cpu().numpy()
+    heavy_e = words[:, 0]
+    a, b = with_grid.cpu().numpy()[heavy_e], bp.f2v.cpu().numpy()[heavy_e]
+    assert np.isfinite(a).all() and heavy_e.size > 1000
+    n = bp.n
+    assert (a[:, :n] == b[:, :n]).all()                         # the particle part is the same code either way
+    if grid == 'uneven':
+        assert (words[:, 15] == 0).all() and (a == b).all()
+        return
+    assert (words[:, 15] == 1).all()
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12)
+    same = (a[:, n:] == b[:, n:]).all(axis=1)                   # edges whose integral points took the direct form
+    live = words[:, 7] >= 24                                    # enough partner particles for the recurrence to pay
+    assert not same[live].all()                                 # the recurrence did run ...
+    if grid == 'wide':
+        assert same[live].any()                                 # ... and the guard did reject edges with exponents ~ +-800
+
+
 def test_device_sampler_statistics(api):
     """Philox/Box-Muller particles: mean/variance of the clipped normal draws, determinism per (seed, iteration)"""
     from lhvi import synth
