@@ -187,9 +187,11 @@ def main():
                          'traffic': measured_traffic('pbp_f2v_heavy_kernel') if world == 1 and args.edges == 10_000_000 else None,
                          'kernel_ms': f2v_ms, 'edges_per_launch': heavy_edges, 'joint_terms_per_launch': terms,
                          'flop_per_term': FLOP_PER_TERM,
-                         'note': 'fp64 compute roof (dense peak of the dtype; VALU instructions, not MFMA). 16 flop per term '
-                                 'need 9 fp64 + 3 int32 issue slots, so the instruction-issue ceiling of the loop is 58 % of '
-                                 'this peak; LDS (2 reads per term) is the co-limiter (DESIGN.md sections 4.3, 5)',
+                         'note': 'fp64 compute roof (dense peak of the dtype; VALU instructions, not MFMA).  Algorithmic count: 16 flop '
+                                 'per (output point, partner particle) term.  Terms at the particles cost 9 fp64 + 3 int32 issue '
+                                 'slots + 2 LDS reads each (issue ceiling 58 % of this peak); terms at the integral points are '
+                                 'tabulated along the uniform grid by one multiplication each plus a lane reduce-scatter '
+                                 '(DESIGN.md sections 4.3, 5)',
                          'hbm': {'achieved': f2v_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': f2v_gbs / HBM_PEAK_GBS,
                                  'algorithmic_bytes_per_launch': f2v_bytes},
                          'sweep_hbm': {'achieved': bytes_e['sweep'] * E_local / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,

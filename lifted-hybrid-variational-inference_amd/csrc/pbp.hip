@@ -93,8 +93,9 @@ __global__ void __launch_bounds__(BLOCK) pbp_uniq_wave_kernel(int V, int n, cons
 // the stated tolerance; it replaces the reference's O(deg^2) re-summation (EPBP:165-174) by O(deg).
 // The first V2F_CACHE rows stay in registers (compile-time indices only: a runtime-indexed register array made
 // hipcc 7.2 emit an out-of-range s_set_gpr_idx store); their loads are issued back to back so that a degree-4
-// variable has four 512-byte rows in flight per wave instead of one.
-constexpr int V2F_CACHE = 8;
+// variable has four 512-byte rows in flight per wave instead of one (eight slots were measured 5 % slower: scalar-register
+// spills; rows beyond the cache are read a second time, out of L2).
+constexpr int V2F_CACHE = 4;
 
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                        double* __restrict__ v2f) {
@@ -620,7 +621,7 @@ __device__ __forceinline__ HeavyData heavy_fetch(const FastDesc& d, const lhvi_g
     return h;
 }
 
-__global__ void __launch_bounds__(BLOCK) pbp_f2v_heavy_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7))) pbp_f2v_heavy_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
                                                              double* __restrict__ f2v, const FastDesc* __restrict__ descs,
                                                              int nitems) {
     __shared__ AB sh_all[BLOCK / WAVE][WAVE];
