@@ -4,16 +4,20 @@
 // Log messages are tabulated per edge in HBM:
 //     f2v[e][0..n)  at the variable's particles      f2v[e][n..n+T)  at its integral points
 //     v2f[e][0..n)  at the variable's particles
-// Kernels (one launch each per sweep):
-//   pbp_v2f_kernel       one wavefront per variable, lane = particle; rows of the incident f2v messages are read
-//                        coalesced (8n bytes each), leave-one-out sums in rv.nb order, wave-shuffle mean/max for
-//                        log_message_balance.  HBM bound (16n B per edge).
-//   pbp_f2v_kernel       one wavefront per edge, lane = output point (new particles + integral points).  The
-//                        partner's particles and its incoming log message are folded into per-particle
-//                        coefficients (alpha, beta, kappa) staged in LDS, so the inner loop over joint particles is
-//                        two FMAs + one fp64 exp.  fp64-VALU bound ((n+T)*n exps per edge).
-//   pbp_proposal_kernel  one wavefront per variable: T-point moments per incident edge (shuffle reductions), site
-//                        update rule, Gaussian product.
+// Kernels of a sweep:
+//   pbp_v2f_kernel            one wavefront per variable, lane = particle; the incident f2v rows are read coalesced (8n
+//                             bytes each), leave-one-out sums in rv.nb order, DPP mean (and, rarely, max) for
+//                             log_message_balance.  HBM bound (16n B per edge).
+//   pbp_proposal_kernel       one wavefront per variable: T-point moments per incident edge (row reductions), site update
+//                             rule, Gaussian product.
+//   pbp_resample_uniq_kernel  Philox / Box-Muller particles keyed by the variable's global id + first-occurrence mask.
+//   pbp_f2v_heavy_kernel      continuous x continuous edges (99 % of the terms): persistent waves over 128-byte edge
+//                             descriptors; partner particle, potential and incoming message folded into (a_j, b_j) records in
+//                             LDS; sum_j exp(a_j + b_j x + k x^2) per output point with a table-driven fused exponential at
+//                             the particles, and by recurrence along the uniform integral-point grid + a lane
+//                             reduce-scatter at the integral points.  fp64-VALU / LDS bound.
+//   pbp_f2v_light_kernel      HybridQuadratic edges with a binary or observed discrete side (no staging).
+//   pbp_f2v_fast_kernel       every other quadratic-family edge;  pbp_f2v_generic_kernel: any potential / arity.
 #include "common.hpp"
 #include "potential.hpp"
 #include "fastmath.hpp"
@@ -535,7 +539,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
 
 // HEAVY edges = the bulk of the work: continuous target, constant x^2 coefficient (continuous x continuous
 // quadratic-family potential, or an observed partner), nj <= 64 partner particles, at most 128 output points.  Same
-// arithmetic as the general kernel above in MODE_CONST, but (a) only this mode, which fits 6+ waves per SIMD, and
+// arithmetic as the general kernel above in MODE_CONST, but (a) only this mode, which fits 7 waves per SIMD, and
 // (b) software-pipelined: while edge k is in its term loops the loads of edge k+1 are already in flight (its descriptor
 // was fetched one edge earlier still), so a wave never sits out a memory round trip between two term loops.
 struct HeavyData { double y, m, x0, x1; };
