@@ -397,3 +397,21 @@ def test_hlbp_coarse_to_fine_matches_reference(api, golden_dir, name):
     for i in hid[:5]:
         assert bp.map(rvs[i]) == pytest.approx(z['map'][i], abs=1e-4)
         assert bp.belief(z['query_x'][i][2], rvs[i]) == pytest.approx(z['belief_mid'][i], rel=1e-5, abs=1e-7)
+
+
+def test_batched_kl_of_tabulated_beliefs(api):
+    """utils.kl_tables: trapezoid of kl_continuous' integrand for every variable at once (device), against the host quad"""
+    from math import exp, pi, sqrt
+    from lhvi import utils
+    rng = np.random.default_rng(3)
+    V, m = 7, 4001
+    mu1, mu2 = rng.uniform(-1, 1, V), rng.uniform(-1, 1, V)
+    s1, s2 = rng.uniform(0.5, 1.5, V), rng.uniform(0.5, 1.5, V)
+    a, b = np.full(V, -14.0), np.full(V, 14.0)
+    x = np.linspace(a, b, m, axis=1)
+    pdf = lambda x, mu, s: np.exp(-0.5 * ((x - mu) / s) ** 2) / (sqrt(2 * pi) * s)
+    got = utils.kl_tables(pdf(x, mu1[:, None], s1[:, None]), pdf(x, mu2[:, None], s2[:, None]), a, b).cpu().numpy()
+    for v in range(V):
+        want = utils.kl_continuous(lambda t: pdf(t, mu1[v], s1[v]), lambda t: pdf(t, mu2[v], s2[v]), -14, 14)
+        assert got[v] == pytest.approx(want, rel=1e-6)
+        assert got[v] == pytest.approx(utils.kl_normal(mu1[v], mu2[v], s1[v], s2[v]), rel=1e-6)

@@ -319,3 +319,38 @@ def test_kalman_flat_builder_equals_object_builder(n, T, missing):
     for t in range(T):
         for i in range(n):
             assert fo.rvs[sid[t, i]] is table[t][i]
+
+
+def test_utils_kl_helpers_have_the_reference_signatures():
+    """utils.py:18-128: KL, kl_discrete, kl_continuous*, kl_normal(mu1, mu2, sig1, sig2)"""
+    from math import exp, log, pi, sqrt
+    from lhvi import utils
+    from lhvi.graph import Domain
+
+    def pdf(mu, sig):
+        return lambda x: exp(-0.5 * ((x - mu) / sig) ** 2) / (sqrt(2 * pi) * sig)
+
+    def logpdf(mu, sig):
+        return lambda x: -0.5 * ((x - mu) / sig) ** 2 - log(sqrt(2 * pi) * sig)
+    mu1, mu2, sig1, sig2 = 0.3, -0.4, 0.8, 1.5
+    closed = utils.kl_normal(mu1, mu2, sig1, sig2)
+    assert closed == pytest.approx(log(sig2 / sig1) + (sig1 ** 2 + (mu1 - mu2) ** 2) / (2 * sig2 ** 2) - 0.5, rel=1e-15)
+    assert utils.kl_continuous(pdf(mu1, sig1), pdf(mu2, sig2), -12, 12) == pytest.approx(closed, rel=1e-7)
+    assert utils.kl_continuous_no_add_const(pdf(mu1, sig1), pdf(mu2, sig2), -5, 5) == pytest.approx(closed, rel=1e-4)
+    assert utils.kl_continuous_logpdf(logpdf(mu1, sig1), logpdf(mu2, sig2), -12, 12) == pytest.approx(closed, rel=1e-7)
+    p, q = np.array([0.2, 0.5, 0.3]), np.array([0.3, 0.3, 0.4])
+    assert utils.kl_discrete(p, q) == pytest.approx(float(np.sum(p * np.log(p / q))), rel=1e-14)
+    dom = Domain((-12, 12), continuous=True, integral_points=np.linspace(-12, 12, 2001))
+    assert utils.KL(pdf(mu1, sig1), pdf(mu2, sig2), dom) == pytest.approx(closed, rel=1e-3)      # Riemann sum of the grid
+    dd = Domain((0, 1, 2))
+    assert utils.KL(lambda x: p[int(x)], lambda x: q[int(x)], dd) == pytest.approx(utils.kl_discrete(p, q), abs=1e-6)
+    compat_dir = os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd', 'compat')
+    sys.path.insert(0, compat_dir)
+    try:
+        sys.modules.pop('utils', None)
+        compat = importlib.import_module('utils')               # `from utils import kl_continuous` of the reference's demos
+        assert compat.kl_normal is utils.kl_normal and compat.kl_continuous is utils.kl_continuous
+        assert compat.log_likelihood is utils.log_likelihood
+    finally:
+        sys.path.remove(compat_dir)
+        sys.modules.pop('utils', None)
