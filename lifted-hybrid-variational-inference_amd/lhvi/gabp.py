@@ -13,10 +13,11 @@ from . import _abi
 from .flat import flatten
 
 
-def _norm_pdf_var(x, mu, var):
+def _norm_pdf_var(x, mu, sig):
     # GaBP.norm_pdf (GaBP.py:14-18): note the normaliser uses the variance, not its square root
+    # (`sig` is the reference's parameter name; in GaBP / GaLBP it holds a variance)
     u = x - mu
-    return np.exp(-u * u * 0.5 / var) / (2.506628274631 * var)
+    return np.exp(-u * u * 0.5 / sig) / (2.506628274631 * sig)
 
 
 class _GaussianSweep:

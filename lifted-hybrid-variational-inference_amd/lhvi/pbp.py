@@ -409,6 +409,27 @@ class _ParticleSweep:
             message[k] = message[k] - shift
         return shift
 
+    def log_area(self, f, a, b, n, shift=None):
+        """``log_area`` with the reference's signature (EPBP:291-308, HLBP:324-341): trapezoid of exp(f(x) - shift) on
+        linspace(a, b, n) for a callable log-density ``f``; returns (area, shift)"""
+        x = np.linspace(a, b, n)
+        d = x[1] - x[0]
+        y = {i: f(v) for i, v in enumerate(x)}
+        if shift is None:
+            shift = self.log_message_balance(y)
+        else:
+            y = {k: val - shift for k, val in y.items()}
+        res, prev = 0, e ** y[0]
+        for i in range(1, n):
+            cur = e ** y[i]
+            res += (prev + cur) * d
+            prev = cur
+        return res * 0.5, shift
+
+    @staticmethod
+    def get_cluster(instance):
+        return instance.cluster
+
     def _log_area(self, v, a, b, npts, shift=None):
         """EPBP.log_area (EPBP:291-308): trapezoid of exp(belief_rv - shift) on linspace(a, b, npts)"""
         x = np.linspace(a, b, npts)
