@@ -217,6 +217,12 @@ class _Variational:
                 out[rv] = self._host('eta_d')[v, :, :int(flat.var_nstates[v])]
         return out
 
+    @property
+    def eta_tau(self):
+        """category logits of the discrete hidden variables, {rv: array [K, #states]} like the reference's ``eta_tau``"""
+        flat = self.flat
+        return {rv: self._host('tau_d')[v, :, :int(flat.var_nstates[v])] for v, rv in enumerate(flat.rvs) if self._disc[v]}
+
     def _w_host(self):
         return self._host('w')
 
@@ -244,8 +250,9 @@ class _Variational:
             v = self._var_index(rv)
             if rv.domain.continuous:
                 eta = self._host('eta_c')[v]
+                xi = x[i] if np.ndim(x[i]) == 0 else float(np.ravel(x[i])[0])     # scipy's optimisers pass 1-element arrays
                 for k in range(self.K):
-                    b[k] *= self.norm_pdf(x[i], eta[k])
+                    b[k] *= self.norm_pdf(xi, eta[k])
             else:
                 d = rv.domain.values.index(x[i])
                 b *= self._host('eta_d')[v, :, d]

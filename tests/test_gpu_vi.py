@@ -40,6 +40,13 @@ def test_vi_matches_reference_golden(api, golden_dir, name):
         return out
 
     vi._upload_params(z['w_tau0'], scatter('eta_c0'), scatter('tau_d0'))
+    # the reference-style parameter views: logits of the discrete variables, keyed by rv
+    tau = vi.eta_tau
+    assert len(tau) == int(np.count_nonzero(vi._disc))
+    for rv_, t in tau.items():
+        v = flat.var_index[rv_]
+        assert t.shape == (vi.K, int(flat.var_nstates[v]))
+        np.testing.assert_array_equal(t, np.nan_to_num(scatter('tau_d0')[v], nan=0.0)[:, :t.shape[1]])
     # fp64 tolerance: same formulas, different summation order (per-edge partials gathered per variable)
     assert vi.free_energy() == pytest.approx(float(z['fe0']), rel=1e-10)
     np.testing.assert_allclose(vi.gradient_w_tau(), z['g_w0'], rtol=1e-8, atol=1e-9)
