@@ -137,6 +137,11 @@ int lhvi_log_likelihood(const lhvi_graph_t* g, const lhvi_pots_t* pots, const do
                                    * profiling aid) */
 #define LHVI_PBP_NO_GRID 128u    /* lhvi_pbp_f2v: integral points always by the direct form (one exponential per term), never by the
                                    * uniform-grid recurrence (testing / profiling aid) */
+#define LHVI_PBP_BESIDE_HEAVY 256u /* lhvi_pbp_f2v with SKIP_HEAVY, issued on a second stream beside a call that runs the heavy
+                                   * kernel: a one-wavefront ~30 us delay is launched first, so that the heavy kernel's persistent
+                                   * workgroups are all resident before these kernels' are dispatched.  They then run in what the
+                                   * heavy kernel leaves free and in its tail (the other order displaces heavy workgroups, which
+                                   * then start late with a full static share of the work list) */
 
 typedef struct lhvi_pbp {
     int32_t n;                  /* particle slots per variable */

@@ -727,6 +727,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7
     }
 }
 
+// holds a stream back for `ticks` of the 100 MHz wall clock (one wavefront, asleep most of the time)
+__global__ void stream_delay_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // LIGHT edges: HybridQuadratic(1 discrete, 1 continuous) with a binary (or observed) discrete side -- the edges between
 // the continuous and the binary variables of the benchmark.  A handful of terms per output point, so the general
 // kernel's staging / splitting / shuffling is all overhead; here nothing goes through LDS but the two tables:
@@ -1344,22 +1350,25 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     static const int heavy_per_cu = blocks_per_cu((const void*)pbp_f2v_heavy_kernel);
     static const int light_per_cu = blocks_per_cu((const void*)pbp_f2v_light_kernel);
     static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel);
+    const int heavy_blocks = heavy_per_cu, side_blocks = 8;
+    if ((s->flags & LHVI_PBP_BESIDE_HEAVY) && (s->flags & LHVI_PBP_SKIP_HEAVY))     // let the other stream's heavy kernel get resident first
+        hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(WAVE), 0, as_stream(stream), (long long)3000);
     if (!(s->flags & LHVI_PBP_SKIP_FAST)) {
         if (s->heavy_desc && s->n_heavy > 0 && !(s->flags & LHVI_PBP_SKIP_HEAVY))
-            hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(min((s->n_heavy + 3) / 4, cus * heavy_per_cu)), dim3(BLOCK), 0, as_stream(stream),
+            hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(min((s->n_heavy + 3) / 4, cus * heavy_blocks)), dim3(BLOCK), 0, as_stream(stream),
                                *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy);
         if (s->light_desc && s->n_light > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
-            hipLaunchKernelGGL(pbp_f2v_light_kernel, dim3(min((s->n_light + 3) / 4, cus * light_per_cu)), dim3(BLOCK), 0, as_stream(stream),
+            hipLaunchKernelGGL(pbp_f2v_light_kernel, dim3(min((s->n_light + 3) / 4, cus * min(light_per_cu, side_blocks))), dim3(BLOCK), 0, as_stream(stream),
                                *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->light_desc), s->n_light);
         if (nfast > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
-            hipLaunchKernelGGL(pbp_f2v_fast_kernel, dim3(min((nfast + 3) / 4, cus * fast_per_cu)), dim3(BLOCK), 0, as_stream(stream),
+            hipLaunchKernelGGL(pbp_f2v_fast_kernel, dim3(min((nfast + 3) / 4, cus * min(fast_per_cu, side_blocks))), dim3(BLOCK), 0, as_stream(stream),
                                *g, *pots, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->fast_desc), pots->param);
     }
     if (!(s->flags & LHVI_PBP_SKIP_GENERIC) && ngen > 0) {
         int pts_log2 = s->generic_edges ? s->generic_pts_log2 : 6;
         if (pts_log2 < 0 || pts_log2 > 6) pts_log2 = 6;
         const int groups = (ngen + (64 >> pts_log2) - 1) / (64 >> pts_log2);
-        hipLaunchKernelGGL(pbp_f2v_generic_kernel, dim3(min((groups + 3) / 4, cus * gen_per_cu)), dim3(BLOCK), 0, as_stream(stream), *g, *pots,
+        hipLaunchKernelGGL(pbp_f2v_generic_kernel, dim3(min((groups + 3) / 4, cus * min(gen_per_cu, side_blocks))), dim3(BLOCK), 0, as_stream(stream), *g, *pots,
                            *s, v2f, f2v, pts_log2);
     }
     return check_launch();

@@ -326,20 +326,7 @@ class ShardedRunner:
 
     # -- phase 2: the rest of the sweep, reading the peers' rows straight from the receive buffer ---------------------
     def _f2v(self, s, f2v_events=None):
-        bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
-        if f2v_events:          # the dominant kernel alone between the events, then the other two
-            base = s.flags
-            s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_LIGHT
-            f2v_events[0].record()
-            _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
-            f2v_events[1].record()
-            s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_HEAVY
-            _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
-            s.flags = base | _abi.PBP_SKIP_FAST
-            _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
-            s.flags = base
-        else:
-            _abi.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, _abi.ptr(bp.v2f), _abi.ptr(bp.f2v), st))
+        self.bp._launch_f2v(s, f2v_events)          # heavy kernel on this stream, the other f2v kernels beside it
 
     def post(self, recv, f2v_events=None):
         """plain schedule: everything after the exchange, over all variables and edges"""

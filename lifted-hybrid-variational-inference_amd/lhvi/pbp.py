@@ -30,6 +30,7 @@ class _ParticleSweep:
     max_log_value = 700
     _epbp_discrete = True
     verbose = False
+    split_f2v_streams = True        # heavy f2v kernel on the current stream, the other f2v kernels beside it on a side stream
 
     # ---- set-up ------------------------------------------------------------------------------
     def _setup(self, graph_like, flat=None, edge_key=None):
@@ -188,19 +189,51 @@ class _ParticleSweep:
             _abi.check(l.lhvi_pbp_proposal(g, self._struct(), _abi.ptr(self.f2v), _abi.ptr(self.eta),
                                            _abi.ptr(self.q_dev), st))
             self._generate_sample()
-            if f2v_events:      # time the dominant (continuous x continuous) kernel alone: three calls, one kernel each
-                s = self._struct()
-                base = s.flags
-                s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_LIGHT
+            self._launch_f2v(self._struct(), f2v_events)
+
+    def _launch_f2v(self, s, f2v_events=None):
+        """the f -> v half sweep.  With a heavy work list the continuous x continuous kernel (fp64-VALU bound, persistent)
+        runs on the current stream and the kernels of the other edges (bound by memory-level parallelism) on a side stream
+        at the same time -- they write disjoint rows of f2v, and the side kernels' waves fill issue slots the heavy kernel
+        leaves idle (measured: 14.97 -> 13.43 ms for the phase on the headline graph).  `f2v_events`: (start, end) events
+        recorded around the heavy kernel on its stream."""
+        l, g, p = _abi.lib(), self.dg.g, self.dg.p
+        args = (_abi.ptr(self.v2f), _abi.ptr(self.f2v))
+        base = s.flags
+        if self.split_f2v_streams and s.n_heavy > 0:
+            torch = _abi.require_gpu()
+            main = torch.cuda.current_stream()
+            if getattr(self, '_f2v_side', None) is None:
+                self._f2v_side = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
+            side, fork, join = self._f2v_side
+            fork.record(main)                                   # everything the f2v kernels read is complete here
+            side.wait_event(fork)
+            s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_LIGHT
+            if f2v_events:
                 f2v_events[0].record()
-                _abi.check(l.lhvi_pbp_f2v(g, p, s, _abi.ptr(self.v2f), _abi.ptr(self.f2v), st))
+            _abi.check(l.lhvi_pbp_f2v(g, p, s, *args, _abi.stream_ptr()))
+            if f2v_events:
                 f2v_events[1].record()
-                s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_HEAVY
-                _abi.check(l.lhvi_pbp_f2v(g, p, s, _abi.ptr(self.v2f), _abi.ptr(self.f2v), st))
-                s.flags = base | _abi.PBP_SKIP_FAST
-                _abi.check(l.lhvi_pbp_f2v(g, p, s, _abi.ptr(self.v2f), _abi.ptr(self.f2v), st))
-            else:
-                _abi.check(l.lhvi_pbp_f2v(g, p, self._struct(), _abi.ptr(self.v2f), _abi.ptr(self.f2v), st))
+            with torch.cuda.stream(side):
+                s.flags = base | _abi.PBP_SKIP_HEAVY | _abi.PBP_BESIDE_HEAVY      # a short delay first: heavy must be resident before these
+                _abi.check(l.lhvi_pbp_f2v(g, p, s, *args, _abi.stream_ptr()))
+                join.record(side)
+            main.wait_event(join)
+            s.flags = base
+            return
+        st = _abi.stream_ptr()
+        if f2v_events:      # time the dominant kernel alone: three calls, one kernel each
+            s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_LIGHT
+            f2v_events[0].record()
+            _abi.check(l.lhvi_pbp_f2v(g, p, s, *args, st))
+            f2v_events[1].record()
+            s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_HEAVY
+            _abi.check(l.lhvi_pbp_f2v(g, p, s, *args, st))
+            s.flags = base | _abi.PBP_SKIP_FAST
+            _abi.check(l.lhvi_pbp_f2v(g, p, s, *args, st))
+            s.flags = base
+        else:
+            _abi.check(l.lhvi_pbp_f2v(g, p, s, *args, st))
 
     # ---- dict views with the reference's keys ------------------------------------------------------
     def _host(self, name):
