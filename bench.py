@@ -90,7 +90,6 @@ def main():
     ap.add_argument('--particles', type=int, default=64)
     ap.add_argument('--grid', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--one-stream', action='store_true', help='all f2v kernels back to back on one stream (tuning aid)')
     args = ap.parse_args()
 
     import torch
@@ -124,7 +123,6 @@ def main():
 
     if world == 1:
         bp = EPBP(None, n=n, proposal_approximation='simple', sampler='device', seed=1)
-        bp.split_f2v_streams = not args.one_stream
         bp._setup(None, flat=flat)
         runner = dist.SingleRunner(bp)
     else:
@@ -156,24 +154,6 @@ def main():
     f2v_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))     # HIP events on the launch stream
     # sharded runs launch the dominant kernel twice per sweep (interior edges while the exchange is in flight, then the rest)
     f2v_ms += float(sum(a.elapsed_time(b) for a, b in getattr(runner, 'f2v_extra', []))) / args.steps
-    # the same kernel with nothing beside it (in the sweep the other f2v kernels run on a second stream at the same time):
-    # three launches on the final state, outside the timed region
-    solo_ms = None
-    if world == 1 and not args.one_stream:
-        from lhvi import _abi as A
-        sp = bp._struct()
-        sp.flags |= A.PBP_SKIP_GENERIC | A.PBP_SKIP_LIGHT
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        scratch = torch.empty_like(bp.f2v)
-        A.check(A.lib().lhvi_pbp_f2v(bp.dg.g, bp.dg.p, sp, A.ptr(bp.v2f), A.ptr(scratch), A.stream_ptr()))
-        e0.record()
-        for _ in range(3):
-            A.check(A.lib().lhvi_pbp_f2v(bp.dg.g, bp.dg.p, sp, A.ptr(bp.v2f), A.ptr(scratch), A.stream_ptr()))
-        e1.record()
-        torch.cuda.synchronize()
-        solo_ms = e0.elapsed_time(e1) / 3
-        del scratch
-
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         sweeps_per_s = args.steps / elapsed
@@ -205,12 +185,6 @@ def main():
                          'unit': 'TFLOP/s', 'frac': f2v_tflops / FP64_PEAK_TFLOPS,
                          'traffic': measured_traffic('pbp_f2v_heavy_kernel') if world == 1 and args.edges == 10_000_000 else None,
                          'kernel_ms': f2v_ms, 'edges_per_launch': heavy_edges, 'joint_terms_per_launch': terms,
-                         'alone': None if solo_ms is None else {
-                             'kernel_ms': solo_ms, 'achieved': terms * FLOP_PER_TERM / (solo_ms * 1e-3) / 1e12,
-                             'frac': terms * FLOP_PER_TERM / (solo_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                             'note': 'the kernel with nothing beside it; in the sweep (kernel_ms, achieved, frac above) the f2v kernels '
-                                     'of the other edges run on a second stream at the same time and share its CUs'},
-                         'flop_per_term': FLOP_PER_TERM,
                          'note': 'fp64 compute roof (dense peak of the dtype; VALU instructions, not MFMA).  Algorithmic count: 16 flop '
                                  'per (output point, partner particle) term.  Terms at the particles cost 9 fp64 + 3 int32 issue '
                                  'slots + 2 LDS reads each (issue ceiling 58 % of this peak); terms at the integral points are '

@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define LHVI_ABI_VERSION 3   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
-                              * 3: lhvi_pbp_t gained var_lo / var_hi */
+#define LHVI_ABI_VERSION 4   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
+                              * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -137,11 +137,6 @@ int lhvi_log_likelihood(const lhvi_graph_t* g, const lhvi_pots_t* pots, const do
                                    * profiling aid) */
 #define LHVI_PBP_NO_GRID 128u    /* lhvi_pbp_f2v: integral points always by the direct form (one exponential per term), never by the
                                    * uniform-grid recurrence (testing / profiling aid) */
-#define LHVI_PBP_BESIDE_HEAVY 256u /* lhvi_pbp_f2v with SKIP_HEAVY, issued on a second stream beside a call that runs the heavy
-                                   * kernel: a one-wavefront ~30 us delay is launched first, so that the heavy kernel's persistent
-                                   * workgroups are all resident before these kernels' are dispatched.  They then run in what the
-                                   * heavy kernel leaves free and in its tail (the other order displaces heavy workgroups, which
-                                   * then start late with a full static share of the work list) */
 
 typedef struct lhvi_pbp {
     int32_t n;                  /* particle slots per variable */
@@ -184,9 +179,16 @@ typedef struct lhvi_pbp {
      * _resample_uniq): they work on [var_lo, var_hi) when var_hi > var_lo, on every variable when both are 0.  A sharded
      * run numbers its interior variables first and sweeps them while the boundary rows are in flight. */
     int32_t var_lo, var_hi;
+    /* optional: LHVI_PBP_TICKET_WORDS 32-bit words of device memory for lhvi_pbp_f2v.  When set, the persistent heavy kernel
+     * cuts its work list into one contiguous range per XCD (each XCD has its own L2) and hands each range out in chunks of
+     * consecutive entries through an atomic counter, which the call resets on its stream: the two directions of a factor
+     * are neighbours in the list, so a wave's consecutive entries share particles and messages in cache, and a workgroup
+     * dispatched late finds less left to do instead of owing a full static share.  NULL: every wave strides over the list. */
+    uint32_t* f2v_ticket;
 } lhvi_pbp_t;
 
 #define LHVI_PBP_DESC_BYTES 128
+#define LHVI_PBP_TICKET_WORDS 8
 /* static per-edge descriptors of the fast work list: lets the persistent f2v kernels fetch everything about an edge with
  * scalar loads.  Must be rebuilt when np / the graph / the potentials change.  Layout (32-bit words unless noted):
  *   0 edge   1 target variable   2 partner variable   3 partner's canonical edge   4 class (lhvi_pbp_classify)

@@ -542,6 +542,55 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
 // arithmetic as the general kernel above in MODE_CONST, but (a) only this mode, which fits 7 waves per SIMD, and
 // (b) software-pipelined: while edge k is in its term loops the loads of edge k+1 are already in flight (its descriptor
 // was fetched one edge earlier still), so a wave never sits out a memory round trip between two term loops.
+// Work distribution of the persistent f2v kernels.  With a ticket word (lhvi_pbp_t.f2v_ticket) the waves claim chunks of
+// WORK_CHUNK consecutive list entries with one atomic add each -- the next chunk is claimed when a chunk is entered and
+// its index read (v_readfirstlane of the returned value) only when the chunk is used up, so the atomic's round trip hides
+// behind WORK_CHUNK edges -- and a workgroup that reaches its CU late (another kernel's workgroups held the slot) simply
+// finds less left to claim.  Without a ticket every wave strides over the list: a late workgroup then still owes its
+// full static share.
+template <int WORK_CHUNK>
+struct WorkCursor {
+    uint32_t* ticket;       // nullptr: static striding
+    int item, limit, left, stride, pending, lo;
+    __device__ __forceinline__ int claim(int lane) const {
+        int v = 0;
+        if (lane == 0) v = lo + (int)atomicAdd(ticket, (uint32_t)WORK_CHUNK);
+        return v;                                           // valid in lane 0
+    }
+    // with tickets the list is cut into one contiguous range per XCD (workgroup i runs on XCD i mod 8, and each XCD has
+    // its own L2: its waves then walk one region of the descriptors, particles and messages), each with its own counter
+    __device__ __forceinline__ bool start(uint32_t* base, int nitems, int lane) {
+        stride = gridDim.x * (BLOCK / WAVE);
+        left = 0; pending = 0; lo = 0; limit = nitems;
+        ticket = base;
+        if (ticket) {
+            const int parts = min((int)gridDim.x, LHVI_PBP_TICKET_WORDS);
+            const int part = blockIdx.x % parts;
+            const int per = ((nitems + parts - 1) / parts + WORK_CHUNK - 1) / WORK_CHUNK * WORK_CHUNK;
+            lo = min(part * per, nitems);
+            limit = min(lo + per, nitems);
+            ticket = base + part;
+            item = __builtin_amdgcn_readfirstlane(claim(lane));
+            pending = claim(lane);
+            left = WORK_CHUNK - 1;
+        } else {
+            item = blockIdx.x * (BLOCK / WAVE) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        }
+        return item < limit;
+    }
+    __device__ __forceinline__ int next() const {           // the entry after `item` (>= limit: none)
+        if (!ticket) return item + stride;
+        return left > 0 ? item + 1 : __builtin_amdgcn_readfirstlane(pending);
+    }
+    __device__ __forceinline__ void advance(int nxt, int lane) {     // move to `nxt` = next()
+        if (ticket) {
+            if (left > 0) --left;
+            else { left = WORK_CHUNK - 1; pending = claim(lane); }
+        }
+        item = nxt;
+    }
+};
+
 struct HeavyData { double y, m, x0, x1; };
 
 // ---- integral points on a uniform grid: sum_j exp(a_j + b_j x_t) for t < 32 with lane = partner particle j ------------
@@ -639,21 +688,21 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7
     // (descs is a kernel argument of its own so that its restrict qualifier holds and the descriptors come through the
     // scalar cache: s_load does not take part in vmcnt, which the prefetched vector loads rely on)
     const int last = nitems - 1;
-    const int nwaves = gridDim.x * (BLOCK / WAVE);
     const int n = s.n, S = s.n + s.T;
-    int item = blockIdx.x * (BLOCK / WAVE) + wid;
-    if (item >= nitems) return;
+    WorkCursor<8> cur;
+    if (!cur.start(s.f2v_ticket, nitems, lane)) return;
     // pipeline: the loads of edge k+1 are issued as soon as edge k has been staged into LDS (its registers are free
     // then, so nothing has to be rotated) and stay in flight through the term loops of edge k; `dn` is the full
     // descriptor of edge k+1, fetched one edge ahead, `d` the seven words the arithmetic of edge k needs
     struct { int32_t e, nj, np, T, gb, grid; double ay, by, c, axy, bx, kx, gx0, gh; } d;
-    FastDesc dn = descs[item];
+    FastDesc dn = descs[cur.item];
     HeavyData h = heavy_fetch(dn, g, s, v2f, lane);
     for (;;) {
         d.e = dn.e; d.nj = dn.nj; d.np = dn.np; d.T = dn.T; d.gb = dn.gb; d.grid = dn.pad[1];
         d.ay = dn.ay; d.by = dn.by; d.c = dn.c; d.axy = dn.axy; d.bx = dn.bx; d.kx = dn.kx; d.gx0 = dn.pad2[0]; d.gh = dn.pad2[1];
-        const bool more = item + nwaves < nitems;
-        dn = descs[__builtin_amdgcn_readfirstlane(min(item + nwaves, last))];
+        const int nxt = cur.next();
+        const bool more = nxt < cur.limit;
+        dn = descs[__builtin_amdgcn_readfirstlane(min(nxt, last))];
         const int np = d.np, nj = d.nj;
         double* out = f2v + (int64_t)d.e * S;
         const double kconst = d.kx;
@@ -723,14 +772,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7
             if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
         }
         if (!more) break;
-        item += nwaves;
+        cur.advance(nxt, lane);
     }
-}
-
-// holds a stream back for `ticks` of the 100 MHz wall clock (one wavefront, asleep most of the time)
-__global__ void stream_delay_kernel(long long ticks) {
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
 // LIGHT edges: HybridQuadratic(1 discrete, 1 continuous) with a binary (or observed) discrete side -- the edges between
@@ -766,21 +809,22 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_light_kernel(lhvi_graph_t g, lh
     __shared__ LogRec sh_log[LOG_TAB_N];
     load_log_table(sh_log);
     load_exp_table(sh_tab);
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int last = nitems - 1;
-    const int nwaves = gridDim.x * (BLOCK / WAVE);
     const int n = s.n, S = s.n + s.T;
-    int item = blockIdx.x * (BLOCK / WAVE) + wid;
-    if (item >= nitems) return;
+    // (static striding: this kernel's entries are short, a late workgroup owes little, and neighbouring waves on neighbouring
+    // entries measured 15 % faster than chunks of 64 through the ticket)
+    WorkCursor<64> work;
+    if (!work.start(nullptr, nitems, lane)) return;
     struct { int32_t e, type, nj, np, T, pce; double pval, A0, b0, c0, A1, b1, c1; } d;
-    FastDesc dn = descs[item];
+    FastDesc dn = descs[work.item];
     LightData h = light_fetch(dn, g, s, v2f, lane);
     for (;;) {
         d.e = dn.e; d.type = dn.pad[0]; d.nj = dn.nj; d.np = dn.np; d.T = dn.T; d.pce = dn.pce; d.pval = dn.pval;
         d.A0 = dn.ay; d.b0 = dn.by; d.c0 = dn.c; d.A1 = dn.axy; d.b1 = dn.bx; d.c1 = dn.kx;
-        const bool more = item + nwaves < nitems;
-        dn = descs[__builtin_amdgcn_readfirstlane(min(item + nwaves, last))];
+        const int nxt = work.next();
+        const bool more = nxt < work.limit;
+        dn = descs[__builtin_amdgcn_readfirstlane(min(nxt, last))];
         double* out = f2v + (int64_t)d.e * S;
         const LightData cur = h;
         if (d.type == 1) {
@@ -809,7 +853,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_light_kernel(lhvi_graph_t g, lh
             if (lane < d.np) out[lane] = res > 0.0 ? log_table(res, sh_log) : -700.0;
         }
         if (!more) break;
-        item += nwaves;
+        work.advance(nxt, lane);
     }
 }
 
@@ -1351,8 +1395,10 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     static const int light_per_cu = blocks_per_cu((const void*)pbp_f2v_light_kernel);
     static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel);
     const int heavy_blocks = heavy_per_cu, side_blocks = 8;
-    if ((s->flags & LHVI_PBP_BESIDE_HEAVY) && (s->flags & LHVI_PBP_SKIP_HEAVY))     // let the other stream's heavy kernel get resident first
-        hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(WAVE), 0, as_stream(stream), (long long)3000);
+    // work ticket of the heavy kernel: reset on this stream right before the launch
+    const bool run_heavy = !(s->flags & LHVI_PBP_SKIP_FAST) && s->heavy_desc && s->n_heavy > 0 && !(s->flags & LHVI_PBP_SKIP_HEAVY);
+    if (s->f2v_ticket && run_heavy && hipMemsetAsync(s->f2v_ticket, 0, LHVI_PBP_TICKET_WORDS * sizeof(uint32_t), as_stream(stream)) != hipSuccess)
+        return LHVI_E_LAUNCH;
     if (!(s->flags & LHVI_PBP_SKIP_FAST)) {
         if (s->heavy_desc && s->n_heavy > 0 && !(s->flags & LHVI_PBP_SKIP_HEAVY))
             hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(min((s->n_heavy + 3) / 4, cus * heavy_blocks)), dim3(BLOCK), 0, as_stream(stream),

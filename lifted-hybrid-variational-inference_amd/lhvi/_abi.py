@@ -50,6 +50,7 @@ class PbpStruct(C.Structure):
         ('bslot', C.c_void_p), ('brow_ptr', C.c_void_p), ('brow_off', C.c_void_p), ('brow_peer', C.c_void_p),
         ('recv', C.c_void_p), ('rank', C.c_int32), ('var_degree', C.c_void_p),
         ('var_lo', C.c_int32), ('var_hi', C.c_int32),
+        ('f2v_ticket', C.c_void_p),
     ]
 
 
@@ -68,8 +69,7 @@ PBP_SKIP_TERMS = 16
 PBP_SKIP_HEAVY = 32
 PBP_SKIP_LIGHT = 64
 PBP_NO_GRID = 128
-PBP_BESIDE_HEAVY = 256
-ABI_VERSION = 3             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
+ABI_VERSION = 4             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
 PBP_DESC_BYTES = 128
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE
 

@@ -326,7 +326,7 @@ class ShardedRunner:
 
     # -- phase 2: the rest of the sweep, reading the peers' rows straight from the receive buffer ---------------------
     def _f2v(self, s, f2v_events=None):
-        self.bp._launch_f2v(s, f2v_events)          # heavy kernel on this stream, the other f2v kernels beside it
+        self.bp._launch_f2v(s, f2v_events)
 
     def post(self, recv, f2v_events=None):
         """plain schedule: everything after the exchange, over all variables and edges"""

@@ -30,7 +30,7 @@ class _ParticleSweep:
     max_log_value = 700
     _epbp_discrete = True
     verbose = False
-    split_f2v_streams = True        # heavy f2v kernel on the current stream, the other f2v kernels beside it on a side stream
+    dynamic_f2v = True              # the persistent f2v kernels claim their work in chunks (else static striding)
 
     # ---- set-up ------------------------------------------------------------------------------
     def _setup(self, graph_like, flat=None, edge_key=None):
@@ -57,6 +57,7 @@ class _ParticleSweep:
         self.particles = dg.zeros(flat.V, n)
         self.old_particles = dg.zeros(flat.V, n)
         self.uniq = torch.zeros(flat.V, n, dtype=torch.uint8, device=dg.device)
+        self.f2v_ticket = torch.zeros(8, dtype=torch.int32, device=dg.device)     # work counters of the heavy f2v kernel (LHVI_PBP_TICKET_WORDS)
         self.flags = (_abi.PBP_EP if self.proposal_approximation == 'EP' else 0) | \
                      (_abi.PBP_EPBP_DISCRETE if self._epbp_discrete else 0)
         self._views = {}
@@ -124,6 +125,7 @@ class _ParticleSweep:
         s.fast_desc = _abi.ptr(getattr(self, 'fast_desc', None))
         s.heavy_desc, s.n_heavy = _abi.ptr(getattr(self, 'heavy_desc', None)), int(getattr(self, 'n_heavy', 0))
         s.light_desc, s.n_light = _abi.ptr(getattr(self, 'light_desc', None)), int(getattr(self, 'n_light', 0))
+        s.f2v_ticket = _abi.ptr(self.f2v_ticket) if self.dynamic_f2v else None
         return s
 
     # ---- sampling ----------------------------------------------------------------------------
@@ -192,37 +194,12 @@ class _ParticleSweep:
             self._launch_f2v(self._struct(), f2v_events)
 
     def _launch_f2v(self, s, f2v_events=None):
-        """the f -> v half sweep.  With a heavy work list the continuous x continuous kernel (fp64-VALU bound, persistent)
-        runs on the current stream and the kernels of the other edges (bound by memory-level parallelism) on a side stream
-        at the same time -- they write disjoint rows of f2v, and the side kernels' waves fill issue slots the heavy kernel
-        leaves idle (measured: 14.97 -> 13.43 ms for the phase on the headline graph).  `f2v_events`: (start, end) events
-        recorded around the heavy kernel on its stream."""
-        l, g, p = _abi.lib(), self.dg.g, self.dg.p
+        """the f -> v half sweep (`lhvi_pbp_f2v`).  `f2v_events`: (start, end) events recorded around the heavy kernel: the
+        call is then split with the SKIP flags into three, one kernel each, on the same stream."""
+        l, g, p, st = _abi.lib(), self.dg.g, self.dg.p, _abi.stream_ptr()
         args = (_abi.ptr(self.v2f), _abi.ptr(self.f2v))
-        base = s.flags
-        if self.split_f2v_streams and s.n_heavy > 0:
-            torch = _abi.require_gpu()
-            main = torch.cuda.current_stream()
-            if getattr(self, '_f2v_side', None) is None:
-                self._f2v_side = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
-            side, fork, join = self._f2v_side
-            fork.record(main)                                   # everything the f2v kernels read is complete here
-            side.wait_event(fork)
-            s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_LIGHT
-            if f2v_events:
-                f2v_events[0].record()
-            _abi.check(l.lhvi_pbp_f2v(g, p, s, *args, _abi.stream_ptr()))
-            if f2v_events:
-                f2v_events[1].record()
-            with torch.cuda.stream(side):
-                s.flags = base | _abi.PBP_SKIP_HEAVY | _abi.PBP_BESIDE_HEAVY      # a short delay first: heavy must be resident before these
-                _abi.check(l.lhvi_pbp_f2v(g, p, s, *args, _abi.stream_ptr()))
-                join.record(side)
-            main.wait_event(join)
-            s.flags = base
-            return
-        st = _abi.stream_ptr()
-        if f2v_events:      # time the dominant kernel alone: three calls, one kernel each
+        if f2v_events:
+            base = s.flags
             s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_LIGHT
             f2v_events[0].record()
             _abi.check(l.lhvi_pbp_f2v(g, p, s, *args, st))

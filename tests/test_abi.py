@@ -32,7 +32,7 @@ def test_header_symbols_are_exported(built):
     assert len(syms) >= 25
     for name in syms:
         assert hasattr(handle, name), 'liblhvi.so does not export %s' % name
-    assert handle.lhvi_version() == 3
+    assert handle.lhvi_version() == 4
 
 
 def test_python_binding_covers_header(built):

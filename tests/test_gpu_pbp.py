@@ -415,25 +415,3 @@ def test_batched_kl_of_tabulated_beliefs(api):
         want = utils.kl_continuous(lambda t: pdf(t, mu1[v], s1[v]), lambda t: pdf(t, mu2[v], s2[v]), -14, 14)
         assert got[v] == pytest.approx(want, rel=1e-6)
         assert got[v] == pytest.approx(utils.kl_normal(mu1[v], mu2[v], s1[v], s2[v]), rel=1e-6)
-
-
-def test_f2v_on_two_streams_equals_one_stream(api):
-    """the heavy kernel on the current stream with the other f2v kernels beside it on a side stream (the default) writes
-    the same messages, bit for bit, as all kernels back to back on one stream -- over several whole sweeps"""
-    import torch
-    from lhvi import synth
-    from lhvi.pbp import EPBP
-    flat = synth.hybrid_mrf_flat(V=20000, deg=4, seed=13)
-    res = []
-    for split in (True, False):
-        bp = EPBP(None, n=64, proposal_approximation='EP', sampler='device', seed=7)
-        bp.split_f2v_streams = split
-        bp._setup(None, flat=flat)
-        assert bp.n_heavy > 0 and bp.n_light > 0
-        _init(api, bp)
-        for _ in range(4):
-            bp.sweep(last=False)
-        torch.cuda.synchronize()
-        res.append((bp.f2v.clone(), bp.v2f.clone(), bp.q_dev.clone(), bp.particles.clone()))
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
