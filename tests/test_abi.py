@@ -3,6 +3,7 @@ into the oracle and fails loudly without a GPU."""
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -77,3 +78,16 @@ def test_product_never_imports_oracle():
     assert hits.strip() == '', hits
     hits = subprocess.run(['grep', '-rIl', 'liboracle', PKG], capture_output=True, text=True).stdout
     assert hits.strip() == '', hits
+
+
+def test_graft_entry_build_runs():
+    """the driver's build check: __graft_entry__.build() compiles (or finds up to date) the library and the oracle and
+    verifies the ABI version and the exported symbols"""
+    import importlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        entry = importlib.import_module('__graft_entry__')
+        entry.build()
+    finally:
+        sys.path.remove(root)
