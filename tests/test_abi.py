@@ -33,7 +33,11 @@ def test_header_symbols_are_exported(built):
     assert len(syms) >= 25
     for name in syms:
         assert hasattr(handle, name), 'liblhvi.so does not export %s' % name
-    assert handle.lhvi_version() == 4
+    # one version number in three places: the header, the library built from it, the Python binding's struct layouts
+    header = open(os.path.join(ROOT, 'include', 'lhvi.h')).read()
+    declared = int(re.search(r'#define\s+LHVI_ABI_VERSION\s+(\d+)', header).group(1))
+    from lhvi import _abi
+    assert handle.lhvi_version() == declared == _abi.ABI_VERSION
 
 
 def test_python_binding_covers_header(built):
