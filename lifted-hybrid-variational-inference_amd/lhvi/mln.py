@@ -1,8 +1,8 @@
-"""Soft-logic operators and MLN potentials (``/root/reference/MLNPotential.py:6-58``).
+"""Soft-logic connectives and Markov-logic potentials (API of ``/root/reference/MLNPotential.py:6-58``).
 
-Same names and values as the reference.  ``MLNPotential.get`` is ``e ** (formula(x) * w)``.  For the
-device the formula is traced once into postfix bytecode (``lhvi.expr``); the kernels then evaluate
-``w * formula(x)`` in log space.
+Truth values live in [0, 1]; the connectives are the product / probabilistic-sum family, and a weighted formula turns
+into the potential ``exp(w * formula(x))`` (hard formulas: the indicator ``formula(x) > 0``).  On the device a formula is
+traced once per arity into postfix bytecode (``lhvi.expr``), which the generic f2v kernel interprets in log space.
 """
 from __future__ import annotations
 
@@ -13,74 +13,91 @@ from .graph import Potential
 from .potentials import POT_MLN, POT_MLN_HARD
 
 
-def and_op(x, y):
-    return x * y
+class SoftLogic:
+    """the connectives, as arithmetic on truth values (plain numbers, NumPy arrays or ``expr`` tracers alike)"""
+
+    @staticmethod
+    def conj(p, q):
+        return p * q
+
+    @staticmethod
+    def disj(p, q):
+        return p + q - p * q
+
+    @staticmethod
+    def neg(p):
+        return 1 - p
+
+    @staticmethod
+    def implies(p, q):
+        return SoftLogic.disj(1 - p, q)
+
+    @staticmethod
+    def iff(p, q):
+        return SoftLogic.implies(p, q) * SoftLogic.implies(q, p)
+
+    @staticmethod
+    def near(p, q):
+        """soft equality of two real values: a negated squared distance (0 when equal)"""
+        return -(p - q) ** 2
 
 
-def or_op(x, y):
-    return x + y - x * y
+# the reference's names
+and_op, or_op, neg_op = SoftLogic.conj, SoftLogic.disj, SoftLogic.neg
+imp_op, bic_op, eq_op = SoftLogic.implies, SoftLogic.iff, SoftLogic.near
 
 
-def neg_op(x):
-    return 1 - x
+class _FormulaPotential(Potential):
+    """a potential defined by a Python formula over the factor's arguments; ``kind`` selects the device interpretation"""
 
+    kind = None
 
-def imp_op(x, y):
-    return or_op(1 - x, y)
-
-
-def bic_op(x, y):
-    return imp_op(x, y) * imp_op(y, x)
-
-
-def eq_op(x, y):
-    return -(x - y) ** 2
-
-
-class _Traced:
-    """Caches the device bytecode per arity."""
+    def __init__(self, formula, w):
+        Potential.__init__(self, symmetric=False)
+        self.formula, self.w = formula, w
+        self._programs = {}
 
     def _program(self, arity):
-        cache = self.__dict__.setdefault('_prog_cache', {})
-        if arity not in cache:
-            cache[arity] = expr.trace(self.formula, arity)
-        return cache[arity]
-
-
-class MLNPotential(_Traced, Potential):
-    def __init__(self, formula, w=1):
-        Potential.__init__(self, symmetric=False)
-        self.formula = formula
-        self.w = w
+        if arity not in self._programs:
+            self._programs[arity] = expr.trace(self.formula, arity)
+        return self._programs[arity]
 
     def get(self, parameters):
-        return e ** (self.formula(parameters) * self.w)
+        return self._value(self.formula(parameters))
+
+    def device_spec(self, domains):
+        program = self._program(len(domains))
+        return self.kind, [float(self.w), float(len(program) // 2)] + program
+
+
+class MLNPotential(_FormulaPotential):
+    kind = POT_MLN
+
+    def __init__(self, formula, w=1):
+        _FormulaPotential.__init__(self, formula, w)
+
+    def _value(self, truth):
+        return e ** (truth * self.w)
 
     def to_log_potential(self):
         return MLNLogPotential(self.formula, self.w)
 
-    def device_spec(self, domains):
-        prog = self._program(len(domains))
-        return POT_MLN, [float(self.w), float(len(prog) // 2)] + prog
 
+class MLNHardPotential(_FormulaPotential):
+    kind = POT_MLN_HARD
 
-class MLNHardPotential(_Traced, Potential):
     def __init__(self, formula):
-        Potential.__init__(self, symmetric=False)
-        self.formula = formula
+        _FormulaPotential.__init__(self, formula, 0.0)
 
-    def get(self, parameters):
-        return 1 if self.formula(parameters) > 0 else 0
-
-    def device_spec(self, domains):
-        prog = self._program(len(domains))
-        return POT_MLN_HARD, [0.0, float(len(prog) // 2)] + prog
+    def _value(self, truth):
+        return 1 if truth > 0 else 0
 
 
 class MLNLogPotential:
+    """the log of an ``MLNPotential`` as a callable: ``w * formula(args)``"""
+
     def __init__(self, formula, w=1):
-        self.formula = formula
-        self.w = w
+        self.formula, self.w = formula, w
 
     def __call__(self, args):
         return self.formula(args) * self.w
