@@ -969,6 +969,8 @@ __device__ __forceinline__ void gdiv(double a0, double a1, double b0, double b1,
 // T-point moments are DPP reductions inside the lane group.  Each group accumulates the information-form sum of its edges; the groups
 // are folded at the end (summation order differs from the reference's edge order by rounding only).
 // ph_out != nullptr: sharded mode -- write the local information-form sums instead of q (lhvi_pbp_proposal_partial)
+// EP: compiled with / without the cavity branch -- the 'simple' rule needs fewer registers (the launcher picks by s.flags)
+template <bool EP>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) pbp_proposal_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                             double* __restrict__ eta, double* __restrict__ q,
                                                             double* __restrict__ ph_out) {
@@ -997,7 +999,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8
         const int e = live ? g.var_edge[k] : g.var_edge[k0];
         const double* msg = f2v + (int64_t)e * S + n;
         const double b0 = eta[2 * e], b1 = eta[2 * e + 1];
-        const bool use_cav = (s.flags & LHVI_PBP_EP) && !(q1 >= b1);
+        const bool use_cav = EP && !(q1 >= b1);
         double c0 = 0.0, c1 = 1.0;
         if (use_cav) gdiv(q0, q1, b0, b1, c0, c1);
         const double csd = sqrt(c1);
@@ -1424,8 +1426,12 @@ int lhvi_pbp_proposal(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* 
     if (int rc = validate_pbp(g, s)) return rc;
     if (!f2v || !eta || !q) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
-    hipLaunchKernelGGL(pbp_proposal_kernel, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0,
-                       as_stream(stream), *g, *s, f2v, eta, q, (double*)nullptr);
+    if (s->flags & LHVI_PBP_EP)
+        hipLaunchKernelGGL(pbp_proposal_kernel<true>, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0,
+                           as_stream(stream), *g, *s, f2v, eta, q, (double*)nullptr);
+    else
+        hipLaunchKernelGGL(pbp_proposal_kernel<false>, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0,
+                           as_stream(stream), *g, *s, f2v, eta, q, (double*)nullptr);
     return check_launch();
 }
 
@@ -1433,8 +1439,12 @@ int lhvi_pbp_proposal_partial(const lhvi_graph_t* g, const lhvi_pbp_t* s, const 
     if (int rc = validate_pbp(g, s)) return rc;
     if (!f2v || !eta || !ph || !s->q) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
-    hipLaunchKernelGGL(pbp_proposal_kernel, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0,
-                       as_stream(stream), *g, *s, f2v, eta, (double*)nullptr, ph);
+    if (s->flags & LHVI_PBP_EP)
+        hipLaunchKernelGGL(pbp_proposal_kernel<true>, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0,
+                           as_stream(stream), *g, *s, f2v, eta, (double*)nullptr, ph);
+    else
+        hipLaunchKernelGGL(pbp_proposal_kernel<false>, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0,
+                           as_stream(stream), *g, *s, f2v, eta, (double*)nullptr, ph);
     return check_launch();
 }
 
