@@ -227,7 +227,9 @@ int lhvi_pbp_classify(const lhvi_graph_t* g, const lhvi_pots_t* pots, uint8_t* e
 int lhvi_pbp_uniq(const lhvi_graph_t* g, int32_t n, const double* particles, const int32_t* np, uint8_t* uniq, void* stream);
 /* EPBP.message_rv_to_f + important_weight + log_message_balance: EPBP.py:156-174,204-215; HLBP.py:173-191,225-236 */
 int lhvi_pbp_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* v2f, void* stream);
-/* EPBP.message_f_to_rv at the new particles + integral points: EPBP.py:176-194,275-285; HLBP.py:193-215 */
+/* EPBP.message_f_to_rv at the new particles + integral points: EPBP.py:176-194,275-285; HLBP.py:193-215.
+ * Up to four kernels on `stream`, one per work list of `s` (heavy_desc, light_desc, fast_edges, generic_edges); the SKIP
+ * flags select among them.  With s->f2v_ticket set the call first resets those words on `stream` (a 32-byte memset). */
 int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f, double* f2v, void* stream);
 /* update_proposal (sites eta [E][2] in/out, q [V][2] in/out): EPBP.py:83-154; HLBP.py:100-171 */
 int lhvi_pbp_proposal(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* eta, double* q, void* stream);
