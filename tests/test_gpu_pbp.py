@@ -415,3 +415,27 @@ def test_batched_kl_of_tabulated_beliefs(api):
         want = utils.kl_continuous(lambda t: pdf(t, mu1[v], s1[v]), lambda t: pdf(t, mu2[v], s2[v]), -14, 14)
         assert got[v] == pytest.approx(want, rel=1e-6)
         assert got[v] == pytest.approx(utils.kl_normal(mu1[v], mu2[v], s1[v], s2[v]), rel=1e-6)
+
+
+def test_heavy_kernel_work_distribution_does_not_change_results(api):
+    """chunks claimed through the ticket (default) against static striding (f2v_ticket = NULL): every edge is computed by
+    the same code either way, so whole sweeps agree bit for bit; also a list shorter than one chunk per XCD range"""
+    import torch
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    for V in (20000, 40):
+        flat = synth.hybrid_mrf_flat(V=V, deg=4, seed=17)
+        res = []
+        for dynamic in (True, False):
+            bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=9)
+            bp.dynamic_f2v = dynamic
+            bp._setup(None, flat=flat)
+            _init(api, bp)
+            for _ in range(3):
+                bp.sweep(last=False)
+            torch.cuda.synchronize()
+            res.append((bp.f2v.clone(), bp.v2f.clone(), bp.q_dev.clone()))
+            assert bool(torch.isfinite(bp.f2v).all())
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+
