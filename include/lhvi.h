@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define LHVI_ABI_VERSION 4   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
-                              * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket */
+#define LHVI_ABI_VERSION 5   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
+                              * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -185,6 +185,13 @@ typedef struct lhvi_pbp {
      * neighbours in memory, and a workgroup dispatched late finds less left to do instead of owing a full static share
      * (13.4 -> 12.0 ms per launch on the 10 M-edge benchmark).  NULL: every wave strides over the list. */
     uint32_t* f2v_ticket;
+    /* optional, lhvi_pbp_proposal only: one record of eight 32-bit words per hidden CONTINUOUS variable, host-built --
+     *   0 variable   1 degree (entries of its var_edge row)   2 grid base in dom_val   3 T   4-7 the first four incident
+     *   edges var_edge[var_ptr[v] + k] (unused: repeat the first) --
+     * so that a wave starts from one scalar load instead of the chain var_value / var_dom -> dom_ptr / var_ptr -> var_edge,
+     * and no wave is launched for an observed or discrete variable.  NULL: the kernel walks the graph arrays. */
+    const int32_t* prop_desc;
+    int32_t n_prop_desc;
 } lhvi_pbp_t;
 
 #define LHVI_PBP_DESC_BYTES 128

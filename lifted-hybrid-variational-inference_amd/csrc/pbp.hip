@@ -975,13 +975,29 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8
                                                             double* __restrict__ eta, double* __restrict__ q,
                                                             double* __restrict__ ph_out) {
     const int lane = threadIdx.x & 63;
-    const int v = __builtin_amdgcn_readfirstlane(var_first(s) + blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
-    if (v >= var_limit(g, s)) return;
-    const int d = g.var_dom[v];
-    if (!is_hidden(g.var_value[v]) || !g.dom_cont[d]) return;
     const int n = s.n, S = s.n + s.T;
-    const int gb = g.dom_ptr[d], T = g.dom_ptr[d + 1] - gb;
-    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    int v, gb, T, lo, hi;
+    int e4[4] = {0, 0, 0, 0};                              // the first four incident edges (descriptor path)
+    const bool listed = s.prop_desc != nullptr;
+    if (listed) {
+        // one 32-byte record per hidden continuous variable instead of the chain var_value / var_dom -> dom_* / var_ptr ->
+        // var_edge: one scalar load, then the message loads; no wave is spent on an observed or discrete variable
+        const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+        if (item >= s.n_prop_desc) return;
+        const int32_t* rec = s.prop_desc + 8 * (int64_t)item;
+        v = rec[0]; gb = rec[2]; T = rec[3];
+        // (the row's position in var_edge is needed only when one pass of four edge groups does not cover it)
+        lo = (rec[1] > 4 || T > 32 || g.edge_count) ? g.var_ptr[v] : 0;       // (a lifted graph sums the row's counts below)
+        hi = lo + rec[1];
+        e4[0] = rec[4]; e4[1] = rec[5]; e4[2] = rec[6]; e4[3] = rec[7];
+    } else {
+        v = __builtin_amdgcn_readfirstlane(var_first(s) + blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+        if (v >= var_limit(g, s)) return;
+        const int d = g.var_dom[v];
+        if (!is_hidden(g.var_value[v]) || !g.dom_cont[d]) return;
+        gb = g.dom_ptr[d]; T = g.dom_ptr[d + 1] - gb;
+        lo = g.var_ptr[v]; hi = g.var_ptr[v + 1];
+    }
     double total = 0.0;
     if (s.var_degree) total = s.var_degree[v];
     else for (int k = lo; k < hi; ++k) total += g.edge_count ? g.edge_count[g.var_edge[k]] : 1.0;
@@ -996,7 +1012,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8
     for (int k0 = lo; k0 < hi; k0 += groups) {
         const int k = k0 + grp;
         const bool live = k < hi;
-        const int e = live ? g.var_edge[k] : g.var_edge[k0];
+        int e;
+        if (listed && k0 == lo && groups == 4) {           // first pass of four groups: the edges are in the record
+            e = grp == 0 ? e4[0] : (grp == 1 ? e4[1] : (grp == 2 ? e4[2] : e4[3]));
+            if (!live) e = e4[0];
+        } else {
+            e = live ? g.var_edge[k] : g.var_edge[k0];
+        }
         const double* msg = f2v + (int64_t)e * S + n;
         const double b0 = eta[2 * e], b1 = eta[2 * e + 1];
         const bool use_cav = EP && !(q1 >= b1);
@@ -1425,7 +1447,17 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
 int lhvi_pbp_proposal(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* eta, double* q, void* stream) {
     if (int rc = validate_pbp(g, s)) return rc;
     if (!f2v || !eta || !q) return LHVI_E_ARG;
+    if (s->prop_desc && (s->n_prop_desc < 0 || s->var_hi > s->var_lo)) return LHVI_E_ARG;    // the list replaces the variable range
     if (g->V == 0) return LHVI_OK;
+    if (s->prop_desc) {
+        if (s->n_prop_desc == 0) return LHVI_OK;
+        const dim3 grid(grid_for((int64_t)s->n_prop_desc * WAVE));
+        if (s->flags & LHVI_PBP_EP)
+            hipLaunchKernelGGL(pbp_proposal_kernel<true>, grid, dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, eta, q, (double*)nullptr);
+        else
+            hipLaunchKernelGGL(pbp_proposal_kernel<false>, grid, dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, eta, q, (double*)nullptr);
+        return check_launch();
+    }
     if (s->flags & LHVI_PBP_EP)
         hipLaunchKernelGGL(pbp_proposal_kernel<true>, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0,
                            as_stream(stream), *g, *s, f2v, eta, q, (double*)nullptr);
@@ -1437,7 +1469,7 @@ int lhvi_pbp_proposal(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* 
 
 int lhvi_pbp_proposal_partial(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* eta, double* ph, void* stream) {
     if (int rc = validate_pbp(g, s)) return rc;
-    if (!f2v || !eta || !ph || !s->q) return LHVI_E_ARG;
+    if (!f2v || !eta || !ph || !s->q || s->prop_desc) return LHVI_E_ARG;      // (sharded runs address variables by range)
     if (g->V == 0) return LHVI_OK;
     if (s->flags & LHVI_PBP_EP)
         hipLaunchKernelGGL(pbp_proposal_kernel<true>, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0,

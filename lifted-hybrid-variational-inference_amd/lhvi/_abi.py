@@ -51,6 +51,7 @@ class PbpStruct(C.Structure):
         ('recv', C.c_void_p), ('rank', C.c_int32), ('var_degree', C.c_void_p),
         ('var_lo', C.c_int32), ('var_hi', C.c_int32),
         ('f2v_ticket', C.c_void_p),
+        ('prop_desc', C.c_void_p), ('n_prop_desc', C.c_int32),
     ]
 
 
@@ -69,7 +70,7 @@ PBP_SKIP_TERMS = 16
 PBP_SKIP_HEAVY = 32
 PBP_SKIP_LIGHT = 64
 PBP_NO_GRID = 128
-ABI_VERSION = 4             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
+ABI_VERSION = 5             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
 PBP_DESC_BYTES = 128
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE
 

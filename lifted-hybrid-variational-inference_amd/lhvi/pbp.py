@@ -30,6 +30,7 @@ class _ParticleSweep:
     max_log_value = 700
     _epbp_discrete = True
     verbose = False
+    listed_proposal = True          # the proposal kernel starts from per-variable records (else it walks the graph arrays)
     dynamic_f2v = True              # the persistent f2v kernels claim their work in chunks (else static striding)
 
     # ---- set-up ------------------------------------------------------------------------------
@@ -85,6 +86,18 @@ class _ParticleSweep:
         tv = flat.edge_var[ge]
         pts = self.np_host[tv] + np.where(flat.var_cont[tv], flat.var_nstates[tv], 0) if ge.size else np.zeros(0, dtype=int)
         self.generic_pts_log2 = int(min(6, max(0, int(np.ceil(np.log2(max(int(pts.max()), 1)))) if ge.size else 6)))
+        # records of the hidden continuous variables for the proposal kernel (include/lhvi.h, lhvi_pbp_t.prop_desc)
+        pv = np.flatnonzero(flat.var_hidden & flat.var_cont)
+        pd = np.zeros((pv.size, 8), dtype=np.int32)
+        pdeg = np.diff(flat.var_ptr)[pv]
+        pdom = flat.var_dom[pv]
+        pd[:, 0], pd[:, 1], pd[:, 2], pd[:, 3] = pv, pdeg, flat.dom_ptr[pdom], sizes[pdom]
+        pbase = flat.var_ptr[pv].astype(np.int64)
+        for k in range(4):
+            if flat.var_edge.size:
+                pd[:, 4 + k] = flat.var_edge[np.minimum(pbase + np.minimum(k, np.maximum(pdeg - 1, 0)), flat.var_edge.size - 1)]
+        self.prop_desc = _abi.to_dev(pd) if pv.size else None
+        self.n_prop_desc = int(pv.size)
         self.fast_desc = self.heavy_desc = self.light_desc = None
         self.n_heavy = self.n_light = 0
         self.heavy_terms = 0
@@ -126,6 +139,8 @@ class _ParticleSweep:
         s.heavy_desc, s.n_heavy = _abi.ptr(getattr(self, 'heavy_desc', None)), int(getattr(self, 'n_heavy', 0))
         s.light_desc, s.n_light = _abi.ptr(getattr(self, 'light_desc', None)), int(getattr(self, 'n_light', 0))
         s.f2v_ticket = _abi.ptr(self.f2v_ticket) if self.dynamic_f2v else None
+        if self.listed_proposal and getattr(self, 'prop_desc', None) is not None:
+            s.prop_desc, s.n_prop_desc = _abi.ptr(self.prop_desc), self.n_prop_desc
         return s
 
     # ---- sampling ----------------------------------------------------------------------------
