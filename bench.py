@@ -18,6 +18,9 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (the launcher's environment normally carries this already)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')
 for p in (ROOT, PKG):
