@@ -439,3 +439,25 @@ def test_heavy_kernel_work_distribution_does_not_change_results(api):
         for a, b in zip(*res):
             assert torch.equal(a, b)
 
+
+def test_proposal_records_do_not_change_results(api):
+    """with the per-variable records (prop_desc) the proposal kernel starts from one scalar load; without them it walks the
+    graph arrays over every variable.  Same arithmetic per variable: whole sweeps agree bit for bit ('EP' and 'simple')"""
+    import torch
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    flat = synth.hybrid_mrf_flat(V=6000, deg=4, seed=23, frac_discrete=0.3)
+    for mode in ('EP', 'simple'):
+        res = []
+        for listed in (True, False):
+            bp = EPBP(None, n=64, proposal_approximation=mode, sampler='device', seed=11)
+            bp.listed_proposal = listed
+            bp._setup(None, flat=flat)
+            _init(api, bp)
+            for _ in range(4):
+                bp.sweep(last=False)
+            torch.cuda.synchronize()
+            res.append((bp.f2v.clone(), bp.q_dev.clone(), bp.eta.clone(), bp.particles.clone()))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+
