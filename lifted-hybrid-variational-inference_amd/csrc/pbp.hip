@@ -1325,12 +1325,17 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
         if (lane < cnt) { *word = 0; *word2 = 0; }
         LHVI_WAVE_SYNC();
         if (dup) {
+            // every group of equal particles contains a suspect lane (the one whose atomics came later), so walking the
+            // suspects' values covers all groups: one step per distinct suspect value -- in practice the two domain bounds
+            uint64_t todo = dup & live;
             dup = 0;
-            for (int k = 0; k < cnt - 1; ++k) {
+            while (todo) {
+                const int k = __builtin_ctzll(todo);
                 const int klo = __builtin_amdgcn_readlane(xlo, k), khi = __builtin_amdgcn_readlane(xhi, k);
-                dup |= __ballot(xlo == klo && xhi == khi) & (~1ull << k);
+                const uint64_t same = __ballot(xlo == klo && xhi == khi) & live;       // every lane holding this value
+                dup |= same & (same - 1);                                             // all but its first occurrence
+                todo &= ~same;
             }
-            dup &= live;
         }
         const int u = (lane < cnt) && !((dup >> lane) & 1);
         if (lane < n) uniq[(int64_t)v * n + lane] = (uint8_t)u;
