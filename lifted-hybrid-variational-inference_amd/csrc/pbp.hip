@@ -1429,14 +1429,18 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     static const int light_per_cu = blocks_per_cu((const void*)pbp_f2v_light_kernel);
     static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel);
     const int heavy_blocks = heavy_per_cu, side_blocks = 8;
-    // work ticket of the heavy kernel: reset on this stream right before the launch
+    // work ticket of the heavy kernel: reset on this stream right before the launch.  Chunks of 8 pay when every wave gets
+    // several of them; a short list (a small graph, the interior part of a shard) keeps one entry per wave and strides
     const bool run_heavy = !(s->flags & LHVI_PBP_SKIP_FAST) && s->heavy_desc && s->n_heavy > 0 && !(s->flags & LHVI_PBP_SKIP_HEAVY);
-    if (s->f2v_ticket && run_heavy && hipMemsetAsync(s->f2v_ticket, 0, LHVI_PBP_TICKET_WORDS * sizeof(uint32_t), as_stream(stream)) != hipSuccess)
+    const int heavy_grid = min((s->n_heavy + 3) / 4, cus * heavy_blocks);
+    lhvi_pbp_t sh = *s;
+    if (sh.f2v_ticket && (int64_t)s->n_heavy < (int64_t)heavy_grid * (BLOCK / WAVE) * 8 * 4) sh.f2v_ticket = nullptr;
+    if (sh.f2v_ticket && run_heavy && hipMemsetAsync(sh.f2v_ticket, 0, LHVI_PBP_TICKET_WORDS * sizeof(uint32_t), as_stream(stream)) != hipSuccess)
         return LHVI_E_LAUNCH;
     if (!(s->flags & LHVI_PBP_SKIP_FAST)) {
         if (s->heavy_desc && s->n_heavy > 0 && !(s->flags & LHVI_PBP_SKIP_HEAVY))
-            hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(min((s->n_heavy + 3) / 4, cus * heavy_blocks)), dim3(BLOCK), 0, as_stream(stream),
-                               *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy);
+            hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(heavy_grid), dim3(BLOCK), 0, as_stream(stream),
+                               *g, sh, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy);
         if (s->light_desc && s->n_light > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
             hipLaunchKernelGGL(pbp_f2v_light_kernel, dim3(min((s->n_light + 3) / 4, cus * min(light_per_cu, side_blocks))), dim3(BLOCK), 0, as_stream(stream),
                                *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->light_desc), s->n_light);
