@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Headline benchmark: full LBP sweeps/s on a 10M-edge hybrid MRF (BASELINE.json metric).
 
 Workload (cfg 4 x10): random sparse hybrid pairwise MRF, V = 2.5M variables (80 %
@@ -9,6 +8,11 @@ Inputs are generated on the host, uploaded once, and resident in HBM before the 
 
 N > 1: the same graph is edge-sharded (factor-partitioned) over the ranks, one RCCL all-to-all of boundary-variable
 partials per sweep (lhvi/dist.py); total work is fixed, so scaling is "strong".
+
+``python3 bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts its own ranks: the parent (which
+never touches the GPU) runs ``python -m torch.distributed.run --nproc-per-node N`` on this same file and exits with
+its return code.  Under ``rocprofv3`` call it as ``-- python3 bench.py ...`` (no ``env`` / shell hop after the profiler
+has initialised the GPU).
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,6 +35,12 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
 FP64_PEAK_TFLOPS = 78.6        # fp64 vector peak
+HBM_TARGET_FRAC = 0.40         # BASELINE.json: ">= 40 % of per-GPU HBM-read roofline"
+FLOP_PER_TERM = 16.0           # algorithmic: 7 fma + 1 add + 1 ldexp per (output point, partner particle) term
+# executed cost of a term at the integral points when the heavy kernel tabulates them along the uniform grid: one
+# multiplication, 1.25 additions of the lane reduce-scatter (10 per lane and batch of 8 points) and the lane's two table
+# exponentials (2 x 16 flop) spread over its T = 32 points
+FLOP_PER_GRID_TERM = 1.0 + 1.25 + 2 * 16.0 / 32.0
 
 
 def algorithmic_bytes_per_edge(n, T):
@@ -41,9 +51,11 @@ def algorithmic_bytes_per_edge(n, T):
 
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/*_traffic.json, written by scripts/summarize_pmc.py with the gfx950 FETCH_SIZE correction); None if absent"""
+    (profiles/*_traffic.json, written by scripts/summarize_pmc.py with the gfx950 FETCH_SIZE correction) and the file it
+    came from; (None, None) if absent.  PMC passes cannot be collected inside a timed run, so this number is read, not
+    measured live."""
     import glob
-    best = None
+    best = src = None
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json'))):
         try:
             d = json.load(open(path))
@@ -51,8 +63,8 @@ def measured_traffic(kernel):
             continue
         for k, v in d.items():
             if k.endswith(kernel):
-                best = v['hbm_bytes']
-    return best
+                best, src = v['hbm_bytes'], os.path.relpath(path, ROOT)
+    return best, src
 
 
 def cpu_baseline(n, T, seconds_target=15.0):
@@ -84,6 +96,33 @@ def cpu_baseline(n, T, seconds_target=15.0):
     return flat.E, sweeps, dt, edge_rate, cores
 
 
+def python_baseline(n, T, budget_s=10.0):
+    """The reference-equivalent pure-Python path (oracle/pyref.py: dict-of-dicts restatement of EPBPLogVersion.py:225-289,
+    pinned against the reference's golden vectors in the CPU suite), single thread, on 1e3- and 1e4-edge graphs of the same
+    generator; the f -> rv half is bounded to `budget_s` seconds of factors and extrapolated linearly (labelled)."""
+    from lhvi import graph, potentials, synth
+    from oracle import pyref
+    out = []
+    for V, budget in ((250, budget_s), (2500, budget_s * 0.6)):
+        flat = synth.hybrid_mrf_flat(V=V, deg=4, seed=123, T=T)
+        out.append(pyref.time_sweep(flat, n, graph, potentials, budget_s=budget))
+    return out
+
+
+def self_launch(n_ranks):
+    """`--gpus N` without a launcher: start N ranks of this file under torch.distributed.run from a parent that has not
+    touched the GPU (and never will); returns the launcher's exit code (non-zero if any rank failed)"""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_ranks),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, LHVI_BENCH_SELF_LAUNCHED='1')
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -95,20 +134,28 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
-    import torch
-    from lhvi import _abi, synth, dist
-    from lhvi.pbp import EPBP
-
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be at least 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))             # before anything imports torch or touches the GPU
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d does not match WORLD_SIZE=%d of the launcher' % (args.gpus, world))
+
+    import torch
+    from lhvi import _abi, synth, dist
+    from lhvi.pbp import EPBP
+
     # LHVI_DIST_BACKEND=gloo rehearses the multi-process path on a box with fewer GPUs than ranks (ranks then share
     # devices and the exchange is staged through the host); the real runs use nccl = RCCL over xGMI, one rank per GPU
     backend = os.environ.get('LHVI_DIST_BACKEND', 'nccl')
-    device_index = local_rank % max(torch.cuda.device_count(), 1) if backend == 'gloo' else local_rank
+    n_dev = torch.cuda.device_count()
+    if backend == 'nccl' and local_rank >= n_dev:
+        raise SystemExit('rank %d has no GPU of its own (%d visible): one rank per GPU over RCCL; LHVI_DIST_BACKEND=gloo '
+                         'rehearses more ranks than GPUs' % (local_rank, n_dev))
+    device_index = local_rank % max(n_dev, 1) if backend == 'gloo' else local_rank
     torch.cuda.set_device(device_index)
     if world > 1:
         import torch.distributed as td
@@ -129,7 +176,10 @@ def main():
         bp._setup(None, flat=flat)
         runner = dist.SingleRunner(bp)
     else:
-        runner = dist.ShardedRunner(flat, n=n, seed=1, rank=rank, world=world)
+        # the factor partition (one breadth-first sweep of the whole graph) is computed on rank 0 only and broadcast; every
+        # rank then builds just its own slice of the plan
+        runner = dist.ShardedRunner(flat, n=n, seed=1, rank=rank, world=world,
+                                    fac_owner=dist.broadcast_partition(flat, rank, world))
     del flat
     runner.init()
 
@@ -169,9 +219,14 @@ def main():
         f2v_bytes = (bytes_e['f2v'] + 8 * (n + T)) * heavy_edges
         f2v_gbs = f2v_bytes / (f2v_ms * 1e-3) / 1e9
         hidden_frac = runner.work_fraction()
-        # fp64 work: 16 flop per (output point, partner particle) term -- 7 fma, 1 add, 1 ldexp
-        FLOP_PER_TERM = 16.0
+        # fp64 work.  Algorithmic: 16 flop per (output point, partner particle) term (SURVEY 8(d) / DESIGN 4.7).  Executed:
+        # the terms at the particles cost exactly that; the terms at the integral points of edges the kernel serves by the
+        # grid recurrence cost FLOP_PER_GRID_TERM (the rest of them take the direct form, 16)
+        grid_terms = runner.heavy_grid_terms()
         f2v_tflops = terms * FLOP_PER_TERM / (f2v_ms * 1e-3) / 1e12
+        exec_tflops = ((terms - grid_terms) * FLOP_PER_TERM + grid_terms * FLOP_PER_GRID_TERM) / (f2v_ms * 1e-3) / 1e12
+        sweep_gbs = bytes_e['sweep'] * E_local / (ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic('pbp_f2v_heavy_kernel') if world == 1 and args.edges == 10_000_000 else (None, None)
         out = {
             'metric': 'lbp_sweeps_per_sec_10M_edge_hybrid_mrf' if args.edges == 10_000_000
                       else 'lbp_sweeps_per_sec_%d_edge_hybrid_mrf' % args.edges, 'value': sweeps_per_s, 'unit': 'sweeps/s',
@@ -181,31 +236,50 @@ def main():
             'config': {'workload': 'cfg4x10 random hybrid pairwise MRF, EPBP particle sweep', 'edges': E_total,
                        'variables': V, 'particles': n, 'integral_points': T, 'proposal': 'simple',
                        'sharding': 'single GPU' if world == 1 else 'factor-partitioned edge shards, 1 all_to_all/sweep overlapped with the interior part'},
-            # the dominant kernel is compute bound (~40 flop per algorithmic byte), so the binding roof is the fp64 dense
-            # peak -- 78.6 TFLOP/s on gfx950 for the vector and the matrix pipe alike; the kernel issues VALU FMAs, its
-            # term (rank-2 outer product + exp) has nothing for MFMA to do.  The HBM view BASELINE.json asks for is in 'hbm'.
-            'roofline': {'bound': 'mfma', 'kernel': 'pbp_f2v_heavy_kernel', 'achieved': f2v_tflops, 'peak': FP64_PEAK_TFLOPS,
+            # the dominant kernel is compute bound (~40 flop per algorithmic byte): its roof is the fp64 VECTOR peak (the
+            # kernel issues VALU FMAs; the term -- rank-2 outer product + exp -- has nothing for MFMA to do, and on gfx950
+            # the fp64 matrix path shares the vector fp64 pipe anyway).  The HBM view BASELINE.json asks for is in 'hbm' /
+            # 'sweep_hbm' with the 0.40 target beside it.
+            'roofline': {'bound': 'fp64_valu', 'kernel': 'pbp_f2v_heavy_kernel', 'achieved': f2v_tflops, 'peak': FP64_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': f2v_tflops / FP64_PEAK_TFLOPS,
-                         'traffic': measured_traffic('pbp_f2v_heavy_kernel') if world == 1 and args.edges == 10_000_000 else None,
+                         'executed': {'achieved': exec_tflops, 'frac': exec_tflops / FP64_PEAK_TFLOPS,
+                                      'grid_terms_per_launch': grid_terms, 'flop_per_grid_term': FLOP_PER_GRID_TERM,
+                                      'note': 'flops the kernel really issues: 16 per term at the particles, %.2f per term at '
+                                              'the integral points tabulated by the grid recurrence' % FLOP_PER_GRID_TERM},
+                         'traffic': traffic, 'traffic_source': ('from_committed_profile: ' + traffic_src) if traffic_src else None,
                          'kernel_ms': f2v_ms, 'edges_per_launch': heavy_edges, 'joint_terms_per_launch': terms,
-                         'note': 'fp64 compute roof (dense peak of the dtype; VALU instructions, not MFMA).  Algorithmic count: 16 flop '
-                                 'per (output point, partner particle) term.  Terms at the particles cost 9 fp64 + 3 int32 issue '
-                                 'slots + 2 LDS reads each (issue ceiling 58 % of this peak); terms at the integral points are '
-                                 'tabulated along the uniform grid by one multiplication each plus a lane reduce-scatter '
-                                 '(DESIGN.md sections 4.3, 5)',
+                         'note': 'achieved = algorithmic count, 16 flop per (output point, partner particle) term, over the HIP-event '
+                                 'time of the launch.  Terms at the particles cost 9 fp64 + 3 int32 issue slots + 2 LDS reads each '
+                                 '(issue ceiling 58 % of this peak); terms at the integral points are tabulated along the uniform '
+                                 'grid by one multiplication each plus a lane reduce-scatter (DESIGN.md sections 4.3, 5)',
                          'hbm': {'achieved': f2v_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': f2v_gbs / HBM_PEAK_GBS,
                                  'algorithmic_bytes_per_launch': f2v_bytes},
-                         'sweep_hbm': {'achieved': bytes_e['sweep'] * E_local / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
-                                       'unit': 'GB/s', 'frac': bytes_e['sweep'] * E_local / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                         'sweep_hbm': {'achieved': sweep_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': sweep_gbs / HBM_PEAK_GBS},
+                         'hbm_target': HBM_TARGET_FRAC,
+                         'hbm_target_met': bool(sweep_gbs / HBM_PEAK_GBS >= HBM_TARGET_FRAC),
+                         'hbm_target_note': 'the sweep needs ~43 fp64 flop per algorithmic byte (machine balance 9.8): at the fp64 '
+                                            'vector peak its HBM fraction cannot exceed ~0.23, so the 0.40 target is out of reach '
+                                            'for n = 64 particles by arithmetic intensity, not by wasted traffic'},
             'hidden_edge_fraction': hidden_frac,
         }
         if not args.no_cpu_baseline and world == 1:
             Es, sw, dt, edge_rate, cores = cpu_baseline(n, T)
+            py = python_baseline(n, T)
             out['cpu_baseline'] = {'value': edge_rate / (2.0 * E_total), 'unit': 'sweeps/s', 'cores': cores, 'kind': 'port',
                                    'edge_messages_per_sec': edge_rate,
                                    'sample': '%d sweeps of the C oracle (OpenMP, %d threads) on a %d-edge graph from the '
                                              'same generator in %.1f s; value = measured edge-message rate / (2 * %d edges)'
-                                             % (sw, cores, Es, dt, E_total)}
+                                             % (sw, cores, Es, dt, E_total),
+                                   'python': {'value': py[0]['edge_messages_per_sec'] / (2.0 * E_total), 'unit': 'sweeps/s', 'cores': 1,
+                                              'kind': 'port (pure-Python dict-of-dicts restatement of EPBPLogVersion.py:225-289, '
+                                                      'oracle/pyref.py; the reference itself cannot travel to this box)',
+                                              'edge_messages_per_sec': py[0]['edge_messages_per_sec'],
+                                              'sample': 'one sweep at n = %d, T = %d on %d- and %d-edge graphs of the same generator; '
+                                                        'the f -> rv half timed on the first %d / %d hidden edges and extrapolated '
+                                                        'linearly; value = edge-message rate of the first / (2 * %d edges)'
+                                                        % (n, T, py[0]['edges'], py[1]['edges'], py[0]['f2v_edges_done'],
+                                                           py[1]['f2v_edges_done'], E_total),
+                                              'runs': py}}
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as td

@@ -98,11 +98,13 @@ class DeviceRefiner(Refiner):
         return self.cg.colors()[0].copy()
 
 
-def run_c2f(g, engine, refiner, iteration, c2f, k_mean_k, k_mean_iteration, draw):
+def run_c2f(g, engine, refiner, iteration, c2f, k_mean_k, k_mean_iteration, draw, observer=None):
     """Drive one coarse-to-fine run.  ``engine`` exposes ``make(flat) -> state``, ``init``, ``v2f``, ``proposal``,
     ``f2v``, ``install(state, host_particles)``, ``gather(array, index)``, ``get(state, name)`` / ``set(state, name, array)``
     for the arrays ``f2v v2f eta q particles old_particles uniq`` and ``host(array)``; ``draw(k, flat, q_host)`` returns the
-    k-th sample as a [V, n] host array.
+    k-th sample as a [V, n] host array.  ``observer(k, rvc, old_fc, G1, pair_phi, st1)`` (optional) is called right before
+    draw k >= 1 with the variable-side state, i.e. what the reference's ``message`` / ``eta_message`` hold at that
+    ``generate_sample`` call: the edge of ground rv r and ground factor f is the pair (rvc[r], old_fc[f]).
     Returns (final state, final flat (factor side consistent), final CompressedGraph, rv colours, factor colours,
     history of (rv colours, factor colours) at every draw)."""
     gflat = flatten(g)
@@ -174,6 +176,8 @@ def run_c2f(g, engine, refiner, iteration, c2f, k_mean_k, k_mean_iteration, draw
             engine.set(st2, name, engine.get(st1, name))
         if not last:
             history.append((rvc.copy(), fc.copy()))
+            if observer is not None:
+                observer(k, rvc, old_fc, G1, pair_phi, st1)
             engine.install(st2, draw(k, G2, engine.host(engine.get(st2, 'q'))))
             k += 1
             engine.f2v(st2)

@@ -59,6 +59,10 @@ class SingleRunner:
         """(edges, joint terms) of the continuous x continuous kernel's work list"""
         return self.bp.n_heavy, self.bp.heavy_terms
 
+    def heavy_grid_terms(self):
+        """joint terms at the integral points of the edges the heavy kernel serves by the grid recurrence"""
+        return self.bp.heavy_grid_terms
+
 
 # =================================================================================================
 # edge sharding
@@ -91,6 +95,35 @@ def bfs_variable_order(flat):
     return pos
 
 
+def partition_factors(flat, world, partition='bfs'):
+    """owner rank of every factor -- the one global step of the sharding (a breadth-first sweep of the whole graph).  In a
+    multi-process run rank 0 computes it and broadcasts the array (``ShardedRunner``); everything else a rank needs is
+    derived from its own slice of the graph."""
+    F = flat.F
+    dtype = np.int32
+    if partition == 'bfs' and world > 1:
+        pos = bfs_variable_order(flat)
+        fpos = np.minimum.reduceat(pos[flat.edge_var], flat.fac_ptr[:-1]) if F else np.zeros(0, dtype=np.int64)
+        forder = np.argsort(fpos, kind='stable')
+        fac_owner = np.empty(F, dtype=dtype)
+        fac_owner[forder] = ((np.arange(F, dtype=np.int64) * world) // max(F, 1)).astype(dtype)
+        return fac_owner
+    return ((np.arange(F, dtype=np.int64) * world) // max(F, 1)).astype(dtype)
+
+
+def broadcast_partition(flat, rank, world, partition='bfs'):
+    """``partition_factors`` on rank 0, broadcast to the other ranks of the initialised process group (4 bytes per factor);
+    the other ranks never run the global breadth-first sweep"""
+    import torch
+    import torch.distributed as td
+    own = partition_factors(flat, world, partition) if rank == 0 else np.empty(flat.F, dtype=np.int32)
+    t = torch.from_numpy(own)
+    if td.get_backend() == 'nccl':
+        t = t.cuda()
+    td.broadcast(t, 0)
+    return t.cpu().numpy()
+
+
 class ShardPlan:
     """Factor-partitioned shard of a ground ``FlatGraph`` for rank ``rank`` of ``world`` (pure NumPy/SciPy, no GPU).
 
@@ -106,21 +139,15 @@ class ShardPlan:
       so the two ends of a pair agree on the order without communicating).
     """
 
-    def __init__(self, flat, rank, world, partition='bfs'):
+    def __init__(self, flat, rank, world, partition='bfs', fac_owner=None):
+        """`fac_owner`: the factor partition when it was computed elsewhere (``partition_factors`` on rank 0); apart from
+        it the plan touches only this rank's factors and the adjacency rows of their variables -- O(E / world) work"""
         from .flat import build_flat
         if flat.lifted or (flat.edge_canon != np.arange(flat.E)).any():
             raise NotImplementedError('sharding expects a ground graph')
         self.rank, self.world = rank, world
-        F = flat.F
-        if partition == 'bfs' and world > 1:
-            pos = bfs_variable_order(flat)
-            fpos = np.minimum.reduceat(pos[flat.edge_var], flat.fac_ptr[:-1]) if F else np.zeros(0, dtype=np.int64)
-            forder = np.argsort(fpos, kind='stable')
-            fac_owner = np.empty(F, dtype=np.int64)
-            fac_owner[forder] = (np.arange(F, dtype=np.int64) * world) // max(F, 1)
-        else:
-            fac_owner = (np.arange(F, dtype=np.int64) * world) // max(F, 1)
-        edge_owner = fac_owner[flat.edge_fac]
+        if fac_owner is None:
+            fac_owner = partition_factors(flat, world, partition)
         self.fac_ids = np.flatnonzero(fac_owner == rank)
         arity = np.diff(flat.fac_ptr)[self.fac_ids]
         local_ptr = np.zeros(self.fac_ids.size + 1, dtype=np.int64)
@@ -129,13 +156,12 @@ class ShardPlan:
         self.edge_ids = (np.repeat(flat.fac_ptr[self.fac_ids].astype(np.int64) - local_ptr[:-1], arity) +
                          np.arange(int(local_ptr[-1]), dtype=np.int64))
         local_edge_var = flat.edge_var[self.edge_ids]
-        gids = np.unique(local_edge_var)
-        degree = np.bincount(flat.edge_var, minlength=flat.V)
-        local_degree = np.bincount(local_edge_var, minlength=flat.V)
+        gids, local_deg = np.unique(local_edge_var, return_counts=True)
+        degree = np.diff(flat.var_ptr)                       # a variable's degree in the whole graph (view, no pass over E)
         # boundary = hidden variable with edges on another rank (observed variables need no sums).  Local numbering: the
         # interior variables first, then the boundary ones, ascending global id inside each block -- the per-variable
         # kernels can then sweep [0, n_interior) while the boundary rows are in flight
-        is_b = (degree[gids] > local_degree[gids]) & np.isnan(flat.var_value[gids])
+        is_b = (degree[gids] > local_deg) & np.isnan(flat.var_value[gids])
         gids = gids[np.argsort(is_b, kind='stable')]
         self.n_interior = int((~is_b).sum())
         self.var_gid = gids.astype(np.int64)
@@ -155,7 +181,13 @@ class ShardPlan:
         self.bslot = np.full(gids.size, -1, dtype=np.int32)
         self.bslot[self.bvars] = np.arange(self.bvars.size, dtype=np.int32)
         bg = gids[self.bvars]
-        keys = np.unique(flat.edge_var.astype(np.int64) * world + edge_owner.astype(np.int64))
+        # (boundary variable, owner rank) pairs from the adjacency rows of THIS rank's boundary variables only
+        bdeg = degree[bg].astype(np.int64)
+        bstart = np.zeros(bg.size + 1, dtype=np.int64)
+        np.cumsum(bdeg, out=bstart[1:])
+        slots = np.repeat(flat.var_ptr[bg].astype(np.int64) - bstart[:-1], bdeg) + np.arange(int(bstart[-1]), dtype=np.int64)
+        owners = fac_owner[flat.edge_fac[flat.var_edge[slots]]].astype(np.int64)
+        keys = np.unique(np.repeat(bg.astype(np.int64), bdeg) * world + owners)
         pair_var, pair_owner = keys // world, keys % world
         # exchange rows: peer-major, shared variables in ascending gid inside a peer block.  Both ends build the same
         # order, so row r of my send buffer and row r of my receive buffer belong to the same (variable, peer).
@@ -221,10 +253,11 @@ class ShardedRunner:
     of the plan's numbering) and prefixes / suffixes of the f2v work lists, so no kernel needs an index list.
     """
 
-    def __init__(self, flat, n, seed, rank, world, proposal_approximation='simple', group=None, overlap=True):
+    def __init__(self, flat, n, seed, rank, world, proposal_approximation='simple', group=None, overlap=True,
+                 fac_owner=None):
         import torch
         from .pbp import EPBP
-        self.plan = plan = ShardPlan(flat, rank, world)
+        self.plan = plan = ShardPlan(flat, rank, world, fac_owner=fac_owner)
         self.rank, self.world, self.group = rank, world, group
         bp = EPBP(None, n=n, proposal_approximation=proposal_approximation, sampler='device', seed=seed)
         bp._setup(None, flat=plan.flat, edge_key=plan.edge_boundary)
@@ -402,3 +435,6 @@ class ShardedRunner:
 
     def heavy_stats(self):
         return self.bp.n_heavy, self.bp.heavy_terms
+
+    def heavy_grid_terms(self):
+        return self.bp.heavy_grid_terms

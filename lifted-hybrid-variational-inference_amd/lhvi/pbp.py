@@ -100,7 +100,7 @@ class _ParticleSweep:
         self.n_prop_desc = int(pv.size)
         self.fast_desc = self.heavy_desc = self.light_desc = None
         self.n_heavy = self.n_light = 0
-        self.heavy_terms = 0
+        self.heavy_terms = self.heavy_grid_terms = 0
         nf = int(self.fast_edges.numel())
         if nf:
             desc = torch.empty(nf * _abi.PBP_DESC_BYTES, dtype=torch.uint8, device=dg.device)
@@ -115,6 +115,10 @@ class _ParticleSweep:
             # (output point, partner particle) terms of the heavy kernel: sum over its edges of (np + T) * nj
             hw = words[heavy].to(torch.int64)
             self.heavy_terms = int(((hw[:, 8] + hw[:, 9]) * hw[:, 7]).sum().item())
+            # of those, the terms at the integral points of edges served by the grid recurrence (word 15: uniform grid;
+            # at least 24 partner particles, T <= 64; the kernel's range guard is data dependent and assumed to pass)
+            on_grid = (hw[:, 15] == 1) & (hw[:, 7] >= 24) & (hw[:, 9] <= 64)
+            self.heavy_grid_terms = int((hw[:, 9] * hw[:, 7])[on_grid].sum().item())
             light = ~heavy & (words[:, 14] != 0)          # word 14: set by lhvi_pbp_describe for the light kernel's edges
             self.light_desc = rows[light].contiguous()
             self.n_light = int(self.light_desc.shape[0])
@@ -329,19 +333,40 @@ class _ParticleSweep:
         _abi.check(l.lhvi_pbp_var_sum(self.dg.g, s, _abi.ptr(self._query_f2v), _abi.ptr(out), st))
         return out
 
-    def map_all(self, steps=5):
-        """MAP of every variable at once: n-point grid on the domain, then ``steps - 1`` times a new n-point grid on the
-        bracket around the best point (the bracket shrinks by (n-1)/2 per step; 5 steps with n = 64 resolve 1e-6 of
-        the domain width, the reference's fminbound stops at 1e-5).  Finds the mode the first grid sees, where
-        ``EPBP.map`` (EPBP:377-394) finds the one fminbound's golden section runs into.  Returns (map, log-belief)
-        as arrays of length V; observed variables return their value."""
+    def map_all(self, steps=5, scan=64):
+        """MAP of every variable at once: a uniform scan of the domain with at least `scan` points (ceil(scan / n) passes
+        of n points, so a solver with few particles still sees a narrow mode), then ``steps - 1`` times a new n-point grid
+        on the bracket around the best point (the bracket shrinks by (n-1)/2 per step; 5 steps with n = 64 resolve 1e-6 of
+        the domain width, the reference's fminbound stops at 1e-5).  Finds the mode the scan sees, where ``EPBP.map``
+        (EPBP:377-394) finds the one fminbound's golden section runs into.  Returns (map, log-belief) as arrays of length
+        V; observed variables return their value."""
         torch = _abi.require_gpu()
         l, st = _abi.lib(), _abi.stream_ptr()
-        x = torch.empty(self.flat.V, self.n, dtype=torch.float64, device=self.particles.device)
-        best = torch.empty(self.flat.V, dtype=torch.float64, device=x.device)
+        n, flat = self.n, self.flat
+        x = torch.empty(flat.V, n, dtype=torch.float64, device=self.particles.device)
+        best = torch.empty(flat.V, dtype=torch.float64, device=x.device)
         val = torch.empty_like(best)
         s = self._struct()
         _abi.check(l.lhvi_pbp_domain_grid(self.dg.g, s, _abi.ptr(x), st))
+        passes = -(-int(scan) // n) if n >= 3 else 1
+        if passes > 1 and bool((flat.var_hidden & flat.var_cont).any()):
+            cont = _abi.to_dev(flat.var_hidden & flat.var_cont)[:, None]
+            lo = _abi.to_dev(np.where(flat.var_cont, flat.dom_lo[flat.var_dom], 0.0))[:, None]
+            hi = _abi.to_dev(np.where(flat.var_cont, flat.dom_hi[flat.var_dom], 1.0))[:, None]
+            h = (hi - lo) / (passes * (n - 1))
+            j = torch.arange(n, dtype=torch.float64, device=x.device)[None, :]
+            bx = bv = None
+            for p in range(passes):                  # pass p covers [lo + p (n-1) h, lo + (p+1)(n-1) h], ends shared
+                xp = torch.where(cont, lo + (p * (n - 1) + j) * h, x)
+                vp, ap = self.belief_rv_all(xp).max(dim=1)
+                xb = xp.gather(1, ap[:, None])[:, 0]
+                if bx is None:
+                    bx, bv = xb, vp
+                else:
+                    better = vp > bv                 # first maximum, like the reference's argmax over a list
+                    bx, bv = torch.where(better, xb, bx), torch.where(better, vp, bv)
+            a, b = torch.maximum(bx[:, None] - h, lo), torch.minimum(bx[:, None] + h, hi)
+            x = torch.where(cont, a + (b - a) * (j / (n - 1)), x).contiguous()
         for _ in range(max(int(steps), 1)):
             logb = self.belief_rv_all(x)
             _abi.check(l.lhvi_pbp_refine_grid(self.dg.g, s, _abi.ptr(logb), _abi.ptr(x), _abi.ptr(best), _abi.ptr(val), st))
@@ -609,7 +634,8 @@ class HybridLBP(_ParticleSweep):
 
         refiner = _c2f.DeviceRefiner(self.g.g)
         st, flat, cg, rvc, fc, history = _c2f.run_c2f(self.g.g, engine, refiner, iteration, c2f, self.k_mean_k,
-                                                      self.k_mean_iteration, draw)
+                                                      self.k_mean_iteration, draw,
+                                                      observer=getattr(self, 'c2f_observer', None))
         self.c2f_history = history
         self.g = cg
         # adopt the final factor-side state for the queries

@@ -200,6 +200,57 @@ def model_rgm_small(cg, C=4, B=3, seed=5):
     return g
 
 
+def model_hmln_small(cg, P=6, T=3, seed=31, two_values=False, points=32):
+    """cfg 3 at fixture size: the paper-popularity hybrid MLN template of
+    Demo/Data/HMLN/GeneratorPaperPopularity.py:7-40 -- same atoms, same three parametric factors with their weights, the
+    t1 != t2 constraint -- grounded by the reference's own RelationalGraph for P papers x T topics, with the demo's domain
+    Domain((-15, 15), integral_points=linspace(0, 10, 32)).  Evidence follows generate_data (:51-72): 70 % of the
+    popularity atoms ~ U(0, 10) (two_values: drawn from {2.5, 7.0}, so a k-means split is seeding-independent), PaperIn
+    of 70 % of the papers for a random subset of topics, half of the SameSession atoms."""
+    import RelationalGraph as RR
+    RG, RM, modelio = cg.RG, cg.RM, cg.modelio
+    rng = np.random.RandomState(seed)
+    papers = ['p%d' % i for i in range(P)]
+    topics = ['t%d' % i for i in range(T)]
+    d_bool = RG.Domain((0, 1))
+    d_real = RG.Domain((-15, 15), continuous=True, integral_points=np.linspace(0, 10, points))
+    lv_p, lv_t = RR.LV(papers), RR.LV(topics)
+    atoms = (RR.Atom(d_bool, logical_variables=(lv_t, lv_t), name='SameSession'),
+             RR.Atom(d_bool, logical_variables=(lv_p, lv_t), name='PaperIn'),
+             RR.Atom(d_real, logical_variables=(lv_t,), name='TopicPopularity'),
+             RR.Atom(d_real, logical_variables=(lv_p,), name='PaperPopularity'))
+    f0 = RR.ParamF(RM.MLNPotential(modelio.FORMULAS['eq1'], w=0.3), nb=['PaperPopularity(p)'])
+    f1 = RR.ParamF(RM.MLNPotential(modelio.FORMULAS['x0_eq12'], w=0.5),
+                   nb=['SameSession(t1,t2)', 'TopicPopularity(t1)', 'TopicPopularity(t2)'],
+                   constrain=lambda sub: sub['t1'] != sub['t2'])
+    f2 = RR.ParamF(RM.MLNPotential(modelio.FORMULAS['x0_eq12'], w=1),
+                   nb=['PaperIn(p,t)', 'PaperPopularity(p)', 'TopicPopularity(t)'])
+    rel_g = RR.RelationalGraph(atoms, (f0, f1, f2))
+    rel_g.ground_graph()
+    draw = (lambda: float(rng.choice([2.5, 7.0]))) if two_values else (lambda: float(rng.uniform(0, 10)))
+    data = {}
+    for x in rng.choice(P, int(P * 0.7), replace=False):
+        data[('PaperPopularity', 'p%d' % x)] = draw()
+    for x in rng.choice(T, int(T * 0.7), replace=False):
+        data[('TopicPopularity', 't%d' % x)] = draw()
+    for x in rng.choice(P, int(P * 0.7), replace=False):
+        for y in rng.choice(T, rng.randint(T), replace=False):
+            data[('PaperIn', 'p%d' % x, 't%d' % y)] = int(rng.choice([0, 1]))
+    for x in range(T):
+        for y in range(T):
+            if x != y and rng.rand() < 0.5:
+                data[('SameSession', 't%d' % x, 't%d' % y)] = int(rng.choice([0, 1]))
+    g, rvs_dict = rel_g.add_evidence(data)
+    # deterministic iteration order for the fixture: rvs in rvs_dict (first use) order, factors by (template, scope)
+    rvs = list(rvs_dict.values())
+    idx = {id(rv): i for i, rv in enumerate(rvs)}
+    tmpl = {id(f0.potential): 0, id(f1.potential): 1, id(f2.potential): 2}
+    g.rvs = rvs
+    g.factors = sorted(g.factors, key=lambda f: (tmpl[id(f.potential)], [idx[id(r)] for r in f.nb]))
+    g.init_nb()
+    return g
+
+
 def _edges(g):
     return [(f, rv) for f in g.factors for rv in f.nb]
 
@@ -240,6 +291,14 @@ def capture_epbp(cg, name, g, n, its, approx, seed):
         else:
             nb.append([i, float(rv.domain.values[0]), float(bp.belief(rv.domain.values[0], rv))])
     rec['belief'] = np.array(nb)
+    # interval probabilities (EPBP:356-375: 5-point over 20-point trapezoid) for every hidden continuous rv
+    pr = []
+    for i, rv in enumerate(g.rvs):
+        if rv.value is None and rv.domain.continuous:
+            lo, hi = rv.domain.values
+            a, b = lo + 0.35 * (hi - lo), lo + 0.6 * (hi - lo)
+            pr.append([i, a, b, float(bp.probability(a, b, rv))])
+    rec['probability'] = np.array(pr).reshape(-1, 4)
     rec['meta'] = json.dumps({'model': cg.modelio.dump_model(g), 'n': n, 'iterations': its, 'approx': approx,
                               'seed': seed, 'solver': 'EPBP'})
     path = os.path.join(cg.OUT, 'pbp_%s.npz' % name)
@@ -314,6 +373,12 @@ def capture_hlbp(cg, name, g, n, its, approx, seed, c2f=-1):
         lb.append([float(bp.belief_rv_query(x, rv, bp.sample)) for x in pts])
         mp.append(float(bp.map(rv)))
         bel.append(float(bp.belief(pts[2], rv)))
+    pr = []                # HLBP:384-403 interval probabilities
+    for i, rv in enumerate(g.rvs):
+        if rv.value is None and rv.domain.continuous:
+            lo, hi = rv.domain.values
+            a, b = lo + 0.35 * (hi - lo), lo + 0.6 * (hi - lo)
+            pr.append([i, a, b, float(bp.probability(a, b, rv))])
     # final samples / q per ground rv (through its cluster)
     V = len(g.rvs)
     sample = np.full((V, n), np.nan)
@@ -330,6 +395,7 @@ def capture_hlbp(cg, name, g, n, its, approx, seed, c2f=-1):
                draw_rv_labels=np.array([l[0] for l in labels]), draw_f_labels=np.array([l[1] for l in labels]),
                rv_label=np.array(rv_label), f_label=np.array(f_label), query_x=np.array(xs), query_logb=np.array(lb),
                map=np.array(mp), belief_mid=np.array(bel), final_sample=sample, final_q=q,
+               probability=np.array(pr).reshape(-1, 4),
                meta=json.dumps({'model': cg.modelio.dump_model(g), 'n': n, 'iterations': its, 'approx': approx,
                                 'seed': seed, 'solver': 'HybridLBP', 'c2f': c2f}))
     path = os.path.join(cg.OUT, 'pbp_%s.npz' % name)
@@ -348,3 +414,9 @@ def capture_pbp(cg):
     capture_hlbp(cg, 'hlbp_kalman_full', cg.model_kalman(3, 5, 1, False), 12, 4, 'EP', 23)
     capture_hlbp(cg, 'hlbp_c2f_rgm', model_rgm_c2f(cg), 10, 5, 'EP', 24, c2f=0)
     capture_hlbp(cg, 'hlbp_c2f_rgm_simple', model_rgm_c2f(cg), 12, 4, 'simple', 25, c2f=0)
+    # cfg 3: paper-popularity HMLN (6 papers x 3 topics), T = 32 integral points, the demo's n = 10 / 'simple'
+    capture_hlbp(cg, 'hlbp_hmln', model_hmln_small(cg), 10, 4, 'simple', 26)
+    capture_hlbp(cg, 'hlbp_hmln_ep', model_hmln_small(cg, 5, 3, seed=33), 10, 3, 'EP', 27)
+    capture_hlbp(cg, 'hlbp_hmln_lifted', model_hmln_small(cg, two_values=True, seed=37), 10, 4, 'simple', 30)
+    capture_hlbp(cg, 'hlbp_c2f_hmln', model_hmln_small(cg, two_values=True), 10, 4, 'simple', 28, c2f=0)
+    capture_epbp(cg, 'epbp_hmln', model_hmln_small(cg, 4, 3, seed=35), 10, 3, 'simple', 29)

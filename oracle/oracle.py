@@ -248,6 +248,30 @@ class PbpOracle:
                 on_iteration(i, self)
 
 
+def interval_probability(log_belief, a, b, lo, hi, max_log_value=700.0):
+    """EPBP.probability / HybridLBP.probability (EPBPLogVersion.py:356-375, HybridLBPLogVersion.py:384-403) on top of
+    ``log_area`` (EPBPLogVersion.py:291-308): 20-point trapezoid of exp(belief_rv - shift) on the domain, shift =
+    log_message_balance of the tabulated values (mean, or max - 700; all 20 keys are distinct indices), then the 5-point
+    trapezoid on [a, b] with the same shift.  `log_belief(xs) -> log-beliefs at the points xs`."""
+    def log_area(a, b, n, shift=None):
+        x = np.linspace(a, b, n)
+        d = x[1] - x[0]
+        y = [float(t) for t in log_belief(x)]
+        if shift is None:
+            mean_m, max_m = sum(y) / len(y), max(y)
+            shift = max_m - max_log_value if max_m - mean_m > max_log_value else mean_m
+        y = [t - shift for t in y]
+        res, prev = 0, np.e ** y[0]
+        for i in range(1, n):
+            cur = np.e ** y[i]
+            res += (prev + cur) * d
+            prev = cur
+        return res * 0.5, shift
+    z, shift = log_area(lo, hi, 20)
+    num, _ = log_area(a, b, 5, shift)
+    return num / z
+
+
 # ---- mixture variational inference ----------------------------------------------------------------
 class OVi(C.Structure):
     _fields_ = [('K', C.c_int32), ('T', C.c_int32), ('Dmax', C.c_int32), ('quirks', C.c_int32),

@@ -56,11 +56,14 @@ def _gloo_worker(rank, world, port, out):
     import torch
     import torch.distributed as td
     from lhvi import synth
-    from lhvi.dist import ShardPlan
+    from lhvi.dist import ShardPlan, broadcast_partition, partition_factors
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     td.init_process_group('gloo', rank=rank, world_size=world)
     flat = synth.hybrid_mrf_flat(V=800, deg=4, seed=4)
-    plan = ShardPlan(flat, rank, world)
+    # the factor partition is computed on rank 0 only and broadcast; the plan is then built from this rank's slice
+    fac_owner = broadcast_partition(flat, rank, world)
+    assert (fac_owner == partition_factors(flat, world)).all()
+    plan = ShardPlan(flat, rank, world, fac_owner=fac_owner)
     W = 5
     rng = np.random.default_rng(0)
     edge_val = rng.normal(size=(flat.E, W))                     # same on every rank
@@ -106,6 +109,39 @@ def test_boundary_exchange_gloo_world2():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert all(nb > 0 for _, _, nb in res)
+
+
+def _run_bench(args, env=None, timeout=600):
+    import subprocess
+    e = dict(os.environ)
+    e.pop('WORLD_SIZE', None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=e, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_rejects_a_launcher_of_another_size():
+    """--gpus must equal the launcher's WORLD_SIZE, whatever the two are (checked before anything touches a GPU)"""
+    for world, gpus in ((4, 2), (1, 2), (2, 1)):
+        r = _run_bench(['--gpus', str(gpus)], env={'WORLD_SIZE': str(world)})
+        assert r.returncode != 0 and 'does not match WORLD_SIZE' in r.stderr
+    assert _run_bench(['--gpus', '0']).returncode != 0
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: the parent (no GPU call) starts two ranks under
+    torch.distributed.run, rank 0 prints the one JSON line; gloo rehearsal backend, both ranks on the box's one GPU.
+    The sharded result of the same command must equal the single-GPU line's workload."""
+    import json
+    r = _run_bench(['--gpus', '2', '--edges', '200000', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'],
+                   env={'LHVI_DIST_BACKEND': 'gloo'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['value'] > 0 and out['config']['edges'] == 200000
+    assert out['scaling'] == 'strong' and out['roofline']['bound'] == 'fp64_valu'
 
 
 @pytest.mark.gpu

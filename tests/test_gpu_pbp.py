@@ -5,7 +5,8 @@ import pytest
 
 import modelio
 from test_oracle_golden import API
-from test_oracle_pbp import EPBP_CASES, HLBP_CASES, load_npz
+from test_oracle_pbp import (C2F_CASES, EPBP_CASES, HLBP_CASES, c2f_table_observer, check_draw_tables, lifted_edge_of,
+                             load_npz)
 
 pytestmark = pytest.mark.gpu
 
@@ -91,7 +92,15 @@ def test_epbp_matches_reference_golden(api, golden_dir, name):
             assert mp[i] == pytest.approx(want, abs=2e-4) or mval[i] >= ref_val - 1e-9
         else:
             assert mp[i] == want
-    # batched interval probabilities (5-point over 20-point trapezoid, EPBP:356-375) against the per-variable query
+    # interval probabilities (5-point over 20-point trapezoid, EPBP:356-375) against the reference's recorded values:
+    # the per-variable query and the batched one
+    pa, pb = np.zeros(flat.V), np.ones(flat.V)
+    for i, a, b, want in z['probability']:
+        assert bp.probability(a, b, rvs[int(i)]) == pytest.approx(want, rel=1e-7, abs=1e-300)
+        pa[int(i)], pb[int(i)] = a, b
+    pall = bp.probability_all(pa, pb).cpu().numpy()
+    for i, a, b, want in z['probability']:
+        assert pall[int(i)] == pytest.approx(want, rel=1e-7, abs=1e-300)
     lo = flat.dom_lo[flat.var_dom]
     pall = bp.probability_all(lo + 0.5, lo + 2.0).cpu().numpy()
     for i in chid[:8]:
@@ -114,12 +123,18 @@ def test_hlbp_matches_reference_golden(api, golden_dir, name):
     g, rvs, factors = modelio.load_model(meta['model'], API)
     samples = z['samples']
 
+    draws = []
+
     def inject(k, flat, q):
+        if k > 0:     # what the reference's message / eta_message hold at this generate_sample call (HLBP:100-118,182-215)
+            check_draw_tables(z, k, rvs, meta['n'], lifted_edge_of(flat), bp.f2v.cpu().numpy(), bp.eta.cpu().numpy())
+        draws.append(k)
         rep = np.array([rvs.index(min(c.rvs)) for c in flat.rvs])
         return samples[k][rep]
 
     bp = HybridLBP(g, n=meta['n'], proposal_approximation=meta['approx'], sampler=inject)
     bp.run(meta['iterations'])
+    assert draws == list(range(meta['iterations']))
     rv_color, f_color = bp.g.colors()
     assert oracle.canonical_labels(rv_color) == z['rv_label'].tolist()     # integer partition: exact
     assert oracle.canonical_labels(f_color) == z['f_label'].tolist()
@@ -133,8 +148,16 @@ def test_hlbp_matches_reference_golden(api, golden_dir, name):
     for i in hid[:6]:
         assert bp.map(rvs[i]) == pytest.approx(z['map'][i], abs=1e-4)
         assert bp.belief(z['query_x'][i][2], rvs[i]) == pytest.approx(z['belief_mid'][i], rel=1e-5, abs=1e-7)
-    # batched queries on the lifted graph (stable partition): one row per cluster
     flat = bp.flat
+    pa, pb = np.zeros(flat.V), np.ones(flat.V)
+    for i, a, b, want in z['probability']:      # HLBP:384-403 against the reference's recorded values
+        assert bp.probability(a, b, rvs[int(i)]) == pytest.approx(want, rel=1e-7, abs=1e-300)
+        c = flat.var_index[rvs[int(i)].cluster]
+        pa[c], pb[c] = a, b
+    pall = bp.probability_all(pa, pb).cpu().numpy()
+    for i, a, b, want in z['probability']:
+        assert pall[flat.var_index[rvs[int(i)].cluster]] == pytest.approx(want, rel=1e-7, abs=1e-300)
+    # batched queries on the lifted graph (stable partition): one row per cluster
     mp, mval = bp.map_all(steps=9 if meta['n'] < 32 else 6)
     for i in hid:
         c = flat.var_index[rvs[i].cluster]
@@ -363,7 +386,7 @@ def test_device_exp_accumulate_accuracy(api):
     assert (y[t + c < -760] == 0).all()
 
 
-@pytest.mark.parametrize('name', ['hlbp_c2f_rgm', 'hlbp_c2f_rgm_simple'])
+@pytest.mark.parametrize('name', C2F_CASES)
 def test_hlbp_coarse_to_fine_matches_reference(api, golden_dir, name):
     """c2f=0: coarse start, per-sweep refinement with message inheritance; partitions and proposals at every draw and the
     final log-beliefs / MAPs / normalised beliefs against the reference (its particles injected per cluster)"""
@@ -379,6 +402,8 @@ def test_hlbp_coarse_to_fine_matches_reference(api, golden_dir, name):
         return samples[k][flat.rep_ground]
 
     bp = HybridLBP(g, n=meta['n'], proposal_approximation=meta['approx'], sampler=inject)
+    # the variable-side message / site tables at every draw against the reference's (HLBP:268-308 inheritance included)
+    bp.c2f_observer = c2f_table_observer(z, rvs, factors, meta['n'], lambda t: t.cpu().numpy())
     bp.run(meta['iterations'], c2f=meta['c2f'])
     hist = bp.c2f_history
     assert len(hist) == z['draw_rv_labels'].shape[0]
@@ -397,6 +422,100 @@ def test_hlbp_coarse_to_fine_matches_reference(api, golden_dir, name):
     for i in hid[:5]:
         assert bp.map(rvs[i]) == pytest.approx(z['map'][i], abs=1e-4)
         assert bp.belief(z['query_x'][i][2], rvs[i]) == pytest.approx(z['belief_mid'][i], rel=1e-5, abs=1e-7)
+    for i, a, b, want in z['probability']:
+        assert bp.probability(a, b, rvs[int(i)]) == pytest.approx(want, rel=1e-7, abs=1e-300)
+
+
+def paper_popularity(P, T, seed, points=32):
+    """the paper-popularity hybrid MLN of Demo/Data/HMLN/GeneratorPaperPopularity.py:7-72 (atoms, the three parametric
+    factors with their weights, evidence pattern of generate_data) built with THIS package's relational API, and the
+    demo's domain Domain((-15, 15), integral_points=linspace(0, 10, 32)) (Demo/HMLN/DemoPaperPopularity.py)"""
+    from lhvi.graph import Domain
+    from lhvi.mln import MLNPotential, eq_op
+    from lhvi.relational import LV, Atom, ParamF, RelationalGraph
+    rng = np.random.default_rng(seed)
+    dom_b = Domain((0, 1))
+    dom_r = Domain((-15, 15), continuous=True, integral_points=np.linspace(0, 10, points))
+    lvp, lvt = LV(['p%d' % i for i in range(P)]), LV(['t%d' % i for i in range(T)])
+    atoms = (Atom(dom_b, (lvt, lvt), 'SameSession'), Atom(dom_b, (lvp, lvt), 'PaperIn'),
+             Atom(dom_r, (lvt,), 'TopicPopularity'), Atom(dom_r, (lvp,), 'PaperPopularity'))
+    pfs = (ParamF(MLNPotential(lambda x: eq_op(x[0], 1), w=0.3), nb=['PaperPopularity(p)']),
+           ParamF(MLNPotential(lambda x: x[0] * eq_op(x[1], x[2]), w=0.5),
+                  nb=['SameSession(t1,t2)', 'TopicPopularity(t1)', 'TopicPopularity(t2)'], constrain=lambda s: s['t1'] != s['t2']),
+           ParamF(MLNPotential(lambda x: x[0] * eq_op(x[1], x[2]), w=1),
+                  nb=['PaperIn(p,t)', 'PaperPopularity(p)', 'TopicPopularity(t)']))
+    rel = RelationalGraph(atoms, pfs)
+    g, table = rel.ground_graph()
+    data = {}
+    for i in rng.choice(P, int(P * 0.7), replace=False):
+        data[('PaperPopularity', 'p%d' % i)] = float(rng.integers(0, 5)) * 2.5     # few distinct values: lifting merges
+    for i in rng.choice(T, int(T * 0.7), replace=False):
+        data[('TopicPopularity', 't%d' % i)] = float(rng.uniform(0, 10))
+    for i in rng.choice(P, int(P * 0.7), replace=False):
+        for j in rng.choice(T, int(rng.integers(T)), replace=False):
+            data[('PaperIn', 'p%d' % i, 't%d' % j)] = int(rng.integers(0, 2))
+    for i in range(T):
+        for j in rng.choice(T, T // 2, replace=False):
+            if i != j:
+                data[('SameSession', 't%d' % i, 't%d' % j)] = int(rng.integers(0, 2))
+    rel.add_evidence(data)
+    g.rvs, g.factors = sorted(g.rvs), sorted(g.factors)
+    g.init_nb()
+    return g, table
+
+
+def test_cfg3_paper_popularity_hmln_full_size_matches_oracle(api):
+    """BASELINE.json cfg 3 at its stated size: the paper-popularity HMLN grounded for 300 papers x 10 topics (V = 3 400,
+    F = 3 390, E = 9 570; ternary MLN factors with one boolean and two continuous arguments), HybridLBP n = 10 with the
+    demo's 32 integral points, lifted (c2f = -1): every sweep's tables against the C oracle on the same lifted graph with
+    the same particles, then beliefs of query atoms within 1e-5"""
+    from lhvi.pbp import HybridLBP
+    from oracle import oracle
+    g, table = paper_popularity(300, 10, seed=3)
+    assert len(g.rvs) == 3400 and len(g.factors) == 3390 and sum(len(f.nb) for f in g.factors) == 9570
+    n, its = 10, 4
+    rng = np.random.default_rng(8)
+    samples = []
+
+    def sampler(k, flat, q):
+        cont = flat.var_hidden & flat.var_cont
+        lo, hi = flat.dom_lo[flat.var_dom], flat.dom_hi[flat.var_dom]
+        out = np.zeros((flat.V, n))
+        out[cont] = np.clip(rng.standard_normal((int(cont.sum()), n)) * np.sqrt(q[cont, 1:2]) + q[cont, 0:1],
+                            lo[cont, None], hi[cont, None])
+        samples.append(out)
+        return out
+
+    bp = HybridLBP(g, n=n, proposal_approximation='simple', sampler=sampler)
+    bp.run(its)
+    flat = bp.flat
+    assert bp.T == 32 and flat.V < 3400                       # lifted: fewer clusters than ground variables
+    o = oracle.PbpOracle(flat, n, ep=False, epbp=False, var_threshold=5)
+    o.run(its, samples)
+    hid_e = flat.var_hidden[flat.edge_var]
+    cont = flat.var_hidden & flat.var_cont
+    np.testing.assert_allclose(bp.q_dev.cpu().numpy()[cont], o.q[cont], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(bp.eta.cpu().numpy()[cont[flat.edge_var]], o.eta[cont[flat.edge_var]], rtol=1e-9, atol=1e-12)
+    npe = o.np[flat.edge_var]
+    live = hid_e[:, None] & (np.arange(n)[None, :] < npe[:, None])
+    np.testing.assert_allclose(bp.v2f.cpu().numpy()[live], o.v2f[live], rtol=RTOL, atol=ATOL)
+    got, want = bp.f2v.cpu().numpy(), o.f2v
+    np.testing.assert_allclose(got[:, :n][live], want[:, :n][live], rtol=RTOL, atol=ATOL)
+    ce = cont[flat.edge_var]
+    np.testing.assert_allclose(got[ce, n:], want[ce, n:], rtol=RTOL, atol=ATOL)
+    # normalised beliefs of the query atoms (PaperPopularity / TopicPopularity, as in the demo) within 1e-5 of the oracle's
+    query = [rv for key, rv in table.items() if key[0] in ('PaperPopularity', 'TopicPopularity') and rv.value is None][:12]
+    for rv in query:
+        c = flat.var_index[rv.cluster]
+        lb = lambda xs: o.belief_points(np.array([c]), np.asarray(xs, dtype=float)[None, :])[0]
+        x = np.linspace(-15, 15, 20)
+        y = lb(x)
+        shift = y.mean() if y.max() - y.mean() <= 700 else y.max() - 700
+        w = np.exp(y - shift)
+        zarea = ((w[:-1] + w[1:]) * (x[1] - x[0])).sum() * 0.5
+        for xq in (2.0, 5.5):
+            want_b = float(np.exp(lb([xq])[0] - shift) / zarea)
+            assert bp.belief(xq, rv) == pytest.approx(want_b, rel=1e-5, abs=1e-12)
 
 
 def test_batched_kl_of_tabulated_beliefs(api):

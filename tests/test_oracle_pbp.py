@@ -11,8 +11,10 @@ from lhvi import lifting
 from lhvi.flat import flatten
 from oracle import oracle
 
-EPBP_CASES = ['epbp_kalman_simple', 'epbp_kalman_ep', 'epbp_kalman_n64', 'epbp_hybrid_ep', 'epbp_hybrid_simple']
-HLBP_CASES = ['hlbp_rgm_small', 'hlbp_hybrid', 'hlbp_kalman_full']
+EPBP_CASES = ['epbp_kalman_simple', 'epbp_kalman_ep', 'epbp_kalman_n64', 'epbp_hybrid_ep', 'epbp_hybrid_simple',
+              'epbp_hmln']
+HLBP_CASES = ['hlbp_rgm_small', 'hlbp_hybrid', 'hlbp_kalman_full', 'hlbp_hmln', 'hlbp_hmln_ep', 'hlbp_hmln_lifted']
+C2F_CASES = ['hlbp_c2f_rgm', 'hlbp_c2f_rgm_simple', 'hlbp_c2f_hmln']
 
 # fp64 tolerance of the log-message tables: the oracle fuses nothing and follows the reference's operation
 # order, so differences come only from libm (pow(e,x) vs CPython's) and the exact-rational mean
@@ -81,6 +83,49 @@ def test_epbp_oracle_matches_reference(golden_dir, name):
     hid = np.flatnonzero(flat.var_hidden)
     got = o.belief_points(hid, z['query_x'][hid])
     np.testing.assert_allclose(got, z['query_logb'][hid], rtol=1e-9, atol=1e-8)
+    check_probability(z, rvs, lambda i, xs: o.belief_points(np.array([i]), np.asarray(xs)[None, :])[0])
+
+
+def check_probability(z, rvs, log_belief_of):
+    """the reference's recorded probability(a, b, rv) (EPBP:356-375 / HLBP:384-403); `log_belief_of(i, xs)`"""
+    if 'probability' not in z.files:
+        return
+    for i, a, b, want in z['probability']:
+        rv = rvs[int(i)]
+        got = oracle.interval_probability(lambda xs: log_belief_of(int(i), xs), a, b, rv.domain.values[0], rv.domain.values[1])
+        assert got == pytest.approx(want, rel=1e-8, abs=1e-300)
+
+
+def check_draw_tables(z, k, rvs, n, edge_of, f2v, eta, c2f=False):
+    """message f -> rv at the integral points and the sites (eta) the reference held at its k-th generate_sample call
+    (recorded per ground rv and per ground factor of it, HLBP:100-118,182-215): `edge_of(rv, f)` -> row of f2v / eta.
+    In a coarse-to-fine run a factor cluster created by the split_factors just before the draw has inherited its sites but
+    not its f -> rv table (HLBP:292-308; it is recomputed right after the draw): those rows are absent from the record."""
+    want_m, want_e = z['draw_f2v_grid'][k], z['draw_eta'][k]
+    checked = 0
+    for i, rv in enumerate(rvs):
+        if rv.value is not None or not rv.domain.continuous:
+            continue
+        T = len(rv.domain.integral_points)
+        for s_, f in enumerate(rv.nb):
+            e = edge_of(rv, f)
+            missing = np.isnan(want_m[i, s_, :T])
+            assert missing.all() if (c2f and missing.any()) else not missing.any()
+            if not missing.any():
+                np.testing.assert_allclose(f2v[e, n:n + T], want_m[i, s_, :T], rtol=RTOL, atol=ATOL,
+                                           err_msg='f2v grid at draw %d rv %d factor %d' % (k, i, s_))
+            np.testing.assert_allclose(eta[e], want_e[i, s_], rtol=1e-9, atol=1e-12,
+                                       err_msg='eta at draw %d rv %d factor %d' % (k, i, s_))
+            checked += 1
+    assert checked
+
+
+def lifted_edge_of(flat):
+    def edge_of(rv, f):
+        fi = flat.fac_index[f.cluster]
+        pos = next(i for i, r in enumerate(f.nb) if r is rv)
+        return int(flat.edge_canon[flat.fac_ptr[fi] + pos])
+    return edge_of
 
 
 @pytest.mark.parametrize('name', HLBP_CASES)
@@ -98,13 +143,16 @@ def test_hlbp_oracle_matches_reference(golden_dir, name):
     rep = np.array([rvs.index(min(c.rvs)) for c in flat.rvs])
     samples = [z['samples'][k][rep] for k in range(z['samples'].shape[0])]
     o = oracle.PbpOracle(flat, meta['n'], ep=meta['approx'] == 'EP', epbp=False, var_threshold=5)
-    o.run(meta['iterations'], samples)
+    # at draw k = i + 1 the reference holds f2v of sweep i - 1 (zeros for i = 0) and the sites of sweep i
+    o.run(meta['iterations'], samples,
+          lambda i, o: i < meta['iterations'] - 1 and check_draw_tables(z, i + 1, rvs, meta['n'], lifted_edge_of(flat), o.f2v, o.eta))
     cl = np.array([flat.var_index[rv.cluster] for rv in rvs])
     hid = np.flatnonzero(gflat.var_hidden)
     np.testing.assert_allclose(o.q[cl][gflat.var_hidden & gflat.var_cont],
                                z['final_q'][gflat.var_hidden & gflat.var_cont], rtol=1e-9)
     got = o.belief_points(cl[hid], z['query_x'][hid])
     np.testing.assert_allclose(got, z['query_logb'][hid], rtol=1e-9, atol=1e-8)
+    check_probability(z, rvs, lambda i, xs: o.belief_points(cl[[i]], np.asarray(xs)[None, :])[0])
 
 
 class OracleRefiner:
@@ -151,7 +199,19 @@ def ground_edges(flat, ground_rv):
     return acc
 
 
-@pytest.mark.parametrize('name', ['hlbp_c2f_rgm', 'hlbp_c2f_rgm_simple'])
+def c2f_table_observer(z, rvs, factors, n, host):
+    """lhvi.c2f observer: the variable-side tables at every draw against the reference's recorded messages / sites"""
+    ridx = {id(rv): i for i, rv in enumerate(rvs)}
+    fidx = {id(f): i for i, f in enumerate(factors)}
+
+    def observer(k, rvc, old_fc, G1, pair_phi, st1):
+        pair = {(int(A), int(phi)): e for e, (A, phi) in enumerate(zip(G1.edge_var, pair_phi))}
+        check_draw_tables(z, k, rvs, n, lambda rv, f: pair[(int(rvc[ridx[id(rv)]]), int(old_fc[fidx[id(f)]]))],
+                          host(st1.f2v), host(st1.eta), c2f=True)
+    return observer
+
+
+@pytest.mark.parametrize('name', C2F_CASES)
 def test_hlbp_c2f_oracle_matches_reference(golden_dir, name):
     """HybridLBP.run(c2f=0) driven through lhvi.c2f with the CPU oracle as the engine vs the reference: partitions at
     every draw (exact), proposals at every draw, final log-beliefs through the ground variables' factors"""
@@ -166,7 +226,8 @@ def test_hlbp_c2f_oracle_matches_reference(golden_dir, name):
         return samples[k][flat.rep_ground]
 
     st, flat, cg, rvc, fc, history = c2f.run_c2f(g, OracleEngine(meta['n'], meta['approx'] == 'EP'), OracleRefiner(g),
-                                                meta['iterations'], meta['c2f'], 2, 10, draw)
+                                                meta['iterations'], meta['c2f'], 2, 10, draw,
+                                                observer=c2f_table_observer(z, rvs, factors, meta['n'], lambda a: a))
     assert len(history) == z['draw_rv_labels'].shape[0]
     for k, (r, f) in enumerate(history):
         assert oracle.canonical_labels(r) == z['draw_rv_labels'][k].tolist(), 'rv partition at draw %d' % k
@@ -186,3 +247,61 @@ def test_hlbp_c2f_oracle_matches_reference(golden_dir, name):
         vals = st.edge_points(edges, np.tile(z['query_x'][i], (edges.size, 1)))
         got = (vals * np.array([acc[e] for e in acc], dtype=float)[:, None]).sum(axis=0)
         np.testing.assert_allclose(got, z['query_logb'][i], rtol=1e-8, atol=1e-6)
+
+    def log_belief(i, xs):
+        acc = ground_edges(flat, rvs[i])
+        edges = np.array(list(acc))
+        vals = st.edge_points(edges, np.tile(np.asarray(xs), (edges.size, 1)))
+        return (vals * np.array([acc[e] for e in acc], dtype=float)[:, None]).sum(axis=0)
+    check_probability(z, rvs, log_belief)
+
+
+@pytest.mark.parametrize('name', ['epbp_kalman_simple', 'epbp_hybrid_ep', 'epbp_hmln'])
+def test_pure_python_restatement_matches_reference(golden_dir, name):
+    """oracle/pyref.py (the dict-of-dicts sweep bench.py times as ``cpu_baseline.python``) against the reference's recorded
+    messages, proposals and sites of every iteration, and its log-beliefs"""
+    from oracle import pyref
+    z, meta = load_npz(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    n, its = meta['n'], meta['iterations']
+    edges = [(f, rv) for f in factors for rv in f.nb]
+    samples = [pyref.sample_dicts(rvs, z['sample'][k]) for k in range(z['sample'].shape[0])]
+    seen = []
+
+    def on_it(i, bp):
+        for e, (f, rv) in enumerate(edges):
+            if rv.value is not None:
+                continue
+            pts = samples[i][rv]
+            np.testing.assert_allclose([bp.message[(rv, f)][x] for x in pts], z['v2f'][i][e, :len(pts)], rtol=1e-12, atol=1e-10)
+            if i > 0:       # f2v of sweep i-1 lives on sample i (+ the integral points); still in place before this sweep's f2v
+                np.testing.assert_allclose([bp.message[(f, rv)][x] for x in pts], z['f2v'][i][e, :len(pts)], rtol=1e-12, atol=1e-10)
+                if rv.domain.continuous:
+                    grid = rv.domain.integral_points
+                    np.testing.assert_allclose([bp.message[(f, rv)][x] for x in grid], z['f2v'][i][e, n:n + len(grid)],
+                                               rtol=1e-12, atol=1e-10)
+            if i < its - 1 and rv.domain.continuous:
+                np.testing.assert_allclose(bp.eta_message[(f, rv)], z['eta'][i][e], rtol=1e-12)
+        if i < its - 1:
+            for k, rv in enumerate(rvs):
+                if rv.value is None and rv.domain.continuous:
+                    np.testing.assert_allclose(bp.q[rv], z['q'][i][k], rtol=1e-12)
+        seen.append(i)
+
+    bp = pyref.DictEPBP(g, n, meta['approx'])
+    # the snapshot of iteration i holds v2f of sweep i and f2v of sweep i-1, both keyed by sample i: check before the install
+    bp.start(samples[0])
+    for i in range(its):
+        bp.v2f_half()
+        if i < its - 1:
+            bp.update_proposal()
+            on_it(i, bp)
+            bp.install(samples[i + 1])
+            bp.f2v_half()
+        else:
+            on_it(i, bp)
+    assert seen == list(range(its))
+    hid = [i for i, rv in enumerate(rvs) if rv.value is None]
+    for i in hid[:4]:
+        got = [bp.belief_rv(x, rvs[i]) for x in z['query_x'][i]]
+        np.testing.assert_allclose(got, z['query_logb'][i], rtol=1e-10, atol=1e-9)
