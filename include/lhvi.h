@@ -135,6 +135,9 @@ int lhvi_log_likelihood(const lhvi_graph_t* g, const lhvi_pots_t* pots, const do
 #define LHVI_PBP_SKIP_HEAVY 32u   /* lhvi_pbp_f2v: do not launch the continuous x continuous (heavy_desc) kernel (profiling aid) */
 #define LHVI_PBP_SKIP_LIGHT 64u   /* lhvi_pbp_f2v: do not launch the kernels of the remaining fast edges (light_desc and fast_edges;
                                    * profiling aid) */
+#define LHVI_PBP_LEAVE_ROOM 256u /* lhvi_pbp_f2v: the persistent kernels launch cus/8 workgroups fewer than fill the device, so that
+                                   * another stream's kernels (RCCL's copy kernels of an overlapped exchange) find free slots at
+                                   * any time instead of waiting for a persistent workgroup to retire.  Set by sharded runs. */
 #define LHVI_PBP_NO_GRID 128u    /* lhvi_pbp_f2v: integral points always by the direct form (one exponential per term), never by the
                                    * uniform-grid recurrence (testing / profiling aid) */
 

@@ -1280,12 +1280,13 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
                                                                  uint64_t seed, uint32_t iteration, double* __restrict__ out,
                                                                  uint8_t* __restrict__ uniq) {
     __shared__ LogRec sh_log[LOG_TAB_N];
-    __shared__ uint32_t sh_bits[BLOCK / WAVE][1 << (UNIQ_HASH_BITS - 5)];
+    __shared__ uint32_t sh_bits[BLOCK / WAVE][2 << (UNIQ_HASH_BITS - 5)];      // per wave: the bitset, then its "hit twice" twin
     load_log_table(sh_log);
-    for (int i = threadIdx.x; i < (BLOCK / WAVE) << (UNIQ_HASH_BITS - 5); i += BLOCK) (&sh_bits[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < (BLOCK / WAVE) * (2 << (UNIQ_HASH_BITS - 5)); i += BLOCK) (&sh_bits[0][0])[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     uint32_t* bits = sh_bits[threadIdx.x >> 6];
+    uint32_t* twice = bits + (1 << (UNIQ_HASH_BITS - 5));
     const int n = s.n;
     const int nwaves = gridDim.x * (BLOCK / WAVE);
     // persistent waves (the table is loaded once per block, not once per four variables)
@@ -1310,19 +1311,28 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
         // in practice runs for the variables with draws clipped to a bound.  Each lane clears its own word afterwards.
         const int xlo = __double2loint(x), xhi = __double2hiint(x);
         const uint64_t live = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1);
-        // two independent hashes into the same bitset: a lane is suspect only if BOTH its bits were already set -- equal
-        // particles always are, different ones for 0.4 % of the variables (with one hash: 12 %, and every false alarm costs
-        // the 63-step exact pass below)
+        // two independent hashes into the same bitset.  The first is decisive: of two equal particles the lane whose
+        // returning atomic OR executes second finds the bit set (whichever lane that is -- no ordering between lanes or
+        // between the two instructions is assumed).  The second only rejects false alarms, and order-independently: a
+        // lane that finds its second bit already set records it in the "twice" bitset, and after the wave has synchronised
+        // every lane asks whether its second bit was hit more than once -- for equal particles it always was.  Suspect =
+        // first bit found set AND second bit hit twice: different particles for 0.4 % of the variables (one hash: 12 %,
+        // and every false alarm costs the exact pass below)
         const uint32_t hsh = ((uint32_t)xlo * 0x9E3779B1u) >> (32 - UNIQ_HASH_BITS);
         const uint32_t hsh2 = (((uint32_t)xhi * 0x85EBCA6Bu) ^ ((uint32_t)xlo * 0xC2B2AE35u)) >> (32 - UNIQ_HASH_BITS);
         uint32_t* word = bits + (hsh >> 5);
         uint32_t* word2 = bits + (hsh2 >> 5);
+        uint32_t* tword2 = twice + (hsh2 >> 5);
         const uint32_t bit = 1u << (hsh & 31), bit2 = 1u << (hsh2 & 31);
-        uint32_t old = 0, old2 = 0;
-        if (lane < cnt) { old = atomicOr(word, bit); old2 = atomicOr(word2, bit2); }
-        uint64_t dup = __ballot(lane < cnt && (old & bit) && (old2 & bit2));
+        uint32_t old = 0;
+        if (lane < cnt) {
+            old = atomicOr(word, bit);
+            if (atomicOr(word2, bit2) & bit2) atomicOr(tword2, bit2);
+        }
         LHVI_WAVE_SYNC();
-        if (lane < cnt) { *word = 0; *word2 = 0; }
+        uint64_t dup = __ballot(lane < cnt && (old & bit) && (*tword2 & bit2));
+        LHVI_WAVE_SYNC();
+        if (lane < cnt) { *word = 0; *word2 = 0; *tword2 = 0; }
         LHVI_WAVE_SYNC();
         if (dup) {
             // every group of equal particles contains a suspect lane (the one whose atomics came later), so walking the
@@ -1429,10 +1439,14 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     static const int light_per_cu = blocks_per_cu((const void*)pbp_f2v_light_kernel);
     static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel);
     const int heavy_blocks = heavy_per_cu, side_blocks = 8;
+    // LEAVE_ROOM (sharded runs): every persistent grid stays cus/8 workgroups short of filling the device, so a collective's
+    // copy kernels on another stream can become resident while these waves run (no kernel here ever waits on another
+    // workgroup, so a full device could only delay such a kernel, never block it -- but a delayed collective is an exposed one)
+    const int spare = (s->flags & LHVI_PBP_LEAVE_ROOM) ? max(cus / 8, 1) : 0;
     // work ticket of the heavy kernel: reset on this stream right before the launch.  Chunks of 8 pay when every wave gets
     // several of them; a short list (a small graph, the interior part of a shard) keeps one entry per wave and strides
     const bool run_heavy = !(s->flags & LHVI_PBP_SKIP_FAST) && s->heavy_desc && s->n_heavy > 0 && !(s->flags & LHVI_PBP_SKIP_HEAVY);
-    const int heavy_grid = min((s->n_heavy + 3) / 4, cus * heavy_blocks);
+    const int heavy_grid = min((s->n_heavy + 3) / 4, max(cus * heavy_blocks - spare, 1));
     lhvi_pbp_t sh = *s;
     if (sh.f2v_ticket && (int64_t)s->n_heavy < (int64_t)heavy_grid * (BLOCK / WAVE) * 8 * 4) sh.f2v_ticket = nullptr;
     if (sh.f2v_ticket && run_heavy && hipMemsetAsync(sh.f2v_ticket, 0, LHVI_PBP_TICKET_WORDS * sizeof(uint32_t), as_stream(stream)) != hipSuccess)
@@ -1442,17 +1456,17 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
             hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(heavy_grid), dim3(BLOCK), 0, as_stream(stream),
                                *g, sh, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy);
         if (s->light_desc && s->n_light > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
-            hipLaunchKernelGGL(pbp_f2v_light_kernel, dim3(min((s->n_light + 3) / 4, cus * min(light_per_cu, side_blocks))), dim3(BLOCK), 0, as_stream(stream),
+            hipLaunchKernelGGL(pbp_f2v_light_kernel, dim3(min((s->n_light + 3) / 4, max(cus * min(light_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0, as_stream(stream),
                                *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->light_desc), s->n_light);
         if (nfast > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
-            hipLaunchKernelGGL(pbp_f2v_fast_kernel, dim3(min((nfast + 3) / 4, cus * min(fast_per_cu, side_blocks))), dim3(BLOCK), 0, as_stream(stream),
+            hipLaunchKernelGGL(pbp_f2v_fast_kernel, dim3(min((nfast + 3) / 4, max(cus * min(fast_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0, as_stream(stream),
                                *g, *pots, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->fast_desc), pots->param);
     }
     if (!(s->flags & LHVI_PBP_SKIP_GENERIC) && ngen > 0) {
         int pts_log2 = s->generic_edges ? s->generic_pts_log2 : 6;
         if (pts_log2 < 0 || pts_log2 > 6) pts_log2 = 6;
         const int groups = (ngen + (64 >> pts_log2) - 1) / (64 >> pts_log2);
-        hipLaunchKernelGGL(pbp_f2v_generic_kernel, dim3(min((groups + 3) / 4, cus * min(gen_per_cu, side_blocks))), dim3(BLOCK), 0, as_stream(stream), *g, *pots,
+        hipLaunchKernelGGL(pbp_f2v_generic_kernel, dim3(min((groups + 3) / 4, max(cus * min(gen_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0, as_stream(stream), *g, *pots,
                            *s, v2f, f2v, pts_log2);
     }
     return check_launch();

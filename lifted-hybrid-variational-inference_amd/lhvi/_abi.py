@@ -70,6 +70,7 @@ PBP_SKIP_TERMS = 16
 PBP_SKIP_HEAVY = 32
 PBP_SKIP_LIGHT = 64
 PBP_NO_GRID = 128
+PBP_LEAVE_ROOM = 256
 ABI_VERSION = 5             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
 PBP_DESC_BYTES = 128
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE

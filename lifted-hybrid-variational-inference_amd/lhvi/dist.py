@@ -295,6 +295,8 @@ class ShardedRunner:
     def _struct(self, part=None):
         """`part`: None = everything, 0 = interior variables, 1 = boundary variables (variable range only)"""
         s = self.bp._struct()
+        if self.overlap:
+            s.flags |= _abi.PBP_LEAVE_ROOM         # the exchange is in flight beside the persistent f2v kernels
         s.bslot, s.var_degree = _abi.ptr(self.bslot), _abi.ptr(self.var_degree)
         s.brow_ptr, s.brow_off, s.brow_peer = _abi.ptr(self.brow_ptr), _abi.ptr(self.brow_off), _abi.ptr(self.brow_peer)
         s.recv, s.rank = _abi.ptr(self.recv), int(self.rank)

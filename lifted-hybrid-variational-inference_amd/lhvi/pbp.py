@@ -48,6 +48,9 @@ class _ParticleSweep:
         nst = flat.var_nstates
         if (flat.var_hidden & ~flat.var_cont & (nst > n)).any():
             raise _abi.LhviError('a discrete variable has more states than particle slots n=%d' % n)
+        if (flat.var_hidden & flat.var_cont & (np.diff(flat.var_ptr) == 0)).any():
+            # the reference fails in gaussian_product (`0 ** -1`, EPBP:30-41) on the first proposal update of such a variable
+            raise ZeroDivisionError('a hidden continuous variable has no incident factor: its proposal is an empty product')
         self.np_host = np.where(flat.var_hidden, np.where(flat.var_cont, n, nst), 0).astype(np.int32)
         self.np_dev = _abi.to_dev(self.np_host)
         S = n + self.T

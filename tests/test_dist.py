@@ -283,6 +283,33 @@ def _rccl_self_worker(port, out):
     td.all_reduce(t, op=td.ReduceOp.MAX)
     torch.cuda.synchronize()
     ok = bool(torch.equal(got, runner.send)) and float(t.item()) == 1.5
+    # the overlapped schedule's stream pattern: the collective started asynchronously (RCCL's copy kernel on RCCL's stream),
+    # the slot-filling persistent f2v kernels launched right behind it on the compute stream (LEAVE_ROOM, as sharded runs
+    # set it), then work.wait().  Both must finish, the received rows must be the sent ones, and the messages must equal
+    # those of the same launch with nothing beside it.
+    from lhvi import _abi
+    from lhvi.pbp import EPBP
+    big = synth.hybrid_mrf_flat(V=60000, deg=4, seed=9)            # heavy list long enough to fill every CU
+    bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=4)
+    bp._setup(None, flat=big)
+    single = dist.SingleRunner(bp)
+    single.init()
+    single.sweep()
+    alone = bp.f2v.clone()
+    sref = bp._struct()
+    _abi.check(_abi.lib().lhvi_pbp_f2v(bp.dg.g, bp.dg.p, sref, _abi.ptr(bp.v2f), _abi.ptr(alone), _abi.stream_ptr()))
+    k2 = 4_000_000                                                  # 32 MB: a copy that takes as long as the f2v launch's start-up
+    send2 = torch.arange(k2, dtype=torch.float64, device='cuda')
+    for it in range(3):
+        recv2 = torch.zeros(k2, dtype=torch.float64, device='cuda')
+        beside = torch.zeros_like(alone)
+        work = td.all_to_all_single(recv2, send2, output_split_sizes=[k2], input_split_sizes=[k2], async_op=True)
+        s2 = bp._struct()
+        s2.flags |= _abi.PBP_LEAVE_ROOM
+        _abi.check(_abi.lib().lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s2, _abi.ptr(bp.v2f), _abi.ptr(beside), _abi.stream_ptr()))
+        work.wait()
+        torch.cuda.synchronize()
+        ok = ok and bool(torch.equal(recv2, send2)) and bool(torch.equal(beside, alone))
     td.destroy_process_group()
     with open(out, 'w') as f:
         f.write('ok' if ok else 'mismatch')
@@ -291,7 +318,8 @@ def _rccl_self_worker(port, out):
 @pytest.mark.gpu
 def test_rccl_exchange_call_path(tmp_path):
     """the RCCL (backend 'nccl') calls of the multi-GPU run -- init with a device id, all_to_all_single with split lists on
-    fp64 device buffers, barrier, max all-reduce -- on the one GPU a test box has (world size 1, rank 0 <-> rank 0)"""
+    fp64 device buffers, barrier, max all-reduce -- on the one GPU a test box has (world size 1, rank 0 <-> rank 0); then
+    the overlapped schedule's pattern, an asynchronous collective with the persistent f2v kernels launched beside it"""
     import torch.multiprocessing as mp
     from lhvi import _abi
     _abi.require_gpu()

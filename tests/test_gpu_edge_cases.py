@@ -63,6 +63,18 @@ def test_degree_one_hidden_variable_raises_like_the_reference(api):
         GaBP(g).run(3)
 
 
+def test_isolated_hidden_variable_raises_like_the_reference(api):
+    """a hidden continuous variable without factors: the reference divides by zero in gaussian_product (EPBP:30-41) on its
+    first proposal update; the device path must not quietly produce NaN particles"""
+    from lhvi.graph import Domain, RV
+    from lhvi.pbp import EPBP
+    g, rvs = _chain(3)
+    g.rvs = rvs + [RV(Domain((-5, 5), continuous=True))]
+    g.init_nb()
+    with pytest.raises(ZeroDivisionError):
+        EPBP(g, n=8, proposal_approximation='simple').run(3)
+
+
 def test_high_degree_hub_matches_oracle(api):
     """star: one hub with 300 pairwise neighbours (exercises the O(deg) v2f path and long CSR rows)"""
     from lhvi import synth, _abi
