@@ -104,22 +104,7 @@ if 'cfg3' in which:
 
 if 'cfg5' in which:
     # cfg 5: RGM template at 10M ground edges, structured evidence; colour refinement on the device, then lifted VI
-    C, B = 2000, 1250
-    flat, sym, rv0, f0 = synth.rgm_flat(C=C, B=B, n_values=0, evidence_ratio=0.0, seed=0)
-    # structured evidence: markets and revenues observed from small value pools, a regular sub-lattice of losses observed
-    V = flat.V
-    val = np.full(V, np.nan)
-    market, loss, revenue = 1, 1 + C, 1 + C + C * B
-    c = np.arange(C); b = np.arange(B)
-    val[market + c[c % 4 == 0]] = (c[c % 4 == 0] // 4 % 5).astype(float) - 2.0
-    val[revenue + b[b % 5 == 0]] = (b[b % 5 == 0] // 5 % 4).astype(float) * 1.5
-    cc, bb = np.meshgrid(c[c % 8 == 1], b[b % 10 == 3], indexing='ij')
-    val[loss + (cc * B + bb).ravel()] = ((cc + bb) % 3).ravel().astype(float)
-    flat.var_value = val
-    rv0 = np.zeros(V, dtype=np.int32)
-    ob = ~np.isnan(val)
-    _, inv = np.unique(val[ob], return_inverse=True)
-    rv0[ob] = 1 + inv
+    flat, sym, rv0, f0 = synth.rgm_structured_flat()          # C = 2000, B = 1250: 10.0 M ground edges, ~10 k rv clusters
     dg5 = _abi.DeviceGraph(flat)                     # graph resident in HBM before the timed region
     lifting.refine_flat(flat, sym, rv0, f0, dg=dg5)  # warm-up (rocPRIM temporary storage, code objects)
     torch.cuda.synchronize()

@@ -80,3 +80,102 @@ def test_full_size_sweep_invariants():
     bp3 = _run(flat_p, 2)
     q3 = bp3.q_dev[cont]
     assert abs(float(q3.sum()) - checksum) <= 1e-9 * abs(checksum)
+
+
+def _independent_stability_check(flat, rvc, fc):
+    """Is (rvc, fc) a fixed point of colour passing?  Checked on the device with torch, independently of csrc/color.hip:
+    factors exactly (cluster id and the scope's cluster ids packed into one int64 -- as many distinct keys as clusters means
+    every cluster is uniform), variables through two 64-bit multiset hashes of the incident factor colours built with other
+    mixing constants than the kernels' fingerprints (a wrong merge would need a simultaneous 128-bit collision here too)"""
+    import torch
+    dev = 'cuda'
+    ev = torch.from_numpy(flat.edge_var.astype(np.int64)).to(dev)
+    ef = torch.from_numpy(flat.edge_fac.astype(np.int64)).to(dev)
+    r = torch.from_numpy(np.asarray(rvc, dtype=np.int64)).to(dev)
+    f = torch.from_numpy(np.asarray(fc, dtype=np.int64)).to(dev)
+    n_rv, n_f = int(r.max()) + 1, int(f.max()) + 1
+    assert n_rv < (1 << 20) and n_f < (1 << 22) and bool((torch.from_numpy(np.diff(flat.fac_ptr)) == 2).all())
+    key = (f << 40) | (r[ev[0::2]] << 20) | r[ev[1::2]]
+    assert int(torch.unique(key).numel()) == n_f
+
+    def mix(x, c1, c2):                       # splitmix-style, wrapping int64 arithmetic
+        x = (x ^ (x >> 31)) * c1
+        x = (x ^ (x >> 29)) * c2
+        return x ^ (x >> 32)
+    fe = f[ef]
+    h1 = torch.zeros(flat.V, dtype=torch.int64, device=dev).index_add_(0, ev, mix(fe + 0x1F3D5B79, -0x61C8864680B583EB, 0x2545F4914F6CDD1D))
+    h2 = torch.zeros(flat.V, dtype=torch.int64, device=dev).index_add_(0, ev, mix(fe * 3 + 0x7ED55D16, 0x369DEA0F31A53F85, -0x4B47D0C5B9E0A4C7))
+    rows = torch.stack([r, h1, h2], dim=1)
+    assert int(torch.unique(rows, dim=0).shape[0]) == n_rv
+    return n_rv, n_f
+
+
+def test_cfg5_rgm_at_10m_ground_edges_lifts_to_10k_clusters():
+    """BASELINE.json cfg 5 at its stated shape: the RGM template at 10.0 M ground edges whose evidence makes colour passing
+    converge to ~10 k rv clusters; refinement on the device, then lifted VI (K = 2, T = 3).
+    Size-independent checks: the partition is a fixed point (independent re-hash), cluster sizes and counts add up to the
+    ground degrees, the 1/25-scale twin (same evidence classes) has the same number of clusters and its partition equals
+    the exact Python colour passing bit for bit, the lifted free energy equals the ground one on the twin (1e-8) and
+    decreases under ADAM at full size."""
+    import torch
+    from lhvi import _abi, lifting, synth
+    from lhvi.vi import VarInference
+    from oracle import oracle
+    _abi.require_gpu()
+    flat, sym, rv0, f0 = synth.rgm_structured_flat()
+    assert flat.E == 10_004_000
+    dg = _abi.DeviceGraph(flat)
+    st = {}
+    rvc, fc = lifting.refine_flat(flat, sym, rv0, f0, dg=dg, stats=st)
+    n_rv, n_f = _independent_stability_check(flat, rvc, fc)
+    assert (n_rv, n_f) == (9956, 19630) and st['rounds'] <= 8
+    # one more round changes nothing
+    rvc2, fc2 = lifting.refine_flat(flat, sym, rvc, fc, dg=dg)
+    assert (rvc2 == rvc).all() and (fc2 == fc).all()
+    del dg
+    # clusters never mix initial colours (hidden / evidence value, potential)
+    assert np.unique(np.stack([rvc, rv0], 1), axis=0).shape[0] == n_rv and np.unique(np.stack([fc, f0], 1), axis=0).shape[0] == n_f
+    lflat = lifting.lift_flat(flat, rvc, fc)
+    assert lflat.V == n_rv and lflat.F == n_f
+    # count / N bookkeeping: a cluster's counts add up to its representative's ground degree, and over all clusters to E
+    deg = np.diff(flat.var_ptr)
+    rep = np.full(n_rv, flat.V, dtype=np.int64)
+    np.minimum.at(rep, rvc, np.arange(flat.V))
+    N = np.add.reduceat(lflat.edge_count[lflat.var_edge], lflat.var_ptr[:-1])
+    np.testing.assert_array_equal(N, deg[rep])
+    assert float((lflat.var_mult * N).sum()) == flat.E and lflat.var_mult.sum() == flat.V and lflat.fac_mult.sum() == flat.F
+    assert (deg == deg[rep][rvc]).all()                           # members of a cluster have the same degree
+    # lifted VI at full size: the free energy goes down under ADAM
+    vi = VarInference(None, 2, 3)
+    vi._setup_flat(lflat)
+    np.random.seed(0)
+    vi.init_param()
+    fe0 = vi.free_energy()
+    vi.is_log, vi.log_fe = True, True
+    vi.time_log, vi.total_time = [], 0
+    vi.alpha, vi.b1, vi.b2, vi.eps, vi.t = 0.1, 0.9, 0.999, 1e-8, 0
+    vi.ADAM_update(20)
+    fes = [fe for _, fe in vi.time_log]
+    assert np.isfinite(fes).all() and fes[-1] < fe0 and fes[-1] < fes[4]
+    # ---- the 1/25-scale twin (one market per class, one revenue per class)
+    small, sym_s, rv0_s, f0_s = synth.rgm_structured_flat(400, 250)
+    rs, fs = lifting.refine_flat(small, sym_s, rv0_s, f0_s)
+    assert (int(rs.max()) + 1, int(fs.max()) + 1) == (n_rv, n_f)
+    ro, fo = oracle.color_passing(small, sym_s, rv0_s, f0_s)                  # exact Python restatement (CGWO:264-271)
+    assert oracle.canonical_labels(rs) == oracle.canonical_labels(ro) and oracle.canonical_labels(fs) == oracle.canonical_labels(fo)
+    lsmall = lifting.lift_flat(small, rs, fs)
+    lv = VarInference(None, 2, 3)
+    lv._setup_flat(lsmall)
+    np.random.seed(1)
+    lv.init_param()
+    gv = VarInference(None, 2, 3)
+    gv._setup_flat(small)
+    gv._upload_params(lv._dev['w_tau'].cpu().numpy(), lv._dev['eta_c'].cpu().numpy()[rs], lv._dev['tau_d'].cpu().numpy()[rs])
+    fl, fg = lv.free_energy(), gv.free_energy()
+    assert fl == pytest.approx(fg, rel=1e-8)
+    # and stays equal along the optimisation: lifted ADAM steps, parameters broadcast to the ground graph
+    lv.is_log = False
+    lv.alpha, lv.b1, lv.b2, lv.eps, lv.t = 0.1, 0.9, 0.999, 1e-8, 0
+    lv.ADAM_update(5)
+    gv._upload_params(lv._dev['w_tau'].cpu().numpy(), lv._dev['eta_c'].cpu().numpy()[rs], lv._dev['tau_d'].cpu().numpy()[rs])
+    assert lv.free_energy() == pytest.approx(gv.free_energy(), rel=1e-8) and lv.free_energy() < fl

@@ -152,3 +152,28 @@ def test_device_log_likelihood_matches_host(api, golden_dir, name):
             assert got == want
         else:
             assert got == pytest.approx(want, rel=1e-12, abs=1e-10)
+
+
+def test_device_evaluators_match_reference_values(api, golden_dir):
+    """lhvi_log_likelihood on the device-resident flat graph against utils.log_likelihood values computed by the reference
+    (tests/golden/utils.json: chain, Kalman, paper-popularity HMLN, RGM/0, and a vanishing factor -> -inf), and the batched
+    utils.kl_tables against the reference's kl_continuous of the same two densities"""
+    import json
+    import os
+    from lhvi import utils
+    from lhvi.flat import flatten
+    rec = json.load(open(os.path.join(golden_dir, 'utils.json')))
+    for case in rec['log_likelihood']:
+        g, rvs, factors = modelio.load_model(case['model'], API)
+        flat = flatten(g, require_device_potentials=True)
+        got = utils.log_likelihood_flat(api.DeviceGraph(flat), np.array(case['x'], dtype=np.float64))
+        assert got == case['value'] if np.isinf(case['value']) else got == pytest.approx(case['value'], rel=1e-12)
+    m = 20001
+    cs = rec['kl']
+    x = np.stack([np.linspace(c['lo'], c['hi'], m) for c in cs])
+    pdf = lambda x, mu, s: np.exp(-((x - mu) / s) ** 2 * 0.5) / (2.506628274631 * s)
+    p = np.stack([pdf(x[i], c['mu1'], c['s1']) for i, c in enumerate(cs)])
+    q = np.stack([pdf(x[i], c['mu2'], c['s2']) for i, c in enumerate(cs)])
+    got = utils.kl_tables(p, q, np.array([c['lo'] for c in cs], dtype=float), np.array([c['hi'] for c in cs], dtype=float)).cpu().numpy()
+    for i, c in enumerate(cs):
+        assert got[i] == pytest.approx(c['kl_continuous'], rel=1e-6, abs=1e-9)

@@ -354,3 +354,65 @@ def test_utils_kl_helpers_have_the_reference_signatures():
     finally:
         sys.path.remove(compat_dir)
         sys.modules.pop('utils', None)
+
+
+def test_utils_match_reference_values(golden_dir):
+    """lhvi.utils (the reference's utils.py surface) against values computed by the reference itself
+    (oracle/capture_utils.py -> tests/golden/utils.json): log_likelihood on four models incl. the -inf convention, KL,
+    kl_discrete, the three kl_continuous variants, kl_normal"""
+    from lhvi import utils
+    rec = load(golden_dir, 'utils')
+    for case in rec['log_likelihood']:
+        g, rvs, factors = modelio.load_model(case['model'], API)
+        asg = {rv: (v if rv.domain.continuous else int(v)) for rv, v in zip(rvs, case['x'])}
+        got = utils.log_likelihood(g, asg)
+        assert got == case['value'] if np.isinf(case['value']) else got == pytest.approx(case['value'], rel=1e-12)
+
+    def pdf(mu, sig):
+        return lambda x: np.exp(-((x - mu) / sig) ** 2 * 0.5) / (2.506628274631 * sig)
+
+    def logpdf(mu, sig):
+        return lambda x: -((x - mu) / sig) ** 2 * 0.5 - np.log(2.506628274631 * sig)
+    for c in rec['kl']:
+        dom = G.Domain((c['lo'], c['hi']), continuous=True, integral_points=np.linspace(c['lo'], c['hi'], c['points']))
+        p, q = pdf(c['mu1'], c['s1']), pdf(c['mu2'], c['s2'])
+        assert utils.KL(p, q, dom) == pytest.approx(c['KL'], rel=1e-12, abs=1e-15)
+        assert utils.kl_continuous(p, q, c['lo'], c['hi']) == pytest.approx(c['kl_continuous'], rel=1e-10, abs=1e-14)
+        assert utils.kl_continuous_no_add_const(p, q, c['lo'], c['hi']) == pytest.approx(c['kl_continuous_no_add_const'], rel=1e-10, abs=1e-14)
+        assert utils.kl_continuous_logpdf(logpdf(c['mu1'], c['s1']), logpdf(c['mu2'], c['s2']), c['lo'], c['hi']) == \
+            pytest.approx(c['kl_continuous_logpdf'], rel=1e-10, abs=1e-14)
+        assert utils.kl_normal(c['mu1'], c['mu2'], c['s1'], c['s2']) == pytest.approx(c['kl_normal'], rel=1e-13, abs=1e-16)
+    d = rec['discrete']
+    tp, tq = np.array(d['p']), np.array(d['q'])
+    assert utils.kl_discrete(tp, tq) == pytest.approx(d['kl_discrete'], rel=1e-13)
+    assert utils.KL(lambda x: tp[x], lambda x: tq[x], G.Domain((0, 1, 2))) == pytest.approx(d['KL'], rel=1e-13)
+
+
+def test_kalman_flat_builder_matches_reference_structure(golden_dir):
+    """the array builder against the graph the reference's own KalmanFilter.grounded_graph built (fixture G2)"""
+    rec = load(golden_dir, 'gauss_g2_kalman')
+    n, T = 4, 5
+    rng = np.random.RandomState(0)
+    A = rng.uniform(-0.5, 0.5, size=(n, n)) + np.eye(n) * 0.5
+    data = rng.uniform(-2, 2, size=(n, T))
+    data[rng.rand(n, T) < 0.3] = 5000
+    data[:, 0] = rng.uniform(-2, 2, size=n)
+    d = G.Domain((-8, 8), continuous=True, integral_points=np.linspace(-8, 8, 32))
+    flat, _ = kalman.KalmanFilter(d, A, 1.5, np.eye(n), 0.7).grounded_flat(T, data)
+    model = rec['model']
+    # same variables (evidence pattern / values), same multiset of (potential class, parameters, scope) factors
+    ref_vals = np.array([np.nan if v is None else v for _, v in model['rvs']])
+    ref_f = sorted((model['potentials'][pi]['cls'], round(model['potentials'][pi]['coeff'], 12), round(model['potentials'][pi]['sig'], 12),
+                    tuple(nb)) for pi, nb in model['factors'])
+    g, rvs, factors = modelio.load_model(model, API)
+    ref_flat = flatten(g)
+    # the fixture lists rvs in the reference's order; the flat builder numbers them in creation order of grounded_graph:
+    # match variables through the object builder's table (pinned to the same fixture by the test above)
+    assert flat.V == len(model['rvs']) and flat.F == len(model['factors']) and flat.E == ref_flat.E
+    assert np.isnan(flat.var_value).sum() == np.isnan(ref_vals).sum()
+    np.testing.assert_allclose(np.sort(flat.var_value[~np.isnan(flat.var_value)]), np.sort(ref_vals[~np.isnan(ref_vals)]), rtol=0, atol=0)
+    kinds = {P.POT_LINEAR_GAUSSIAN: 'LinearGaussianPotential', P.POT_X2: 'X2Potential', P.POT_XY: 'XYPotential'}
+    got_f = sorted((kinds[int(flat.pot_kind[p])], round(float(flat.pot_param[flat.pot_off[p]]), 12),
+                    round(float(flat.pot_param[flat.pot_off[p] + 1]), 12)) for p in flat.fac_pot)
+    assert got_f == sorted(t[:3] for t in ref_f)
+    assert sorted(np.diff(flat.var_ptr).tolist()) == sorted(np.diff(ref_flat.var_ptr).tolist())      # same degree sequence
