@@ -112,6 +112,33 @@ int lhvi_gabp_v2f(const lhvi_graph_t* g, const double* f2v, double* v2f, void* s
 int lhvi_gabp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const double* v2f, double* f2v, void* stream);
 /* `iterations` flooding sweeps; the last one skips f2v: GaBP.run GaBP.py:140-169, GaLBP.run GaLBP.py:159-181 */
 int lhvi_gabp_run(const lhvi_graph_t* g, const lhvi_pots_t* pots, double* f2v, double* v2f, int iterations, void* stream);
+/* Pull form of the Gaussian sweep (one launch per iteration; replaces the pair lhvi_gabp_v2f + lhvi_gabp_f2v of
+ * GaBP.run GaBP.py:152-165 / GaLBP.run GaLBP.py:160-177 for graphs whose factors are unary or pairwise -- every factor
+ * GaBP.message_f_to_rv knows a closed form for, GaBP.py:37-138).  Messages live in variable-CSR ("slot") order,
+ * slot k = (variable slot_var[k], edge var_edge[k]); the f -> v message of a slot is recomputed from the partner's
+ * previous v -> f message instead of being stored.  The caller builds the plan once per graph:
+ *   pslot[k]  slot of the partner argument's (canonical) edge when the partner variable is hidden, else -1
+ *   info[k]   4 * potential index + code; code 0 = unary factor, 1 / 2 = pairwise factor with this variable at
+ *             position 0 / 1, 3 = any other arity (vacuous message (0, Inf), GaBP.py:138)
+ *   pval[k]   the partner's evidence value (unused when pslot[k] >= 0 or code is 0 / 3)
+ *   count[k]  lifted graphs: rv.count[f] of the slot (GaLBP.py:24-34); NULL on a ground graph
+ * Results equal the two-kernel path bit for bit (same expressions, same summation order). */
+typedef struct lhvi_gabp_plan {
+    const int32_t* pslot;
+    const int32_t* info;
+    const double* pval;
+    const double* count;
+} lhvi_gabp_plan_t;
+size_t lhvi_gabp_pull_workspace_bytes(const lhvi_graph_t* g);
+/* one sweep: v_next[k] = message_rv_to_f of slot k given the f -> v messages implied by v_prev (first != 0: given the
+ * initial messages (0, 1); v_prev is not read).  v_prev, v_next: [nnz][2], distinct. */
+int lhvi_gabp_pull(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_gabp_plan_t* plan, const double* v_prev,
+                   double* v_next, int first, void* stream);
+/* lhvi_gabp_run through the pull form: same f2v [E][2] / v2f [E][2] (edge order) on return.  ws: caller-owned scratch of
+ * lhvi_gabp_pull_workspace_bytes(g) bytes. */
+int lhvi_gabp_run_pull(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_gabp_plan_t* plan, double* f2v, double* v2f,
+                       int iterations, void* ws, size_t ws_bytes, void* stream);
+
 /* per-variable product of incoming messages -> mu_var [V][2]; evidence rows get (value, 0):
  * GaBP.get_belief_params GaBP.py:187-200, GaLBP.map GaLBP.py:201-217 */
 int lhvi_gabp_marginals(const lhvi_graph_t* g, const double* f2v, double* mu_var, void* stream);

@@ -243,6 +243,101 @@ __global__ void __launch_bounds__(BLOCK) gabp_marginal_hub_kernel(lhvi_graph_t g
     if (lane == 0) st2(out, v, var * H, var);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pull form of the sweep: ONE kernel per iteration, messages kept in variable-CSR ("slot") order.
+// For pairwise / unary factors the f -> v message of an edge is a closed form of ONE v -> f message (the partner's), so
+// it never has to exist in memory: slot k's thread evaluates the closed form for its own incoming edge (one 16-byte gather
+// of the partner's previous v -> f message, the only random access of the sweep), parks it in LDS, and after a barrier
+// every slot of the variable sums the row out of LDS -- in rv.nb order, leave-one-out as a direct sum, the same expressions
+// as gabp_f2v_kernel + gabp_v2f_kernel, hence the same bits.  A row that crosses the block's slot range recomputes the
+// outside entries.  Per slot and sweep: 16 B gathered + 16 B stored in order + 20 B of plan instead of two random 16-byte
+// accesses, two in-order ones and two launches.
+struct PullPlan { const int32_t* pslot; const int32_t* info; const double* pval; const double* count; };
+
+__device__ __forceinline__ double2 pull_incoming(const lhvi_pots_t& pots, const PullPlan& pl, const double* __restrict__ vprev, int j) {
+    const int info = pl.info[j];
+    const int code = info & 3, pot = info >> 2;
+    const int kind = pots.kind[pot];
+    const double* par = pots.param + pots.off[pot];
+    const int arity = code == 0 ? 1 : (code == 3 ? 3 : 2), pos = code == 2 ? 1 : 0;
+    bool partner_hidden = false;
+    double u = 0.0, sv = 0.0, y = 0.0;
+    if (arity == 2) {
+        const int ps = pl.pslot[j];
+        partner_hidden = ps >= 0;
+        if (partner_hidden) { const double2 m = ld2(vprev, ps); u = m.x; sv = m.y; }
+        else y = pl.pval[j];
+    }
+    return f2v_closed_form(kind, par, arity, pos, partner_hidden, u, sv, y);
+}
+
+__global__ void __launch_bounds__(BLOCK) gabp_pull_kernel(lhvi_graph_t g, lhvi_pots_t pots, PullPlan pl,
+                                                         const double* __restrict__ vprev, double* __restrict__ vnext, int first) {
+    __shared__ double2 sh[BLOCK];
+    const int k0 = blockIdx.x * BLOCK;
+    const int k = k0 + threadIdx.x;
+    const bool live = k < g.nnz;
+    int v = 0;
+    bool hid = false;
+    if (live) { v = g.slot_var[k]; hid = is_hidden(g.var_value[v]); }
+    // first sweep: every f -> v message still is its initial value (0, 1) (GaBP.py:143-150)
+    sh[threadIdx.x] = (live && hid && !first) ? pull_incoming(pots, pl, vprev, k) : make_double2(0.0, 1.0);
+    __syncthreads();
+    if (!live) return;
+    if (!hid) { st2(vnext, k, NAN, NAN); return; }
+    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    if (g.hub_vars && hi - lo > GABP_HUB_DEGREE) return;        // gabp_pull_hub_kernel
+    double H = 0.0, P = 0.0;
+    for (int j = lo; j < hi; ++j) {
+        double c = pl.count ? pl.count[j] : 1.0;
+        if (pl.count) { if (j == k) c -= 1.0; }
+        else if (j == k) continue;
+        const double2 m = (j >= k0 && j < k0 + BLOCK) ? sh[j - k0] : (first ? make_double2(0.0, 1.0) : pull_incoming(pots, pl, vprev, j));
+        if (m.y != m.y) H -= pl.count ? m.x * c : m.x;
+        else {
+            const double p = 1.0 / m.y;
+            if (pl.count) { H += p * m.x * c; P += p * c; }
+            else          { H += p * m.x;     P += p; }
+        }
+    }
+    const double var = 1.0 / P;
+    st2(vnext, k, var * H, var);
+}
+
+__global__ void __launch_bounds__(BLOCK) gabp_pull_hub_kernel(lhvi_graph_t g, lhvi_pots_t pots, PullPlan pl,
+                                                             const double* __restrict__ vprev, double* __restrict__ vnext, int first) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (i >= g.n_hubs) return;
+    const int v = g.hub_vars[i];
+    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    if (hi - lo <= GABP_HUB_DEGREE || !is_hidden(g.var_value[v])) return;     // observed rows: written by gabp_pull_kernel
+    double H = 0.0, P = 0.0;
+    for (int j = lo + lane; j < hi; j += 64) {
+        const double c = pl.count ? pl.count[j] : 1.0;
+        const double2 m = first ? make_double2(0.0, 1.0) : pull_incoming(pots, pl, vprev, j);
+        if (m.y != m.y) H -= m.x * c;
+        else { const double p = 1.0 / m.y; H += p * m.x * c; P += p * c; }
+    }
+    H = dpp_wave_reduce(H, SumOp()); P = dpp_wave_reduce(P, SumOp());
+    for (int j = lo + lane; j < hi; j += 64) {
+        const double2 m = first ? make_double2(0.0, 1.0) : pull_incoming(pots, pl, vprev, j);
+        double h = H, p = P;
+        if (m.y != m.y) h += m.x;
+        else { const double q = 1.0 / m.y; h -= q * m.x; p -= q; }
+        const double var = 1.0 / p;
+        st2(vnext, j, var * h, var);
+    }
+}
+
+// slot order -> edge order (the layout of lhvi_gabp_v2f / _f2v / _marginals and of the solvers' message views)
+__global__ void __launch_bounds__(BLOCK) gabp_unpack_kernel(lhvi_graph_t g, const double* __restrict__ vslot, double* __restrict__ v2f) {
+    const int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= g.nnz) return;
+    const double2 m = ld2(vslot, k);
+    st2(v2f, g.var_edge[k], m.x, m.y);
+}
+
 static int validate(const lhvi_graph_t* g) {
     if (!g) return LHVI_E_ARG;
     if (g->V < 0 || g->F < 0 || g->E < 0 || g->nnz < 0) return LHVI_E_ARG;
@@ -293,6 +388,55 @@ int lhvi_gabp_run(const lhvi_graph_t* g, const lhvi_pots_t* pots, double* f2v, d
             if (int rc = lhvi_gabp_f2v(g, pots, v2f, f2v, stream)) return rc;
     }
     return LHVI_OK;
+}
+
+size_t lhvi_gabp_pull_workspace_bytes(const lhvi_graph_t* g) {
+    return g ? (size_t)2 * (size_t)(g->nnz > 0 ? g->nnz : 1) * 16 : 0;
+}
+
+static int validate_plan(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_gabp_plan_t* plan) {
+    if (int rc = validate(g)) return rc;
+    if (!pots || !plan || (g->F > 0 && (!pots->kind || !pots->off))) return LHVI_E_ARG;
+    if (g->nnz > 0 && (!plan->pslot || !plan->info || !plan->pval || !g->slot_var)) return LHVI_E_ARG;
+    return LHVI_OK;
+}
+
+int lhvi_gabp_pull(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_gabp_plan_t* plan, const double* v_prev,
+                   double* v_next, int first, void* stream) {
+    if (int rc = validate_plan(g, pots, plan)) return rc;
+    if (g->nnz == 0) return LHVI_OK;
+    if (!v_next || (!first && !v_prev) || v_prev == v_next) return LHVI_E_ARG;
+    PullPlan pl;
+    pl.pslot = plan->pslot; pl.info = plan->info; pl.pval = plan->pval; pl.count = plan->count;
+    hipLaunchKernelGGL(gabp_pull_kernel, dim3(grid_for(g->nnz)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, pl, v_prev, v_next, first);
+    if (g->hub_vars && g->n_hubs > 0)
+        hipLaunchKernelGGL(gabp_pull_hub_kernel, dim3(grid_for((int64_t)g->n_hubs * 64)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, pl,
+                           v_prev, v_next, first);
+    return check_launch();
+}
+
+int lhvi_gabp_run_pull(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_gabp_plan_t* plan, double* f2v, double* v2f,
+                       int iterations, void* ws, size_t ws_bytes, void* stream) {
+    if (iterations < 0) return LHVI_E_ARG;
+    if (int rc = validate_plan(g, pots, plan)) return rc;
+    if (int rc = lhvi_gabp_init(g, f2v, v2f, stream)) return rc;
+    if (iterations == 0 || g->nnz == 0) return LHVI_OK;
+    if (!ws || ws_bytes < lhvi_gabp_pull_workspace_bytes(g)) return LHVI_E_ARG;
+    double* a = (double*)ws;
+    double* b = a + (size_t)2 * g->nnz;
+    for (int i = 0; i < iterations; ++i) {
+        if (int rc = lhvi_gabp_pull(g, pots, plan, a, b, i == 0, stream)) return rc;
+        double* t = a; a = b; b = t;
+    }
+    // a = v -> f of the last sweep, b = of the one before: the f -> v messages the reference ends with (its last sweep skips
+    // that half, GaBP.py:161) are the closed forms of b
+    const dim3 grid(grid_for(g->nnz));
+    if (iterations >= 2) {
+        hipLaunchKernelGGL(gabp_unpack_kernel, grid, dim3(BLOCK), 0, as_stream(stream), *g, b, v2f);
+        if (int rc = lhvi_gabp_f2v(g, pots, v2f, f2v, stream)) return rc;
+    }
+    hipLaunchKernelGGL(gabp_unpack_kernel, grid, dim3(BLOCK), 0, as_stream(stream), *g, a, v2f);
+    return check_launch();
 }
 
 int lhvi_gabp_marginals(const lhvi_graph_t* g, const double* f2v, double* mu_var, void* stream) {

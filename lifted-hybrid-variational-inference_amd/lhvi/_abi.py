@@ -35,6 +35,10 @@ class GraphStruct(C.Structure):
     ]
 
 
+class GabpPlanStruct(C.Structure):
+    _fields_ = [('pslot', C.c_void_p), ('info', C.c_void_p), ('pval', C.c_void_p), ('count', C.c_void_p)]
+
+
 class PotsStruct(C.Structure):
     _fields_ = [('P', C.c_int32), ('kind', C.c_void_p), ('off', C.c_void_p), ('param', C.c_void_p)]
 
@@ -76,6 +80,7 @@ PBP_DESC_BYTES = 128
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE
 
 _G, _P, _S, _VI = C.POINTER(GraphStruct), C.POINTER(PotsStruct), C.POINTER(PbpStruct), C.POINTER(ViStruct)
+_GP = C.POINTER(GabpPlanStruct)
 _vp, _i32, _i64, _u32, _u64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/lhvi.h declares (tests/test_abi.py checks)
@@ -89,6 +94,9 @@ SIGNATURES = {
     'lhvi_gabp_f2v': (C.c_int, [_G, _P, _vp, _vp, _vp]),
     'lhvi_gabp_run': (C.c_int, [_G, _P, _vp, _vp, C.c_int, _vp]),
     'lhvi_gabp_marginals': (C.c_int, [_G, _vp, _vp, _vp]),
+    'lhvi_gabp_pull_workspace_bytes': (C.c_size_t, [_G]),
+    'lhvi_gabp_pull': (C.c_int, [_G, _P, _GP, _vp, _vp, C.c_int, _vp]),
+    'lhvi_gabp_run_pull': (C.c_int, [_G, _P, _GP, _vp, _vp, C.c_int, _vp, C.c_size_t, _vp]),
     'lhvi_pbp_uniq': (C.c_int, [_G, _i32, _vp, _vp, _vp, _vp]),
     'lhvi_pbp_classify': (C.c_int, [_G, _P, _vp, _vp]),
     'lhvi_pbp_describe': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _vp]),

@@ -20,10 +20,35 @@ def _norm_pdf_var(x, mu, sig):
     return np.exp(-u * u * 0.5 / sig) / (2.506628274631 * sig)
 
 
+def pull_plan(flat):
+    """host arrays of ``lhvi_gabp_plan_t`` (include/lhvi.h): per variable-CSR slot the slot of the partner argument's
+    edge (-1: none / observed), 4 * potential index + position code, the partner's evidence value, and on a lifted graph
+    the slot's count"""
+    ve = flat.var_edge.astype(np.int64)
+    nnz = ve.size
+    edge_slot = np.full(max(flat.E, 1), -1, dtype=np.int64)
+    edge_slot[ve] = np.arange(nnz)
+    f = flat.edge_fac[ve].astype(np.int64)
+    base = flat.fac_ptr[f].astype(np.int64)
+    arity = flat.fac_ptr[f + 1] - base
+    pos = ve - base
+    code = np.where(arity == 1, 0, np.where(arity == 2, 1 + pos, 3))
+    pe = np.where(arity == 2, base + (1 - np.minimum(pos, 1)), ve)       # partner edge of a pairwise factor
+    pce = flat.edge_canon[pe].astype(np.int64)
+    pval = flat.var_value[flat.edge_var[pe]]
+    pslot = np.where((arity == 2) & np.isnan(pval), edge_slot[pce], -1)
+    if ((arity == 2) & np.isnan(pval) & (pslot < 0)).any():
+        raise _abi.LhviError('a hidden partner argument has no variable-side slot')
+    return dict(pslot=pslot.astype(np.int32), info=(flat.fac_pot[f].astype(np.int64) * 4 + code).astype(np.int32),
+                pval=np.ascontiguousarray(pval, dtype=np.float64),
+                count=np.ascontiguousarray(flat.edge_count[ve], dtype=np.float64) if flat.lifted else None)
+
+
 class _GaussianSweep:
     """State shared by the ground and the lifted solver: flat graph, device buffers, result cache."""
 
     verbose = False
+    pull = True       # one launch per sweep, messages in slot order (lhvi_gabp_run_pull); False: the v2f / f2v kernel pair
 
     def _check_degrees(self, flat):
         # the reference raises ZeroDivisionError (0 ** -1) when a hidden variable has no other incoming
@@ -43,7 +68,19 @@ class _GaussianSweep:
         mv = dg.empty(flat.V, 2)
         l = _abi.lib()
         s = _abi.stream_ptr()
-        _abi.check(l.lhvi_gabp_run(dg.g, dg.p, _abi.ptr(f2v), _abi.ptr(v2f), int(iteration), s))
+        if self.pull and flat.var_edge.size:
+            torch = _abi.require_gpu()
+            host = pull_plan(flat)
+            dev = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
+            plan = _abi.GabpPlanStruct()
+            plan.pslot, plan.info, plan.pval, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'pval', 'count'))
+            nbytes = int(l.lhvi_gabp_pull_workspace_bytes(dg.g))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dg.device)
+            _abi.check(l.lhvi_gabp_run_pull(dg.g, dg.p, plan, _abi.ptr(f2v), _abi.ptr(v2f), int(iteration), _abi.ptr(ws),
+                                            nbytes, s))
+            self._plan_dev = dev
+        else:
+            _abi.check(l.lhvi_gabp_run(dg.g, dg.p, _abi.ptr(f2v), _abi.ptr(v2f), int(iteration), s))
         _abi.check(l.lhvi_gabp_marginals(dg.g, _abi.ptr(f2v), _abi.ptr(mv), s))
         self.flat, self.dg = flat, dg
         self.f2v_dev, self.v2f_dev, self.mu_var_dev = f2v, v2f, mv
