@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define LHVI_ABI_VERSION 5   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
-                              * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc */
+#define LHVI_ABI_VERSION 6   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
+                              * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -307,6 +307,9 @@ typedef struct lhvi_vi {
     const double* w;            /* [K] softmax(w_tau) */
     const double* eta_c;        /* [V][K][2] (mu, var) for continuous hidden variables */
     const double* eta_d;        /* [V][K][Dmax] category probabilities for discrete hidden variables */
+    const double* obs_var;      /* [V] or NULL.  C2FVarInference.py:120-136,253-261: obs_var[v] > 0 makes the evidence cluster v
+                                 * a Gaussian observation N(var_value[v], obs_var[v]) -- T quadrature nodes in every expectation,
+                                 * its pdf in every belief, no parameters; 0 = exact evidence (or not evidence at all) */
 } lhvi_vi_t;
 
 /* gradient_w_tau / gradient_mu_var / gradient_category_tau / free_energy: VarInference.py:57-195,

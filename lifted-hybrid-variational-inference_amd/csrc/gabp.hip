@@ -273,26 +273,37 @@ __device__ __forceinline__ double2 pull_incoming(const lhvi_pots_t& pots, const 
 
 __global__ void __launch_bounds__(BLOCK) gabp_pull_kernel(lhvi_graph_t g, lhvi_pots_t pots, PullPlan pl,
                                                          const double* __restrict__ vprev, double* __restrict__ vnext, int first) {
-    __shared__ double2 sh[BLOCK];
+    // LDS holds the f -> v messages of every slot of every (non-hub) row that touches this block's slot range: the rows
+    // straddling the block's ends are staged whole, so the sums below never leave LDS
+    constexpr int CAP = BLOCK + 2 * GABP_HUB_DEGREE;
+    __shared__ double2 sh[CAP];
     const int k0 = blockIdx.x * BLOCK;
-    const int k = k0 + threadIdx.x;
-    const bool live = k < g.nnz;
-    int v = 0;
-    bool hid = false;
-    if (live) { v = g.slot_var[k]; hid = is_hidden(g.var_value[v]); }
-    // first sweep: every f -> v message still is its initial value (0, 1) (GaBP.py:143-150)
-    sh[threadIdx.x] = (live && hid && !first) ? pull_incoming(pots, pl, vprev, k) : make_double2(0.0, 1.0);
+    const int kend = min(k0 + BLOCK, g.nnz);
+    int lo_ext = k0, hi_ext = kend;
+    {
+        const int vf = g.slot_var[k0], vl = g.slot_var[kend - 1];
+        const int a = g.var_ptr[vf], b = g.var_ptr[vl + 1];
+        if (g.var_ptr[vf + 1] - a <= GABP_HUB_DEGREE) lo_ext = a;         // (a hub row is served by gabp_pull_hub_kernel)
+        if (b - g.var_ptr[vl] <= GABP_HUB_DEGREE) hi_ext = b;
+    }
+    for (int j = lo_ext + threadIdx.x; j < hi_ext; j += BLOCK) {
+        // first sweep: every f -> v message still is its initial value (0, 1) (GaBP.py:143-150)
+        const bool hid = is_hidden(g.var_value[g.slot_var[j]]);
+        sh[j - lo_ext] = (hid && !first) ? pull_incoming(pots, pl, vprev, j) : make_double2(0.0, 1.0);
+    }
     __syncthreads();
-    if (!live) return;
-    if (!hid) { st2(vnext, k, NAN, NAN); return; }
+    const int k = k0 + threadIdx.x;
+    if (k >= g.nnz) return;
+    const int v = g.slot_var[k];
+    if (!is_hidden(g.var_value[v])) { st2(vnext, k, NAN, NAN); return; }
     const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
-    if (g.hub_vars && hi - lo > GABP_HUB_DEGREE) return;        // gabp_pull_hub_kernel
+    if (hi - lo > GABP_HUB_DEGREE) return;                      // gabp_pull_hub_kernel
     double H = 0.0, P = 0.0;
     for (int j = lo; j < hi; ++j) {
         double c = pl.count ? pl.count[j] : 1.0;
         if (pl.count) { if (j == k) c -= 1.0; }
         else if (j == k) continue;
-        const double2 m = (j >= k0 && j < k0 + BLOCK) ? sh[j - k0] : (first ? make_double2(0.0, 1.0) : pull_incoming(pots, pl, vprev, j));
+        const double2 m = sh[j - lo_ext];
         if (m.y != m.y) H -= pl.count ? m.x * c : m.x;
         else {
             const double p = 1.0 / m.y;
@@ -397,7 +408,7 @@ size_t lhvi_gabp_pull_workspace_bytes(const lhvi_graph_t* g) {
 static int validate_plan(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_gabp_plan_t* plan) {
     if (int rc = validate(g)) return rc;
     if (!pots || !plan || (g->F > 0 && (!pots->kind || !pots->off))) return LHVI_E_ARG;
-    if (g->nnz > 0 && (!plan->pslot || !plan->info || !plan->pval || !g->slot_var)) return LHVI_E_ARG;
+    if (g->nnz > 0 && (!plan->pslot || !plan->info || !plan->pval || !g->slot_var || !g->hub_vars)) return LHVI_E_ARG;
     return LHVI_OK;
 }
 

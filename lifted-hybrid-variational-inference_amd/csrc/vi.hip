@@ -30,6 +30,11 @@ __device__ __forceinline__ int vi_state_index(const lhvi_graph_t& g, int v, doub
     return (int)x;
 }
 
+// C2FVarInference (C2FVarInference.py:120-136,253-261): an evidence cluster whose members' values differ is a Gaussian
+// observation N(value, variance) -- obs_var[v] > 0 marks it.  It is integrated with T quadrature nodes like a hidden
+// continuous variable, multiplies every mixture component of a belief by its pdf, and owns no parameters.
+__device__ __forceinline__ bool is_gobs(const lhvi_vi_t& p, int v) { return p.obs_var != nullptr && p.obs_var[v] > 0.0; }
+
 // VarInference.norm_pdf (VI:26-30): the normaliser is 2.5066 * var (sic)
 __device__ __forceinline__ double norm_pdf_var(double x, double mu, double var) {
     const double u = x - mu;
@@ -40,14 +45,17 @@ __device__ __forceinline__ double norm_pdf_var(double x, double mu, double var) 
 __device__ double rvs_belief(const lhvi_graph_t& g, const lhvi_vi_t& p, const double* x, const int* idx, const int* vars, int m) {
     for (int i = 0; i < m; ++i) {
         const double val = g.var_value[vars[i]];
-        if (!is_hidden(val) && x[i] != val) return 0.0;
+        if (!is_hidden(val) && !is_gobs(p, vars[i]) && x[i] != val) return 0.0;
     }
     double s = 0.0;
     for (int k = 0; k < p.K; ++k) {
         double b = p.w[k];
         for (int i = 0; i < m; ++i) {
             const int v = vars[i];
-            if (!is_hidden(g.var_value[v])) continue;
+            if (!is_hidden(g.var_value[v])) {
+                if (is_gobs(p, v)) b *= norm_pdf_var(x[i], g.var_value[v], p.obs_var[v]);
+                continue;
+            }
             if (v_cont(g, v)) { const double* e = p.eta_c + ((int64_t)v * p.K + k) * 2; b *= norm_pdf_var(x[i], e[0], e[1]); }
             else b *= p.eta_d[((int64_t)v * p.K + k) * p.Dmax + idx[i]];
         }
@@ -59,13 +67,14 @@ __device__ double rvs_belief(const lhvi_graph_t& g, const lhvi_vi_t& p, const do
 // node t of variable v's axis under component k (the (is_continuous, eta) argument of expectation(), VI:40-55)
 struct Node { double x, w; int idx; };
 __device__ __forceinline__ int axis_len(const lhvi_graph_t& g, const lhvi_vi_t& p, int v) {
-    if (!is_hidden(g.var_value[v])) return 1;
+    if (!is_hidden(g.var_value[v])) return is_gobs(p, v) ? p.T : 1;
     return v_cont(g, v) ? p.T : v_nstates(g, v);
 }
 __device__ __forceinline__ Node axis_node(const lhvi_graph_t& g, const lhvi_vi_t& p, int v, int k, int t) {
     Node nd;
     const double val = g.var_value[v];
-    if (!is_hidden(val)) { nd.x = val; nd.w = 1.0; nd.idx = vi_state_index(g, v, val); }
+    if (!is_hidden(val) && is_gobs(p, v)) { nd.x = sqrt(2 * p.obs_var[v]) * p.gh_x[t] + val; nd.w = p.gh_w[t]; nd.idx = 0; }
+    else if (!is_hidden(val)) { nd.x = val; nd.w = 1.0; nd.idx = vi_state_index(g, v, val); }
     else if (v_cont(g, v)) {
         const double* e = p.eta_c + ((int64_t)v * p.K + k) * 2;
         nd.x = sqrt(2 * e[1]) * p.gh_x[t] + e[0]; nd.w = p.gh_w[t]; nd.idx = 0;
@@ -131,7 +140,7 @@ __device__ double pinned_expectation(const lhvi_graph_t& g, const lhvi_pots_t& p
             if (is_hidden(g.var_value[v])) {
                 if (p.quirks) { nx[a] = Dt; nw[a] = v_cont(g, v) ? 2 : v_nstates(g, v); }   // VI:147-150
                 else { nx[a] = axis_len(g, p, v); nw[a] = nx[a]; }
-            }
+            } else if (is_gobs(p, v)) { nx[a] = p.T; nw[a] = p.T; }                       // C2FVI:221-223: a proper axis
             totx *= nx[a]; totw *= nw[a];
         }
     }
@@ -147,7 +156,8 @@ __device__ double pinned_expectation(const lhvi_graph_t& g, const lhvi_pots_t& p
                 const int ixs = (int)(rx % nx[a]); rx /= nx[a];
                 const int iws = (int)(rw % nw[a]); rw /= nw[a];
                 const double val = g.var_value[v];
-                if (!is_hidden(val)) { x[a] = val; idx[a] = vi_state_index(g, v, val); }
+                if (!is_hidden(val) && is_gobs(p, v)) { const Node nd = axis_node(g, p, v, k, ixs); x[a] = nd.x; idx[a] = 0; w *= p.gh_w[iws]; }
+                else if (!is_hidden(val)) { x[a] = val; idx[a] = vi_state_index(g, v, val); }
                 else if (p.quirks) {
                     x[a] = tvals[ixs]; idx[a] = vi_state_index(g, v, x[a]);
                     w *= v_cont(g, v) ? p.eta_c[((int64_t)v * p.K + k) * 2 + iws] : p.eta_d[((int64_t)v * p.K + k) * p.Dmax + iws];
@@ -212,26 +222,30 @@ __device__ __forceinline__ void vi_factor_cc(const lhvi_graph_t& g, const lhvi_p
     const int v0 = g.edge_var[base], v1 = g.edge_var[base + 1];
     const double val0 = g.var_value[v0], val1 = g.var_value[v1];
     const bool h0 = is_hidden(val0), h1 = is_hidden(val1);
+    const bool go0 = !h0 && is_gobs(p, v0), go1 = !h1 && is_gobs(p, v1);        // Gaussian observations: an axis, no parameters
+    const bool a0 = h0 || go0, a1 = h1 || go1;
     const double* e0 = p.eta_c + ((int64_t)v0 * p.K + k) * 2;
     const double* e1 = p.eta_c + ((int64_t)v1 * p.K + k) * 2;
-    const double mu0 = e0[0], var0 = e0[1], mu1 = e1[0], var1 = e1[1];
-    const double s0 = h0 ? sqrt(2 * var0) : 0.0, s1 = h1 ? sqrt(2 * var1) : 0.0;
-    const int n0 = h0 ? p.T : 1, n1 = h1 ? p.T : 1;
+    const double mu0 = go0 ? val0 : e0[0], var0 = go0 ? p.obs_var[v0] : e0[1], mu1 = go1 ? val1 : e1[0], var1 = go1 ? p.obs_var[v1] : e1[1];
+    const double s0 = a0 ? sqrt(2 * var0) : 0.0, s1 = a1 ? sqrt(2 * var1) : 0.0;
+    const int n0 = a0 ? p.T : 1, n1 = a1 ? p.T : 1;
     const int pot = g.fac_pot[f];
     const int kind = pots.kind[pot];
     const double* par = pots.param + pots.off[pot];
     double E = 0.0, Em0 = 0.0, Ev0 = 0.0, Em1 = 0.0, Ev1 = 0.0;
     for (int t0 = 0; t0 < n0; ++t0) {
-        const double x0 = h0 ? s0 * p.gh_x[t0] + mu0 : val0, w0 = h0 ? p.gh_w[t0] : 1.0;
+        const double x0 = a0 ? s0 * p.gh_x[t0] + mu0 : val0, w0 = a0 ? p.gh_w[t0] : 1.0;
         for (int t1 = 0; t1 < n1; ++t1) {
-            const double x1 = h1 ? s1 * p.gh_x[t1] + mu1 : val1, w1 = h1 ? p.gh_w[t1] : 1.0;
+            const double x1 = a1 ? s1 * p.gh_x[t1] + mu1 : val1, w1 = a1 ? p.gh_w[t1] : 1.0;
             const double w = 1.0 * w0 * w1;
             const double phi = exp_core(pot_log_cc(kind, par, x0, x1), sh_tab);
             double b = 0.0;                                   // rvs_belief: the mixture at (x0, x1), evidence agrees by construction
             for (int kk = 0; kk < p.K; ++kk) {
                 double t = p.w[kk];
                 if (h0) { const double* e = p.eta_c + ((int64_t)v0 * p.K + kk) * 2; t *= norm_pdf_var_fast(x0, e[0], e[1], sh_tab); }
+                else if (go0) t *= norm_pdf_var_fast(x0, mu0, var0, sh_tab);
                 if (h1) { const double* e = p.eta_c + ((int64_t)v1 * p.K + kk) * 2; t *= norm_pdf_var_fast(x1, e[0], e[1], sh_tab); }
+                else if (go1) t *= norm_pdf_var_fast(x1, mu1, var1, sh_tab);
                 b += t;
             }
             const double F = log_table(phi + 1e-100, sh_log) - log_table(b + 1e-100, sh_log);

@@ -63,6 +63,7 @@ class ViStruct(C.Structure):
     _fields_ = [
         ('K', C.c_int32), ('T', C.c_int32), ('Dmax', C.c_int32), ('quirks', C.c_int32),
         ('gh_x', C.c_void_p), ('gh_w', C.c_void_p), ('w', C.c_void_p), ('eta_c', C.c_void_p), ('eta_d', C.c_void_p),
+        ('obs_var', C.c_void_p),
     ]
 
 
@@ -75,7 +76,7 @@ PBP_SKIP_HEAVY = 32
 PBP_SKIP_LIGHT = 64
 PBP_NO_GRID = 128
 PBP_LEAVE_ROOM = 256
-ABI_VERSION = 5             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
+ABI_VERSION = 6             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
 PBP_DESC_BYTES = 128
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE
 

@@ -1,0 +1,308 @@
+"""Coarse-to-fine lifted variational inference: ``C2FVarInference.VarInference`` of the reference
+(``C2FVarInference.py:11-461``) on the GPU.
+
+The reference starts from the coarsest lifting -- continuous evidence merged regardless of its values
+(``CompressedGraph.init_cluster(False)``, C2FVI:302) -- and treats an evidence cluster whose members' values differ as a
+*Gaussian observation* N(mean, variance) (C2FVI:120-136, 253-261).  Every ``update_obs_its`` ADAM iterations it splits the
+evidence clusters whose standard deviation exceeds a shrinking threshold by k-means (C2FVI:33-37, CGWO:236-247), re-runs
+colour passing, and lets the new clusters inherit the parameters and ADAM moments of the cluster they came from
+(C2FVI:39-60).  This file restates that schedule on colour arrays; the numerical work of a round -- the expectation step
+with Gaussian observations and the ADAM updates on the round's lifted graph -- is done by an *engine* (the HIP kernels of
+``csrc/vi.hip`` in the product, the CPU oracle in the tests), so the schedule itself is pure host logic.
+
+Because clusters only ever split and children inherit, the parameters are kept per GROUND variable between rounds: a
+round gathers them through each cluster's first member and scatters them back afterwards.
+
+Documented deviation (same as ``lhvi/c2f.py``): the reference seeds k-means and draws the initial parameters in the
+iteration order of Python ``set``s of objects, which changes from run to run; here both follow ground-variable order.
+Identical whenever a cluster holds at most ``k_mean_k`` distinct values and the initial parameters are injected
+(``init=``), as in the golden fixtures.
+"""
+from __future__ import annotations
+
+import time
+from math import sqrt
+
+import numpy as np
+
+from . import _abi
+from .c2f import DeviceRefiner, _first_member
+from .flat import flatten
+from .lifting import CompressedGraph, initial_colors, kmeans_assign
+from .vi import _Variational
+
+
+def _parents(old, new):
+    """parent (old colour) of every new colour; a refinement never merges"""
+    n = int(new.max()) + 1
+    return old[_first_member(new, n)]
+
+
+def evidence_variances(values, rvc):
+    """{cluster: np.var of its members' values} for the evidence clusters (``SuperRV.get_variance``, CGWO:38-39)"""
+    obs = ~np.isnan(values)
+    return {int(c): float(np.var(values[(rvc == c) & obs])) for c in np.unique(rvc[obs])}
+
+
+def split_rvs_tracked(refiner, values, rvc, fc, tracked):
+    """``VarInference.split_rvs`` (C2FVI:39-60): one structural refinement of the rv clusters; an evidence cluster that
+    splits puts all its pieces into ``clustered_evidence``, one that stays whole and has a single member leaves it"""
+    new = refiner.rvs(fc, rvc)
+    parent = _parents(rvc, new)
+    nchild = np.bincount(parent, minlength=int(rvc.max()) + 1)
+    size = np.bincount(new)
+    obs = ~np.isnan(values)
+    out = set()
+    for c in np.unique(new[obs]):
+        p = int(parent[c])
+        if nchild[p] > 1:
+            out.add(int(c))
+        elif p in tracked and size[c] > 1:
+            out.add(int(c))
+    return new, out
+
+
+def cp_run(refiner, values, rvc, fc, tracked):
+    """``VarInference.cp_run`` (C2FVI:62-67)"""
+    prev = -1
+    while prev != int(rvc.max()) + 1:
+        prev = int(rvc.max()) + 1
+        fc = refiner.factors(rvc, fc)
+        rvc, tracked = split_rvs_tracked(refiner, values, rvc, fc, tracked)
+    return rvc, fc, tracked
+
+
+def split_evidence_pass(values, rvc, tracked, k, iteration, epsilon):
+    """``CompressedGraph.split_evidence`` (CGWO:236-247): one pass over the clusters in ``clustered_evidence``"""
+    rvc = rvc.copy()
+    tracked = set(tracked)
+    nxt = int(rvc.max()) + 1
+    for c in sorted(tracked):
+        members = np.flatnonzero(rvc == c)
+        vals = values[members]
+        if not (np.sqrt(np.var(vals)) > epsilon):
+            continue
+        assign = kmeans_assign(vals, k, iteration)
+        if assign is None:                         # a single member or a single value: nothing to split
+            if members.size == 1:
+                tracked.discard(c)
+            continue
+        for idx in range(int(assign.max()) + 1):   # piece 0 keeps the colour (the reference reuses the SuperRV instance)
+            sel = members[assign == idx]
+            if idx > 0 and sel.size:
+                rvc[sel] = nxt
+                cid, nxt = nxt, nxt + 1
+            else:
+                cid = c
+            if sel.size and np.var(values[sel]) > epsilon:        # (variance here, its square root above: CGWO:239,244)
+                tracked.add(cid)
+    return rvc, tracked
+
+
+def split_evidence(values, rvc, tracked, k, iteration, epsilon):
+    """``VarInference.split_evidence`` (C2FVI:33-37): passes until the number of clusters stops changing"""
+    prev = -1
+    while prev != int(rvc.max()) + 1:
+        prev = int(rvc.max()) + 1
+        rvc, tracked = split_evidence_pass(values, rvc, tracked, k, iteration, epsilon)
+    return rvc, tracked
+
+
+def run_c2fvi(g, engine, refiner, K, iteration, lr, opts, init=None, observer=None):
+    """Drive one coarse-to-fine run.  ``engine.stage(flat, obs_var)`` returns an object with ``load(params)``,
+    ``adam(n, t, lr) -> [free energy after every update]``, ``dump() -> params`` where params is a dict of arrays
+    ``w_tau [K]``, ``eta_c [V,K,2]``, ``tau_d [V,K,D]`` and the ADAM moments ``m_* / s_*`` of each.
+    ``opts``: the reference's class attributes (k_mean_k, k_mean_its, update_obs_its, output_its, min_obs_var, gaussian_obs).
+    ``init``: (eta_c [Vg,K,2], tau_d [Vg,K,D]) per ground variable to start from instead of drawing (C2FVI:263-279).
+    ``observer(round, dict)`` sees the state right before every round's ADAM updates.
+    Returns dict(rvc, fc, flat, cg, stage, params (per ground variable), fe_log, obs_var)."""
+    gflat = flatten(g)
+    values = gflat.var_value
+    obs = ~np.isnan(values)
+    hid_c, hid_d = gflat.var_hidden & gflat.var_cont, gflat.var_hidden & ~gflat.var_cont
+    D = int(gflat.var_nstates[hid_d].max()) if hid_d.any() else 1
+    rvc, fc = initial_colors(g, is_split_cont_evidence=False)                       # C2FVI:302
+    tracked = set(int(c) for c in np.unique(rvc[obs & gflat.var_cont]))             # CGWO:204-210
+    Vg = gflat.V
+    P = dict(w_tau=np.zeros(K), eta_c=np.ones((Vg, K, 2)), tau_d=np.zeros((Vg, K, D)))
+    if init is not None:
+        P['eta_c'] = np.nan_to_num(np.array(init[0], dtype=np.float64), nan=1.0)
+        src = np.nan_to_num(np.array(init[1], dtype=np.float64), nan=0.0)
+        P['tau_d'][:, :, :min(D, src.shape[2])] = src[:, :, :D]
+    else:                                                                           # one draw per coarse hidden cluster
+        for c in np.unique(rvc[gflat.var_hidden]):
+            members = np.flatnonzero(rvc == c)
+            if gflat.var_cont[members[0]]:
+                P['eta_c'][members, :, 0] = np.random.rand(K) * 3 - 1.5
+            else:
+                d = int(gflat.var_nstates[members[0]])
+                P['tau_d'][members, :, :d] = np.random.rand(K, d) * 10
+    for name in ('w_tau', 'eta_c', 'tau_d'):
+        P['m_' + name] = np.zeros_like(P[name])
+        P['s_' + name] = np.zeros_like(P[name])
+    t = 0
+    rvc, fc, tracked = cp_run(refiner, values, rvc, fc, tracked)                    # C2FVI:324
+    ev = evidence_variances(values, rvc)
+    epsilon = max([sqrt(v) for v in ev.values()] + [0])                             # C2FVI:326-331
+    d = epsilon * opts['update_obs_its'] / (iteration - opts['output_its'])
+    epsilon -= d
+    fe_log = []
+    stage = flat = cg = obs_var = None
+    for rnd in range(int(iteration / opts['update_obs_its'])):                      # C2FVI:338-345
+        rvc, tracked = split_evidence(values, rvc, tracked, opts['k_mean_k'], opts['k_mean_its'], epsilon)
+        rvc, fc, tracked = cp_run(refiner, values, rvc, fc, tracked)
+        epsilon = max(epsilon - d, opts['min_obs_var'])
+        cg = CompressedGraph(g)
+        cg.set_colors(rvc, fc)
+        flat = flatten(cg, require_device_potentials=True)
+        rep = _first_member(rvc, flat.V)
+        ev = evidence_variances(values, rvc)
+        obs_var = np.zeros(flat.V)
+        if opts['gaussian_obs']:
+            for c, v in ev.items():
+                if v > opts['min_obs_var']:
+                    obs_var[c] = v
+        if observer is not None:
+            observer(rnd, dict(rvc=rvc, fc=fc, tracked=set(tracked), flat=flat, obs_var=obs_var, params=P, t=t))
+        stage = engine.stage(flat, obs_var)
+        local = {name: (a if name.endswith('w_tau') else np.ascontiguousarray(a[rep])) for name, a in P.items()}
+        stage.load(local)
+        fe_log += stage.adam(opts['update_obs_its'], t, lr)
+        t += opts['update_obs_its']
+        for name, a in stage.dump().items():           # (a round without discrete hidden variables keeps a narrower tau_d)
+            if name.endswith('w_tau'):
+                P[name] = np.array(a, dtype=np.float64)
+            else:
+                P[name][..., :a.shape[-1]] = a[rvc]
+    return dict(rvc=rvc, fc=fc, flat=flat, cg=cg, stage=stage, params=P, fe_log=fe_log, obs_var=obs_var, t=t)
+
+
+class _DeviceStage(_Variational):
+    """one round of the schedule on the device: the lifted graph of the round, Gaussian observations, ADAM"""
+
+    def __init__(self, owner, flat, obs_var):
+        self.K, self.T = owner.K, owner.T
+        self.quad_x, self.quad_w = owner.quad_x, owner.quad_w
+        self.reference_quirks = owner.reference_quirks
+        self.var_threshold = owner.var_threshold
+        self.time_log, self._dev, self._cache = [], None, {}
+        self._setup_flat(flat)
+        self._dev['obs_var'] = _abi.to_dev(np.ascontiguousarray(obs_var, dtype=np.float64))
+
+    def _struct(self):
+        p = super()._struct()
+        if 'obs_var' in self._dev:
+            p.obs_var = _abi.ptr(self._dev['obs_var'])
+        return p
+
+    def load(self, P):
+        self._upload_params(P['w_tau'], P['eta_c'], P['tau_d'])
+        d = self._dev
+        for name in ('w_tau', 'eta_c', 'tau_d'):
+            for pre in ('m_', 's_'):
+                src = np.zeros(tuple(d[name].shape))
+                a = np.asarray(P[pre + name], dtype=np.float64)
+                src[tuple(slice(0, min(x, y)) for x, y in zip(src.shape, a.shape))] = a[tuple(slice(0, min(x, y)) for x, y in zip(src.shape, a.shape))]
+                d[pre + name].copy_(_abi.to_dev(src))
+
+    def adam(self, n, t, lr):
+        self.is_log, self.log_fe = True, True
+        self.time_log, self.total_time = [], 0
+        self.alpha, self.b1, self.b2, self.eps, self.t = lr, 0.9, 0.999, 1e-8, t
+        self.ADAM_update(n)
+        return [fe for _, fe in self.time_log]
+
+    def dump(self):
+        d = self._dev
+        out = {}
+        for name in ('w_tau', 'eta_c', 'tau_d'):
+            for pre in ('', 'm_', 's_'):
+                out[pre + name] = d[pre + name].cpu().numpy()
+        return out
+
+
+class _DeviceEngine:
+    def __init__(self, owner):
+        self.owner = owner
+
+    def stage(self, flat, obs_var):
+        return _DeviceStage(self.owner, flat, obs_var)
+
+
+class VarInference(_Variational):
+    """``C2FVarInference.VarInference``: same constructor, class attributes, ``run`` / ``free_energy`` / ``belief`` /
+    ``map`` surface and ``w`` / ``eta`` / ``time_log`` attributes as the reference (C2FVI:11-31,298-352,436-461)."""
+
+    var_threshold = 0.1
+    k_mean_k = 2
+    k_mean_its = 10
+    update_obs_its = 10
+    output_its = 0
+    min_obs_var = 0
+    gaussian_obs = True
+
+    def __init__(self, g, num_mixtures=5, num_quadrature_points=3):
+        self._ground = g
+        self.g = CompressedGraph(g)
+        self._init_common(num_mixtures, num_quadrature_points)
+        self.init = None              # (eta_c, tau_d) per ground variable to start from (parity tests inject the reference's draw)
+        self.observer = None
+        self.refiner = None           # lhvi.c2f.Refiner; default: colour refinement on the device
+
+    def _options(self):
+        return {k: getattr(self, k) for k in ('k_mean_k', 'k_mean_its', 'update_obs_its', 'output_its', 'min_obs_var', 'gaussian_obs')}
+
+    def run(self, iteration=100, lr=0.1, is_log=True, log_fe=True):
+        self.is_log, self.log_fe = is_log, log_fe
+        t0 = time.process_time()
+        res = run_c2fvi(self._ground, _DeviceEngine(self), self.refiner or DeviceRefiner(self._ground), self.K, iteration, lr,
+                        self._options(), init=self.init, observer=self.observer)
+        self._result = res
+        self.g = res['cg']
+        st = res['stage']
+        self.flat, self.dg, self._dev, self._cache = st.flat, st.dg, st._dev, {}
+        self._cont, self._disc, self.Dmax = st._cont, st._disc, st.Dmax
+        self.obs_var = res['obs_var']
+        self.t = res['t']
+        if is_log:
+            self.total_time = time.process_time() - t0
+            n = max(len(res['fe_log']), 1)
+            self.time_log = [[self.total_time * (i + 1) / n, fe] for i, fe in enumerate(res['fe_log'])]
+
+    def _struct(self):
+        p = super()._struct()
+        if self._dev is not None and 'obs_var' in self._dev:
+            p.obs_var = _abi.ptr(self._dev['obs_var'])
+        return p
+
+    def _graph_like(self):
+        return self.g
+
+    def _ground_graph(self):
+        return self._ground
+
+    def _var_index(self, rv):
+        c = getattr(rv, 'cluster', None)
+        return self.flat.var_index[c if c in self.flat.var_index else rv]
+
+    def rvs_belief(self, x, rvs):
+        """C2FVI:243-261: a Gaussian observation contributes its pdf to every component instead of pinning x"""
+        b = np.copy(self._w_host())
+        for i, rv in enumerate(rvs):
+            v = self._var_index(rv)
+            if rv.value is not None:
+                if self.gaussian_obs and self.obs_var[v] > self.min_obs_var:
+                    b *= self.norm_pdf(x[i], (self.flat.var_value[v], self.obs_var[v]))
+                elif x[i] != rv.value:
+                    return 0
+            elif rv.domain.continuous:
+                eta = self._host('eta_c')[v]
+                xi = x[i] if np.ndim(x[i]) == 0 else float(np.ravel(x[i])[0])
+                for k in range(self.K):
+                    b[k] *= self.norm_pdf(xi, eta[k])
+            else:
+                b *= self._host('eta_d')[v, :, rv.domain.values.index(x[i])]
+        return np.sum(b)
+
+    def belief(self, x, rv):
+        return self.rvs_belief((x,), (rv.cluster,))        # C2FVI:436-437 (queries take ground rvs)

@@ -162,16 +162,46 @@ def initial_colors_flat(flat, is_split_cont_evidence=True):
     return rv_color, f_color, sym_row[flat.fac_pot]
 
 
-def split_evidence_colors(values, rv_color, k=2, iteration=10, epsilon=0.0, use_sqrt=True):
-    """``SuperRV.split_by_evidence`` (``CompressedGraphWithObs.py:78-130``) applied to every evidence cluster whose
-    spread exceeds ``epsilon`` -- ``sqrt(variance) > epsilon`` in ``CompressedGraph.split_evidence`` (CGWO:236-247),
-    ``variance > epsilon`` in ``HybridLBP.split_evidence`` (HLBP:250-266).  k-means over the distinct member values with
-    multiplicities; cluster 0 keeps the old colour, the others get fresh colours.
+def kmeans_assign(vals, k=2, iteration=10):
+    """the k-means of ``SuperRV.split_by_evidence`` (``CompressedGraphWithObs.py:78-130``) on the member values of one
+    evidence cluster: distinct values with multiplicities, centroids seeded with the first k distinct values, ``iteration``
+    Lloyd rounds, members assigned to the nearest final centroid (first on ties).  Returns the piece index of every member,
+    or None when the cluster cannot be split (a single member, or fewer than two distinct values).
 
-    The reference seeds the centroids with the first k distinct values in the iteration order of a Python ``set`` of RV
-    objects, i.e. in an order that changes from run to run; here the order is the ground-variable order, which makes the
-    split deterministic (identical to the reference whenever the outcome does not depend on the seeding, e.g. when a
-    cluster holds at most k distinct values)."""
+    The reference seeds the centroids in the iteration order of a Python ``set`` of RV objects, i.e. in an order that
+    changes from run to run; here the order is the order of ``vals`` (ground-variable order), which makes the split
+    deterministic (identical to the reference whenever the outcome does not depend on the seeding, e.g. when a cluster
+    holds at most k distinct values)."""
+    vals = np.asarray(vals, dtype=np.float64)
+    if vals.size <= 1:
+        return None
+    distinct, counts = [], {}
+    for v in vals.tolist():                     # insertion order = ground order
+        if v not in counts:
+            distinct.append(v)
+            counts[v] = 0
+        counts[v] += 1
+    kk = min(k, len(distinct))
+    if kk <= 1:
+        return None
+    centroids = np.array(distinct[:kk], dtype=np.float64)
+    table = np.zeros((kk, 2))
+    for _ in range(iteration):
+        for v in distinct:
+            idx = int(np.abs(centroids - v).argmin())
+            table[idx, 0] += v * counts[v]
+            table[idx, 1] += counts[v]
+        for idx in range(kk):
+            centroids[idx] = table[idx, 0] / table[idx, 1]
+        table.fill(0)
+    return np.array([int(np.abs(centroids - v).argmin()) for v in vals.tolist()])
+
+
+def split_evidence_colors(values, rv_color, k=2, iteration=10, epsilon=0.0, use_sqrt=True):
+    """``SuperRV.split_by_evidence`` (``CompressedGraphWithObs.py:78-130``, ``kmeans_assign``) applied to every evidence
+    cluster whose spread exceeds ``epsilon`` -- ``sqrt(variance) > epsilon`` in ``CompressedGraph.split_evidence``
+    (CGWO:236-247), ``variance > epsilon`` in ``HybridLBP.split_evidence`` (HLBP:250-266).  Piece 0 keeps the old colour,
+    the others get fresh colours."""
     values = np.asarray(values, dtype=np.float64)
     rv_color = np.array(rv_color, dtype=np.int32)
     next_color = int(rv_color.max()) + 1 if rv_color.size else 0
@@ -184,27 +214,10 @@ def split_evidence_colors(values, rv_color, k=2, iteration=10, epsilon=0.0, use_
         var = np.var(vals)
         if not ((np.sqrt(var) if use_sqrt else var) > epsilon):
             continue
-        distinct, counts = [], {}
-        for v in vals.tolist():                     # insertion order = ground order
-            if v not in counts:
-                distinct.append(v)
-                counts[v] = 0
-            counts[v] += 1
-        kk = min(k, len(distinct))
-        if kk <= 1:
+        assign = kmeans_assign(vals, k, iteration)
+        if assign is None:
             continue
-        centroids = np.array(distinct[:kk], dtype=np.float64)
-        table = np.zeros((kk, 2))
-        for _ in range(iteration):
-            for v in distinct:
-                idx = int(np.abs(centroids - v).argmin())
-                table[idx, 0] += v * counts[v]
-                table[idx, 1] += counts[v]
-            for idx in range(kk):
-                centroids[idx] = table[idx, 0] / table[idx, 1]
-            table.fill(0)
-        assign = np.array([int(np.abs(centroids - v).argmin()) for v in vals.tolist()])
-        for idx in range(1, kk):
+        for idx in range(1, int(assign.max()) + 1):
             sel = members[assign == idx]
             if sel.size:
                 rv_color[sel] = next_color

@@ -14,6 +14,10 @@
 typedef struct {
     int32_t K, T, Dmax, quirks;
     const double *gh_x, *gh_w, *w, *eta_c, *eta_d;
+    /* C2FVarInference.py:120-136,253-261: an evidence cluster whose members' values differ is a Gaussian observation
+     * N(value, variance): obs_var[v] > 0 marks it (NULL: none).  It is integrated with T quadrature nodes like a hidden
+     * continuous variable, multiplies every mixture component of a belief by its pdf, and has no parameters of its own. */
+    const double *obs_var;
 } ovi_t;
 
 #define MAXN 64
@@ -21,6 +25,7 @@ typedef struct {
 typedef struct { int n; double x[MAXN], w[MAXN]; int idx[MAXN]; } axis_t;
 
 static int hidden(double v) { return v != v; }
+static int gobs(const ovi_t *p, int v) { return p->obs_var && p->obs_var[v] > 0.0; }
 static int is_cont(const ograph_t *g, int v) { return g->dom_cont[g->var_dom[v]]; }
 static int nstates(const ograph_t *g, int v) { int d = g->var_dom[v]; return g->dom_ptr[d + 1] - g->dom_ptr[d]; }
 static const double *states(const ograph_t *g, int v) { return g->dom_val + g->dom_ptr[g->var_dom[v]]; }
@@ -44,7 +49,10 @@ static double rvs_belief(const ograph_t *g, const ovi_t *p, const double *x, con
     for (int k = 0; k < p->K; ++k) b[k] = p->w[k];
     for (int i = 0; i < m; ++i) {
         int v = vars[i];
-        if (!hidden(g->var_value[v])) { if (x[i] != g->var_value[v]) return 0.0; }
+        if (!hidden(g->var_value[v])) {
+            if (gobs(p, v)) { for (int k = 0; k < p->K; ++k) b[k] *= norm_pdf_var(x[i], g->var_value[v], p->obs_var[v]); }
+            else if (x[i] != g->var_value[v]) return 0.0;
+        }
         else if (is_cont(g, v)) {
             for (int k = 0; k < p->K; ++k) { const double *e = p->eta_c + ((long)v * p->K + k) * 2; b[k] *= norm_pdf_var(x[i], e[0], e[1]); }
         } else {
@@ -58,7 +66,11 @@ static double rvs_belief(const ograph_t *g, const ovi_t *p, const double *x, con
 
 /* the (is_continuous, eta) argument of expectation() for variable v under component k (VI:64-70) */
 static void axis_of(const ograph_t *g, const ovi_t *p, int v, int k, axis_t *a) {
-    if (!hidden(g->var_value[v])) { a->n = 1; a->x[0] = g->var_value[v]; a->w[0] = 1.0; a->idx[0] = state_index(g, v, a->x[0]); }
+    if (!hidden(g->var_value[v]) && gobs(p, v)) {
+        a->n = p->T;
+        for (int t = 0; t < p->T; ++t) { a->x[t] = sqrt(2 * p->obs_var[v]) * p->gh_x[t] + g->var_value[v]; a->w[t] = p->gh_w[t]; a->idx[t] = 0; }
+    }
+    else if (!hidden(g->var_value[v])) { a->n = 1; a->x[0] = g->var_value[v]; a->w[0] = 1.0; a->idx[0] = state_index(g, v, a->x[0]); }
     else if (is_cont(g, v)) {
         const double *e = p->eta_c + ((long)v * p->K + k) * 2;
         a->n = p->T;
@@ -139,13 +151,19 @@ static double pinned_expectation(const ograph_t *g, const ovi_t *p, int f, int p
     }
     /* quirk mode */
     int nx[MAX_ARITY], nw[MAX_ARITY], oth[MAX_ARITY], m = 0;
-    double wl[MAX_ARITY][MAXN];
+    double wl[MAX_ARITY][MAXN], xl[MAX_ARITY][MAXN];
     long totx = 1, totw = 1;
     for (int a = 0; a < arity; ++a) {
         if (a == pos) continue;
         int v = g->edge_var[base + a];
         oth[m] = a;
-        if (!hidden(g->var_value[v])) { nx[m] = 1; nw[m] = 1; wl[m][0] = 1.0; }
+        if (!hidden(g->var_value[v]) && gobs(p, v)) {     /* C2FVI:221-223: (True, (value, variance)) */
+            axis_t ax;
+            axis_of(g, p, v, k, &ax);
+            nx[m] = nw[m] = ax.n;
+            for (int t = 0; t < ax.n; ++t) { xl[m][t] = ax.x[t]; wl[m][t] = ax.w[t]; }
+        }
+        else if (!hidden(g->var_value[v])) { nx[m] = 1; nw[m] = 1; wl[m][0] = 1.0; }
         else {
             nx[m] = Dt;
             if (is_cont(g, v)) { nw[m] = 2; wl[m][0] = p->eta_c[((long)v * p->K + k) * 2]; wl[m][1] = p->eta_c[((long)v * p->K + k) * 2 + 1]; }
@@ -164,7 +182,8 @@ static double pinned_expectation(const ograph_t *g, const ovi_t *p, int f, int p
         for (int j = 0; j < m; ++j) {
             int a = oth[j], v = g->edge_var[base + a];
             w *= wl[j][iws[j]];
-            if (!hidden(g->var_value[v])) { x[a] = g->var_value[v]; idx[a] = state_index(g, v, x[a]); }
+            if (!hidden(g->var_value[v]) && gobs(p, v)) { x[a] = xl[j][ixs[j]]; idx[a] = 0; }
+            else if (!hidden(g->var_value[v])) { x[a] = g->var_value[v]; idx[a] = state_index(g, v, x[a]); }
             else { x[a] = tvals[ixs[j]]; idx[a] = state_index(g, v, x[a]); }
         }
         x[pos] = tvals[d]; idx[pos] = d;

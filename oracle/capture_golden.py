@@ -9,7 +9,7 @@ The reference is pure Python; it imports under Python 3.10 / NumPy 2 once three 
 modified or copied: models are built with the reference's own classes, its solvers are run, and only
 *data* (serialised models, messages, marginals, partitions) is written out.
 
-usage: python oracle/capture_golden.py [gauss] [color] [pbp] [vi]
+usage: python oracle/capture_golden.py [gauss] [color] [pbp] [vi] [c2fvi]
 """
 import collections
 import collections.abc
@@ -248,3 +248,6 @@ if __name__ == '__main__':
     if 'vi' in what:
         from capture_vi import capture_vi
         capture_vi(sys.modules[__name__])
+    if 'c2fvi' in what:
+        from capture_vi import capture_c2f
+        capture_c2f(sys.modules[__name__])

@@ -200,7 +200,7 @@ def model_rgm_small(cg, C=4, B=3, seed=5):
     return g
 
 
-def model_hmln_small(cg, P=6, T=3, seed=31, two_values=False, points=32):
+def model_hmln_small(cg, P=6, T=3, seed=31, two_values=False, points=32, values=None):
     """cfg 3 at fixture size: the paper-popularity hybrid MLN template of
     Demo/Data/HMLN/GeneratorPaperPopularity.py:7-40 -- same atoms, same three parametric factors with their weights, the
     t1 != t2 constraint -- grounded by the reference's own RelationalGraph for P papers x T topics, with the demo's domain
@@ -227,7 +227,10 @@ def model_hmln_small(cg, P=6, T=3, seed=31, two_values=False, points=32):
                    nb=['PaperIn(p,t)', 'PaperPopularity(p)', 'TopicPopularity(t)'])
     rel_g = RR.RelationalGraph(atoms, (f0, f1, f2))
     rel_g.ground_graph()
-    draw = (lambda: float(rng.choice([2.5, 7.0]))) if two_values else (lambda: float(rng.uniform(0, 10)))
+    if values is not None:
+        draw = lambda: float(rng.choice(list(values)))
+    else:
+        draw = (lambda: float(rng.choice([2.5, 7.0]))) if two_values else (lambda: float(rng.uniform(0, 10)))
     data = {}
     for x in rng.choice(P, int(P * 0.7), replace=False):
         data[('PaperPopularity', 'p%d' % x)] = draw()

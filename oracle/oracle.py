@@ -276,7 +276,7 @@ def interval_probability(log_belief, a, b, lo, hi, max_log_value=700.0):
 class OVi(C.Structure):
     _fields_ = [('K', C.c_int32), ('T', C.c_int32), ('Dmax', C.c_int32), ('quirks', C.c_int32),
                 ('gh_x', C.c_void_p), ('gh_w', C.c_void_p), ('w', C.c_void_p), ('eta_c', C.c_void_p),
-                ('eta_d', C.c_void_p)]
+                ('eta_d', C.c_void_p), ('obs_var', C.c_void_p)]
 
 
 def softmax_rows(x):
@@ -288,9 +288,11 @@ def softmax_rows(x):
 class ViOracle:
     """Flat-array twin of VarInference / LiftedVarInference (parameters for every variable, unused rows ignored)."""
 
-    def __init__(self, flat, K, T, quirks=1):
+    def __init__(self, flat, K, T, quirks=1, obs_var=None):
+        """`obs_var` [V]: variance of Gaussian observation clusters (C2FVarInference), 0 elsewhere; None = none"""
         from numpy.polynomial.hermite import hermgauss
         self.flat, self.hg, self.K, self.T, self.quirks = flat, HostGraph(flat), K, T, quirks
+        self.obs_var = None if obs_var is None else np.ascontiguousarray(obs_var, dtype=np.float64)
         self.gh_x, self.gh_w = hermgauss(T)
         self.gh_w = self.gh_w / np.sqrt(np.pi)
         disc = flat.var_hidden & ~flat.var_cont
@@ -325,6 +327,7 @@ class ViOracle:
         p.K, p.T, p.Dmax, p.quirks = self.K, self.T, self.Dmax, self.quirks
         self._keep = [np.ascontiguousarray(a) for a in (self.gh_x, self.gh_w, self.w, self.eta_c, self.eta_d)]
         p.gh_x, p.gh_w, p.w, p.eta_c, p.eta_d = (_p(a) for a in self._keep)
+        p.obs_var = _p(self.obs_var) if self.obs_var is not None else None
         g_w = np.zeros(self.K)
         g_c = np.zeros((self.flat.V, self.K, 2))
         g_d = np.zeros((self.flat.V, self.K, self.Dmax))
@@ -334,17 +337,21 @@ class ViOracle:
         g_d[~self.disc] = 0.0
         return g_w, g_c, g_d, float(fe[0])
 
-    def run(self, iterations, lr=0.1):
-        """ADAM_update (VI:249-300); returns the free energy logged after every update"""
+    def run(self, iterations, lr=0.1, moments=None, t0=0):
+        """ADAM_update (VI:249-300); returns the free energy logged after every update.  `moments`: dict with the first /
+        second moment arrays m_w_tau, s_w_tau, m_eta_c, s_eta_c, m_tau_d, s_tau_d to continue from (updated in place;
+        C2FVarInference carries them across its rounds); `t0`: updates already done (bias correction)"""
         b1, b2, eps = 0.9, 0.999, 1e-8
-        mw, sw = np.zeros(self.K), np.zeros(self.K)
-        mc, sc = np.zeros_like(self.eta_c), np.zeros_like(self.eta_c)
-        md, sd = np.zeros_like(self.tau_d), np.zeros_like(self.tau_d)
+        if moments is None:
+            moments = {}
+        mw, sw = moments.setdefault('m_w_tau', np.zeros(self.K)), moments.setdefault('s_w_tau', np.zeros(self.K))
+        mc, sc = moments.setdefault('m_eta_c', np.zeros_like(self.eta_c)), moments.setdefault('s_eta_c', np.zeros_like(self.eta_c))
+        md, sd = moments.setdefault('m_tau_d', np.zeros_like(self.tau_d)), moments.setdefault('s_tau_d', np.zeros_like(self.tau_d))
         log = []
         adam = lib().oracle_adam_step
         adam.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_double, C.c_double,
                          C.c_double, C.c_double, C.c_int, C.c_double]
-        for t in range(1, iterations + 1):
+        for t in range(t0 + 1, t0 + iterations + 1):
             g_w, g_c, g_d, _ = self.grad()
             for theta, m, s, g, stride in ((self.w_tau, mw, sw, g_w, 0), (self.eta_c, mc, sc, g_c, 2),
                                            (self.tau_d, md, sd, g_d, 0)):

@@ -33,10 +33,23 @@ if 'gauss' in which:
     t_v = ev_time(lambda: _abi.check(l.lhvi_gabp_v2f(dg.g, _abi.ptr(f2v), _abi.ptr(v2f), st)))
     t_f = ev_time(lambda: _abi.check(l.lhvi_gabp_f2v(dg.g, dg.p, _abi.ptr(v2f), _abi.ptr(f2v), st)))
     bytes_sweep = 76.0 * flat.E
-    out(config='gaussian sweep, random pairwise MRF', edges=flat.E, v2f_ms=t_v, f2v_ms=t_f,
+    out(config='gaussian sweep, random pairwise MRF, v2f + f2v kernel pair', edges=flat.E, v2f_ms=t_v, f2v_ms=t_f,
         sweeps_per_s=1e3 / (t_v + t_f), algorithmic_GBs=bytes_sweep / ((t_v + t_f) * 1e-3) / 1e9,
         hbm_frac=bytes_sweep / ((t_v + t_f) * 1e-3) / 8e12)
-    del dg, f2v, v2f, mv
+    # pull form: one launch per sweep, messages in slot order
+    from lhvi.gabp import pull_plan
+    host = pull_plan(flat)
+    dev = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
+    plan = _abi.GabpPlanStruct()
+    plan.pslot, plan.info, plan.pval, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'pval', 'count'))
+    nnz = int(flat.var_edge.size)
+    va, vb = dg.empty(nnz, 2), dg.empty(nnz, 2)
+    _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 1, st))
+    _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(vb), _abi.ptr(va), 0, st))
+    t_p = ev_time(lambda: _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 0, st)))
+    out(config='gaussian sweep, random pairwise MRF, pull form (lhvi_gabp_pull)', edges=flat.E, sweep_ms=t_p, sweeps_per_s=1e3 / t_p,
+        algorithmic_GBs=bytes_sweep / (t_p * 1e-3) / 1e9, hbm_frac=bytes_sweep / (t_p * 1e-3) / 8e12)
+    del dg, f2v, v2f, mv, va, vb
 
 if 'cfg2' in which:
     # cfg 2: RGM template C=100, B=50 (E=20 200), GaBP ground and GaLBP lifted, 20 sweeps
@@ -45,7 +58,16 @@ if 'cfg2' in which:
     f2v, v2f = dg.empty(flat.E, 2), dg.empty(flat.E, 2)
     l, st = _abi.lib(), _abi.stream_ptr()
     t = ev_time(lambda: _abi.check(l.lhvi_gabp_run(dg.g, dg.p, _abi.ptr(f2v), _abi.ptr(v2f), 20, st)))
-    out(config='cfg2 RGM C=100 B=50 ground GaBP', edges=flat.E, ms_20_sweeps=t, sweeps_per_s=20e3 / t)
+    out(config='cfg2 RGM C=100 B=50 ground GaBP, kernel pair', edges=flat.E, ms_20_sweeps=t, sweeps_per_s=20e3 / t)
+    from lhvi.gabp import pull_plan
+    host = pull_plan(flat)
+    dev = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
+    plan = _abi.GabpPlanStruct()
+    plan.pslot, plan.info, plan.pval, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'pval', 'count'))
+    nb = int(l.lhvi_gabp_pull_workspace_bytes(dg.g))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dg.device)
+    t = ev_time(lambda: _abi.check(l.lhvi_gabp_run_pull(dg.g, dg.p, plan, _abi.ptr(f2v), _abi.ptr(v2f), 20, _abi.ptr(ws), nb, st)))
+    out(config='cfg2 RGM C=100 B=50 ground GaBP, pull form', edges=flat.E, ms_20_sweeps=t, sweeps_per_s=20e3 / t)
     t0 = time.perf_counter()
     rvc, fc = lifting.refine_flat(flat, sym, rv0, f0)
     torch.cuda.synchronize()

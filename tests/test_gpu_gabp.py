@@ -210,7 +210,7 @@ def test_pull_form_equals_the_kernel_pair_bit_for_bit(api, case):
     from lhvi import synth, lifting
     its = 7
     if case == 'lifted_rgm':
-        g, sym, rv0, f0 = synth.rgm_flat(C=60, B=40, n_values=3, evidence_ratio=0.25, seed=2)
+        g, sym, rv0, f0 = synth.rgm_structured_flat(80, 50, A=40, R=25)
         rvc, fc = lifting.refine_flat(g, sym, rv0, f0)
         flat = lifting.lift_flat(g, rvc, fc)
         assert flat.lifted and flat.V < g.V

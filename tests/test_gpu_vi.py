@@ -177,3 +177,36 @@ def test_device_evaluators_match_reference_values(api, golden_dir):
     got = utils.kl_tables(p, q, np.array([c['lo'] for c in cs], dtype=float), np.array([c['hi'] for c in cs], dtype=float)).cpu().numpy()
     for i, c in enumerate(cs):
         assert got[i] == pytest.approx(c['kl_continuous'], rel=1e-6, abs=1e-9)
+
+
+@pytest.mark.parametrize('name', ['c2f_rgm_k2', 'c2f_hmln_k2'])
+def test_c2f_var_inference_matches_reference(api, golden_dir, name):
+    """C2FVarInference on the device (coarse-to-fine lifting with Gaussian observation clusters, csrc/vi.hip through
+    lhvi_vi_t.obs_var) against the reference: every round's partition / inherited parameters / ADAM moments, the free
+    energy after each of the 30 updates, final parameters, beliefs and MAPs of the ground variables"""
+    from lhvi.c2fvi import VarInference as C2FVI
+    from test_oracle_vi import c2fvi_round_checker
+    from oracle import oracle
+    z, meta = load_vi(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    vi = C2FVI(g, meta['K'], meta['T'])
+    vi.update_obs_its = meta['update_obs_its']
+    vi.init = (z['eta_c0'], z['tau_d0'])
+    seen = []
+    vi.observer = c2fvi_round_checker(z, rvs, seen)
+    vi.run(meta['iterations'], lr=meta['lr'])
+    assert seen == list(range(meta['iterations'] // meta['update_obs_its']))
+    res = vi._result
+    assert oracle.canonical_labels(res['rvc']) == z['final_rv_label'].tolist()
+    np.testing.assert_allclose([fe for _, fe in vi.time_log], z['fe_log'], rtol=1e-8)
+    cont = np.array([rv.value is None and rv.domain.continuous for rv in rvs])
+    np.testing.assert_allclose(res['params']['eta_c'][cont], z['final_eta_c'][cont], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(vi.w, z['w_final'], rtol=1e-8)
+    assert vi.free_energy() == pytest.approx(float(z['fe_final']), rel=1e-8)
+    for i, rv in enumerate(rvs):
+        if rv.value is None:
+            x = 0.5 if rv.domain.continuous else rv.domain.values[0]
+            assert vi.belief(x, rv) == pytest.approx(z['belief_mid'][i], rel=1e-7, abs=1e-300)
+            assert vi.map(rv) == pytest.approx(z['map'][i], abs=1e-4)
+        else:
+            assert vi.map(rv) == rv.value

@@ -66,3 +66,99 @@ def test_vi_oracle_matches_reference(golden_dir, name):
     np.testing.assert_allclose(log, z['fe_log'], rtol=1e-8)
     np.testing.assert_allclose(o.w, z['w_final'], rtol=1e-8)
     np.testing.assert_allclose(o.eta_c[gather][cont], z['eta_c_final'][cont], rtol=1e-8, atol=1e-10)
+
+
+# ---- C2FVarInference (coarse-to-fine lifted VI with Gaussian observation clusters) -----------------------------------
+C2F_CASES = ['c2f_rgm_k2', 'c2f_hmln_k2']
+C2F_OPTS = dict(k_mean_k=2, k_mean_its=10, output_its=0, min_obs_var=0, gaussian_obs=True)
+
+
+class OracleViEngine:
+    """lhvi.c2fvi engine backed by the CPU oracle"""
+
+    def __init__(self, K, T):
+        self.K, self.T = K, T
+
+    def stage(self, flat, obs_var):
+        eng = self
+
+        class Stage:
+            def __init__(self):
+                self.o = oracle.ViOracle(flat, eng.K, eng.T, quirks=1, obs_var=obs_var)
+                self.mom = {}
+
+            def load(self, P):
+                self.o.set_params(P['w_tau'], P['eta_c'], P['tau_d'])
+                for name in ('w_tau', 'eta_c', 'tau_d'):
+                    ref = getattr(self.o, name)
+                    for pre in ('m_', 's_'):
+                        a = np.zeros_like(ref)
+                        src = np.asarray(P[pre + name], dtype=float)
+                        a[..., :min(a.shape[-1], src.shape[-1])] = src[..., :a.shape[-1]]
+                        self.mom[pre + name] = a
+
+            def adam(self, n, t, lr):
+                return self.o.run(n, lr, moments=self.mom, t0=t)
+
+            def dump(self):
+                return dict(w_tau=self.o.w_tau, eta_c=self.o.eta_c, tau_d=self.o.tau_d, **self.mom)
+        return Stage()
+
+
+def c2fvi_round_checker(z, rvs, seen):
+    """observer for lhvi.c2fvi.run_c2fvi: the state right before every round's ADAM updates against what the reference
+    held at that point -- partitions (exact), evidence clusters' value / variance and clustered_evidence membership,
+    inherited parameters and ADAM moments, update counter"""
+    cont = np.array([rv.value is None and rv.domain.continuous for rv in rvs])
+    disc = np.array([rv.value is None and not rv.domain.continuous for rv in rvs])
+    ev = np.array([rv.value is not None for rv in rvs])
+
+    def observer(r, st):
+        rvc, flat, P = st['rvc'], st['flat'], st['params']
+        assert oracle.canonical_labels(rvc) == z['round_rv_label'][r].tolist(), 'rv partition of round %d' % r
+        assert oracle.canonical_labels(st['fc']) == z['round_f_label'][r].tolist(), 'factor partition of round %d' % r
+        np.testing.assert_allclose(flat.var_value[rvc][ev], z['round_value'][r][ev], rtol=1e-15)
+        np.testing.assert_allclose(np.array([np.var([rvs[m].value for m in np.flatnonzero(rvc == rvc[i])]) for i in np.flatnonzero(ev)]),
+                                   z['round_variance'][r][ev], rtol=1e-13, atol=1e-300)
+        np.testing.assert_allclose(st['obs_var'][rvc][ev], z['round_variance'][r][ev], rtol=1e-13, atol=1e-300)
+        tracked = np.array([int(rvc[i]) in st['tracked'] for i in range(len(rvs))], dtype=np.int8)
+        # (membership matters only for clusters that can still split: more than one member with different values)
+        live = ev & (z['round_variance'][r] > 0)
+        assert (tracked[live] == z['round_tracked'][r][live]).all()
+        np.testing.assert_allclose(P['eta_c'][cont], z['round_eta_c'][r][cont], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(P['m_eta_c'][cont], z['round_m_c'][r][cont], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(P['s_eta_c'][cont], z['round_s_c'][r][cont], rtol=1e-8, atol=1e-14)
+        if disc.any():
+            D = z['round_tau_d'].shape[-1]
+            np.testing.assert_allclose(P['tau_d'][disc][:, :, :D], np.nan_to_num(z['round_tau_d'][r][disc]), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(P['w_tau'], z['round_w_tau'][r], rtol=1e-8, atol=1e-12)
+        assert st['t'] == int(z['round_t'][r])
+        seen.append(r)
+    return observer
+
+
+def check_c2fvi_result(z, rvs, res):
+    cont = np.array([rv.value is None and rv.domain.continuous for rv in rvs])
+    assert oracle.canonical_labels(res['rvc']) == z['final_rv_label'].tolist()
+    assert oracle.canonical_labels(res['fc']) == z['final_f_label'].tolist()
+    np.testing.assert_allclose(res['fe_log'], z['fe_log'], rtol=1e-8)
+    np.testing.assert_allclose(res['params']['eta_c'][cont], z['final_eta_c'][cont], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(res['params']['w_tau'], z['final_w_tau'], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize('name', C2F_CASES)
+def test_c2fvi_oracle_matches_reference(golden_dir, name):
+    """the coarse-to-fine schedule of lhvi.c2fvi driven by the CPU oracle (Gaussian observation clusters in every
+    expectation, oracle/c/vi_oracle.c) against the reference's C2FVarInference: every round's partition and inherited
+    state, the free energy after each of the 30 ADAM updates, the final parameters"""
+    from lhvi import c2fvi
+    from test_oracle_pbp import OracleRefiner
+    z, meta = load_vi(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    seen = []
+    res = c2fvi.run_c2fvi(g, OracleViEngine(meta['K'], meta['T']), OracleRefiner(g), meta['K'], meta['iterations'], meta['lr'],
+                          dict(C2F_OPTS, update_obs_its=meta['update_obs_its']), init=(z['eta_c0'], z['tau_d0']),
+                          observer=c2fvi_round_checker(z, rvs, seen))
+    assert seen == list(range(meta['iterations'] // meta['update_obs_its']))
+    assert (np.nan_to_num(z['round_variance']) > 0).any()          # the fixture does exercise Gaussian observations
+    check_c2fvi_result(z, rvs, res)
