@@ -289,7 +289,11 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_kernel(lhvi_graph_t g, lhvi_p
     for (int j = lo_ext + threadIdx.x; j < hi_ext; j += BLOCK) {
         // first sweep: every f -> v message still is its initial value (0, 1) (GaBP.py:143-150)
         const bool hid = is_hidden(g.var_value[g.slot_var[j]]);
-        sh[j - lo_ext] = (hid && !first) ? pull_incoming(pots, pl, vprev, j) : make_double2(0.0, 1.0);
+        const double2 m = (hid && !first) ? pull_incoming(pots, pl, vprev, j) : make_double2(0.0, 1.0);
+        // staged in information form (p * mu, p), p = 1 / var -- the products every slot of the row would form anyway, so
+        // the row sums below are additions only; a `None` variance (NaN) keeps (mu, NaN)
+        const double p = 1.0 / m.y;
+        sh[j - lo_ext] = (m.y != m.y) ? m : make_double2(p * m.x, p);
     }
     __syncthreads();
     const int k = k0 + threadIdx.x;
@@ -305,11 +309,8 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_kernel(lhvi_graph_t g, lhvi_p
         else if (j == k) continue;
         const double2 m = sh[j - lo_ext];
         if (m.y != m.y) H -= pl.count ? m.x * c : m.x;
-        else {
-            const double p = 1.0 / m.y;
-            if (pl.count) { H += p * m.x * c; P += p * c; }
-            else          { H += p * m.x;     P += p; }
-        }
+        else if (pl.count) { H += m.x * c; P += m.y * c; }
+        else               { H += m.x;     P += m.y; }
     }
     const double var = 1.0 / P;
     st2(vnext, k, var * H, var);

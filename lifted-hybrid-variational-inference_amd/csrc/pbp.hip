@@ -403,6 +403,14 @@ __device__ __forceinline__ double fast_accumulate_uniform(const AB* __restrict__
     if (UNROLL == 4) {                  // four chains: fewer LDS round trips per term; worth its registers in the heavy kernel only
         double acc2 = 0.0, acc3 = 0.0;
         for (; j + 4 <= jn; j += 4) {
+#ifdef LHVI_HEAVY_STAGED
+            if (MODE == MODE_CONST) {
+                const AB r0 = sh[j], r1 = sh[j + 1], r2 = sh[j + 2], r3 = sh[j + 3];
+                exp_accumulate4(acc0, acc1, acc2, acc3, fma(r0.b, X1, r0.a), fma(r1.b, X1, r1.a), fma(r2.b, X1, r2.a),
+                                fma(r3.b, X1, r3.a), sft.magic, tab);
+                continue;
+            }
+#endif
             acc0 = fast_term<MODE>(acc0, sh, shk, tab, j, X1, X2, sft.magic);
             acc1 = fast_term<MODE>(acc1, sh, shk, tab, j + 1, X1, X2, sft.magic);
             acc2 = fast_term<MODE>(acc2, sh, shk, tab, j + 2, X1, X2, sft.magic);
@@ -548,7 +556,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
 // behind WORK_CHUNK edges -- and a workgroup that reaches its CU late (another kernel's workgroups held the slot) simply
 // finds less left to claim.  Without a ticket every wave strides over the list: a late workgroup then still owes its
 // full static share.
-template <int WORK_CHUNK>
+template <int WORK_CHUNK, int WAVES_PER_BLOCK = BLOCK / WAVE>
 struct WorkCursor {
     uint32_t* ticket;       // nullptr: static striding
     int item, limit, left, stride, pending, lo;
@@ -560,7 +568,7 @@ struct WorkCursor {
     // with tickets the list is cut into one contiguous range per XCD (workgroup i runs on XCD i mod 8, and each XCD has
     // its own L2: its waves then walk one region of the descriptors, particles and messages), each with its own counter
     __device__ __forceinline__ bool start(uint32_t* base, int nitems, int lane) {
-        stride = gridDim.x * (BLOCK / WAVE);
+        stride = gridDim.x * WAVES_PER_BLOCK;
         left = 0; pending = 0; lo = 0; limit = nitems;
         ticket = base;
         if (ticket) {
@@ -574,7 +582,7 @@ struct WorkCursor {
             pending = claim(lane);
             left = WORK_CHUNK - 1;
         } else {
-            item = blockIdx.x * (BLOCK / WAVE) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            item = blockIdx.x * WAVES_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         }
         return item < limit;
     }
@@ -592,6 +600,18 @@ struct WorkCursor {
 };
 
 struct HeavyData { double y, m, x0, x1; };
+
+// launch shape of the heavy kernel (tuning knobs; the defaults are what ships)
+#ifndef LHVI_HEAVY_BLOCK
+#define LHVI_HEAVY_BLOCK 256
+#endif
+#ifndef LHVI_HEAVY_WAVES
+#define LHVI_HEAVY_WAVES 7
+#endif
+#ifndef LHVI_HEAVY_UNROLL
+#define LHVI_HEAVY_UNROLL 4
+#endif
+constexpr int HEAVY_BLOCK = LHVI_HEAVY_BLOCK;
 
 // ---- integral points on a uniform grid: sum_j exp(a_j + b_j x_t) for t < 32 with lane = partner particle j ------------
 // G_{t+1,j} = G_{t,j} * exp(b_j h) replaces the exponential per (t, j) by one multiplication; the sums over j are then a
@@ -674,10 +694,10 @@ __device__ __forceinline__ HeavyData heavy_fetch(const FastDesc& d, const lhvi_g
     return h;
 }
 
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7))) pbp_f2v_heavy_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
+__global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI_HEAVY_WAVES, LHVI_HEAVY_WAVES))) pbp_f2v_heavy_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
                                                              double* __restrict__ f2v, const FastDesc* __restrict__ descs,
                                                              int nitems) {
-    __shared__ AB sh_all[BLOCK / WAVE][WAVE];
+    __shared__ AB sh_all[HEAVY_BLOCK / WAVE][WAVE];
     __shared__ double sh_tab[EXP_TAB_N];
     __shared__ LogRec sh_log[LOG_TAB_N];
     load_log_table(sh_log);
@@ -689,7 +709,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7
     // scalar cache: s_load does not take part in vmcnt, which the prefetched vector loads rely on)
     const int last = nitems - 1;
     const int n = s.n, S = s.n + s.T;
-    WorkCursor<8> cur;
+    WorkCursor<8, HEAVY_BLOCK / WAVE> cur;
     if (!cur.start(s.f2v_ticket, nitems, lane)) return;
     // pipeline: the loads of edge k+1 are issued as soon as edge k has been staged into LDS (its registers are free
     // then, so nothing has to be rotated) and stay in flight through the term loops of edge k; `dn` is the full
@@ -751,7 +771,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7
                 const bool valid = pl < rem;
                 const double X1 = valid ? g.dom_val[d.gb + t0 + pl] : 0.0, C = kconst * X1 * X1;
                 const int chunk = (s.flags & LHVI_PBP_SKIP_TERMS) ? 0 : (nj + split - 1) >> (6 - lw);
-                double acc = fast_accumulate_uniform<MODE_CONST, 4>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
+                double acc = fast_accumulate_uniform<MODE_CONST, LHVI_HEAVY_UNROLL>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
                 for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
                 if (valid && sub == 0) out[n + t0 + pl] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
             }
@@ -767,7 +787,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7
             const double xv = r == 0 ? x0 : x1;
             const double X1 = valid ? xv : 0.0, C = kconst * X1 * X1;
             const int chunk = (s.flags & LHVI_PBP_SKIP_TERMS) ? 0 : (nj + split - 1) >> (6 - lw);   // flag 16: tuning aid, skips the term loop
-            double acc = fast_accumulate_uniform<MODE_CONST, 4>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
+            double acc = fast_accumulate_uniform<MODE_CONST, LHVI_HEAVY_UNROLL>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
             for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
             if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
         }
@@ -783,15 +803,18 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 7
 //   type 2 (discrete target):    lane = partner particle j, one wave reduction per target state p of
 //                                exp(A_p y_j^2 + b_p y_j + c_p + m_j)
 // Same software pipeline as the heavy kernel (descriptor one edge ahead, vector loads in flight during the arithmetic).
-struct LightData { double a, b; };      // type 1: own points of round 0 / 1;  type 2: partner particle and its message
+struct LightData { double a, b, m0, m1; };   // type 1: own points of round 0 / 1 + the messages of the partner's (at most
+                                             // two) states;  type 2: partner particle and its message
 
 __device__ __forceinline__ LightData light_fetch(const FastDesc& d, const lhvi_graph_t& g, const lhvi_pbp_t& s,
                                                  const double* __restrict__ v2f, int lane) {
     LightData h;
-    h.a = 0.0; h.b = 0.0;
+    h.a = 0.0; h.b = 0.0; h.m0 = 0.0; h.m1 = 0.0;
     const int n = s.n;
     if (d.pad[0] == 1) {
         const int np = d.np, npts = d.np + d.T;
+        // wave-uniform, fetched with the rest of the edge (one edge ahead) instead of at the head of its arithmetic
+        if (is_hidden(d.pval)) { h.m0 = v2f[(int64_t)d.pce * n]; if (d.nj > 1) h.m1 = v2f[(int64_t)d.pce * n + 1]; }
         if (lane < npts) h.a = lane < np ? s.particles[(int64_t)d.tv * n + lane] : g.dom_val[d.gb + lane - np];
         const int pp = 64 + lane;
         if (pp < npts) h.b = pp < np ? s.particles[(int64_t)d.tv * n + pp] : g.dom_val[d.gb + pp - np];
@@ -828,9 +851,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_light_kernel(lhvi_graph_t g, lh
         double* out = f2v + (int64_t)d.e * S;
         const LightData cur = h;
         if (d.type == 1) {
-            // messages of the (at most two) partner states: wave-uniform values
-            double m0 = 0.0, m1 = 0.0;
-            if (is_hidden(d.pval)) { m0 = v2f[(int64_t)d.pce * n]; if (d.nj > 1) m1 = v2f[(int64_t)d.pce * n + 1]; }
+            const double m0 = cur.m0, m1 = cur.m1;       // messages of the (at most two) partner states
             if (more) h = light_fetch(dn, g, s, v2f, lane);
             const int npts = d.np + d.T;
 #pragma nounroll
@@ -1266,9 +1287,9 @@ static unsigned persistent_grid(int64_t items, int per_cu) {
     return (unsigned)(want < cap ? want : cap);
 }
 
-static int blocks_per_cu(const void* kernel) {
+static int blocks_per_cu(const void* kernel, int block = BLOCK) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess || nb < 1) nb = 4;
     return nb > 8 ? 8 : nb;
 }
 
@@ -1435,7 +1456,7 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     const int nfast = s->fast_edges ? s->n_fast : g->E, ngen = s->generic_edges ? s->n_generic : g->E;
     static const int cus = device_cus();
     static const int fast_per_cu = blocks_per_cu((const void*)pbp_f2v_fast_kernel);
-    static const int heavy_per_cu = blocks_per_cu((const void*)pbp_f2v_heavy_kernel);
+    static const int heavy_per_cu = blocks_per_cu((const void*)pbp_f2v_heavy_kernel, HEAVY_BLOCK);
     static const int light_per_cu = blocks_per_cu((const void*)pbp_f2v_light_kernel);
     static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel);
     const int heavy_blocks = heavy_per_cu, side_blocks = 8;
@@ -1446,14 +1467,15 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     // work ticket of the heavy kernel: reset on this stream right before the launch.  Chunks of 8 pay when every wave gets
     // several of them; a short list (a small graph, the interior part of a shard) keeps one entry per wave and strides
     const bool run_heavy = !(s->flags & LHVI_PBP_SKIP_FAST) && s->heavy_desc && s->n_heavy > 0 && !(s->flags & LHVI_PBP_SKIP_HEAVY);
-    const int heavy_grid = min((s->n_heavy + 3) / 4, max(cus * heavy_blocks - spare, 1));
+    constexpr int HWPB = HEAVY_BLOCK / WAVE;
+    const int heavy_grid = min((s->n_heavy + HWPB - 1) / HWPB, max(cus * heavy_blocks - spare * (BLOCK / WAVE) / HWPB, 1));
     lhvi_pbp_t sh = *s;
-    if (sh.f2v_ticket && (int64_t)s->n_heavy < (int64_t)heavy_grid * (BLOCK / WAVE) * 8 * 4) sh.f2v_ticket = nullptr;
+    if (sh.f2v_ticket && (int64_t)s->n_heavy < (int64_t)heavy_grid * HWPB * 8 * 4) sh.f2v_ticket = nullptr;
     if (sh.f2v_ticket && run_heavy && hipMemsetAsync(sh.f2v_ticket, 0, LHVI_PBP_TICKET_WORDS * sizeof(uint32_t), as_stream(stream)) != hipSuccess)
         return LHVI_E_LAUNCH;
     if (!(s->flags & LHVI_PBP_SKIP_FAST)) {
         if (s->heavy_desc && s->n_heavy > 0 && !(s->flags & LHVI_PBP_SKIP_HEAVY))
-            hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(heavy_grid), dim3(BLOCK), 0, as_stream(stream),
+            hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(heavy_grid), dim3(HEAVY_BLOCK), 0, as_stream(stream),
                                *g, sh, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy);
         if (s->light_desc && s->n_light > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
             hipLaunchKernelGGL(pbp_f2v_light_kernel, dim3(min((s->n_light + 3) / 4, max(cus * min(light_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0, as_stream(stream),

@@ -262,6 +262,7 @@ class VarInference(_Variational):
         st = res['stage']
         self.flat, self.dg, self._dev, self._cache = st.flat, st.dg, st._dev, {}
         self._cont, self._disc, self.Dmax = st._cont, st._disc, st.Dmax
+        self._uniform_states, self._has_disc = st._uniform_states, st._has_disc
         self.obs_var = res['obs_var']
         self.t = res['t']
         if is_log:

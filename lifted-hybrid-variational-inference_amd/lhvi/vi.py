@@ -67,6 +67,10 @@ class _Variational:
         nst = np.where(disc, flat.var_nstates, 0)
         md = (np.arange(self.Dmax)[None, :] < nst[:, None]).astype(np.float64)
         d['mask_d'] = _abi.to_dev(np.repeat(md[:, None, :], K, 1))
+        # one softmax launch serves every discrete row when they all have the same number of states
+        kinds = set(nst[disc].tolist())
+        self._uniform_states = int(next(iter(kinds))) if len(kinds) == 1 else 0
+        self._has_disc = bool(disc.any())
 
     def _struct(self):
         d = self._dev
@@ -81,11 +85,9 @@ class _Variational:
         d, l, st = self._dev, _abi.lib(), _abi.stream_ptr()
         _abi.check(l.lhvi_softmax_rows(_abi.ptr(d['w_tau']), _abi.ptr(d['w']), 1, self.K, self.K, st))
         flat = self.flat
-        # rows have different lengths (per-variable #states): one launch per distinct #states
-        nst = np.where(self._disc, flat.var_nstates, 0)
-        if self._disc.any():
-            if len(set(nst[self._disc].tolist())) == 1:
-                D = int(nst[self._disc][0])
+        if self._has_disc:
+            if self._uniform_states:
+                D = self._uniform_states
                 _abi.check(l.lhvi_softmax_rows(_abi.ptr(d['tau_d']), _abi.ptr(d['eta_d']), flat.V * self.K, D, self.Dmax, st))
             else:
                 torch = _abi.require_gpu()
@@ -164,12 +166,20 @@ class _Variational:
         self.ADAM_update(iteration)
 
     def ADAM_update(self, iteration):
-        """VI:249-300: all gradients from the pre-update parameters, then one ADAM step per array"""
+        """VI:249-300: all gradients from the pre-update parameters, then one ADAM step per array.  The loop never waits
+        for the device: the free energy the reference logs after an update is the one the NEXT iteration's gradient pass
+        computes anyway (same parameters), so it is copied into a device buffer there (one extra pass after the last
+        update) and read back once at the end; ``time_log`` times are the loop's CPU time spread evenly over its updates."""
         d, l = self._dev, _abi.lib()
-        for _ in range(iteration):
-            start = time.process_time()
+        torch = _abi.require_gpu()
+        log_dev = bool(self.is_log and self.log_fe)
+        fe_buf = torch.empty(max(iteration, 1), dtype=torch.float64, device=self.dg.device) if log_dev else None
+        start = time.process_time()
+        for i in range(iteration):
             self.t += 1
             self._grad()
+            if log_dev and i > 0:
+                fe_buf[i - 1:i].copy_(d['fe'])
             st = _abi.stream_ptr()
             d['g_c'].mul_(d['mask_c'])
             d['g_d'].mul_(d['mask_d'])
@@ -178,16 +188,24 @@ class _Variational:
                                             _abi.ptr(d[grad]), d[name].numel(), self.t, float(self.alpha), self.b1, self.b2,
                                             self.eps, stride, float(self.var_threshold), st))
             self._refresh()
-            if self.is_log:
+            if self.is_log and not self.log_fe:          # the reference's other log: -log phi at the current MAP (host queries)
                 self.total_time += time.process_time() - start
-                if self.log_fe:
-                    fe = self.free_energy()
-                else:
-                    from .utils import log_likelihood
-                    fe = log_likelihood(self._ground_graph(), {rv: self.map(rv) for rv in self._ground_graph().rvs})
+                from .utils import log_likelihood
+                fe = log_likelihood(self._ground_graph(), {rv: self.map(rv) for rv in self._ground_graph().rvs})
                 if self.verbose:
                     print(fe, self.total_time)
                 self.time_log.append([self.total_time, fe])
+                start = time.process_time()
+        if log_dev and iteration > 0:
+            self._grad()
+            fe_buf[iteration - 1:iteration].copy_(d['fe'])
+            fes = fe_buf.cpu().numpy()                   # the only synchronisation of the loop
+            elapsed = time.process_time() - start
+            for i in range(iteration):
+                self.total_time += elapsed / iteration
+                if self.verbose:
+                    print(float(fes[i]), self.total_time)
+                self.time_log.append([self.total_time, float(fes[i])])
 
     def GD_update(self, iteration, lr):
         """VI:302-331: plain gradient descent on the same gradients"""
