@@ -135,20 +135,22 @@ def test_compat_modules_mirror_reference_imports():
     try:
         for name in ('Graph', 'Potential', 'MLNPotential', 'RelationalGraph', 'KalmanFilter', 'CompressedGraphWithObs',
                      'CompressedGraphSorted', 'GaBP', 'GaLBP', 'EPBPLogVersion', 'HybridLBPLogVersion', 'VarInference',
-                     'LiftedVarInference', 'utils'):
+                     'LiftedVarInference', 'C2FVarInference', 'utils'):
             sys.modules.pop(name, None)
             importlib.import_module(name)
         ns = {}
         exec('from RelationalGraph import *\nfrom MLNPotential import *\nfrom Potential import GaussianPotential\n'
              'from GaBP import GaBP\nfrom EPBPLogVersion import EPBP\nfrom HybridLBPLogVersion import HybridLBP\n'
              'from VarInference import VarInference as VI\nfrom LiftedVarInference import VarInference as LVI\n'
+             'from C2FVarInference import VarInference as C2FVI\n'
              'from CompressedGraphSorted import CompressedGraphSorted\n'
              'd = Domain((-1, 1), continuous=True, integral_points=linspace(-1, 1, 5))\n', ns)
         assert ns['VI'] is not ns['LVI'] and ns['d'].continuous
+        assert ns['C2FVI'].update_obs_its == 10 and ns['C2FVI'].gaussian_obs is True        # C2FVI:11-18
     finally:
         sys.path.remove(compat)
         for name in ('Graph', 'Potential', 'MLNPotential', 'RelationalGraph', 'KalmanFilter', 'utils', 'GaBP', 'GaLBP',
-                     'VarInference', 'LiftedVarInference', 'EPBPLogVersion', 'HybridLBPLogVersion',
+                     'VarInference', 'LiftedVarInference', 'C2FVarInference', 'EPBPLogVersion', 'HybridLBPLogVersion',
                      'CompressedGraphWithObs', 'CompressedGraphSorted'):
             sys.modules.pop(name, None)
 
@@ -416,3 +418,15 @@ def test_kalman_flat_builder_matches_reference_structure(golden_dir):
                     round(float(flat.pot_param[flat.pot_off[p] + 1]), 12)) for p in flat.fac_pot)
     assert got_f == sorted(t[:3] for t in ref_f)
     assert sorted(np.diff(flat.var_ptr).tolist()) == sorted(np.diff(ref_flat.var_ptr).tolist())      # same degree sequence
+
+
+def test_design_numbers_are_the_committed_profiles():
+    """DESIGN.md section 5's measured-numbers block is the verbatim output of scripts/design_numbers.py on the committed
+    profiles/r02_* files: a number cannot be quoted there that no file holds"""
+    import re
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'design_numbers.py'), 'r02'], capture_output=True, text=True,
+                         check=True).stdout.strip()
+    text = open(os.path.join(ROOT, 'DESIGN.md')).read()
+    m = re.search(r'<!-- numbers:begin \(scripts/design_numbers.py\) -->\n(.*?)\n<!-- numbers:end -->', text, re.S)
+    assert m and m.group(1).strip() == out
