@@ -117,16 +117,15 @@ int lhvi_gabp_run(const lhvi_graph_t* g, const lhvi_pots_t* pots, double* f2v, d
  * GaBP.message_f_to_rv knows a closed form for, GaBP.py:37-138).  Messages live in variable-CSR ("slot") order,
  * slot k = (variable slot_var[k], edge var_edge[k]); the f -> v message of a slot is recomputed from the partner's
  * previous v -> f message instead of being stored.  The caller builds the plan once per graph:
- *   pslot[k]  slot of the partner argument's (canonical) edge when the partner variable is hidden, else -1
+ *   pslot[k]  slot of the partner argument's (canonical) edge when the partner variable is hidden; -1 - (partner variable)
+ *             when it is observed (its value is read from var_value); unused for codes 0 and 3
  *   info[k]   4 * potential index + code; code 0 = unary factor, 1 / 2 = pairwise factor with this variable at
  *             position 0 / 1, 3 = any other arity (vacuous message (0, Inf), GaBP.py:138)
- *   pval[k]   the partner's evidence value (unused when pslot[k] >= 0 or code is 0 / 3)
  *   count[k]  lifted graphs: rv.count[f] of the slot (GaLBP.py:24-34); NULL on a ground graph
  * Results equal the two-kernel path bit for bit (same expressions, same summation order). */
 typedef struct lhvi_gabp_plan {
     const int32_t* pslot;
     const int32_t* info;
-    const double* pval;
     const double* count;
 } lhvi_gabp_plan_t;
 size_t lhvi_gabp_pull_workspace_bytes(const lhvi_graph_t* g);

@@ -250,11 +250,12 @@ __global__ void __launch_bounds__(BLOCK) gabp_marginal_hub_kernel(lhvi_graph_t g
 // of the partner's previous v -> f message, the only random access of the sweep), parks it in LDS, and after a barrier
 // every slot of the variable sums the row out of LDS -- in rv.nb order, leave-one-out as a direct sum, the same expressions
 // as gabp_f2v_kernel + gabp_v2f_kernel, hence the same bits.  A row that crosses the block's slot range recomputes the
-// outside entries.  Per slot and sweep: 16 B gathered + 16 B stored in order + 20 B of plan instead of two random 16-byte
+// outside entries.  Per slot and sweep: 16 B gathered + 16 B stored in order + 12 B of plan and CSR instead of two random 16-byte
 // accesses, two in-order ones and two launches.
-struct PullPlan { const int32_t* pslot; const int32_t* info; const double* pval; const double* count; };
+struct PullPlan { const int32_t* pslot; const int32_t* info; const double* count; };
 
-__device__ __forceinline__ double2 pull_incoming(const lhvi_pots_t& pots, const PullPlan& pl, const double* __restrict__ vprev, int j) {
+__device__ __forceinline__ double2 pull_incoming(const lhvi_graph_t& g, const lhvi_pots_t& pots, const PullPlan& pl,
+                                                 const double* __restrict__ vprev, int j) {
     const int info = pl.info[j];
     const int code = info & 3, pot = info >> 2;
     const int kind = pots.kind[pot];
@@ -266,7 +267,7 @@ __device__ __forceinline__ double2 pull_incoming(const lhvi_pots_t& pots, const 
         const int ps = pl.pslot[j];
         partner_hidden = ps >= 0;
         if (partner_hidden) { const double2 m = ld2(vprev, ps); u = m.x; sv = m.y; }
-        else y = pl.pval[j];
+        else y = g.var_value[-1 - ps];              // observed partner: pslot holds -1 - (its variable)
     }
     return f2v_closed_form(kind, par, arity, pos, partner_hidden, u, sv, y);
 }
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_kernel(lhvi_graph_t g, lhvi_p
     for (int j = lo_ext + threadIdx.x; j < hi_ext; j += BLOCK) {
         // first sweep: every f -> v message still is its initial value (0, 1) (GaBP.py:143-150)
         const bool hid = is_hidden(g.var_value[g.slot_var[j]]);
-        const double2 m = (hid && !first) ? pull_incoming(pots, pl, vprev, j) : make_double2(0.0, 1.0);
+        const double2 m = (hid && !first) ? pull_incoming(g, pots, pl, vprev, j) : make_double2(0.0, 1.0);
         // staged in information form (p * mu, p), p = 1 / var -- the products every slot of the row would form anyway, so
         // the row sums below are additions only; a `None` variance (NaN) keeps (mu, NaN)
         const double p = 1.0 / m.y;
@@ -327,13 +328,13 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_hub_kernel(lhvi_graph_t g, lh
     double H = 0.0, P = 0.0;
     for (int j = lo + lane; j < hi; j += 64) {
         const double c = pl.count ? pl.count[j] : 1.0;
-        const double2 m = first ? make_double2(0.0, 1.0) : pull_incoming(pots, pl, vprev, j);
+        const double2 m = first ? make_double2(0.0, 1.0) : pull_incoming(g, pots, pl, vprev, j);
         if (m.y != m.y) H -= m.x * c;
         else { const double p = 1.0 / m.y; H += p * m.x * c; P += p * c; }
     }
     H = dpp_wave_reduce(H, SumOp()); P = dpp_wave_reduce(P, SumOp());
     for (int j = lo + lane; j < hi; j += 64) {
-        const double2 m = first ? make_double2(0.0, 1.0) : pull_incoming(pots, pl, vprev, j);
+        const double2 m = first ? make_double2(0.0, 1.0) : pull_incoming(g, pots, pl, vprev, j);
         double h = H, p = P;
         if (m.y != m.y) h += m.x;
         else { const double q = 1.0 / m.y; h -= q * m.x; p -= q; }
@@ -409,7 +410,7 @@ size_t lhvi_gabp_pull_workspace_bytes(const lhvi_graph_t* g) {
 static int validate_plan(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_gabp_plan_t* plan) {
     if (int rc = validate(g)) return rc;
     if (!pots || !plan || (g->F > 0 && (!pots->kind || !pots->off))) return LHVI_E_ARG;
-    if (g->nnz > 0 && (!plan->pslot || !plan->info || !plan->pval || !g->slot_var || !g->hub_vars)) return LHVI_E_ARG;
+    if (g->nnz > 0 && (!plan->pslot || !plan->info || !g->slot_var || !g->hub_vars)) return LHVI_E_ARG;
     return LHVI_OK;
 }
 
@@ -419,7 +420,7 @@ int lhvi_gabp_pull(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_ga
     if (g->nnz == 0) return LHVI_OK;
     if (!v_next || (!first && !v_prev) || v_prev == v_next) return LHVI_E_ARG;
     PullPlan pl;
-    pl.pslot = plan->pslot; pl.info = plan->info; pl.pval = plan->pval; pl.count = plan->count;
+    pl.pslot = plan->pslot; pl.info = plan->info; pl.count = plan->count;
     hipLaunchKernelGGL(gabp_pull_kernel, dim3(grid_for(g->nnz)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, pl, v_prev, v_next, first);
     if (g->hub_vars && g->n_hubs > 0)
         hipLaunchKernelGGL(gabp_pull_hub_kernel, dim3(grid_for((int64_t)g->n_hubs * 64)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, pl,

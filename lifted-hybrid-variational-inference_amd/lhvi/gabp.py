@@ -22,8 +22,7 @@ def _norm_pdf_var(x, mu, sig):
 
 def pull_plan(flat):
     """host arrays of ``lhvi_gabp_plan_t`` (include/lhvi.h): per variable-CSR slot the slot of the partner argument's
-    edge (-1: none / observed), 4 * potential index + position code, the partner's evidence value, and on a lifted graph
-    the slot's count"""
+    edge (observed partner: -1 - its variable), 4 * potential index + position code, and on a lifted graph the slot's count"""
     ve = flat.var_edge.astype(np.int64)
     nnz = ve.size
     edge_slot = np.full(max(flat.E, 1), -1, dtype=np.int64)
@@ -35,12 +34,12 @@ def pull_plan(flat):
     code = np.where(arity == 1, 0, np.where(arity == 2, 1 + pos, 3))
     pe = np.where(arity == 2, base + (1 - np.minimum(pos, 1)), ve)       # partner edge of a pairwise factor
     pce = flat.edge_canon[pe].astype(np.int64)
-    pval = flat.var_value[flat.edge_var[pe]]
-    pslot = np.where((arity == 2) & np.isnan(pval), edge_slot[pce], -1)
-    if ((arity == 2) & np.isnan(pval) & (pslot < 0)).any():
+    pvar = flat.edge_var[pe].astype(np.int64)
+    hidden_partner = (arity == 2) & np.isnan(flat.var_value[pvar])
+    if (hidden_partner & (edge_slot[pce] < 0)).any():
         raise _abi.LhviError('a hidden partner argument has no variable-side slot')
+    pslot = np.where(hidden_partner, edge_slot[pce], -1 - pvar)
     return dict(pslot=pslot.astype(np.int32), info=(flat.fac_pot[f].astype(np.int64) * 4 + code).astype(np.int32),
-                pval=np.ascontiguousarray(pval, dtype=np.float64),
                 count=np.ascontiguousarray(flat.edge_count[ve], dtype=np.float64) if flat.lifted else None)
 
 
@@ -73,7 +72,7 @@ class _GaussianSweep:
             host = pull_plan(flat)
             dev = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
             plan = _abi.GabpPlanStruct()
-            plan.pslot, plan.info, plan.pval, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'pval', 'count'))
+            plan.pslot, plan.info, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'count'))
             nbytes = int(l.lhvi_gabp_pull_workspace_bytes(dg.g))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dg.device)
             _abi.check(l.lhvi_gabp_run_pull(dg.g, dg.p, plan, _abi.ptr(f2v), _abi.ptr(v2f), int(iteration), _abi.ptr(ws),

@@ -188,7 +188,7 @@ def _run_both_forms(api, flat, iterations):
     host = pull_plan(flat)
     dev = {k: (api.to_dev(a) if a is not None else None) for k, a in host.items()}
     plan = api.GabpPlanStruct()
-    plan.pslot, plan.info, plan.pval, plan.count = (api.ptr(dev[k]) for k in ('pslot', 'info', 'pval', 'count'))
+    plan.pslot, plan.info, plan.count = (api.ptr(dev[k]) for k in ('pslot', 'info', 'count'))
     nbytes = int(l.lhvi_gabp_pull_workspace_bytes(dg.g))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dg.device)
     for pull in (False, True):
