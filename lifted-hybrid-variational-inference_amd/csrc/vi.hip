@@ -124,16 +124,17 @@ __global__ void __launch_bounds__(BLOCK) vi_var_kernel(lhvi_graph_t g, lhvi_vi_t
 }
 
 // expectation over the other slots with slot `pos` pinned to state d (gradient_category_tau, VI:133-160)
+template <int MAXA>
 __device__ double pinned_expectation(const lhvi_graph_t& g, const lhvi_pots_t& pots, const lhvi_vi_t& p, int f, int base,
                                      int arity, const int* vars, int pos, int d, int k) {
     const int tv = vars[pos];
     const int Dt = v_nstates(g, tv);
     const double* tvals = v_states(g, tv);
-    double x[LHVI_MAX_ARITY];
-    int idx[LHVI_MAX_ARITY], nx[LHVI_MAX_ARITY], nw[LHVI_MAX_ARITY];
+    double x[MAXA];
+    int idx[MAXA], nx[MAXA], nw[MAXA];
     int64_t totx = 1, totw = 1;
 #pragma unroll
-    for (int a = 0; a < LHVI_MAX_ARITY; ++a) {
+    for (int a = 0; a < MAXA; ++a) {
         x[a] = 0.0; idx[a] = 0; nx[a] = 1; nw[a] = 1;
         if (a < arity && a != pos) {
             const int v = vars[a];
@@ -150,7 +151,7 @@ __device__ double pinned_expectation(const lhvi_graph_t& g, const lhvi_pots_t& p
         int64_t rx = i, rw = i;
         double w = 1.0;
 #pragma unroll
-        for (int a = LHVI_MAX_ARITY - 1; a >= 0; --a) {
+        for (int a = MAXA - 1; a >= 0; --a) {
             if (a < arity && a != pos) {
                 const int v = vars[a];
                 const int ixs = (int)(rx % nx[a]); rx /= nx[a];
@@ -279,6 +280,9 @@ __global__ void __launch_bounds__(BLOCK) vi_factor_cc_kernel(lhvi_graph_t g, lhv
 }
 
 
+// compiled for scopes of up to 3 and up to MAXA variables: every per-slot array lives in registers, and the three-slot
+// build (all of the reference's MLN templates but robot mapping) needs half of them
+template <int MAXA>
 __global__ void __launch_bounds__(BLOCK) vi_factor_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
                                                          double* __restrict__ pe_c, double* __restrict__ pe_d) {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -286,10 +290,11 @@ __global__ void __launch_bounds__(BLOCK) vi_factor_kernel(lhvi_graph_t g, lhvi_p
     const int f = (int)(i / p.K), k = (int)(i % p.K);
     if (vi_is_cc(g, pots, f)) return;                      // served by vi_factor_cc_kernel
     const int base = g.fac_ptr[f], arity = g.fac_ptr[f + 1] - base;
-    int vars[LHVI_MAX_ARITY], len[LHVI_MAX_ARITY], it[LHVI_MAX_ARITY], idx[LHVI_MAX_ARITY];
-    double x[LHVI_MAX_ARITY], wt[LHVI_MAX_ARITY], Em[LHVI_MAX_ARITY], Ev[LHVI_MAX_ARITY];
+    if (MAXA == 3 ? arity > 3 : arity <= 3) return;        // the other build's factors
+    int vars[MAXA], len[MAXA], it[MAXA], idx[MAXA];
+    double x[MAXA], wt[MAXA], Em[MAXA], Ev[MAXA];
 #pragma unroll
-    for (int a = 0; a < LHVI_MAX_ARITY; ++a) {
+    for (int a = 0; a < MAXA; ++a) {
         vars[a] = a < arity ? g.edge_var[base + a] : 0;
         len[a] = a < arity ? axis_len(g, p, vars[a]) : 1;
         it[a] = 0; idx[a] = 0; x[a] = 0.0; wt[a] = 1.0; Em[a] = 0.0; Ev[a] = 0.0;
@@ -298,13 +303,13 @@ __global__ void __launch_bounds__(BLOCK) vi_factor_kernel(lhvi_graph_t g, lhvi_p
     for (;;) {
         double w = 1.0;
 #pragma unroll
-        for (int a = 0; a < LHVI_MAX_ARITY; ++a) {
+        for (int a = 0; a < MAXA; ++a) {
             if (a < arity) { const Node nd = axis_node(g, p, vars[a], k, it[a]); x[a] = nd.x; idx[a] = nd.idx; wt[a] = nd.w; w *= nd.w; }
         }
         const double F = F_of(g, pots, p, f, x, idx, vars, arity);
         E += w * F;
 #pragma unroll
-        for (int a = 0; a < LHVI_MAX_ARITY; ++a) {
+        for (int a = 0; a < MAXA; ++a) {
             if (a < arity && is_hidden(g.var_value[vars[a]]) && v_cont(g, vars[a])) {
                 const double* e = p.eta_c + ((int64_t)vars[a] * p.K + k) * 2;
                 Em[a] += w * (F * (x[a] - e[0]));
@@ -315,7 +320,7 @@ __global__ void __launch_bounds__(BLOCK) vi_factor_kernel(lhvi_graph_t g, lhvi_p
         for (; a >= 0; --a) {
             bool carry = true;
 #pragma unroll
-            for (int b = 0; b < LHVI_MAX_ARITY; ++b) if (b == a) { if (++it[b] < len[b]) carry = false; else it[b] = 0; }
+            for (int b = 0; b < MAXA; ++b) if (b == a) { if (++it[b] < len[b]) carry = false; else it[b] = 0; }
             if (!carry) break;
         }
         if (a < 0) break;
@@ -323,13 +328,13 @@ __global__ void __launch_bounds__(BLOCK) vi_factor_kernel(lhvi_graph_t g, lhvi_p
     ef[i] = (g.fac_mult ? g.fac_mult[f] : 1.0) * E;
     // per-edge partials; only the first position of a variable in the scope contributes (f.nb.index(rv), LVI:112,146)
 #pragma unroll
-    for (int a = 0; a < LHVI_MAX_ARITY; ++a) {
+    for (int a = 0; a < MAXA; ++a) {
         if (a >= arity) continue;
         const int e = base + a, v = vars[a];
         double c0 = 0.0, c1 = 0.0;
         bool first = true;
 #pragma unroll
-        for (int b = 0; b < LHVI_MAX_ARITY; ++b) if (b < a && vars[b] == v) first = false;
+        for (int b = 0; b < MAXA; ++b) if (b < a && vars[b] == v) first = false;
         const bool hid = is_hidden(g.var_value[v]);
         const double c = g.edge_count ? g.edge_count[e] : 1.0;
         if (hid && first && v_cont(g, v)) {
@@ -341,7 +346,7 @@ __global__ void __launch_bounds__(BLOCK) vi_factor_kernel(lhvi_graph_t g, lhvi_p
         pe_c[((int64_t)e * p.K + k) * 2 + 1] = c1;
         for (int d = 0; d < p.Dmax; ++d) {
             double val = 0.0;
-            if (hid && first && !v_cont(g, v) && d < v_nstates(g, v)) val = c * pinned_expectation(g, pots, p, f, base, arity, vars, a, d, k);
+            if (hid && first && !v_cont(g, v) && d < v_nstates(g, v)) val = c * pinned_expectation<MAXA>(g, pots, p, f, base, arity, vars, a, d, k);
             pe_d[((int64_t)e * p.K + k) * p.Dmax + d] = val;
         }
     }
@@ -572,7 +577,8 @@ int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t
             const int64_t want = ((int64_t)g->F * p->K + BLOCK - 1) / BLOCK;
             hipLaunchKernelGGL(vi_factor_cc_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d);
         }
-        hipLaunchKernelGGL(vi_factor_kernel, dim3(grid_for((int64_t)g->F * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d);
+        hipLaunchKernelGGL(vi_factor_kernel<3>, dim3(grid_for((int64_t)g->F * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d);
+        hipLaunchKernelGGL(vi_factor_kernel<LHVI_MAX_ARITY>, dim3(grid_for((int64_t)g->F * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d);
     }
     if (g->V > 0)
     {
