@@ -423,22 +423,29 @@ def lift_flat(flat, rv_color, f_color):
     edge_canon[order] = order[run_start]
     del canon_sorted
     # variable side: the representative ground rv's incident factors, grouped by factor colour in first-seen order
+    # (vectorised: one pass over the representatives' adjacency rows instead of a Python loop per cluster)
+    deg = (flat.var_ptr[rep_v + 1] - flat.var_ptr[rep_v]).astype(np.int64)
+    start = np.zeros(nV + 1, dtype=np.int64)
+    np.cumsum(deg, out=start[1:])
+    slots = np.repeat(flat.var_ptr[rep_v].astype(np.int64) - start[:-1], deg) + np.arange(int(start[-1]), dtype=np.int64)
+    owner = np.repeat(np.arange(nV, dtype=np.int64), deg)
+    fcol = f_color[flat.edge_fac[flat.var_edge[slots]]]
+    key = owner * nF + fcol                                   # (cluster, factor colour) pairs along the rows
+    uniq, first, cnt = np.unique(key, return_index=True, return_counts=True)
+    order = np.argsort(first, kind='stable')                  # first-seen order (rows are contiguous per cluster)
+    uniq, cnt = uniq[order], cnt[order]
+    pc, pf = uniq // nF, uniq % nF
+    canon_e = np.flatnonzero(edge_canon == np.arange(E))
+    ckey = edge_fac[canon_e].astype(np.int64) * nV + edge_var[canon_e]
+    csort = np.argsort(ckey, kind='stable')
+    pos = np.searchsorted(ckey[csort], pf * nV + pc)
+    if pos.size and ((pos >= ckey.size).any() or (ckey[csort][np.minimum(pos, ckey.size - 1)] != pf * nV + pc).any()):
+        raise _abi.LhviError('lift_flat: a (cluster, factor colour) pair of a representative has no lifted edge -- the partition is not stable')
+    var_edge = canon_e[csort][pos].astype(np.int32)
+    counts = np.ones(E, dtype=np.float64)
+    counts[var_edge] = cnt
     var_ptr = np.zeros(nV + 1, dtype=np.int32)
-    var_edge, counts = [], np.ones(E, dtype=np.float64)
-    pair_to_edge = {}
-    for e in np.flatnonzero(edge_canon == np.arange(E)):
-        pair_to_edge[(int(edge_fac[e]), int(edge_var[e]))] = int(e)
-    for c in range(nV):
-        v = rep_v[c]
-        seen = {}
-        for k in range(flat.var_ptr[v], flat.var_ptr[v + 1]):
-            fc = int(f_color[flat.edge_fac[flat.var_edge[k]]])
-            seen[fc] = seen.get(fc, 0) + 1
-        for fc, cnt in seen.items():
-            e = pair_to_edge[(fc, c)]
-            var_edge.append(e)
-            counts[e] = cnt
-        var_ptr[c + 1] = len(var_edge)
+    np.cumsum(np.bincount(pc, minlength=nV), out=var_ptr[1:])
     edge_count = counts[edge_canon]
     mult_v = np.bincount(rv_color, minlength=nV).astype(np.float64)
     mult_f = np.bincount(f_color, minlength=nF).astype(np.float64)
@@ -452,7 +459,7 @@ def lift_flat(flat, rv_color, f_color):
         val[obs] = sums[obs] / mult_v[obs]
     return FlatGraph(
         V=nV, F=nF, E=E, fac_ptr=fac_ptr, edge_var=edge_var, edge_fac=edge_fac, edge_pos=edge_pos,
-        edge_canon=edge_canon, var_ptr=var_ptr, var_edge=np.array(var_edge, dtype=np.int32).reshape(-1),
+        edge_canon=edge_canon, var_ptr=var_ptr, var_edge=var_edge.reshape(-1),
         edge_count=edge_count, lifted=True, fac_pot=flat.fac_pot[rep_f].astype(np.int32),
         pot_kind=flat.pot_kind, pot_off=flat.pot_off, pot_param=flat.pot_param,
         var_value=val, var_dom=flat.var_dom[rep_v].astype(np.int32), var_mult=mult_v, fac_mult=mult_f,
