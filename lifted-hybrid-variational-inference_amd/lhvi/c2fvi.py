@@ -200,10 +200,11 @@ class _DeviceStage(_Variational):
         d = self._dev
         for name in ('w_tau', 'eta_c', 'tau_d'):
             for pre in ('m_', 's_'):
-                src = np.zeros(tuple(d[name].shape))
-                a = np.asarray(P[pre + name], dtype=np.float64)
-                src[tuple(slice(0, min(x, y)) for x, y in zip(src.shape, a.shape))] = a[tuple(slice(0, min(x, y)) for x, y in zip(src.shape, a.shape))]
-                d[pre + name].copy_(_abi.to_dev(src))
+                dst = np.zeros(tuple(d[name].shape))
+                src = np.asarray(P[pre + name], dtype=np.float64)
+                w = min(dst.shape[-1], src.shape[-1])        # (a round's tau_d is as wide as ITS widest discrete variable)
+                dst[..., :w] = src[..., :w]
+                d[pre + name].copy_(_abi.to_dev(dst))
 
     def adam(self, n, t, lr):
         self.is_log, self.log_fe = True, True
