@@ -600,6 +600,29 @@ class HybridLBP(_ParticleSweep):
         self.sampler, self.seed = sampler, seed
         self.query_cache = dict()
 
+    @classmethod
+    def on_flat(cls, lifted_flat, n=50, proposal_approximation='EP', sampler='device', seed=0):
+        """The lifted sweep on a ready-made lifted ``FlatGraph`` (``lifting.lift_flat`` of a stable partition, e.g. of a
+        relational template grounded straight into arrays: ``ground_flat`` -> ``initial_colors_flat`` -> ``refine_flat`` ->
+        ``lift_flat``) -- no Python object per ground atom anywhere.  Run with ``run_flat``; query with the batched calls
+        (``belief_rv_all``, ``map_all``, ``belief_all``, ``probability_all``), whose rows are clusters."""
+        if not lifted_flat.lifted:
+            raise ValueError('on_flat expects a lifted FlatGraph (lifting.lift_flat)')
+        self = cls.__new__(cls)
+        self.g = None
+        self.n, self.k_mean_k, self.k_mean_iteration = n, 2, 10
+        self.proposal_approximation, self.sampler, self.seed = proposal_approximation, sampler, seed
+        self.query_cache = dict()
+        self._flat_in = lifted_flat
+        return self
+
+    def run_flat(self, iteration=10):
+        """``run(iteration, c2f=-1)`` for a solver made by ``on_flat`` (the partition is stable by construction)"""
+        self.query_cache = dict()
+        self._setup(None, flat=self._flat_in)
+        self._run_sweeps(iteration)
+        self._stable_partition = True
+
     def run(self, iteration=10, log_enable=False, c2f=-1):
         """``HybridLBP.run`` (HLBP:430-536).  ``c2f == -1``: colour passing to the stable partition, then the sweeps.
         ``c2f >= 0``: coarse start (continuous evidence merged regardless of value), evidence clusters are split by

@@ -12,7 +12,8 @@ world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 flat = synth.hybrid_mrf_flat(V=E // 4, deg=4, seed=0)
 group = dist.LoopbackGroup(world)
 t0 = time.perf_counter()
-runners = [dist.ShardedRunner(flat, n=64, seed=1, rank=r, world=world, group=group) for r in range(world)]
+fac_owner = dist.partition_factors(flat, world)           # the one global step, done once (rank 0's job in a real run)
+runners = [dist.ShardedRunner(flat, n=64, seed=1, rank=r, world=world, group=group, fac_owner=fac_owner) for r in range(world)]
 print('plans + setup: %.1f s' % (time.perf_counter() - t0), flush=True)
 for r in runners:
     r.init()
