@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define LHVI_ABI_VERSION 6   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
-                              * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t */
+#define LHVI_ABI_VERSION 7   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
+                              * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t;  7: lhvi_pbp_t gained pair_desc */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -221,6 +221,15 @@ typedef struct lhvi_pbp {
      * and no wave is launched for an observed or discrete variable.  NULL: the kernel walks the graph arrays. */
     const int32_t* prop_desc;
     int32_t n_prop_desc;
+    /* optional, lhvi_pbp_f2v only: the light edges again, one LHVI_PBP_DESC_BYTES-byte record per FACTOR (both edges of a
+     * HybridQuadratic(1 discrete, 1 continuous) factor share its per-state coefficients), host-built from light_desc --
+     *   words 0 e_c  1 e_d  (edge to the continuous / discrete variable, -1 = that variable is observed)   2 v_c  3 v_d
+     *   4 np_c  5 T  6 grid base  7 live states of v_d   8-9 val_c  10-11 val_d (doubles, NaN = hidden)
+     *   12-23 A0 b0 c0 A1 b1 c1 (doubles)   24 / 25 rows of v2f with the discrete / continuous variable's message
+     * When set, one kernel over these records replaces the light kernel (twice the bytes in flight per wave, half the
+     * descriptor traffic; same messages bit for bit).  NULL: light_desc is used. */
+    const void* pair_desc;
+    int32_t n_pair;
 } lhvi_pbp_t;
 
 #define LHVI_PBP_DESC_BYTES 128

@@ -878,6 +878,98 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_light_kernel(lhvi_graph_t g, lh
     }
 }
 
+// PAIRS: the two light edges of one HybridQuadratic(1 discrete, 1 continuous) factor served by one list entry.  The light
+// kernel above is bound by memory-level parallelism -- one edge in flight per wave plus one prefetched -- and the two edges
+// of such a factor share the potential's per-state coefficients but read different rows (the continuous variable's new
+// particles for the message to it; its old particles and its v -> f row for the message to the discrete variable).  One
+// 128-byte descriptor per factor therefore doubles the bytes a wave keeps in flight at the same scalar-register budget and
+// halves the descriptor traffic.  Same expressions per edge as the light kernel (bit-identical messages).
+struct PairDesc {
+    int32_t e_c, e_d;            // edge to the continuous / to the discrete variable; -1: that variable is observed (no message)
+    int32_t v_c, v_d;
+    int32_t np_c, T, gb, ns;     // particles of v_c (hidden), its grid size / base in dom_val, live states of v_d (1 when observed)
+    double val_c, val_d;         // evidence values, NaN = hidden
+    double A0, b0, c0, A1, b1, c1;   // log phi = A_s x^2 + b_s x + c_s for the (at most two) live states s of v_d
+    int32_t mc, md;              // rows of v2f holding the discrete variable's (mc) / the continuous variable's (md) message to the factor
+    int32_t pad[6];
+};
+static_assert(sizeof(PairDesc) == LHVI_PBP_DESC_BYTES, "PairDesc is part of the ABI (LHVI_PBP_DESC_BYTES)");
+
+struct PairData { double x0, x1, m0, m1, y, mj; };
+
+__device__ __forceinline__ PairData pair_fetch(const PairDesc& d, const lhvi_graph_t& g, const lhvi_pbp_t& s,
+                                               const double* __restrict__ v2f, int lane) {
+    PairData h;
+    h.x0 = 0.0; h.x1 = 0.0; h.m0 = 0.0; h.m1 = 0.0; h.y = d.val_c; h.mj = 0.0;
+    const int n = s.n;
+    if (d.e_c >= 0) {
+        const int np = d.np_c, npts = d.np_c + d.T;
+        if (lane < npts) h.x0 = lane < np ? s.particles[(int64_t)d.v_c * n + lane] : g.dom_val[d.gb + lane - np];
+        const int pp = 64 + lane;
+        if (pp < npts) h.x1 = pp < np ? s.particles[(int64_t)d.v_c * n + pp] : g.dom_val[d.gb + pp - np];
+        if (is_hidden(d.val_d)) { h.m0 = v2f[(int64_t)d.mc * n]; if (d.ns > 1) h.m1 = v2f[(int64_t)d.mc * n + 1]; }
+    }
+    if (d.e_d >= 0 && is_hidden(d.val_c) && lane < d.np_c) {
+        h.y = s.old_particles[(int64_t)d.v_c * n + lane];
+        h.mj = v2f[(int64_t)d.md * n + lane];
+    }
+    return h;
+}
+
+__global__ void __launch_bounds__(BLOCK) pbp_f2v_pair_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
+                                                            double* __restrict__ f2v, const PairDesc* __restrict__ descs,
+                                                            int nitems) {
+    __shared__ double sh_tab[EXP_TAB_N];
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    load_log_table(sh_log);
+    load_exp_table(sh_tab);
+    const int lane = threadIdx.x & 63;
+    const int last = nitems - 1;
+    const int n = s.n, S = s.n + s.T;
+    WorkCursor<64> work;
+    if (!work.start(nullptr, nitems, lane)) return;
+    struct { int32_t e_c, e_d, np_c, T, ns; double val_c, A0, b0, c0, A1, b1, c1; } d;
+    PairDesc dn = descs[work.item];
+    PairData h = pair_fetch(dn, g, s, v2f, lane);
+    for (;;) {
+        d.e_c = dn.e_c; d.e_d = dn.e_d; d.np_c = dn.np_c; d.T = dn.T; d.ns = dn.ns; d.val_c = dn.val_c;
+        d.A0 = dn.A0; d.b0 = dn.b0; d.c0 = dn.c0; d.A1 = dn.A1; d.b1 = dn.b1; d.c1 = dn.c1;
+        const int nxt = work.next();
+        const bool more = nxt < work.limit;
+        dn = descs[__builtin_amdgcn_readfirstlane(min(nxt, last))];
+        const PairData cur = h;
+        if (more) h = pair_fetch(dn, g, s, v2f, lane);
+        if (d.e_c >= 0) {
+            // message to the continuous variable: lane = output point, log sum over the discrete variable's live states
+            double* out = f2v + (int64_t)d.e_c * S;
+            const int npts = d.np_c + d.T;
+#pragma nounroll
+            for (int r = 0; r < 2; ++r) {
+                const int p = 64 * r + lane;
+                if (64 * r >= npts) break;
+                const double x = r == 0 ? cur.x0 : cur.x1;
+                double acc = exp_core(fma(x, fma(x, d.A0, d.b0), d.c0 + cur.m0), sh_tab);
+                if (d.ns > 1) acc += exp_core(fma(x, fma(x, d.A1, d.b1), d.c1 + cur.m1), sh_tab);
+                if (p < npts) out[p < d.np_c ? p : n + (p - d.np_c)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
+            }
+        }
+        if (d.e_d >= 0) {
+            // message to the discrete variable: lane = particle of the continuous variable, one wave reduction per state
+            double* out = f2v + (int64_t)d.e_d * S;
+            const int nj = is_hidden(d.val_c) ? d.np_c : 1;
+            const double y = cur.y, m = cur.mj;
+            double res = wave_sum(lane < nj ? exp_core(fma(y, fma(y, d.A0, d.b0), d.c0 + m), sh_tab) : 0.0);
+            if (d.ns > 1) {
+                const double sum1 = wave_sum(lane < nj ? exp_core(fma(y, fma(y, d.A1, d.b1), d.c1 + m), sh_tab) : 0.0);
+                if (lane == 1) res = sum1;
+            }
+            if (lane < d.ns) out[lane] = res > 0.0 ? log_table(res, sh_log) : -700.0;
+        }
+        if (!more) break;
+        work.advance(nxt, lane);
+    }
+}
+
 // test hook: y[i] = exp_core(x[i])
 __global__ void __launch_bounds__(BLOCK) debug_exp_kernel(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
     __shared__ double sh_tab[EXP_TAB_N];
@@ -1477,7 +1569,11 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
         if (s->heavy_desc && s->n_heavy > 0 && !(s->flags & LHVI_PBP_SKIP_HEAVY))
             hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(heavy_grid), dim3(HEAVY_BLOCK), 0, as_stream(stream),
                                *g, sh, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy);
-        if (s->light_desc && s->n_light > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
+        if (s->pair_desc && s->n_pair > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT)) {
+            static const int pair_per_cu = blocks_per_cu((const void*)pbp_f2v_pair_kernel);
+            hipLaunchKernelGGL(pbp_f2v_pair_kernel, dim3(min((s->n_pair + 3) / 4, max(cus * min(pair_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0,
+                               as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const PairDesc*>(s->pair_desc), s->n_pair);
+        } else if (s->light_desc && s->n_light > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
             hipLaunchKernelGGL(pbp_f2v_light_kernel, dim3(min((s->n_light + 3) / 4, max(cus * min(light_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0, as_stream(stream),
                                *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->light_desc), s->n_light);
         if (nfast > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))

@@ -56,6 +56,7 @@ class PbpStruct(C.Structure):
         ('var_lo', C.c_int32), ('var_hi', C.c_int32),
         ('f2v_ticket', C.c_void_p),
         ('prop_desc', C.c_void_p), ('n_prop_desc', C.c_int32),
+        ('pair_desc', C.c_void_p), ('n_pair', C.c_int32),
     ]
 
 
@@ -76,7 +77,7 @@ PBP_SKIP_HEAVY = 32
 PBP_SKIP_LIGHT = 64
 PBP_NO_GRID = 128
 PBP_LEAVE_ROOM = 256
-ABI_VERSION = 6             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
+ABI_VERSION = 7             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
 PBP_DESC_BYTES = 128
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE
 

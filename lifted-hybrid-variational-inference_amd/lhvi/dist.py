@@ -316,6 +316,8 @@ class ShardedRunner:
         s.heavy_desc, s.n_heavy = (bp.heavy_desc.data_ptr() + off * D if cnt else None), cnt
         off, cnt = cut(bp.n_light, pc['light'])
         s.light_desc, s.n_light = (bp.light_desc.data_ptr() + off * D if cnt else None), cnt
+        off, cnt = cut(int(getattr(bp, 'n_pair', 0)), pc.get('pair', 0))
+        s.pair_desc, s.n_pair = (bp.pair_desc.data_ptr() + off * D if cnt else None), cnt
         off, cnt = cut(int(bp.fast_edges.numel()), pc['fast'])
         if cnt:
             s.fast_edges, s.fast_desc = bp.fast_edges.data_ptr() + 4 * off, bp.fast_desc.data_ptr() + off * D

@@ -32,6 +32,7 @@ class _ParticleSweep:
     verbose = False
     listed_proposal = True          # the proposal kernel starts from per-variable records (else it walks the graph arrays)
     dynamic_f2v = True              # the persistent f2v kernels claim their work in chunks (else static striding)
+    paired_light = True             # the light edges are served per factor (pair_desc) instead of per edge (light_desc)
 
     # ---- set-up ------------------------------------------------------------------------------
     def _setup(self, graph_like, flat=None, edge_key=None):
@@ -101,8 +102,9 @@ class _ParticleSweep:
                 pd[:, 4 + k] = flat.var_edge[np.minimum(pbase + np.minimum(k, np.maximum(pdeg - 1, 0)), flat.var_edge.size - 1)]
         self.prop_desc = _abi.to_dev(pd) if pv.size else None
         self.n_prop_desc = int(pv.size)
-        self.fast_desc = self.heavy_desc = self.light_desc = None
-        self.n_heavy = self.n_light = 0
+        self.fast_desc = self.heavy_desc = self.light_desc = self.pair_desc = None
+        self.n_heavy = self.n_light = self.n_pair = 0
+        self.part_counts['pair'] = 0
         self.heavy_terms = self.heavy_grid_terms = 0
         nf = int(self.fast_edges.numel())
         if nf:
@@ -132,6 +134,58 @@ class _ParticleSweep:
             self._fast_list = self.fast_edges if self.fast_edges.numel() else pad
             self.part_counts.update(heavy=first_part(all_fast[heavy]), light=first_part(all_fast[light]),
                                     fast=first_part(self.fast_edges))
+            self._build_pairs(key_dev)
+
+    def _build_pairs(self, key_dev):
+        """``lhvi_pbp_t.pair_desc``: one record per HybridQuadratic(1 discrete, 1 continuous) factor from the per-edge light
+        descriptors (words 0 e, 1 target, 2 partner, 3 partner's canonical edge, 7 nj, 8 np, 9 T, 10 grid base, 12-13 partner
+        value, 14 type, 16-27 coefficients), on the device.  A type-1 entry (continuous target) is joined with the type-2 entry
+        (discrete target) of the same factor when there is one; what is left of either type becomes a one-sided record."""
+        torch = _abi.require_gpu()
+        if not self.paired_light or self.light_desc is None or self.n_light == 0:
+            return
+        dev = self.light_desc.device
+        w = self.light_desc.view(torch.int32).view(-1, 32).long()
+        dd = self.light_desc.view(torch.float64).view(-1, 16)
+        i1, i2 = torch.nonzero(w[:, 14] == 1).flatten(), torch.nonzero(w[:, 14] == 2).flatten()
+        w1, w2, d1, d2 = w[i1], w[i2], dd[i1], dd[i2]
+        lookup = torch.full((max(self.flat.E, 1),), -1, dtype=torch.int64, device=dev)
+        lookup[w2[:, 0]] = torch.arange(i2.numel(), device=dev)
+        j = torch.where(torch.isnan(d1[:, 6]), lookup[w1[:, 3]], torch.full_like(w1[:, 3], -1))      # partner hidden: its own entry
+        taken = torch.zeros(i2.numel(), dtype=torch.bool, device=dev)
+        taken[j[j >= 0]] = True
+        rest = torch.nonzero(~taken).flatten()
+        n1, n2 = int(i1.numel()), int(rest.numel())
+        out = torch.zeros(n1 + n2, 128, dtype=torch.uint8, device=dev)
+        ow, od = out.view(torch.int32).view(-1, 32), out.view(torch.float64).view(-1, 16)
+        nan = float('nan')
+        if n1:
+            jj = j.clamp_min(0)
+            has = j >= 0
+            ow[:n1, 0] = w1[:, 0].int()
+            ow[:n1, 1] = torch.where(has, w2[jj, 0], torch.full_like(jj, -1)).int() if i2.numel() else -1
+            ow[:n1, 2], ow[:n1, 3] = w1[:, 1].int(), w1[:, 2].int()
+            ow[:n1, 4], ow[:n1, 5], ow[:n1, 6], ow[:n1, 7] = w1[:, 8].int(), w1[:, 9].int(), w1[:, 10].int(), w1[:, 7].int()
+            od[:n1, 4], od[:n1, 5] = nan, d1[:, 6]
+            od[:n1, 6:12] = d1[:, 8:14]
+            ow[:n1, 24] = w1[:, 3].int()
+            ow[:n1, 25] = (torch.where(has, w2[jj, 3], torch.zeros_like(jj)).int() if i2.numel() else 0)
+        if n2:
+            r2, rd = w2[rest], d2[rest]
+            ow[n1:, 0], ow[n1:, 1] = -1, r2[:, 0].int()
+            ow[n1:, 2], ow[n1:, 3] = r2[:, 2].int(), r2[:, 1].int()
+            ow[n1:, 4], ow[n1:, 7] = r2[:, 7].int(), r2[:, 8].int()
+            od[n1:, 4], od[n1:, 5] = rd[:, 6], nan
+            od[n1:, 6:12] = rd[:, 8:14]
+            ow[n1:, 25] = r2[:, 3].int()
+        first = 0
+        if key_dev is not None and n1 + n2:      # sharded runs: records of factors that touch no boundary variable first
+            edge = torch.where(ow[:, 0] >= 0, ow[:, 0], ow[:, 1]).long()
+            order = torch.sort(key_dev[edge], stable=True).indices
+            out = out[order].contiguous()
+            first = int((key_dev[edge] == 0).sum().item())
+        self.pair_desc, self.n_pair = out, n1 + n2
+        self.part_counts['pair'] = first
 
     def _struct(self):
         s = _abi.PbpStruct()
@@ -145,6 +199,8 @@ class _ParticleSweep:
         s.fast_desc = _abi.ptr(getattr(self, 'fast_desc', None))
         s.heavy_desc, s.n_heavy = _abi.ptr(getattr(self, 'heavy_desc', None)), int(getattr(self, 'n_heavy', 0))
         s.light_desc, s.n_light = _abi.ptr(getattr(self, 'light_desc', None)), int(getattr(self, 'n_light', 0))
+        if self.paired_light and getattr(self, 'pair_desc', None) is not None:
+            s.pair_desc, s.n_pair = _abi.ptr(self.pair_desc), int(self.n_pair)
         s.f2v_ticket = _abi.ptr(self.f2v_ticket) if self.dynamic_f2v else None
         if self.listed_proposal and getattr(self, 'prop_desc', None) is not None:
             s.prop_desc, s.n_prop_desc = _abi.ptr(self.prop_desc), self.n_prop_desc

@@ -662,3 +662,32 @@ def test_lifted_particle_sweep_on_arrays_matches_object_path(api):
             assert ba[ca, 0] == pytest.approx(bo[co, 0], rel=1e-8)
             checked += 1
     assert checked > 10
+
+
+@pytest.mark.parametrize('frac_discrete,evidence', [(0.3, 0.1), (0.5, 0.4), (0.2, 0.0)])
+def test_pair_records_do_not_change_results(api, frac_discrete, evidence):
+    """the light edges served per factor (lhvi_pbp_t.pair_desc, pbp_f2v_pair_kernel) against per edge (light_desc): the same
+    expressions per edge, so whole sweeps agree bit for bit -- with hidden / observed variables on either side of the factors"""
+    import torch
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    flat = synth.hybrid_mrf_flat(V=8000, deg=4, seed=31, frac_discrete=frac_discrete, evidence_ratio=evidence)
+    res = []
+    for paired in (True, False):
+        bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=13)
+        bp.paired_light = paired
+        bp._setup(None, flat=flat)
+        assert (bp.n_pair > 0) == paired and bp.n_light > 0
+        if paired:       # every light edge appears in exactly one record
+            w = bp.pair_desc.view(torch.int32).view(-1, 32)
+            edges = torch.cat([w[:, 0][w[:, 0] >= 0], w[:, 1][w[:, 1] >= 0]])
+            light_e = bp.light_desc.view(torch.int32).view(-1, 32)[:, 0]
+            assert torch.equal(torch.sort(edges).values, torch.sort(light_e).values)
+        _init(api, bp)
+        for _ in range(4):
+            bp.sweep(last=False)
+        torch.cuda.synchronize()
+        res.append((bp.f2v.clone(), bp.v2f.clone(), bp.q_dev.clone()))
+        assert bool(torch.isfinite(bp.f2v).all())
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
