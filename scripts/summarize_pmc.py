@@ -13,14 +13,15 @@ prof = os.path.join(ROOT, 'profiles')
 
 
 def counters(d):
-    f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+    # (gpurun merges every call's outputs into the same directory: take the newest collection)
+    f = sorted(glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime, reverse=True)
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f[0])):
         acc[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 
 
-st = glob.glob(os.path.join(stats_dir, '**', '*kernel_stats.csv'), recursive=True)
+st = sorted(glob.glob(os.path.join(stats_dir, '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime, reverse=True)
 if st:
     shutil.copy(st[0], os.path.join(prof, tag + '_kernel_stats.csv'))
 fetch, write = counters(fetch_dir), counters(write_dir)
