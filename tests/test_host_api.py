@@ -430,3 +430,22 @@ def test_design_numbers_are_the_committed_profiles():
     text = open(os.path.join(ROOT, 'DESIGN.md')).read()
     m = re.search(r'<!-- numbers:begin \(scripts/design_numbers.py\) -->\n(.*?)\n<!-- numbers:end -->', text, re.S)
     assert m and m.group(1).strip() == out
+
+
+def test_c2fvi_evidence_bookkeeping():
+    """lhvi.c2fvi's restatement of CompressedGraph.split_evidence (CGWO:236-247) on colour arrays: only clusters in
+    `clustered_evidence` are examined, the standard deviation decides whether a cluster splits but the VARIANCE whether a
+    piece is tracked again, piece 0 keeps the colour, single-member clusters leave the set"""
+    from lhvi import c2fvi
+    vals = np.array([np.nan, 1.0, 1.0, 9.0, 9.5, np.nan, 4.0, 4.0, 20.0])
+    rvc = np.array([0, 1, 1, 1, 1, 0, 2, 2, 3], dtype=np.int32)
+    # cluster 1 {1, 1, 9, 9.5}: std 4.1 > 3 -> k-means splits {1, 1} | {9, 9.5}; the second piece (variance 0.0625) is not
+    # tracked at epsilon = 3 but piece 0 keeps its place in the set; cluster 2 is not tracked and stays; 3 is a singleton
+    out, tracked = c2fvi.split_evidence_pass(vals, rvc, {1, 3}, 2, 10, 3.0)
+    assert out.tolist() == [0, 1, 1, 4, 4, 0, 2, 2, 3] and tracked == {1, 3}
+    out2, tracked2 = c2fvi.split_evidence(vals, out, {1, 3, 4}, 2, 10, 0.0)
+    assert sorted(set(out2.tolist())) == [0, 1, 2, 3, 4, 5] and out2[3] != out2[4]          # {9} | {9.5} at epsilon 0
+    assert c2fvi.evidence_variances(vals, out2)[2] == 0.0 and 3 in tracked2                  # (a singleton is only dropped when examined)
+    # an untracked cluster is never split, whatever its spread (the path dependence the fixtures avoid)
+    out3, _ = c2fvi.split_evidence(vals, rvc, set(), 2, 10, 0.0)
+    assert (out3 == rvc).all()
