@@ -141,6 +141,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise LhviError('HIP extension %s not built; run `python -c "import __graft_entry__ as g; g.build()"`'
                             % LIB_PATH)
+        # PyTorch-ROCm ships its own copy of the HIP runtime: it has to be in the process BEFORE liblhvi.so is loaded, or the
+        # library binds to the system's copy and its launches see none of torch's devices, streams or allocations
+        # (hipErrorNoDevice on the first launch)
+        _torch()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             try:
