@@ -208,3 +208,35 @@ def test_graph_compositions_against_oracle(api, frac_discrete, evidence):
         np.testing.assert_allclose(bp.v2f.cpu().numpy()[hid_e], o.v2f[hid_e], rtol=1e-9, atol=1e-7)
         np.testing.assert_allclose(bp.f2v.cpu().numpy()[hid_e], o.f2v[hid_e], rtol=1e-9, atol=1e-7)
         np.testing.assert_allclose(bp.q_dev.cpu().numpy()[flat.var_hidden], o.q[flat.var_hidden], rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_shapes_against_oracle(api, seed):
+    """random mixtures of what the work lists are made of -- particle count, grid size, degree, share of discrete variables,
+    evidence, proposal rule -- three sweeps each against the oracle with the device's particles"""
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    from oracle import oracle
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([8, 16, 24, 33, 48, 64]))
+    T = int(rng.choice([0, 9, 16, 32, 40]))
+    deg = int(rng.choice([3, 4, 6]))
+    V = int(rng.integers(300, 900)) // 2 * 2 * (2 if deg % 2 else 1)
+    flat = synth.hybrid_mrf_flat(V=V, deg=deg, seed=int(rng.integers(1 << 20)), frac_discrete=float(rng.uniform(0, 0.7)),
+                                 evidence_ratio=float(rng.uniform(0, 0.5)), T=T)
+    ep = bool(rng.integers(2)) and T > 0
+    bp = EPBP(None, n=n, proposal_approximation='EP' if ep else 'simple', sampler='device', seed=seed)
+    bp._setup(None, flat=flat)
+    l, st = api.lib(), api.stream_ptr()
+    api.check(l.lhvi_pbp_init(bp.dg.g, bp._struct(), api.ptr(bp.eta), api.ptr(bp.q_dev), api.ptr(bp.f2v), api.ptr(bp.v2f), st))
+    bp._generate_sample()
+    o = oracle.PbpOracle(flat, n, ep=ep, epbp=True, var_threshold=3)
+    o.init()
+    o.set_particles(bp.particles.cpu().numpy())
+    hid_e = flat.var_hidden[flat.edge_var]
+    for _ in range(3):
+        bp.sweep(last=False)
+        o.step_v2f(); o.step_proposal(); o.set_particles(bp.particles.cpu().numpy()); o.step_f2v()
+        np.testing.assert_allclose(bp.v2f.cpu().numpy()[hid_e][:, :n], o.v2f[hid_e], rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(bp.f2v.cpu().numpy()[hid_e], o.f2v[hid_e], rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(bp.q_dev.cpu().numpy()[flat.var_hidden], o.q[flat.var_hidden], rtol=1e-9, atol=1e-10)
