@@ -27,8 +27,9 @@
 extern "C" {
 #endif
 
-#define LHVI_ABI_VERSION 7   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
-                              * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t;  7: lhvi_pbp_t gained pair_desc */
+#define LHVI_ABI_VERSION 8   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
+                              * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t;  7: lhvi_pbp_t gained pair_desc;
+                              * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -164,6 +165,11 @@ int lhvi_log_likelihood(const lhvi_graph_t* g, const lhvi_pots_t* pots, const do
 #define LHVI_PBP_LEAVE_ROOM 256u /* lhvi_pbp_f2v: the persistent kernels launch cus/8 workgroups fewer than fill the device, so that
                                    * another stream's kernels (RCCL's copy kernels of an overlapped exchange) find free slots at
                                    * any time instead of waiting for a persistent workgroup to retire.  Set by sharded runs. */
+#define LHVI_PBP_CQ 512u         /* route MLN factors whose formula is conditionally quadratic (lhvi/expr.py::cq_block: a polynomial of degree <= 2
+                                   * in the continuous arguments for every state of the discrete ones, e.g. x[0] * eq_op(x[1], x[2]),
+                                   * Demo/Data/HMLN/GeneratorPaperPopularity.py:28-40) to the quadratic-family kernels instead of the
+                                   * generic interpreter kernel: set it for lhvi_pbp_classify / _describe / _describe_cq AND lhvi_pbp_f2v */
+#define LHVI_PBP_SKIP_CQ 1024u   /* lhvi_pbp_f2v: do not launch the kernel of the cq_desc list (profiling aid) */
 #define LHVI_PBP_NO_GRID 128u    /* lhvi_pbp_f2v: integral points always by the direct form (one exponential per term), never by the
                                    * uniform-grid recurrence (testing / profiling aid) */
 
@@ -230,6 +236,11 @@ typedef struct lhvi_pbp {
      * descriptor traffic; same messages bit for bit).  NULL: light_desc is used. */
     const void* pair_desc;
     int32_t n_pair;
+    /* optional, lhvi_pbp_f2v only: [n_cq][2 * LHVI_PBP_DESC_BYTES] records from lhvi_pbp_describe_cq for the edges of class 4
+     * (conditionally quadratic factors with a hidden discrete and a hidden continuous partner, or two hidden continuous
+     * partners of a discrete target); served by their own kernel. */
+    const void* cq_desc;
+    int32_t n_cq;
 } lhvi_pbp_t;
 
 #define LHVI_PBP_DESC_BYTES 128
@@ -246,6 +257,16 @@ typedef struct lhvi_pbp {
  * The host builds heavy_desc / light_desc / fast_desc by splitting the rows on words 4, 6, 7, 8 + 9 and 14. */
 int lhvi_pbp_describe(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const int32_t* edges, int32_t count,
                       void* desc_out, void* stream);
+/* descriptors of the class-4 edges (2 * LHVI_PBP_DESC_BYTES each).  Layout (32-bit words unless noted):
+ *   0 edge   1 target variable   2 type (1 = continuous target, hidden discrete partner z + continuous partner y: the message is
+ *   log sum_s sum_j exp(a_sj + b_sj x + k_s x^2); 2 = discrete target, two hidden continuous partners x, y: S sums over the n^2
+ *   joint particles)   3 S = coefficient sets (states of z / of the target)   4 np   5 T   6 grid base   7 variable of y
+ *   8 v2f row of y   9 particles of y (1 = observed or absent)   10 variable of z (type 2: of x)   11 v2f row of z (type 1: -1 =
+ *   none; type 2: of x)   12 states of z (type 2: particles of x)   14-15 value of an observed y (double, NaN = hidden)
+ *   16-63 S x six doubles (ay, by, c, axy, bx, kx): log phi_s = kx x^2 + (ay y + by) y + c + (axy y + bx) x
+ * EPBP.message_f_to_rv on such factors: EPBP.py:176-194 with MLNPotential.get MLNPotential.py:36-37. */
+int lhvi_pbp_describe_cq(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const int32_t* edges, int32_t count,
+                         void* desc_out, void* stream);
 /* Batched queries (extension; EPBP.belief_rv EPBP:196-202 for every variable at once).  Tabulate the messages at n query
  * points per variable by running lhvi_pbp_f2v with s->particles = the query points [V][n] and s->old_particles = the
  * current sample into a scratch f2v buffer, then
@@ -265,8 +286,10 @@ int lhvi_debug_exp_acc(const double* x, const double* c, double* y, int64_t n, v
 int lhvi_debug_log(const double* x, double* y, int64_t n, int32_t which, void* stream);
 
 /* edge_class[e]: 0 = no message (observed target / alias edge), 1|2 = quadratic-family (continuous | discrete target),
- * 3 = generic potential.  Static per (graph, potentials); the host turns it into the two work lists above. */
-int lhvi_pbp_classify(const lhvi_graph_t* g, const lhvi_pots_t* pots, uint8_t* edge_class, void* stream);
+ * 3 = generic potential, 4 = conditionally quadratic with two hidden partners (only with LHVI_PBP_CQ in s->flags; `s` may be
+ * NULL otherwise -- it is read for flags, n and np only).  Static per (graph, evidence, potentials, particle counts); the
+ * host turns it into the work lists above. */
+int lhvi_pbp_classify(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, uint8_t* edge_class, void* stream);
 
 /* uniq[v][j] = no i<j with particles[v][i] == particles[v][j]  (dict-key collapse, EPBP.py:236-242) */
 int lhvi_pbp_uniq(const lhvi_graph_t* g, int32_t n, const double* particles, const int32_t* np, uint8_t* uniq, void* stream);

@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include "potential.hpp"
 #include "fastmath.hpp"
+#include "cq.hpp"
 
 namespace lhvi {
 
@@ -257,14 +258,28 @@ __device__ double f2v_point_generic(const lhvi_graph_t& g, const lhvi_pots_t& po
 //   (1) continuous target, log phi quadratic in it (Gaussian / Quadratic / LinearGaussian / XY / HybridQuadratic with
 //       the discrete partner): X1 = x, X2 = x^2, C = 0, (a, b, k) = coefficients given the partner particle + message;
 //   (2) discrete target of a HybridQuadratic(1 disc, 1 cont): X1 = b_d, X2 = A_d, C = c_d, (a, b, k) = (m_j, y_j, y_j^2).
-// Everything else (tables, MLN formulas, arity != 2) takes the GENERIC kernel.
-enum { EDGE_SKIP = 0, EDGE_FAST_CONT = 1, EDGE_FAST_DISC = 2, EDGE_GENERIC = 3 };
+// Conditionally quadratic MLN formulas (cq.hpp; with LHVI_PBP_CQ set): resolved against the evidence they are edges of
+// class 1 / 2 again (served by the heavy / light kernels through descriptors that carry the resolved coefficients) or,
+// with a hidden discrete and a hidden continuous partner or two hidden continuous partners, edges of class 4 (EDGE_CQ).
+// Everything else (tables, other MLN formulas, arity != 2) takes the GENERIC kernel.
+enum { EDGE_SKIP = 0, EDGE_FAST_CONT = 1, EDGE_FAST_DISC = 2, EDGE_GENERIC = 3, EDGE_CQ = 4 };
 
-__device__ __forceinline__ int classify_edge(const lhvi_graph_t& g, const lhvi_pots_t& pots, int e) {
+// s.np / s.n / s.flags are all the classification reads of `s`
+__device__ __forceinline__ int classify_edge(const lhvi_graph_t& g, const lhvi_pots_t& pots, const lhvi_pbp_t& s, int e) {
     if (canon(g.edge_canon, e) != e) return EDGE_SKIP;
     const int tv = g.edge_var[e];
     if (!is_hidden(g.var_value[tv])) return EDGE_SKIP;
     const int f = g.edge_fac[e], base = g.fac_ptr[f], arity = g.fac_ptr[f + 1] - base, pos = e - base;
+    if ((s.flags & LHVI_PBP_CQ) && s.np && pots.kind[g.fac_pot[f]] == LHVI_POT_MLN) {
+        CqInfo ci;
+        const int route = cq_analyze(g, pots, s.np, s.n, e, ci);
+        if (route == CQ_NONE) return EDGE_GENERIC;
+        const int dom = g.var_dom[tv];
+        const int T = g.dom_cont[dom] ? g.dom_ptr[dom + 1] - g.dom_ptr[dom] : 0;
+        if (s.np[tv] + T > 128 || s.np[tv] > 64) return EDGE_GENERIC;      // the descriptor kernels' output-point limits
+        if (route == CQ_MIX || route == CQ_JOINT) return EDGE_CQ;
+        return route == CQ_LIGHT2 ? EDGE_FAST_DISC : EDGE_FAST_CONT;
+    }
     if (arity != 2) return EDGE_GENERIC;
     const int pv = g.edge_var[base + (1 - pos)];
     if (pv == tv) return EDGE_GENERIC;
@@ -300,24 +315,46 @@ static_assert(sizeof(FastDesc) == LHVI_PBP_DESC_BYTES, "FastDesc is part of the 
 __device__ __forceinline__ FastDesc make_fast_desc(const lhvi_graph_t& g, const lhvi_pots_t& pots, const lhvi_pbp_t& s, int e) {
     FastDesc d;
     d.e = e;
-    d.cls = classify_edge(g, pots, e);
+    d.cls = classify_edge(g, pots, s, e);
     d.tv = g.edge_var[e];
     const int f = g.edge_fac[e], base = g.fac_ptr[f];
     d.pos = e - base;
-    const int pe = base + (1 - d.pos);
-    d.pv = g.edge_var[pe];
-    d.pce = canon(g.edge_canon, pe);
     const int pot = g.fac_pot[f];
     d.kind = pots.kind[pot];
     d.par_off = pots.off[pot];
-    d.pval = g.var_value[d.pv];
-    d.nj = is_hidden(d.pval) ? s.np[d.pv] : 1;
     const int dom = g.var_dom[d.tv];
     d.np = s.np[d.tv];
     d.gb = g.dom_ptr[dom];
     d.T = (d.cls == EDGE_FAST_CONT) ? g.dom_ptr[dom + 1] - d.gb : 0;
     d.pad[0] = d.pad[1] = 0;
     d.ay = d.by = d.c = d.axy = d.bx = d.kx = d.pad2[0] = d.pad2[1] = 0.0;
+    d.pv = 0; d.pce = 0; d.pval = 0.0; d.nj = 1;
+    const bool cq = d.kind == LHVI_POT_MLN;               // (an MLN edge is on the fast list only through its conditional-quadratic view)
+    CqInfo ci;
+    if (cq) {
+        cq_analyze(g, pots, s.np, s.n, e, ci);
+        // the descriptor of the kernel that serves the resolved edge: heavy (word 6 != HYBRID_QUADRATIC, word 14 == 0) or
+        // light (word 6 == HYBRID_QUADRATIC, word 14 = type); partner = the one hidden partner left, if any
+        if (ci.route == CQ_HEAVY) {
+            d.kind = LHVI_POT_QUADRATIC;
+            d.pv = ci.yv; d.pce = ci.yce; d.nj = ci.ny; d.pval = ci.yval;
+            d.ay = ci.ay[0]; d.by = ci.by[0]; d.c = ci.c[0]; d.axy = ci.axy[0]; d.bx = ci.bx[0]; d.kx = ci.kx[0];
+        } else if (ci.route == CQ_LIGHT1 || ci.route == CQ_LIGHT2) {
+            d.kind = LHVI_POT_HYBRID_QUADRATIC;
+            const bool t1 = ci.route == CQ_LIGHT1;
+            d.pv = t1 ? ci.zv : ci.yv; d.pce = t1 ? ci.zce : ci.yce; d.nj = t1 ? ci.nz : ci.ny;
+            d.pval = __builtin_nan("");
+            d.ay = ci.kx[0]; d.by = ci.bx[0]; d.c = ci.c[0];
+            if (ci.S > 1) { d.axy = ci.kx[1]; d.bx = ci.bx[1]; d.kx = ci.c[1]; }
+            d.pad[0] = t1 ? 1 : 2;
+        }
+    } else {
+        const int pe = base + (1 - d.pos);
+        d.pv = g.edge_var[pe];
+        d.pce = canon(g.edge_canon, pe);
+        d.pval = g.var_value[d.pv];
+        d.nj = is_hidden(d.pval) ? s.np[d.pv] : 1;
+    }
     // uniform integral-point grid (the reference's Domain default is a linspace): x_t = x0 + t h to a few ulp.  The heavy
     // kernel then tabulates exp(a + b x_t) along t by multiplication instead of one exponential per point
     if (d.cls == EDGE_FAST_CONT && d.T >= 2) {
@@ -329,7 +366,7 @@ __device__ __forceinline__ FastDesc make_fast_desc(const lhvi_graph_t& g, const 
         if (uniform) { d.pad[1] = 1; d.pad2[0] = x0; d.pad2[1] = h; }
     }
     Quad2 q;
-    if (d.cls == EDGE_FAST_CONT && d.kind != LHVI_POT_HYBRID_QUADRATIC && quad2_of(d.kind, pots.param + d.par_off, 0, q)) {
+    if (!cq && d.cls == EDGE_FAST_CONT && d.kind != LHVI_POT_HYBRID_QUADRATIC && quad2_of(d.kind, pots.param + d.par_off, 0, q)) {
         if (d.pos == 0) { d.ay = q.a11; d.by = q.b1; d.axy = q.axy; d.bx = q.b0; d.kx = q.a00; }
         else            { d.ay = q.a00; d.by = q.b0; d.axy = q.axy; d.bx = q.b1; d.kx = q.a11; }
         d.c = q.c;
@@ -338,7 +375,7 @@ __device__ __forceinline__ FastDesc make_fast_desc(const lhvi_graph_t& g, const 
     // or an observed discrete partner): log phi = A_s x^2 + b_s x + c_s per discrete point s, resolved here as
     // (A_0, b_0, c_0, A_1, b_1, c_1) for the light kernel.  pad[0]: 1 = continuous target / discrete partner,
     // 2 = discrete target / continuous partner, 0 = not a light edge
-    if (d.kind == LHVI_POT_HYBRID_QUADRATIC && (d.cls == EDGE_FAST_CONT || d.cls == EDGE_FAST_DISC)) {
+    if (!cq && d.kind == LHVI_POT_HYBRID_QUADRATIC && (d.cls == EDGE_FAST_CONT || d.cls == EDGE_FAST_DISC)) {
         const double* par = pots.param + d.par_off;
         const int nst = (int)par[2];
         const bool cont_target = d.cls == EDGE_FAST_CONT;
@@ -970,6 +1007,143 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_pair_kernel(lhvi_graph_t g, lhv
     }
 }
 
+// CQ edges (cq.hpp): factors whose log potential is quadratic in two continuous arguments for every state of a discrete one --
+// the ternary formulas of the reference's hybrid MLNs, x[0] * eq_op(x[1], x[2]) -- with more than one hidden partner:
+//   type 1 (MIX)    continuous target x, hidden discrete partner z (S states), continuous partner y (hidden, or folded):
+//                   exp(message) = sum_s sum_j exp(a_sj + b_sj x + k_s x^2),  a_sj = (ay_s y_j + by_s) y_j + c_s + m_y[j] + m_z[s]
+//                   -- S heavy-style sums over the same staged particles, one per state, added before the log
+//   type 2 (JOINT)  discrete target with S states, two hidden continuous partners x (lane = particle i) and y (staged):
+//                   exp(message)[s] = sum_i sum_j exp(a_sj + b_sj x_i + (k_s x_i^2 + m_x[i])) -- the heavy kernel's particle round
+//                   with the lane's own message folded into its per-point constant, then a wave reduction over i
+// Same term loop as the heavy kernel (fast_accumulate_uniform: 9 fp64 + 3 int32 VALU instructions per term).
+struct CqDesc {
+    int32_t e, tv, type, S;          // edge, target variable, 1 = MIX / 2 = JOINT, coefficient sets
+    int32_t np, T, gb, yv;           // target particles (JOINT: = S states), grid points, grid base; staged partner's variable
+    int32_t yce, ny, zv, zce;        // staged partner's v2f row and particles (1: observed / absent); z: variable and v2f row (MIX: -1 = none)
+    int32_t nz, pad;                 // MIX: states of z; JOINT: particles of the lane-side partner
+    double yval;                     // NaN: the staged partner is hidden
+    double coef[LHVI_CQ_MAX_STATES][6];   // per set (ay, by, c, axy, bx, kx)
+};
+static_assert(sizeof(CqDesc) == 2 * LHVI_PBP_DESC_BYTES, "CqDesc is part of the ABI (2 * LHVI_PBP_DESC_BYTES)");
+
+__global__ void __launch_bounds__(BLOCK) pbp_describe_cq_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
+                                                               const int32_t* __restrict__ edges, int count,
+                                                               CqDesc* __restrict__ out) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const int e = edges[i];
+    CqInfo ci;
+    const int route = cq_analyze(g, pots, s.np, s.n, e, ci);
+    CqDesc d;
+    d.e = e; d.tv = g.edge_var[e];
+    d.type = route == CQ_MIX ? 1 : (route == CQ_JOINT ? 2 : 0);       // 0: not a CQ edge -- the kernel skips the entry
+    d.S = ci.S;
+    const int dom = g.var_dom[d.tv];
+    d.np = s.np[d.tv];
+    d.gb = g.dom_ptr[dom];
+    d.T = g.dom_cont[dom] ? g.dom_ptr[dom + 1] - d.gb : 0;
+    d.yv = ci.yv; d.yce = ci.yce; d.ny = ci.ny; d.zv = ci.zv; d.zce = ci.zce; d.nz = ci.nz; d.pad = 0;
+    d.yval = ci.yval;
+    for (int k = 0; k < LHVI_CQ_MAX_STATES; ++k) {
+        const bool on = d.type != 0 && k < ci.S;
+        d.coef[k][0] = on ? ci.ay[k] : 0.0; d.coef[k][1] = on ? ci.by[k] : 0.0; d.coef[k][2] = on ? ci.c[k] : 0.0;
+        d.coef[k][3] = on ? ci.axy[k] : 0.0; d.coef[k][4] = on ? ci.bx[k] : 0.0; d.coef[k][5] = on ? ci.kx[k] : 0.0;
+    }
+    out[i] = d;
+}
+
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) pbp_f2v_cq_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
+                                                          double* __restrict__ f2v, const CqDesc* __restrict__ descs,
+                                                          int nitems) {
+    __shared__ AB sh_all[BLOCK / WAVE][WAVE];
+    __shared__ double sh_tab[EXP_TAB_N];
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    load_log_table(sh_log);
+    load_exp_table(sh_tab);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    AB* sh = sh_all[wid];
+    const int n = s.n, S = s.n + s.T;
+    const int nwaves = gridDim.x * (BLOCK / WAVE);
+    for (int item = blockIdx.x * (BLOCK / WAVE) + wid; item < nitems; item += nwaves) {
+        const CqDesc& d = descs[item];                      // wave-uniform address: scalar loads
+        const int type = d.type, ny = d.ny, nst = d.S;
+        if (type == 0) continue;
+        double* out = f2v + (int64_t)d.e * S;
+        // the staged partner's particles and message
+        double y = d.yval, my = 0.0;
+        if (is_hidden(d.yval)) { y = 0.0; if (lane < ny) { y = s.old_particles[(int64_t)d.yv * n + lane]; my = v2f[(int64_t)d.yce * n + lane]; } }
+        if (type == 1) {
+            const int np = d.np, npts = d.np + d.T;
+            // this lane's output points of the (at most two) rounds
+            double xr[2] = {0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int rem = npts - 64 * r;
+                if (rem > 0) {
+                    const int pl = lane & ((1 << round_log2_width(rem)) - 1), pp = 64 * r + pl;
+                    if (pl < rem) xr[r] = pp < np ? s.particles[(int64_t)d.tv * n + pp] : g.dom_val[d.gb + pp - np];
+                }
+            }
+            double mz = 0.0;                                  // the discrete partner's message at its states (lane = state)
+            if (d.zce >= 0 && lane < nst) mz = v2f[(int64_t)d.zce * n + lane];
+            double tot[2] = {0.0, 0.0};
+            for (int st = 0; st < nst; ++st) {
+                const double ay = d.coef[st][0], by = d.coef[st][1], c = d.coef[st][2], axy = d.coef[st][3], bx = d.coef[st][4],
+                             kx = d.coef[st][5];
+                const double ms = readlane_f64(mz, st);
+                AB mine;
+                mine.a = -800.0; mine.b = 0.0;             // padding: exp(-800) underflows to exactly 0
+                if (lane < ny) { mine.a = (ay * y + by) * y + c + my + ms; mine.b = axy * y + bx; }
+                LHVI_WAVE_SYNC();
+                sh[lane] = mine;
+                LHVI_WAVE_SYNC();
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int rem = npts - 64 * r;
+                    if (rem > 0) {
+                        const int lw = round_log2_width(rem);
+                        const int width = 1 << lw, split = 64 >> lw, sub = lane >> lw, pl = lane & (width - 1);
+                        const double X1 = pl < rem ? xr[r] : 0.0, C = kx * X1 * X1;
+                        const int chunk = (ny + split - 1) >> (6 - lw);
+                        double acc = fast_accumulate_uniform<MODE_CONST, 4>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
+                        for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+                        tot[r] += acc;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int rem = npts - 64 * r;
+                if (rem > 0) {
+                    const int lw = round_log2_width(rem);
+                    const int sub = lane >> lw, pl = lane & ((1 << lw) - 1), p = 64 * r + pl;
+                    if (pl < rem && sub == 0) out[p < np ? p : n + (p - np)] = tot[r] > 0.0 ? log_table(tot[r], sh_log) : -700.0;
+                }
+            }
+        } else {
+            const int nx = d.nz;
+            double x = 0.0, mx = 0.0;
+            if (lane < nx) { x = s.old_particles[(int64_t)d.zv * n + lane]; mx = v2f[(int64_t)d.zce * n + lane]; }
+            double res = 0.0;
+            for (int st = 0; st < nst; ++st) {
+                const double ay = d.coef[st][0], by = d.coef[st][1], c = d.coef[st][2], axy = d.coef[st][3], bx = d.coef[st][4],
+                             kx = d.coef[st][5];
+                AB mine;
+                mine.a = -800.0; mine.b = 0.0;
+                if (lane < ny) { mine.a = (ay * y + by) * y + c + my; mine.b = axy * y + bx; }
+                LHVI_WAVE_SYNC();
+                sh[lane] = mine;
+                LHVI_WAVE_SYNC();
+                double acc = fast_accumulate_uniform<MODE_CONST, 4>(sh, nullptr, sh_tab, ny, x, 0.0, fma(kx * x, x, mx));
+                acc = wave_sum(lane < nx ? acc : 0.0);
+                if (lane == st) res = acc;
+            }
+            if (lane < nst) out[lane] = res > 0.0 ? log_table(res, sh_log) : -700.0;
+        }
+    }
+}
+
 // test hook: y[i] = exp_core(x[i])
 __global__ void __launch_bounds__(BLOCK) debug_exp_kernel(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
     __shared__ double sh_tab[EXP_TAB_N];
@@ -999,9 +1173,9 @@ __global__ void __launch_bounds__(BLOCK) debug_exp_acc_kernel(const double* __re
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) pbp_classify_kernel(lhvi_graph_t g, lhvi_pots_t pots, uint8_t* __restrict__ cls) {
+__global__ void __launch_bounds__(BLOCK) pbp_classify_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s, uint8_t* __restrict__ cls) {
     const int e = blockIdx.x * BLOCK + threadIdx.x;
-    if (e < g.E) cls[e] = (uint8_t)classify_edge(g, pots, e);
+    if (e < g.E) cls[e] = (uint8_t)classify_edge(g, pots, s, e);
 }
 
 // GENERIC edges: lane = output point, sequential joint loop per lane.  A wave serves 64 >> pts_log2 edges at once:
@@ -1021,7 +1195,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_generic_kernel(lhvi_graph_t g, 
         const int item = grp * per_wave + slot;
         if (item >= nitems) continue;
         const int e = s.generic_edges ? s.generic_edges[item] : item;
-        if (classify_edge(g, pots, e) != EDGE_GENERIC) continue;
+        if (classify_edge(g, pots, s, e) != EDGE_GENERIC) continue;
         const int tv = g.edge_var[e];
         const int n = s.n, S = s.n + s.T;
         const int d = g.var_dom[tv];
@@ -1492,10 +1666,12 @@ int lhvi_pbp_uniq(const lhvi_graph_t* g, int32_t n, const double* particles, con
     return check_launch();
 }
 
-int lhvi_pbp_classify(const lhvi_graph_t* g, const lhvi_pots_t* pots, uint8_t* edge_class, void* stream) {
+int lhvi_pbp_classify(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, uint8_t* edge_class, void* stream) {
     if (!g || !pots || !edge_class) return LHVI_E_ARG;
+    if (s && (s->flags & LHVI_PBP_CQ) && (!s->np || s->n <= 0)) return LHVI_E_ARG;
     if (g->E == 0) return LHVI_OK;
-    hipLaunchKernelGGL(pbp_classify_kernel, dim3(grid_for(g->E)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, edge_class);
+    lhvi_pbp_t none = {};
+    hipLaunchKernelGGL(pbp_classify_kernel, dim3(grid_for(g->E)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, s ? *s : none, edge_class);
     return check_launch();
 }
 
@@ -1507,6 +1683,17 @@ int lhvi_pbp_describe(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi
     if (!edges || !desc_out) return LHVI_E_ARG;
     hipLaunchKernelGGL(pbp_describe_kernel, dim3(grid_for(count)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, *s, edges, count,
                        reinterpret_cast<FastDesc*>(desc_out));
+    return check_launch();
+}
+
+int lhvi_pbp_describe_cq(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const int32_t* edges, int32_t count,
+                         void* desc_out, void* stream) {
+    if (int rc = validate_pbp(g, s)) return rc;
+    if (!pots || count < 0) return LHVI_E_ARG;
+    if (count == 0) return LHVI_OK;
+    if (!edges || !desc_out) return LHVI_E_ARG;
+    hipLaunchKernelGGL(pbp_describe_cq_kernel, dim3(grid_for(count)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, *s, edges, count,
+                       reinterpret_cast<CqDesc*>(desc_out));
     return check_launch();
 }
 
@@ -1543,6 +1730,7 @@ int lhvi_pbp_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, 
 int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f, double* f2v, void* stream) {
     if (int rc = validate_pbp(g, s)) return rc;
     if (!pots || !v2f || !f2v || !s->old_particles) return LHVI_E_ARG;
+    if ((s->flags & LHVI_PBP_CQ) && (!s->fast_edges || !s->generic_edges)) return LHVI_E_ARG;   // (conditional-quadratic routing needs the work lists)
     if (g->E == 0) return LHVI_OK;
     // persistent grids sized from the measured residency: CUs x resident workgroups per CU, every wave strides over its list
     const int nfast = s->fast_edges ? s->n_fast : g->E, ngen = s->generic_edges ? s->n_generic : g->E;
@@ -1579,6 +1767,11 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
         if (nfast > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT))
             hipLaunchKernelGGL(pbp_f2v_fast_kernel, dim3(min((nfast + 3) / 4, max(cus * min(fast_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0, as_stream(stream),
                                *g, *pots, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->fast_desc), pots->param);
+    }
+    if (s->cq_desc && s->n_cq > 0 && !(s->flags & LHVI_PBP_SKIP_CQ)) {
+        static const int cq_per_cu = blocks_per_cu((const void*)pbp_f2v_cq_kernel);
+        hipLaunchKernelGGL(pbp_f2v_cq_kernel, dim3(min((s->n_cq + 3) / 4, max(cus * min(cq_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0,
+                           as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const CqDesc*>(s->cq_desc), s->n_cq);
     }
     if (!(s->flags & LHVI_PBP_SKIP_GENERIC) && ngen > 0) {
         int pts_log2 = s->generic_edges ? s->generic_pts_log2 : 6;

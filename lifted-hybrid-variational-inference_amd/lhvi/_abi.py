@@ -57,6 +57,7 @@ class PbpStruct(C.Structure):
         ('f2v_ticket', C.c_void_p),
         ('prop_desc', C.c_void_p), ('n_prop_desc', C.c_int32),
         ('pair_desc', C.c_void_p), ('n_pair', C.c_int32),
+        ('cq_desc', C.c_void_p), ('n_cq', C.c_int32),
     ]
 
 
@@ -77,7 +78,9 @@ PBP_SKIP_HEAVY = 32
 PBP_SKIP_LIGHT = 64
 PBP_NO_GRID = 128
 PBP_LEAVE_ROOM = 256
-ABI_VERSION = 7             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
+PBP_CQ = 512
+PBP_SKIP_CQ = 1024
+ABI_VERSION = 8             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
 PBP_DESC_BYTES = 128
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE
 
@@ -100,8 +103,9 @@ SIGNATURES = {
     'lhvi_gabp_pull': (C.c_int, [_G, _P, _GP, _vp, _vp, C.c_int, _vp]),
     'lhvi_gabp_run_pull': (C.c_int, [_G, _P, _GP, _vp, _vp, C.c_int, _vp, C.c_size_t, _vp]),
     'lhvi_pbp_uniq': (C.c_int, [_G, _i32, _vp, _vp, _vp, _vp]),
-    'lhvi_pbp_classify': (C.c_int, [_G, _P, _vp, _vp]),
+    'lhvi_pbp_classify': (C.c_int, [_G, _P, _S, _vp, _vp]),
     'lhvi_pbp_describe': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _vp]),
+    'lhvi_pbp_describe_cq': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _vp]),
     'lhvi_log_likelihood_workspace_bytes': (C.c_size_t, [_G]),
     'lhvi_log_likelihood': (C.c_int, [_G, _P, _vp, _vp, _vp, C.c_size_t, _vp]),
     'lhvi_pbp_var_sum': (C.c_int, [_G, _S, _vp, _vp, _vp]),

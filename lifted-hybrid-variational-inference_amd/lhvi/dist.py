@@ -318,6 +318,8 @@ class ShardedRunner:
         s.light_desc, s.n_light = (bp.light_desc.data_ptr() + off * D if cnt else None), cnt
         off, cnt = cut(int(getattr(bp, 'n_pair', 0)), pc.get('pair', 0))
         s.pair_desc, s.n_pair = (bp.pair_desc.data_ptr() + off * D if cnt else None), cnt
+        off, cnt = cut(int(getattr(bp, 'n_cq', 0)), pc.get('cq', 0))
+        s.cq_desc, s.n_cq = (bp.cq_desc.data_ptr() + off * 2 * D if cnt else None), cnt
         off, cnt = cut(int(bp.fast_edges.numel()), pc['fast'])
         if cnt:
             s.fast_edges, s.fast_desc = bp.fast_edges.data_ptr() + 4 * off, bp.fast_desc.data_ptr() + off * D

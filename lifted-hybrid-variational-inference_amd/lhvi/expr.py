@@ -131,6 +131,134 @@ def trace(formula, arity):
     return flat
 
 
+class NotConditionallyQuadratic(Exception):
+    pass
+
+
+CQ_MAGIC = 17233.0          # first word of the conditional-quadratic block behind a formula's bytecode (csrc/potential.hpp)
+
+
+class _Poly:
+    """polynomial of total degree <= 2 in (at most) two continuous arguments: {(i, j): coefficient}"""
+
+    __slots__ = ('t',)
+
+    def __init__(self, t):
+        self.t = {k: v for k, v in t.items() if v != 0.0 or k == (0, 0)}
+
+    @property
+    def const(self):
+        return all(k == (0, 0) for k in self.t)
+
+    def value(self):
+        return self.t.get((0, 0), 0.0)
+
+    def add(self, o, sign=1.0):
+        t = dict(self.t)
+        for k, v in o.t.items():
+            t[k] = t.get(k, 0.0) + sign * v
+        return _Poly(t)
+
+    def mul(self, o):
+        t = {}
+        for (i, j), a in self.t.items():
+            for (k, l), b in o.t.items():
+                if a == 0.0 or b == 0.0:
+                    continue
+                if i + j + k + l > 2:
+                    raise NotConditionallyQuadratic('degree above 2')
+                t[(i + k, j + l)] = t.get((i + k, j + l), 0.0) + a * b
+        return _Poly(t)
+
+
+def conditional_quadratic(flat, roles):
+    """Evaluate a traced program symbolically for every joint state of its discrete arguments.
+
+    ``roles[a]`` = tuple of the state values of a discrete argument, or ``None`` for a continuous one.  Returns
+    ``(dims, coef)``: ``coef[cfg]`` = ``(a00, axy, a11, b0, b1, c)`` with
+    ``formula(x) = a00 u^2 + axy u v + a11 v^2 + b0 u + b1 v + c`` for ``u, v`` = the continuous arguments in argument
+    order and ``cfg`` the mixed-radix index of the discrete states (first discrete argument most significant).
+    Raises ``NotConditionallyQuadratic`` when some state's restriction is not such a polynomial (or there are no / more
+    than two continuous arguments).  The reference's hybrid MLN formulas are all of this family:
+    ``x[0] * eq_op(x[1], x[2])`` with ``eq_op(a, b) = -(a - b) ** 2`` (MLNPotential.py:26-27,
+    Demo/Data/HMLN/GeneratorPaperPopularity.py:28-40, GeneratorRobotMapping.py:60-75)."""
+    import itertools
+    cont = [a for a, r in enumerate(roles) if r is None]
+    disc = [a for a, r in enumerate(roles) if r is not None]
+    if not 1 <= len(cont) <= 2:
+        raise NotConditionallyQuadratic('needs one or two continuous arguments')
+    cpos = {a: i for i, a in enumerate(cont)}
+    dims = [len(roles[a]) for a in disc]
+    coef = []
+    for states in itertools.product(*[range(d) for d in dims]):
+        val = {a: float(roles[a][k]) for a, k in zip(disc, states)}
+        st = []
+        for i in range(0, len(flat), 2):
+            op, v = int(flat[i]), flat[i + 1]
+            if op == OP_ARG:
+                a = int(v)
+                st.append(_Poly({(0, 0): val[a]}) if a in val else _Poly({((1, 0) if cpos[a] == 0 else (0, 1)): 1.0}))
+            elif op == OP_CONST:
+                st.append(_Poly({(0, 0): v}))
+            elif op == OP_NEG:
+                st[-1] = _Poly({k: -c for k, c in st[-1].t.items()})
+            elif op == OP_SQR:
+                st[-1] = st[-1].mul(st[-1])
+            elif op == OP_ABS:
+                if not st[-1].const:
+                    raise NotConditionallyQuadratic('abs of a non-constant')
+                st[-1] = _Poly({(0, 0): abs(st[-1].value())})
+            else:
+                b = st.pop()
+                a = st.pop()
+                if op == OP_ADD:
+                    st.append(a.add(b))
+                elif op == OP_SUB:
+                    st.append(a.add(b, -1.0))
+                elif op == OP_MUL:
+                    st.append(a.mul(b))
+                elif op == OP_DIV:
+                    if not b.const or b.value() == 0.0:
+                        raise NotConditionallyQuadratic('division by a non-constant')
+                    st.append(a.mul(_Poly({(0, 0): 1.0 / b.value()})))
+                elif op == OP_POW:
+                    if a.const and b.const:
+                        st.append(_Poly({(0, 0): a.value() ** b.value()}))
+                    elif b.const and b.value() in (0.0, 1.0, 2.0):
+                        st.append({0.0: _Poly({(0, 0): 1.0}), 1.0: a, 2.0: a.mul(a)}[b.value()])
+                    else:
+                        raise NotConditionallyQuadratic('power of a non-constant')
+                else:
+                    if not (a.const and b.const):
+                        raise NotConditionallyQuadratic('comparison of non-constants')
+                    x, y = a.value(), b.value()
+                    st.append(_Poly({(0, 0): float({OP_EQ: x == y, OP_NE: x != y, OP_LT: x < y, OP_LE: x <= y,
+                                                    OP_GT: x > y, OP_GE: x >= y}[op])}))
+        p = st[-1].t
+        coef.append([p.get((2, 0), 0.0), p.get((1, 1), 0.0), p.get((0, 2), 0.0), p.get((1, 0), 0.0), p.get((0, 1), 0.0),
+                     p.get((0, 0), 0.0)])
+    return dims, coef
+
+
+def cq_block(flat, roles, w):
+    """the parameter block appended behind an MLN potential's bytecode when its formula is conditionally quadratic:
+    ``[CQ_MAGIC, arity, Nd, Nc, role[arity], dims[Nd], coef[ncfg][6]]`` with ``role[a]`` = index among the discrete
+    arguments, or ``-1 - index`` among the continuous ones; coefficients already multiplied by the weight (log phi)"""
+    dims, coef = conditional_quadratic(flat, roles)
+    role, nd, nc = [], 0, 0
+    for r in roles:
+        if r is None:
+            role.append(float(-1 - nc))
+            nc += 1
+        else:
+            role.append(float(nd))
+            nd += 1
+    out = [CQ_MAGIC, float(len(roles)), float(nd), float(nc)] + role + [float(d) for d in dims]
+    for row in coef:
+        out += [float(w) * c for c in row]
+    return out
+
+
 def run(flat, x):
     """Host interpreter of a traced program (used by tests to check tracing against the lambda)."""
     st = []

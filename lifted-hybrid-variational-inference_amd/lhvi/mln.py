@@ -65,9 +65,14 @@ class _FormulaPotential(Potential):
     def get(self, parameters):
         return self._value(self.formula(parameters))
 
+    cq_max_states = 4096        # joint discrete states a conditional-quadratic view may tabulate
+
     def device_spec(self, domains):
         program = self._program(len(domains))
-        return self.kind, [float(self.w), float(len(program) // 2)] + program
+        return self.kind, [float(self.w), float(len(program) // 2)] + program + self._cq_tail(program, domains)
+
+    def _cq_tail(self, program, domains):
+        return []
 
 
 class MLNPotential(_FormulaPotential):
@@ -78,6 +83,20 @@ class MLNPotential(_FormulaPotential):
 
     def _value(self, truth):
         return e ** (truth * self.w)
+
+    def _cq_tail(self, program, domains):
+        """conditional-quadratic view of the formula (``expr.cq_block``), appended behind the bytecode: the evaluators
+        ignore it, the f -> v work-list builder routes such factors to the quadratic-family kernels (csrc/pbp.hip)"""
+        roles = [None if d.continuous else tuple(d.values) for d in domains]
+        states = 1
+        for r in roles:
+            states *= 1 if r is None else len(r)
+        if states > self.cq_max_states:
+            return []
+        try:
+            return expr.cq_block(program, roles, self.w)
+        except expr.NotConditionallyQuadratic:
+            return []
 
     def to_log_potential(self):
         return MLNLogPotential(self.formula, self.w)

@@ -33,6 +33,7 @@ class _ParticleSweep:
     listed_proposal = True          # the proposal kernel starts from per-variable records (else it walks the graph arrays)
     dynamic_f2v = True              # the persistent f2v kernels claim their work in chunks (else static striding)
     paired_light = True             # the light edges are served per factor (pair_desc) instead of per edge (light_desc)
+    cq_routing = True               # conditionally quadratic MLN formulas go to the quadratic-family kernels (else: generic kernel)
 
     # ---- set-up ------------------------------------------------------------------------------
     def _setup(self, graph_like, flat=None, edge_key=None):
@@ -64,24 +65,30 @@ class _ParticleSweep:
         self.uniq = torch.zeros(flat.V, n, dtype=torch.uint8, device=dg.device)
         self.f2v_ticket = torch.zeros(8, dtype=torch.int32, device=dg.device)     # work counters of the heavy f2v kernel (LHVI_PBP_TICKET_WORDS)
         self.flags = (_abi.PBP_EP if self.proposal_approximation == 'EP' else 0) | \
-                     (_abi.PBP_EPBP_DISCRETE if self._epbp_discrete else 0)
+                     (_abi.PBP_EPBP_DISCRETE if self._epbp_discrete else 0) | \
+                     (_abi.PBP_CQ if self.cq_routing and bool((flat.pot_kind == 8).any()) else 0)
         self._views = {}
         self._draws = 0
+        self.cq_desc, self.n_cq = None, 0
+        self.fast_edges = self.generic_edges = self._fast_list = self._generic_list = torch.zeros(1, dtype=torch.int32, device=dg.device)
         # static work lists of the f -> v half sweep (which kernel serves which edge)
         cls = torch.zeros(max(flat.E, 1), dtype=torch.uint8, device=dg.device)
-        _abi.check(_abi.lib().lhvi_pbp_classify(dg.g, dg.p, _abi.ptr(cls), _abi.stream_ptr()))
+        _abi.check(_abi.lib().lhvi_pbp_classify(dg.g, dg.p, self._struct(), _abi.ptr(cls), _abi.stream_ptr()))
         cls = cls[:flat.E]
         self.fast_edges = torch.nonzero((cls == 1) | (cls == 2)).flatten().to(torch.int32)
         self.generic_edges = torch.nonzero(cls == 3).flatten().to(torch.int32)
+        self.cq_edges = torch.nonzero(cls == 4).flatten().to(torch.int32)
         key_dev = None
         if edge_key is not None:
             key_dev = _abi.to_dev(np.ascontiguousarray(edge_key, dtype=np.int32))
             self.fast_edges = self.fast_edges[torch.sort(key_dev[self.fast_edges.long()], stable=True).indices].contiguous()
             self.generic_edges = self.generic_edges[torch.sort(key_dev[self.generic_edges.long()], stable=True).indices].contiguous()
+            self.cq_edges = self.cq_edges[torch.sort(key_dev[self.cq_edges.long()], stable=True).indices].contiguous()
 
         def first_part(edges):      # entries of an (ordered) edge list with key 0
             return int((key_dev[edges.long()] == 0).sum().item()) if key_dev is not None and edges.numel() else 0
-        self.part_counts = {'heavy': 0, 'light': 0, 'fast': 0, 'generic': first_part(self.generic_edges)}
+        self.part_counts = {'heavy': 0, 'light': 0, 'fast': 0, 'generic': first_part(self.generic_edges),
+                            'cq': first_part(self.cq_edges)}
         pad = torch.zeros(1, dtype=torch.int32, device=dg.device)       # keeps the pointers non-null when a list is empty
         self._fast_list = self.fast_edges if self.fast_edges.numel() else pad
         self._generic_list = self.generic_edges if self.generic_edges.numel() else pad
@@ -104,6 +111,18 @@ class _ParticleSweep:
         self.n_prop_desc = int(pv.size)
         self.fast_desc = self.heavy_desc = self.light_desc = self.pair_desc = None
         self.n_heavy = self.n_light = self.n_pair = 0
+        self.cq_terms = 0
+        ncq = int(self.cq_edges.numel())
+        if ncq:
+            # two-partner edges of conditionally quadratic factors (include/lhvi.h, lhvi_pbp_describe_cq)
+            cqd = torch.empty(ncq * 2 * _abi.PBP_DESC_BYTES, dtype=torch.uint8, device=dg.device)
+            _abi.check(_abi.lib().lhvi_pbp_describe_cq(dg.g, dg.p, self._struct(), _abi.ptr(self.cq_edges), ncq,
+                                                       _abi.ptr(cqd), _abi.stream_ptr()))
+            self.cq_desc, self.n_cq = cqd, ncq
+            cw = cqd.view(torch.int32).view(ncq, 2 * _abi.PBP_DESC_BYTES // 4).to(torch.int64)
+            # (output point, partner particle, state) terms: type 1: (np + T) * ny * S;  type 2: S * nx * ny
+            self.cq_terms = int(torch.where(cw[:, 2] == 1, (cw[:, 4] + cw[:, 5]) * cw[:, 9] * cw[:, 3],
+                                            cw[:, 3] * cw[:, 12] * cw[:, 9]).sum().item())
         self.part_counts['pair'] = 0
         self.heavy_terms = self.heavy_grid_terms = 0
         nf = int(self.fast_edges.numel())
@@ -201,6 +220,7 @@ class _ParticleSweep:
         s.light_desc, s.n_light = _abi.ptr(getattr(self, 'light_desc', None)), int(getattr(self, 'n_light', 0))
         if self.paired_light and getattr(self, 'pair_desc', None) is not None:
             s.pair_desc, s.n_pair = _abi.ptr(self.pair_desc), int(self.n_pair)
+        s.cq_desc, s.n_cq = _abi.ptr(getattr(self, 'cq_desc', None)), int(getattr(self, 'n_cq', 0))
         s.f2v_ticket = _abi.ptr(self.f2v_ticket) if self.dynamic_f2v else None
         if self.listed_proposal and getattr(self, 'prop_desc', None) is not None:
             s.prop_desc, s.n_prop_desc = _abi.ptr(self.prop_desc), self.n_prop_desc

@@ -518,6 +518,62 @@ def test_cfg3_paper_popularity_hmln_full_size_matches_oracle(api):
             assert bp.belief(xq, rv) == pytest.approx(want_b, rel=1e-5, abs=1e-12)
 
 
+@pytest.mark.parametrize('solver, n', [('epbp', 12), ('epbp', 64), ('hlbp', 16)])
+def test_conditionally_quadratic_routing_equals_the_generic_kernel(api, solver, n):
+    """The reference's HMLN formulas (x[0] * eq_op(x[1], x[2]), MLNPotential.py:26-27) are quadratic in the continuous
+    arguments per state of the boolean: with LHVI_PBP_CQ their edges are served by the heavy / light / cq kernels.  Same
+    graph, same particles, routing on vs off (every MLN edge through the bytecode interpreter of the generic kernel):
+    every table of every sweep within 1e-9, and every route must actually occur."""
+    from lhvi.pbp import EPBP, HybridLBP
+    g, table = paper_popularity(40, 5, seed=5)
+    rng = np.random.default_rng(n)
+    its = 4
+    draws = []
+
+    def sampler(k, flat, q):
+        if k == len(draws):
+            cont = flat.var_hidden & flat.var_cont
+            lo, hi = flat.dom_lo[flat.var_dom], flat.dom_hi[flat.var_dom]
+            out = np.zeros((flat.V, n))
+            out[cont] = np.clip(rng.standard_normal((int(cont.sum()), n)) * np.sqrt(q[cont, 1:2]) + q[cont, 0:1],
+                                lo[cont, None], hi[cont, None])
+            draws.append(out)
+        return draws[k]
+
+    runs = []
+    for routed in (True, False):
+        bp = (EPBP(g, n=n, proposal_approximation='simple', sampler=sampler) if solver == 'epbp'
+              else HybridLBP(g, n=n, proposal_approximation='EP', sampler=sampler))
+        bp.cq_routing = routed
+        bp.run(its)
+        runs.append(bp)
+    a, b = runs
+    assert a.flags & api.PBP_CQ and not (b.flags & api.PBP_CQ)
+    assert b.n_cq == 0 and b.n_heavy == 0 and b.n_light == 0 and int(b.generic_edges.numel()) > 0
+    import torch
+    types = a.cq_desc.view(torch.int32).view(a.n_cq, 64)[:, 2].cpu().numpy()
+    assert a.n_heavy > 0 and a.n_light > 0 and (types == 1).any() and (types == 2).any()
+    # what is left on the generic list are the messages to booleans whose other arguments are all observed
+    assert int(a.generic_edges.numel()) < int(b.generic_edges.numel())
+    flat = a.flat
+    hid_e = flat.var_hidden[flat.edge_var] & (flat.edge_canon == np.arange(flat.E))
+    npe = a.np_host[flat.edge_var]
+    live = hid_e[:, None] & (np.arange(n)[None, :] < npe[:, None])
+    ce = hid_e & flat.var_cont[flat.edge_var]
+    fa, fb = a.f2v.cpu().numpy(), b.f2v.cpu().numpy()
+    np.testing.assert_allclose(fa[:, :n][live], fb[:, :n][live], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(fa[ce, n:], fb[ce, n:], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(a.v2f.cpu().numpy()[live], b.v2f.cpu().numpy()[live], rtol=1e-9, atol=1e-9)
+    cont = flat.var_hidden & flat.var_cont
+    np.testing.assert_allclose(a.q_dev.cpu().numpy()[cont], b.q_dev.cpu().numpy()[cont], rtol=1e-9, atol=1e-12)
+    # and the routed run against the C oracle (bytecode evaluation on the host)
+    from oracle import oracle
+    o = oracle.PbpOracle(flat, n, ep=(solver == 'hlbp'), epbp=(solver == 'epbp'), var_threshold=3 if solver == 'epbp' else 5)
+    o.run(its, draws)
+    np.testing.assert_allclose(fa[:, :n][live], o.f2v[:, :n][live], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(fa[ce, n:], o.f2v[ce, n:], rtol=RTOL, atol=ATOL)
+
+
 def test_batched_kl_of_tabulated_beliefs(api):
     """utils.kl_tables: trapezoid of kl_continuous' integrand for every variable at once (device), against the host quad"""
     from math import exp, pi, sqrt

@@ -449,3 +449,47 @@ def test_c2fvi_evidence_bookkeeping():
     # an untracked cluster is never split, whatever its spread (the path dependence the fixtures avoid)
     out3, _ = c2fvi.split_evidence(vals, rvc, set(), 2, 10, 0.0)
     assert (out3 == rvc).all()
+
+
+def test_conditional_quadratic_view_of_the_reference_formulas():
+    """every hybrid formula the reference ships (Demo/Data/HMLN/GeneratorPaperPopularity.py:28-40,
+    GeneratorRobotMapping.py:60-75) has a conditional-quadratic view that reproduces the lambda on random points; formulas
+    outside the family (cubic terms, comparisons of continuous arguments, no continuous argument) have none"""
+    from lhvi import expr
+    from lhvi.graph import Domain
+    from lhvi.mln import MLNPotential, eq_op, neg_op, or_op
+    rng = np.random.default_rng(0)
+    b = Domain((0, 1))
+    r = Domain((-15, 15), continuous=True, integral_points=np.linspace(0, 10, 20))
+    tri = Domain((0, 1, 2))
+    cases = [(lambda x: x[0] * eq_op(x[1], x[2]), 0.5, (b, r, r)), (lambda x: eq_op(x[0], 1), 0.3, (r,)),
+             (lambda x: x[0] * eq_op(x[1], 0.341), 3.754, (b, r)), (lambda x: x[1] * eq_op(x[0], x[2]) + 0.5 * x[1], 2.0, (r, b, r)),
+             (lambda x: (x[0] == 2) * x[2] * x[3] - x[1] * x[2] ** 2 / 4, 1.5, (tri, b, r, r))]
+    for formula, w, doms in cases:
+        pot = MLNPotential(formula, w)
+        kind, par = pot.device_spec(doms)
+        ncode = int(par[1])
+        tail = par[2 + 2 * ncode:]
+        assert tail and tail[0] == expr.CQ_MAGIC
+        arity, nd, nc = int(tail[1]), int(tail[2]), int(tail[3])
+        role, dims = [int(v) for v in tail[4:4 + arity]], [int(v) for v in tail[4 + arity:4 + arity + nd]]
+        coef = np.array(tail[4 + arity + nd:]).reshape(-1, 6)
+        assert arity == len(doms) and coef.shape[0] == int(np.prod(dims)) if dims else 1
+        for _ in range(50):
+            x, cfg, cont = [], 0, []
+            for a, d in enumerate(doms):
+                if d.continuous:
+                    x.append(float(rng.uniform(-15, 15)))
+                    cont.append(x[-1])
+                else:
+                    k = int(rng.integers(len(d.values)))
+                    x.append(d.values[k])
+                    cfg = cfg * len(d.values) + k
+            u, v = cont[0], (cont[1] if nc == 2 else 0.0)
+            c = coef[cfg]
+            got = c[0] * u * u + c[1] * u * v + c[2] * v * v + c[3] * u + c[4] * v + c[5]
+            assert got == pytest.approx(w * formula(x), rel=1e-12, abs=1e-10)
+    for formula, doms in [(lambda x: x[0] * x[1] ** 2 * x[2], (b, r, r)), (lambda x: (x[1] > x[2]) * x[0], (b, r, r)),
+                          (lambda x: or_op(neg_op(x[0]), neg_op(x[1])), (b, b)), (lambda x: x[0] * x[1] * x[2], (r, r, r))]:
+        kind, par = MLNPotential(formula, 1.0).device_spec(doms)
+        assert len(par) == 2 + 2 * int(par[1])
