@@ -231,6 +231,13 @@ class GroundKeys:
         i = int(np.searchsorted(self.used, d))
         return int(self.rank[i]) if i < self.used.size and self.used[i] == d else -1
 
+    def var_ids(self, name, lin):
+        """vectorised ``var_id``: variable indices of the instances of atom `name` with row-major instance numbers `lin`
+        (over the atom's logical variables); -1 where no factor mentions the instance"""
+        d = self.base[self.atom_ids[name]] + np.asarray(lin, dtype=np.int64)
+        i = np.minimum(np.searchsorted(self.used, d), self.used.size - 1)
+        return np.where(self.used[i] == d, self.rank[i], -1)
+
     def key_of(self, v):
         a = int(self.var_atom[v])
         atom, sh = self.atoms[a], self.shapes[a]

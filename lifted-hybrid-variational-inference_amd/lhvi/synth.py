@@ -182,3 +182,47 @@ def hybrid_mrf_flat(V=250000, deg=4, seed=0, frac_discrete=0.2, evidence_ratio=0
     value[ev & is_disc] = rng.integers(0, 2, size=int((ev & is_disc).sum()))
     return build_flat(fac_ptr, edge_var, fac_pot, specs, value, is_disc.astype(np.int32), [dc, db])
 
+
+
+def paper_popularity_flat(P=300, T=10, seed=0, points=32):
+    """cfg 3 at any size, on arrays: the paper-popularity hybrid MLN (Demo/Data/HMLN/GeneratorPaperPopularity.py:7-40: atoms,
+    the three weighted formulas, the t1 != t2 constraint) grounded by ``RelationalGraph.ground_flat`` with the evidence pattern
+    of its ``generate_data`` (:51-72: 70 % of the paper / topic popularities ~ U(0, 10); for 70 % of the papers a random
+    subset of their PaperIn atoms; SameSession pairs) and the demo's domain ``Domain((-15, 15), integral_points =
+    linspace(0, 10, points))``.  Returns (flat, keys)."""
+    from .mln import MLNPotential, eq_op
+    from .relational import LV, Atom, ParamF, RelationalGraph
+    rng = np.random.default_rng(seed)
+    dom_b = Domain((0, 1))
+    dom_r = Domain((-15, 15), continuous=True, integral_points=np.linspace(0, 10, points))
+    lvp, lvt = LV(['p%d' % i for i in range(P)]), LV(['t%d' % i for i in range(T)])
+    atoms = (Atom(dom_b, (lvt, lvt), 'SameSession'), Atom(dom_b, (lvp, lvt), 'PaperIn'),
+             Atom(dom_r, (lvt,), 'TopicPopularity'), Atom(dom_r, (lvp,), 'PaperPopularity'))
+    differ = lambda s: s['t1'] != s['t2']
+    differ.vectorized = True
+    pfs = (ParamF(MLNPotential(lambda x: eq_op(x[0], 1), w=0.3), nb=['PaperPopularity(p)']),
+           ParamF(MLNPotential(lambda x: x[0] * eq_op(x[1], x[2]), w=0.5),
+                  nb=['SameSession(t1,t2)', 'TopicPopularity(t1)', 'TopicPopularity(t2)'], constrain=differ),
+           ParamF(MLNPotential(lambda x: x[0] * eq_op(x[1], x[2]), w=1),
+                  nb=['PaperIn(p,t)', 'PaperPopularity(p)', 'TopicPopularity(t)']))
+    flat, keys = RelationalGraph(atoms, pfs).ground_flat(None)
+    value = np.full(flat.V, np.nan)
+
+    def observe(name, lin, vals):
+        v = keys.var_ids(name, lin)
+        value[v[v >= 0]] = np.asarray(vals, dtype=np.float64)[v >= 0]
+    pp = rng.choice(P, int(P * 0.7), replace=False)
+    observe('PaperPopularity', pp, rng.uniform(0, 10, pp.size))
+    tp = rng.choice(T, int(T * 0.7), replace=False)
+    observe('TopicPopularity', tp, rng.uniform(0, 10, tp.size))
+    papers = rng.choice(P, int(P * 0.7), replace=False)
+    cnt = rng.integers(0, T, papers.size)                       # np.random.randint(num_topic) topics per chosen paper
+    mask = np.argsort(rng.random((papers.size, T)), axis=1) < cnt[:, None]      # a random subset of that size per row
+    pi, ti = np.nonzero(mask)
+    observe('PaperIn', papers[pi] * T + ti, rng.integers(0, 2, pi.size))
+    t1 = np.repeat(np.arange(T), T // 2)
+    t2 = rng.integers(0, T, t1.size)
+    keep = t1 != t2
+    observe('SameSession', t1[keep] * T + t2[keep], rng.integers(0, 2, int(keep.sum())))
+    flat.var_value = value
+    return flat, keys

@@ -124,6 +124,63 @@ if 'cfg3' in which:
         rv_clusters=bp.g.num_rv_clusters, f_clusters=bp.g.num_factor_clusters, seconds_10_sweeps_incl_lifting=dt,
         example_map=float(bp.map(table[('TopicPopularity', 't0')])))
 
+if 'cfg3s' in which:
+    # cfg 3 scaled (SURVEY 8(d) cfg 3 template): P papers x T topics grounded straight into arrays, EPBP semantics
+    # on the ground graph, n = 64 particles, 32 integral points, 'simple' proposals, device sampler.  Device time per sweep
+    # (HIP events, after set-up) with the conditional-quadratic routing and with every MLN edge on the generic kernel.
+    from lhvi.pbp import EPBP
+    P_, T_ = int(os.environ.get('CFG3_P', 30000)), int(os.environ.get('CFG3_T', 30))
+    t0 = time.perf_counter()
+    flat, keys = synth.paper_popularity_flat(P_, T_, seed=0)
+    t_ground = time.perf_counter() - t0
+    res = {}
+    for routed in (True, False):
+        bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=1)
+        bp.cq_routing = routed
+        t0 = time.perf_counter()
+        bp._setup(None, flat=flat)
+        torch.cuda.synchronize()
+        t_setup = time.perf_counter() - t0
+        _abi.check(_abi.lib().lhvi_pbp_init(bp.dg.g, bp._struct(), _abi.ptr(bp.eta), _abi.ptr(bp.q_dev), _abi.ptr(bp.f2v),
+                                            _abi.ptr(bp.v2f), _abi.stream_ptr()))
+        bp._generate_sample()
+        for _ in range(2):
+            bp.sweep()
+        torch.cuda.synchronize()
+        reps = 5 if routed else 2
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        fev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for (a, b), (fa, fb) in zip(ev, fev):
+            a.record()
+            _abi.check(_abi.lib().lhvi_pbp_v2f(bp.dg.g, bp._struct(), _abi.ptr(bp.f2v), _abi.ptr(bp.v2f), _abi.stream_ptr()))
+            _abi.check(_abi.lib().lhvi_pbp_proposal(bp.dg.g, bp._struct(), _abi.ptr(bp.f2v), _abi.ptr(bp.eta), _abi.ptr(bp.q_dev), _abi.stream_ptr()))
+            bp._generate_sample()
+            fa.record()
+            bp._launch_f2v(bp._struct())
+            fb.record()
+            b.record()
+        torch.cuda.synchronize()
+        sweep_ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+        f2v_ms = float(np.median([a.elapsed_time(b) for a, b in fev]))
+        res[routed] = dict(sweep_ms=sweep_ms, f2v_ms=f2v_ms, setup_s=t_setup, heavy=bp.n_heavy, heavy_terms=bp.heavy_terms, pair=bp.n_pair,
+                           light=bp.n_light, cq=bp.n_cq, cq_terms=bp.cq_terms, generic=int(bp.generic_edges.numel()),
+                           finite=bool(torch.isfinite(bp.f2v).all().item()))
+        if routed:
+            ref = bp.q_dev.clone()
+        else:
+            qdiff = float((bp.q_dev - ref).abs().max().item())
+        del bp
+    r, u = res[True], res[False]
+    terms = r['heavy_terms'] + r['cq_terms']
+    out(config='cfg3 scaled: paper-popularity HMLN %d papers x %d topics, ground EPBP n=64 T=32 simple' % (P_, T_), rvs=int(flat.V),
+        factors=int(flat.F), edges=int(flat.E), hidden=int(flat.var_hidden.sum()), max_degree=int(np.diff(flat.var_ptr).max()),
+        grounding_host_s=t_ground, setup_s=r['setup_s'], sweep_ms=r['sweep_ms'], f2v_ms=r['f2v_ms'], sweeps_per_s=1e3 / r['sweep_ms'],
+        edge_messages_per_s=2e3 * flat.E / r['sweep_ms'], heavy_edges=r['heavy'], pair_records=r['pair'], cq_edges=r['cq'],
+        generic_edges=r['generic'], heavy_terms=r['heavy_terms'], cq_terms=r['cq_terms'],
+        f2v_fp64_TFLOPs_at_16_flop_per_term=16.0 * terms / (r['f2v_ms'] * 1e-3) / 1e12, finite=r['finite'],
+        generic_routing_sweep_ms=u['sweep_ms'], generic_routing_f2v_ms=u['f2v_ms'], generic_routing_generic_edges=u['generic'],
+        generic_routing_f2v_TFLOPs_same_terms=16.0 * terms / (u['f2v_ms'] * 1e-3) / 1e12, max_abs_q_diff_routed_vs_generic=qdiff)
+
 if 'cfg5' in which:
     # cfg 5: RGM template at 10M ground edges, structured evidence; colour refinement on the device, then lifted VI
     flat, sym, rv0, f0 = synth.rgm_structured_flat()          # C = 2000, B = 1250: 10.0 M ground edges, ~10 k rv clusters
