@@ -226,3 +226,37 @@ def paper_popularity_flat(P=300, T=10, seed=0, points=32):
     observe('SameSession', t1[keep] * T + t2[keep], rng.integers(0, 2, int(keep.sum())))
     flat.var_value = value
     return flat, keys
+
+
+def concat_flats(flats):
+    """disjoint union of ground ``FlatGraph``s that share their potential table and domains (e.g. one relational template
+    grounded several times with different evidence): variables, factors and edges of copy k follow those of copy k - 1"""
+    import copy
+    f0 = flats[0]
+    for f in flats[1:]:
+        if not (np.array_equal(f.pot_param, f0.pot_param) and np.array_equal(f.pot_off, f0.pot_off)
+                and np.array_equal(f.dom_val, f0.dom_val) and np.array_equal(f.dom_ptr, f0.dom_ptr)) or f.lifted:
+            raise ValueError('concat_flats needs ground graphs over the same potentials and domains')
+    vo = np.cumsum([0] + [f.V for f in flats])
+    fo = np.cumsum([0] + [f.F for f in flats])
+    eo = np.cumsum([0] + [f.E for f in flats])
+    cat = lambda name, off=None, tail=False: np.concatenate(
+        [(getattr(f, name)[1:] if tail and k else getattr(f, name)) + (0 if off is None else off[k]) for k, f in enumerate(flats)]
+    ).astype(getattr(f0, name).dtype)
+    out = copy.copy(f0)
+    out.__dict__.pop('_view_cache', None)
+    out.V, out.F, out.E = int(vo[-1]), int(fo[-1]), int(eo[-1])
+    out.fac_ptr, out.var_ptr = cat('fac_ptr', eo, True), cat('var_ptr', eo, True)
+    out.edge_var, out.edge_fac, out.edge_pos = cat('edge_var', vo), cat('edge_fac', fo), cat('edge_pos')
+    out.edge_canon, out.var_edge = cat('edge_canon', eo), cat('var_edge', eo)
+    for name in ('edge_count', 'fac_pot', 'var_value', 'var_dom', 'var_mult', 'fac_mult'):
+        setattr(out, name, cat(name))
+    out.rvs, out.factors, out.var_index, out.fac_index = [], [], {}, {}
+    return out
+
+
+def paper_popularity_copies(copies, P=300, T=10, seed=0, points=32):
+    """`copies` independent groundings of the paper-popularity HMLN at its reference size (cfg 3: 300 papers x 10 topics,
+    E = 9 570 each), each with its own evidence draw -- the "same graph x k" scaling BASELINE.json uses for cfg 4, which keeps
+    every variable's degree (and with it the range of the log messages) what the reference's own model has"""
+    return concat_flats([paper_popularity_flat(P, T, seed + k, points)[0] for k in range(copies)])

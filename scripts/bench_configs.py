@@ -125,13 +125,14 @@ if 'cfg3' in which:
         example_map=float(bp.map(table[('TopicPopularity', 't0')])))
 
 if 'cfg3s' in which:
-    # cfg 3 scaled (SURVEY 8(d) cfg 3 template): P papers x T topics grounded straight into arrays, EPBP semantics
-    # on the ground graph, n = 64 particles, 32 integral points, 'simple' proposals, device sampler.  Device time per sweep
-    # (HIP events, after set-up) with the conditional-quadratic routing and with every MLN edge on the generic kernel.
+    # cfg 3 scaled (SURVEY 8(d) cfg 3 template): CFG3_COPIES independent groundings of the reference-size model (300 papers x 10
+    # topics, own evidence each) -- or, with CFG3_P / CFG3_T, one grounding of that size -- straight into arrays; EPBP semantics on
+    # the ground graph, n = 64 particles, 32 integral points, 'simple' proposals, device sampler.  Device time per sweep (HIP events,
+    # after set-up) with the conditional-quadratic routing and with every MLN edge on the generic kernel.
     from lhvi.pbp import EPBP
-    P_, T_ = int(os.environ.get('CFG3_P', 30000)), int(os.environ.get('CFG3_T', 30))
+    P_, T_, K_ = int(os.environ.get('CFG3_P', 300)), int(os.environ.get('CFG3_T', 10)), int(os.environ.get('CFG3_COPIES', 286))
     t0 = time.perf_counter()
-    flat, keys = synth.paper_popularity_flat(P_, T_, seed=0)
+    flat = synth.paper_popularity_copies(K_, P_, T_, seed=0)
     t_ground = time.perf_counter() - t0
     res = {}
     for routed in (True, False):
@@ -172,13 +173,13 @@ if 'cfg3s' in which:
         del bp
     r, u = res[True], res[False]
     terms = r['heavy_terms'] + r['cq_terms']
-    out(config='cfg3 scaled: paper-popularity HMLN %d papers x %d topics, ground EPBP n=64 T=32 simple' % (P_, T_), rvs=int(flat.V),
+    out(config='cfg3 scaled: %d x paper-popularity HMLN %d papers x %d topics, ground EPBP n=64 T=32 simple' % (K_, P_, T_), rvs=int(flat.V),
         factors=int(flat.F), edges=int(flat.E), hidden=int(flat.var_hidden.sum()), max_degree=int(np.diff(flat.var_ptr).max()),
         grounding_host_s=t_ground, setup_s=r['setup_s'], sweep_ms=r['sweep_ms'], f2v_ms=r['f2v_ms'], sweeps_per_s=1e3 / r['sweep_ms'],
         edge_messages_per_s=2e3 * flat.E / r['sweep_ms'], heavy_edges=r['heavy'], pair_records=r['pair'], cq_edges=r['cq'],
         generic_edges=r['generic'], heavy_terms=r['heavy_terms'], cq_terms=r['cq_terms'],
         f2v_fp64_TFLOPs_at_16_flop_per_term=16.0 * terms / (r['f2v_ms'] * 1e-3) / 1e12, finite=r['finite'],
-        generic_routing_sweep_ms=u['sweep_ms'], generic_routing_f2v_ms=u['f2v_ms'], generic_routing_generic_edges=u['generic'],
+        generic_routing_sweep_ms=u['sweep_ms'], generic_routing_f2v_ms=u['f2v_ms'], generic_routing_generic_edges=u['generic'], generic_routing_finite=u['finite'],
         generic_routing_f2v_TFLOPs_same_terms=16.0 * terms / (u['f2v_ms'] * 1e-3) / 1e12, max_abs_q_diff_routed_vs_generic=qdiff)
 
 if 'cfg5' in which:
