@@ -34,7 +34,7 @@ for k in fetch:
     traffic[k] = {'read_bytes': rd, 'write_bytes': wr, 'hbm_bytes': rd + wr}
 json.dump(traffic, open(os.path.join(prof, tag + '_traffic.json'), 'w'), indent=1)
 lines = ['# %s PMC summary (per launch averages)\n' % tag, '| kernel | read GB (2x FETCH_SIZE) | write GB | ' + ' | '.join([]) + '\n']
-lines = ['# %s PMC summary (per-launch averages; bench.py on the 10M-edge hybrid MRF)\n\n' % tag,
+lines = ['# %s PMC summary (per-launch averages; see the file name for the workload)\n\n' % tag,
          '| kernel | HBM read GB (2 x FETCH_SIZE) | HBM write GB |\n|---|---|---|\n']
 for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]['hbm_bytes']):
     lines.append('| %s | %.3f | %.3f |\n' % (k, v['read_bytes'] / 1e9, v['write_bytes'] / 1e9))
