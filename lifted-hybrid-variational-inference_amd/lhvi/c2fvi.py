@@ -72,8 +72,10 @@ def cp_run(refiner, values, rvc, fc, tracked):
     return rvc, fc, tracked
 
 
-def split_evidence_pass(values, rvc, tracked, k, iteration, epsilon):
-    """``CompressedGraph.split_evidence`` (CGWO:236-247): one pass over the clusters in ``clustered_evidence``"""
+def split_evidence_pass(values, rvc, tracked, k, iteration, epsilon, member_order=None):
+    """``CompressedGraph.split_evidence`` (CGWO:236-247): one pass over the clusters in ``clustered_evidence``.
+    ``member_order(members) -> permutation or None``: the order in which k-means walks a cluster's members (default: ground
+    order; the reference walks a Python set, see ``lifting.kmeans_assign``)"""
     rvc = rvc.copy()
     tracked = set(tracked)
     nxt = int(rvc.max()) + 1
@@ -82,7 +84,7 @@ def split_evidence_pass(values, rvc, tracked, k, iteration, epsilon):
         vals = values[members]
         if not (np.sqrt(np.var(vals)) > epsilon):
             continue
-        assign = kmeans_assign(vals, k, iteration)
+        assign = kmeans_assign(vals, k, iteration, order=member_order(members) if member_order else None)
         if assign is None:                         # a single member or a single value: nothing to split
             if members.size == 1:
                 tracked.discard(c)
@@ -99,12 +101,12 @@ def split_evidence_pass(values, rvc, tracked, k, iteration, epsilon):
     return rvc, tracked
 
 
-def split_evidence(values, rvc, tracked, k, iteration, epsilon):
+def split_evidence(values, rvc, tracked, k, iteration, epsilon, member_order=None):
     """``VarInference.split_evidence`` (C2FVI:33-37): passes until the number of clusters stops changing"""
     prev = -1
     while prev != int(rvc.max()) + 1:
         prev = int(rvc.max()) + 1
-        rvc, tracked = split_evidence_pass(values, rvc, tracked, k, iteration, epsilon)
+        rvc, tracked = split_evidence_pass(values, rvc, tracked, k, iteration, epsilon, member_order)
     return rvc, tracked
 
 
@@ -149,7 +151,8 @@ def run_c2fvi(g, engine, refiner, K, iteration, lr, opts, init=None, observer=No
     fe_log = []
     stage = flat = cg = obs_var = None
     for rnd in range(int(iteration / opts['update_obs_its'])):                      # C2FVI:338-345
-        rvc, tracked = split_evidence(values, rvc, tracked, opts['k_mean_k'], opts['k_mean_its'], epsilon)
+        rvc, tracked = split_evidence(values, rvc, tracked, opts['k_mean_k'], opts['k_mean_its'], epsilon,
+                                      opts.get('kmeans_member_order'))
         rvc, fc, tracked = cp_run(refiner, values, rvc, fc, tracked)
         epsilon = max(epsilon - d, opts['min_obs_var'])
         cg = CompressedGraph(g)
@@ -249,9 +252,11 @@ class VarInference(_Variational):
         self.init = None              # (eta_c, tau_d) per ground variable to start from (parity tests inject the reference's draw)
         self.observer = None
         self.refiner = None           # lhvi.c2f.Refiner; default: colour refinement on the device
+        self.kmeans_member_order = None   # members -> permutation: the order k-means walks a cluster in (default: ground order)
 
     def _options(self):
-        return {k: getattr(self, k) for k in ('k_mean_k', 'k_mean_its', 'update_obs_its', 'output_its', 'min_obs_var', 'gaussian_obs')}
+        return {k: getattr(self, k) for k in ('k_mean_k', 'k_mean_its', 'update_obs_its', 'output_its', 'min_obs_var', 'gaussian_obs',
+                                              'kmeans_member_order')}
 
     def run(self, iteration=100, lr=0.1, is_log=True, log_fe=True):
         self.is_log, self.log_fe = is_log, log_fe

@@ -162,7 +162,7 @@ def initial_colors_flat(flat, is_split_cont_evidence=True):
     return rv_color, f_color, sym_row[flat.fac_pot]
 
 
-def kmeans_assign(vals, k=2, iteration=10):
+def kmeans_assign(vals, k=2, iteration=10, order=None):
     """the k-means of ``SuperRV.split_by_evidence`` (``CompressedGraphWithObs.py:78-130``) on the member values of one
     evidence cluster: distinct values with multiplicities, centroids seeded with the first k distinct values, ``iteration``
     Lloyd rounds, members assigned to the nearest final centroid (first on ties).  Returns the piece index of every member,
@@ -171,12 +171,13 @@ def kmeans_assign(vals, k=2, iteration=10):
     The reference seeds the centroids in the iteration order of a Python ``set`` of RV objects, i.e. in an order that
     changes from run to run; here the order is the order of ``vals`` (ground-variable order), which makes the split
     deterministic (identical to the reference whenever the outcome does not depend on the seeding, e.g. when a cluster
-    holds at most k distinct values)."""
+    holds at most k distinct values).  ``order``: a permutation of the members to walk them in instead -- a test that has
+    recorded the reference's set order for this cluster replays it through this argument."""
     vals = np.asarray(vals, dtype=np.float64)
     if vals.size <= 1:
         return None
     distinct, counts = [], {}
-    for v in vals.tolist():                     # insertion order = ground order
+    for v in (vals if order is None else vals[np.asarray(order)]).tolist():   # insertion order = ground order
         if v not in counts:
             distinct.append(v)
             counts[v] = 0

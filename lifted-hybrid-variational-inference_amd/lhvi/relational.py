@@ -222,11 +222,16 @@ class GroundKeys:
         self.used, self.rank, self.var_dense, self.var_atom, self._index_of = used, rank, var_dense, var_atom, index_of
 
     def var_id(self, key):
-        a = self.atom_ids[key[0]]
+        a = self.atom_ids.get(key[0])
+        if a is None or len(key) - 1 != len(self.shapes[a]):
+            return -1                   # (evidence about something the model does not ground is ignored, RelationalGraph.py:94-102)
         atom, sh = self.atoms[a], self.shapes[a]
         lin = 0
         for k, inst in enumerate(key[1:]):
-            lin = lin * sh[k] + self._index_of(atom.lvs[k])[inst]
+            i = self._index_of(atom.lvs[k]).get(inst)
+            if i is None:
+                return -1
+            lin = lin * sh[k] + i
         d = self.base[a] + lin
         i = int(np.searchsorted(self.used, d))
         return int(self.rank[i]) if i < self.used.size and self.used[i] == d else -1

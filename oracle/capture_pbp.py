@@ -258,6 +258,15 @@ def _edges(g):
     return [(f, rv) for f in g.factors for rv in f.nb]
 
 
+def _safe(fn, *args):
+    """a query of the reference, NaN where the reference itself fails: its normalisers exponentiate unnormalised
+    log-beliefs (EPBP:342, HLBP:372), which overflows on models with strong evidence (the robot-mapping HMLN)"""
+    try:
+        return float(fn(*args))
+    except OverflowError:
+        return float('nan')
+
+
 def capture_epbp(cg, name, g, n, its, approx, seed):
     import EPBPLogVersion as REP
     np.random.seed(seed)
@@ -290,9 +299,9 @@ def capture_epbp(cg, name, g, n, its, approx, seed):
                 continue
             done_c += 1
             x0 = xs[i][2]
-            nb.append([i, x0, float(bp.belief(x0, rv))])
+            nb.append([i, x0, _safe(bp.belief, x0, rv)])
         else:
-            nb.append([i, float(rv.domain.values[0]), float(bp.belief(rv.domain.values[0], rv))])
+            nb.append([i, float(rv.domain.values[0]), _safe(bp.belief, rv.domain.values[0], rv)])
     rec['belief'] = np.array(nb)
     # interval probabilities (EPBP:356-375: 5-point over 20-point trapezoid) for every hidden continuous rv
     pr = []
@@ -300,7 +309,7 @@ def capture_epbp(cg, name, g, n, its, approx, seed):
         if rv.value is None and rv.domain.continuous:
             lo, hi = rv.domain.values
             a, b = lo + 0.35 * (hi - lo), lo + 0.6 * (hi - lo)
-            pr.append([i, a, b, float(bp.probability(a, b, rv))])
+            pr.append([i, a, b, _safe(bp.probability, a, b, rv)])
     rec['probability'] = np.array(pr).reshape(-1, 4)
     rec['meta'] = json.dumps({'model': cg.modelio.dump_model(g), 'n': n, 'iterations': its, 'approx': approx,
                               'seed': seed, 'solver': 'EPBP'})
@@ -375,13 +384,13 @@ def capture_hlbp(cg, name, g, n, its, approx, seed, c2f=-1):
         xs.append([float(x) for x in pts])
         lb.append([float(bp.belief_rv_query(x, rv, bp.sample)) for x in pts])
         mp.append(float(bp.map(rv)))
-        bel.append(float(bp.belief(pts[2], rv)))
+        bel.append(_safe(bp.belief, pts[2], rv))
     pr = []                # HLBP:384-403 interval probabilities
     for i, rv in enumerate(g.rvs):
         if rv.value is None and rv.domain.continuous:
             lo, hi = rv.domain.values
             a, b = lo + 0.35 * (hi - lo), lo + 0.6 * (hi - lo)
-            pr.append([i, a, b, float(bp.probability(a, b, rv))])
+            pr.append([i, a, b, _safe(bp.probability, a, b, rv)])
     # final samples / q per ground rv (through its cluster)
     V = len(g.rvs)
     sample = np.full((V, n), np.nan)

@@ -203,9 +203,24 @@ def capture_c2fvi(cg, name, g, K, T, seed, iterations, lr, update_obs_its=10):
         snaps.append(('round', _c2f_state(cg, vi, g)))
         orig_adam(n)
     vi.init_param, vi.ADAM_update = init_param, adam
+    # k-means of an evidence cluster is seeded in the iteration order of a Python set of RV objects (CGWO:83-97), which
+    # differs from run to run: record the order every split saw (observation only -- the original method runs unchanged)
+    import CompressedGraphWithObs as CGWO
+    index = {id(rv): i for i, rv in enumerate(g.rvs)}
+    orders = {}
+    orig_split = CGWO.SuperRV.split_by_evidence
+
+    def split_by_evidence(self, k=2, iteration=10):
+        seen = [index[id(rv)] for rv in self.rvs]
+        orders[','.join(map(str, sorted(seen)))] = seen
+        return orig_split(self, k, iteration)
+    CGWO.SuperRV.split_by_evidence = split_by_evidence
     np.random.seed(seed)
-    with cg.quiet():
-        vi.run(iterations, lr=lr)
+    try:
+        with cg.quiet():
+            vi.run(iterations, lr=lr)
+    finally:
+        CGWO.SuperRV.split_by_evidence = orig_split
     vi.ADAM_update = orig_adam
     rec = {}
     init = [s for k, s in snaps if k == 'init'][0]
@@ -224,7 +239,8 @@ def capture_c2fvi(cg, name, g, K, T, seed, iterations, lr, update_obs_its=10):
                                   if rv.value is None else np.nan for rv in rvs])
     rec['map'] = np.array([float(vi.map(rv)) for rv in rvs])
     rec['meta'] = json.dumps({'model': cg.modelio.dump_model(g), 'K': K, 'T': T, 'seed': seed, 'iterations': iterations,
-                              'lr': lr, 'update_obs_its': update_obs_its, 'solver': 'C2FVarInference'})
+                              'lr': lr, 'update_obs_its': update_obs_its, 'solver': 'C2FVarInference',
+                              'kmeans_orders': orders})
     path = os.path.join(cg.OUT, 'vi_%s.npz' % name)
     np.savez_compressed(path, **rec)
     print('wrote', path, os.path.getsize(path), 'bytes', 'rounds', len(rounds),

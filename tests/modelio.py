@@ -19,6 +19,11 @@ FORMULAS = {
     'x0_eq1c': lambda x: x[0] * eq_op(x[1], 0.341),
     'nand': lambda x: (1 - x[0]) + (1 - x[1]) - (1 - x[0]) * (1 - x[1]),
     'any3': lambda x: 1 - (x[0] == 0) * (x[1] == 0) * (x[2] == 0),
+    # the robot-mapping template (Demo/Data/HMLN/GeneratorRobotMapping.py:41-75)
+    'rm_aligned': lambda x: 1 - (x[0] == 1) * (x[1] == 1) * (x[2] == 0) * (x[3] == 1) * (1 - x[4]),
+    'x0_eq_0.1': lambda x: x[0] * eq_op(x[1], 0.1),
+    'x0_eq_0.02': lambda x: x[0] * eq_op(x[1], 0.02),
+    'x0_eq_0.001': lambda x: x[0] * eq_op(x[1], 0.001),
 }
 _FORMULA_NAME = {id(f): k for k, f in FORMULAS.items()}
 

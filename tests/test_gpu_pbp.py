@@ -73,6 +73,10 @@ def test_epbp_matches_reference_golden(api, golden_dir, name):
         assert bp.map(rvs[i]) == pytest.approx(z['map'][i], abs=1e-4)
     for i, x0, want in z['belief']:
         # "marginals within 1e-5 of the CPU reference" (BASELINE.json north_star)
+        if np.isnan(want):       # the reference's own normaliser overflowed here (e ** log-belief, EPBP:342): so does the restated one
+            with pytest.raises(OverflowError):
+                bp.belief(x0, rvs[int(i)])
+            continue
         assert bp.belief(x0, rvs[int(i)]) == pytest.approx(want, rel=1e-5, abs=1e-7)
     # batched queries: every variable in one f2v launch -- the recorded log-beliefs again, and the reference's MAPs
     k = z['query_x'].shape[1]
@@ -108,8 +112,9 @@ def test_epbp_matches_reference_golden(api, golden_dir, name):
     assert np.isnan(pall[[i for i in range(flat.V) if i not in chid]]).all()
     # discrete rows of belief_all: normalised over the states, like EPBP.belief
     ball = bp.belief_all(np.zeros((flat.V, 2))).cpu().numpy()
+    overflowed = {int(i) for i, x0, want in z['belief'] if np.isnan(want)}
     for i in hid:
-        if not flat.var_cont[i]:
+        if not flat.var_cont[i] and i not in overflowed:
             vals = list(rvs[i].domain.values)
             for k in range(min(2, len(vals))):
                 assert ball[i, k] == pytest.approx(bp.belief(vals[k], rvs[i]), rel=1e-10)
@@ -145,9 +150,11 @@ def test_hlbp_matches_reference_golden(api, golden_dir, name):
     for i in hid:
         if rvs[i].domain.continuous:
             np.testing.assert_allclose(Q[rvs[i].cluster], z['final_q'][i], rtol=1e-9)
+    overflowed = {i for i in hid if np.isnan(z['belief_mid'][i])}     # the reference's normaliser overflowed (e ** log-belief, HLBP:372)
     for i in hid[:6]:
         assert bp.map(rvs[i]) == pytest.approx(z['map'][i], abs=1e-4)
-        assert bp.belief(z['query_x'][i][2], rvs[i]) == pytest.approx(z['belief_mid'][i], rel=1e-5, abs=1e-7)
+        if i not in overflowed:
+            assert bp.belief(z['query_x'][i][2], rvs[i]) == pytest.approx(z['belief_mid'][i], rel=1e-5, abs=1e-7)
     flat = bp.flat
     pa, pb = np.zeros(flat.V), np.ones(flat.V)
     for i, a, b, want in z['probability']:      # HLBP:384-403 against the reference's recorded values
@@ -177,6 +184,8 @@ def test_hlbp_matches_reference_golden(api, golden_dir, name):
     lo = np.array([rv.domain.values[0] for rv in flat.rvs], dtype=float)
     pall = bp.probability_all(lo + 0.25, lo + 1.5).cpu().numpy()
     for c, i in first.items():
+        if i in overflowed:
+            continue
         if rvs[i].domain.continuous:
             assert ball[c, 0] == pytest.approx(z['belief_mid'][i], rel=1e-5, abs=1e-7)
             assert ball[c, 0] == pytest.approx(bp.belief(z['query_x'][i][2], rvs[i]), rel=1e-10)

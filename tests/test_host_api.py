@@ -282,7 +282,9 @@ def test_flat_grounding_matches_reference_grounding(golden_dir):
         R.ParamF(M.MLNPotential(lambda x: x[0] * M.eq_op(x[1], x[2]), w=0.5),
                  nb=['SameSession(t1,t2)', 'TopicPopularity(t1)', 'TopicPopularity(t2)'], constrain=lambda sub: sub['t1'] != sub['t2']),
         R.ParamF(M.MLNPotential(lambda x: x[0] * M.eq_op(x[1], x[2]), w=1), nb=['PaperIn(p,t)', 'PaperPopularity(p)', 'TopicPopularity(t)'])))
-    for name, rel in (('rgm_100x10', rgm), ('paper_popularity_300x10', pp)):
+    from lhvi import generators
+    for name, rel in (('rgm_100x10', rgm), ('paper_popularity_300x10', pp), ('rgm_100x10', generators.rgm()),
+                      ('paper_popularity_300x10', generators.paper_popularity()), ('robot_mapping', generators.robot_mapping())):
         flat, keys = rel.ground_flat()
         want = rec[name]
         assert sorted(list(keys.key_of(v)) for v in range(flat.V)) == want['rvs']
@@ -493,3 +495,46 @@ def test_conditional_quadratic_view_of_the_reference_formulas():
                           (lambda x: or_op(neg_op(x[0]), neg_op(x[1])), (b, b)), (lambda x: x[0] * x[1] * x[2], (r, r, r))]:
         kind, par = MLNPotential(formula, 1.0).device_spec(doms)
         assert len(par) == 2 + 2 * int(par[1])
+
+
+def test_robot_mapping_model_matches_the_reference_demo(golden_dir, tmp_path):
+    """The reference's second HMLN demo (Demo/HMLN/DemoRobotMapping.py:11-27 on Demo/Data/HMLN/GeneratorRobotMapping.py):
+    ``generators.robot_mapping()`` grounded by the object path and by ``ground_flat`` against the reference's own grounding,
+    the demo's evidence (raw data + closed world; recorded by oracle/capture_robot.py) applied through both paths, and the
+    raw-data parser on a text with the same constructs (comment blocks, valued atoms, atoms naming no ground variable)"""
+    import gzip, json
+    from lhvi import generators
+    rec = json.load(gzip.open(os.path.join(golden_dir, 'grounding.json.gz'), 'rt'))['robot_mapping']
+    rel = generators.robot_mapping()
+    g, table = rel.ground_graph()
+    assert sorted(list(k) for k in table) == rec['rvs']
+    assert len(g.rvs) == 1591 and len(g.factors) == 3182 and sum(len(f.nb) for f in g.factors) == 14282
+    key_of = {id(rv): list(k) for k, rv in table.items()}
+    pf_of = {id(pf.potential): i for i, pf in enumerate(rel.param_factors)}
+    assert sorted([pf_of[id(f.potential)], [key_of[id(rv)] for rv in f.nb]] for f in g.factors) == rec['factors']
+    # arity-5 formula, constants and the depth domain whose integral points leave the domain
+    assert max(len(f.nb) for f in g.factors) == 5
+    depth = table[('Depth', 'A1_1')].domain
+    assert depth.values == (0, 0.5) and depth.integral_points.max() == 1.0
+    # evidence: the demo's dict through add_evidence and through ground_flat
+    data = {tuple(k): v for k, v in rec['evidence']}
+    data.update({tuple(k): 1 for k in rec['raw_keys_without_atom']})       # e.g. SegType(A1_1, Door): names no atom, ignored
+    rel.add_evidence(data)
+    hidden = [k for k, rv in table.items() if rv.value is None]
+    from collections import Counter
+    assert Counter(k[0] for k in hidden) == {'SegType': 111, 'PartOf': 55, 'Depth': 20, 'Length': 9}
+    flat, keys = generators.robot_mapping().ground_flat(data)
+    assert int(flat.var_hidden.sum()) == 195
+    for v in range(flat.V):
+        val = table[keys.key_of(v)].value
+        assert (val is None and np.isnan(flat.var_value[v])) or val == flat.var_value[v]
+    # closed world: what the demo adds to the raw data is every non-query discrete atom that the data does not mention
+    raw = {k: v for k, v in data.items() if not (k[0] == 'Aligned' and v == 0)}
+    filled = generators.closed_world(table, raw, query=('SegType', 'PartOf', 'Length', 'Depth'))
+    assert {k: float(v) for k, v in filled.items() if k in table} == {tuple(k): v for k, v in rec['evidence']}
+    # the parser
+    text = 'PartOf(A1_2,LA1)\n\nSegType(A1_1,Door)\n/*\nSegType(A1_10,Wall)\n*/\nLength(A1_1) 0.0979\n/* x */\nDepth(A1_3) 0.02\nAligned(A1_2,A1_1)\n'
+    path = tmp_path / 'raw'
+    path.write_text(text)
+    # (a one-line comment opens a block that only a later "*/" line closes, exactly as the reference's parser behaves)
+    assert generators.load_raw_data(str(path)) == {('PartOf', 'A1_2', 'LA1'): 1, ('SegType', 'A1_1', 'Door'): 1, ('Length', 'A1_1'): 0.0979}

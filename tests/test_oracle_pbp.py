@@ -12,8 +12,9 @@ from lhvi.flat import flatten
 from oracle import oracle
 
 EPBP_CASES = ['epbp_kalman_simple', 'epbp_kalman_ep', 'epbp_kalman_n64', 'epbp_hybrid_ep', 'epbp_hybrid_simple',
-              'epbp_hmln']
-HLBP_CASES = ['hlbp_rgm_small', 'hlbp_hybrid', 'hlbp_kalman_full', 'hlbp_hmln', 'hlbp_hmln_ep', 'hlbp_hmln_lifted']
+              'epbp_hmln', 'epbp_robot']
+HLBP_CASES = ['hlbp_rgm_small', 'hlbp_hybrid', 'hlbp_kalman_full', 'hlbp_hmln', 'hlbp_hmln_ep', 'hlbp_hmln_lifted',
+              'hlbp_robot']
 C2F_CASES = ['hlbp_c2f_rgm', 'hlbp_c2f_rgm_simple', 'hlbp_c2f_hmln']
 
 # fp64 tolerance of the log-message tables: the oracle fuses nothing and follows the reference's operation

@@ -12,7 +12,7 @@ from lhvi.flat import flatten
 from oracle import oracle
 
 VI_CASES = ['kalman_k1', 'kalman_k3', 'hybrid_k2', 'hybrid_k1_t5', 'rgm_small_k2']
-LVI_CASES = ['lifted_rgm_small_k2', 'lifted_kalman_full_k2', 'lifted_hybrid_k2']
+LVI_CASES = ['lifted_rgm_small_k2', 'lifted_kalman_full_k2', 'lifted_hybrid_k2', 'lifted_robot_k2']
 
 
 def load_vi(golden_dir, name):
@@ -69,7 +69,7 @@ def test_vi_oracle_matches_reference(golden_dir, name):
 
 
 # ---- C2FVarInference (coarse-to-fine lifted VI with Gaussian observation clusters) -----------------------------------
-C2F_CASES = ['c2f_rgm_k2', 'c2f_hmln_k2']
+C2F_CASES = ['c2f_rgm_k2', 'c2f_hmln_k2', 'c2f_robot_k2']
 C2F_OPTS = dict(k_mean_k=2, k_mean_its=10, output_its=0, min_obs_var=0, gaussian_obs=True)
 
 
@@ -137,6 +137,22 @@ def c2fvi_round_checker(z, rvs, seen):
     return observer
 
 
+def kmeans_order_of(meta):
+    """replay of the set order the reference's k-means walked each evidence cluster in (recorded by oracle/capture_vi.py;
+    fixtures without the record keep ground order: their clusters never hold more than k distinct values)"""
+    rec = meta.get('kmeans_orders')
+    if not rec:
+        return None
+
+    def order(members):
+        seen = rec.get(','.join(map(str, sorted(int(m) for m in members))))
+        if seen is None:
+            return None
+        pos = {int(m): i for i, m in enumerate(members)}
+        return [pos[i] for i in seen]
+    return order
+
+
 def check_c2fvi_result(z, rvs, res):
     cont = np.array([rv.value is None and rv.domain.continuous for rv in rvs])
     assert oracle.canonical_labels(res['rvc']) == z['final_rv_label'].tolist()
@@ -157,8 +173,8 @@ def test_c2fvi_oracle_matches_reference(golden_dir, name):
     g, rvs, factors = modelio.load_model(meta['model'], API)
     seen = []
     res = c2fvi.run_c2fvi(g, OracleViEngine(meta['K'], meta['T']), OracleRefiner(g), meta['K'], meta['iterations'], meta['lr'],
-                          dict(C2F_OPTS, update_obs_its=meta['update_obs_its']), init=(z['eta_c0'], z['tau_d0']),
-                          observer=c2fvi_round_checker(z, rvs, seen))
+                          dict(C2F_OPTS, update_obs_its=meta['update_obs_its'], kmeans_member_order=kmeans_order_of(meta)),
+                          init=(z['eta_c0'], z['tau_d0']), observer=c2fvi_round_checker(z, rvs, seen))
     assert seen == list(range(meta['iterations'] // meta['update_obs_its']))
     assert (np.nan_to_num(z['round_variance']) > 0).any()          # the fixture does exercise Gaussian observations
     check_c2fvi_result(z, rvs, res)
