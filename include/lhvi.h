@@ -29,7 +29,8 @@ extern "C" {
 
 #define LHVI_ABI_VERSION 8   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
                               * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t;  7: lhvi_pbp_t gained pair_desc;
-                              * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq */
+                              * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq; the colour
+                              *    refinement calls take a method and return four result words */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -357,15 +358,23 @@ int lhvi_adam_step(double* theta, double* m, double* s, const double* g, int64_t
 int lhvi_softmax_rows(const double* tau, double* out, int64_t rows, int32_t cols, int32_t stride, void* stream);
 
 /* ---- Colour refinement (CompressedGraphWithObs.py / CompressedGraphSorted.py) --------------------
- * One half-round each; colours are dense int32 ids.  ws: lhvi_color_workspace_bytes(g) bytes. */
+ * One half-round each; colours are dense int32 ids (the rank of the item's 64-bit signature fingerprint among the distinct
+ * fingerprints).  ws: lhvi_color_workspace_bytes(g) bytes.
+ * result: device int32[4] = {number of colours, fingerprint collision (two items agree on the first 64-bit fingerprint and
+ * differ on the second: retry), table overflow (method 0 only: repeat the call with method 1), 0}.
+ * method 0: the signature kernel finds-or-inserts each fingerprint in a 1 M-slot hash table and only the distinct keys are
+ *           sorted (the answer has few of them: ~30 k on a 10 M-edge relational graph);
+ * method 1: radix sort of all items' fingerprints.  Both give the same colours. */
+#define LHVI_COLOR_HASH 0
+#define LHVI_COLOR_SORT 1
 size_t lhvi_color_workspace_bytes(const lhvi_graph_t* g);
 /* SuperF.split_by_structure CGWO.py:152-175: signature = (old colour, nb rv colours [sorted iff symmetric]) */
 int lhvi_color_refine_factors(const lhvi_graph_t* g, const uint8_t* pot_symmetric_per_factor, const int32_t* rv_color,
-                              const int32_t* f_color, int32_t* f_color_out, int32_t* n_colors_out,
-                              void* ws, size_t ws_bytes, void* stream);
+                              const int32_t* f_color, int32_t* f_color_out, int32_t* result,
+                              void* ws, size_t ws_bytes, int32_t method, void* stream);
 /* SuperRV.split_by_structure CGWO.py:47-76: signature = (old colour, sorted multiset of nb factor colours) */
 int lhvi_color_refine_rvs(const lhvi_graph_t* g, const int32_t* f_color, const int32_t* rv_color,
-                          int32_t* rv_color_out, int32_t* n_colors_out, void* ws, size_t ws_bytes, void* stream);
+                          int32_t* rv_color_out, int32_t* result, void* ws, size_t ws_bytes, int32_t method, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,14 @@
 // fingerprint is a *sum* of per-neighbour mixes: integer addition commutes, so the multiset needs no
 // sorting and the atomics below are deterministic.
 //
-// Bound: HBM (gathers + a 64-bit radix sort), ~120 B per edge per round.
+// Two ways to turn fingerprints into dense colours, with identical results (colour = rank of h1 among the distinct h1):
+//   method 0  hash table: the kernel that builds an item's fingerprint also finds-or-inserts it in an open-addressing table of
+//             TABLE_SLOTS 64-bit keys (the answer has few distinct keys: ~30 k at 10 M edges), the thread whose insertion
+//             succeeded appends (key, slot) to the list of distinct keys, only that list is sorted, and every item reads its
+//             colour through its slot.  More than TABLE_SLOTS / 2 distinct keys raise the overflow flag: the caller repeats the
+//             half round with method 1.
+//   method 1  radix sort of all n keys + flag + scan + scatter (n log n traffic: ~120 B per edge per round).
+// Bound: HBM (the colour gathers of the signature kernels).
 #include "common.hpp"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -30,13 +37,12 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {   // splitmix64 finalise
 
 constexpr uint64_t SEED1 = 0x243F6A8885A308D3ull, SEED2 = 0x13198A2E03707344ull;
 
-__global__ void __launch_bounds__(BLOCK) factor_sig_kernel(lhvi_graph_t g, const uint8_t* __restrict__ symmetric,
-                                                          const int32_t* __restrict__ rv_color,
-                                                          const int32_t* __restrict__ f_color, uint64_t seed,
-                                                          uint64_t* __restrict__ h1, uint64_t* __restrict__ h2,
-                                                          uint32_t* __restrict__ idx) {
-    int f = blockIdx.x * BLOCK + threadIdx.x;
-    if (f >= g.F) return;
+constexpr uint64_t EMPTY_KEY = ~0ull;          // never a fingerprint: h1 == EMPTY_KEY is mapped to EMPTY_KEY - 1 in both methods
+__device__ __forceinline__ uint64_t key_of(uint64_t h) { return h == EMPTY_KEY ? EMPTY_KEY - 1 : h; }
+
+__device__ __forceinline__ void factor_sig(const lhvi_graph_t& g, const uint8_t* __restrict__ symmetric,
+                                           const int32_t* __restrict__ rv_color, const int32_t* __restrict__ f_color,
+                                           uint64_t seed, int f, uint64_t& o1, uint64_t& o2) {
     const int base = g.fac_ptr[f];
     const int a = min(g.fac_ptr[f + 1] - base, LHVI_MAX_ARITY);
     int32_t c[LHVI_MAX_ARITY];
@@ -58,6 +64,18 @@ __global__ void __launch_bounds__(BLOCK) factor_sig_kernel(lhvi_graph_t g, const
             a2 = mix64(a2 ^ (((uint64_t)(uint32_t)c[p] + 0x51ull) * 0xD6E8FEB86659FD93ull));
         }
     }
+    o1 = key_of(a1); o2 = a2;
+}
+
+__global__ void __launch_bounds__(BLOCK) factor_sig_kernel(lhvi_graph_t g, const uint8_t* __restrict__ symmetric,
+                                                          const int32_t* __restrict__ rv_color,
+                                                          const int32_t* __restrict__ f_color, uint64_t seed,
+                                                          uint64_t* __restrict__ h1, uint64_t* __restrict__ h2,
+                                                          uint32_t* __restrict__ idx) {
+    int f = blockIdx.x * BLOCK + threadIdx.x;
+    if (f >= g.F) return;
+    uint64_t a1, a2;
+    factor_sig(g, symmetric, rv_color, f_color, seed, f, a1, a2);
     h1[f] = a1; h2[f] = a2; idx[f] = (uint32_t)f;
 }
 
@@ -93,7 +111,7 @@ __global__ void __launch_bounds__(BLOCK) rv_sig_accum_kernel(lhvi_graph_t g, con
     if (hi - lo > HUB_DEGREE) return;
     uint64_t a = 0, b = 0;
     for (int k = lo; k < hi; ++k) sig_terms(g, f_color, seed, k, a, b);
-    h1[v] += a; h2[v] += b;
+    h1[v] = key_of(h1[v] + a); h2[v] += b;
 }
 
 __global__ void __launch_bounds__(BLOCK) rv_sig_accum_hub_kernel(lhvi_graph_t g, const int32_t* __restrict__ f_color,
@@ -111,7 +129,116 @@ __global__ void __launch_bounds__(BLOCK) rv_sig_accum_hub_kernel(lhvi_graph_t g,
         a += ((uint64_t)(uint32_t)__shfl_xor((int)(a >> 32), off) << 32) | (uint32_t)__shfl_xor((int)a, off);
         b += ((uint64_t)(uint32_t)__shfl_xor((int)(b >> 32), off) << 32) | (uint32_t)__shfl_xor((int)b, off);
     }
-    if (lane == 0) { h1[v] += a; h2[v] += b; }
+    if (lane == 0) { h1[v] = key_of(h1[v] + a); h2[v] += b; }
+}
+
+// ---- method 0: hash table -------------------------------------------------------------------------------------------------
+constexpr int TABLE_BITS = 20;
+constexpr uint32_t TABLE_SLOTS = 1u << TABLE_BITS;          // 1 M slots: up to 512 k distinct colours per half round
+constexpr uint32_t MAX_DISTINCT = TABLE_SLOTS / 2;
+constexpr int MAX_PROBES = 4096;
+
+struct Table {
+    uint64_t* keys;         // [TABLE_SLOTS] EMPTY_KEY or a fingerprint h1
+    uint64_t* h2;           // [TABLE_SLOTS] h2 of the item that inserted the key
+    int32_t* rank;          // [TABLE_SLOTS] colour of the slot's key
+    uint64_t* dkeys;        // [MAX_DISTINCT] distinct keys in insertion order, EMPTY_KEY beyond the count
+    uint32_t* dslot;        // [MAX_DISTINCT] their slots
+    uint64_t* dkeys_sorted;
+    uint32_t* dslot_sorted;
+    uint32_t* slot;         // [n] slot of every item
+    uint32_t* count;        // [2] number of distinct keys, overflow flag
+};
+
+// slot of `key`, inserting it if absent.  Slots only ever go from EMPTY_KEY to a key, so a plain (possibly stale) load that
+// shows another key or this key is final, and one that shows EMPTY_KEY is settled by the compare-and-swap.
+__device__ __forceinline__ uint32_t find_or_insert(const Table& t, uint64_t key, uint64_t h2) {
+    uint32_t s = (uint32_t)(key >> 17) & (TABLE_SLOTS - 1);
+    for (int probe = 0; probe < MAX_PROBES; ++probe) {
+        uint64_t cur = t.keys[s];
+        if (cur == EMPTY_KEY) {
+            cur = atomicCAS((unsigned long long*)&t.keys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (cur == EMPTY_KEY) {                     // this thread inserted the key: it owns the slot's h2 and the list entry
+                t.h2[s] = h2;
+                const uint32_t pos = atomicAdd(&t.count[0], 1u);
+                if (pos < MAX_DISTINCT) { t.dkeys[pos] = key; t.dslot[pos] = s; }
+                else t.count[1] = 1;
+                return s;
+            }
+        }
+        if (cur == key) return s;
+        s = (s + 1) & (TABLE_SLOTS - 1);
+    }
+    t.count[1] = 1;                                     // a probe sequence this long means the table is (nearly) full
+    return 0;
+}
+
+__global__ void __launch_bounds__(BLOCK) factor_insert_kernel(lhvi_graph_t g, const uint8_t* __restrict__ symmetric,
+                                                             const int32_t* __restrict__ rv_color,
+                                                             const int32_t* __restrict__ f_color, uint64_t seed,
+                                                             uint64_t* __restrict__ h2, Table t) {
+    const int f = blockIdx.x * BLOCK + threadIdx.x;
+    if (f >= g.F) return;
+    uint64_t a1, a2;
+    factor_sig(g, symmetric, rv_color, f_color, seed, f, a1, a2);
+    h2[f] = a2;
+    t.slot[f] = find_or_insert(t, a1, a2);
+}
+
+__global__ void __launch_bounds__(BLOCK) rv_insert_kernel(lhvi_graph_t g, const int32_t* __restrict__ f_color,
+                                                         const int32_t* __restrict__ rv_color, uint64_t seed,
+                                                         uint64_t* __restrict__ h2, Table t) {
+    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v >= g.V) return;
+    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    if (hi - lo > HUB_DEGREE) return;
+    uint64_t a = mix64((uint64_t)(uint32_t)rv_color[v] ^ seed ^ SEED2);
+    uint64_t b = mix64(((uint64_t)(uint32_t)rv_color[v] + seed) * 0xA24BAED4963EE407ull + SEED1);
+    for (int k = lo; k < hi; ++k) sig_terms(g, f_color, seed, k, a, b);
+    a = key_of(a);
+    h2[v] = b;
+    t.slot[v] = find_or_insert(t, a, b);
+}
+
+__global__ void __launch_bounds__(BLOCK) rv_insert_hub_kernel(lhvi_graph_t g, const int32_t* __restrict__ f_color,
+                                                             const int32_t* __restrict__ rv_color, uint64_t seed,
+                                                             uint64_t* __restrict__ h2, Table t) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (i >= (g.hub_vars ? g.n_hubs : g.V)) return;
+    const int v = g.hub_vars ? g.hub_vars[i] : i;
+    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    if (hi - lo <= HUB_DEGREE) return;
+    uint64_t a = 0, b = 0;
+    for (int k = lo + lane; k < hi; k += 64) sig_terms(g, f_color, seed, k, a, b);
+    for (int off = 32; off > 0; off >>= 1) {
+        a += ((uint64_t)(uint32_t)__shfl_xor((int)(a >> 32), off) << 32) | (uint32_t)__shfl_xor((int)a, off);
+        b += ((uint64_t)(uint32_t)__shfl_xor((int)(b >> 32), off) << 32) | (uint32_t)__shfl_xor((int)b, off);
+    }
+    if (lane == 0) {
+        a = key_of(a + mix64((uint64_t)(uint32_t)rv_color[v] ^ seed ^ SEED2));
+        b += mix64(((uint64_t)(uint32_t)rv_color[v] + seed) * 0xA24BAED4963EE407ull + SEED1);
+        h2[v] = b;
+        t.slot[v] = find_or_insert(t, a, b);
+    }
+}
+
+// colour of a slot = position of its key among the sorted distinct keys
+__global__ void __launch_bounds__(BLOCK) slot_rank_kernel(Table t) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t n = min(t.count[0], MAX_DISTINCT);
+    if (i < n) t.rank[t.dslot_sorted[i]] = (int32_t)i;
+}
+
+// result: [0] number of colours, [1] fingerprint collision, [2] table overflow
+__global__ void __launch_bounds__(BLOCK) assign_kernel(int n, Table t, const uint64_t* __restrict__ h2,
+                                                      int32_t* __restrict__ color_out, int32_t* __restrict__ result) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0) { result[0] = (int32_t)min(t.count[0], MAX_DISTINCT); if (t.count[1]) result[2] = 1; }
+    if (i >= n) return;
+    const uint32_t s = t.slot[i];
+    color_out[i] = t.rank[s];
+    if (t.h2[s] != h2[i]) result[1] = 1;               // equal h1, different h2: the host retries with another seed
 }
 
 __global__ void __launch_bounds__(BLOCK) flag_kernel(int n, const uint64_t* __restrict__ key_sorted,
@@ -144,6 +271,7 @@ struct Workspace {
     int32_t *flag, *rank;
     void* temp;
     size_t temp_bytes;
+    Table table;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -153,7 +281,11 @@ static size_t temp_bytes_for(size_t n) {
     (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                               (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
     (void)rocprim::inclusive_scan(nullptr, b, (int32_t*)nullptr, (int32_t*)nullptr, n, rocprim::plus<int32_t>(), (hipStream_t)0);
-    return align_up(a > b ? a : b);
+    size_t c = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, c, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                              (uint32_t*)nullptr, (size_t)MAX_DISTINCT, 0, 64, (hipStream_t)0);
+    a = a > b ? a : b;
+    return align_up(a > c ? a : c);
 }
 
 static size_t carve(Workspace* w, void* base, size_t n) {
@@ -165,7 +297,32 @@ static size_t carve(Workspace* w, void* base, size_t n) {
     w->flag = (int32_t*)take(n * 4); w->rank = (int32_t*)take(n * 4);
     w->temp_bytes = temp_bytes_for(n);
     w->temp = take(w->temp_bytes);
+    Table& t = w->table;
+    t.keys = (uint64_t*)take((size_t)TABLE_SLOTS * 8); t.h2 = (uint64_t*)take((size_t)TABLE_SLOTS * 8);
+    t.rank = (int32_t*)take((size_t)TABLE_SLOTS * 4);
+    t.dkeys = (uint64_t*)take((size_t)MAX_DISTINCT * 8); t.dkeys_sorted = (uint64_t*)take((size_t)MAX_DISTINCT * 8);
+    t.dslot = (uint32_t*)take((size_t)MAX_DISTINCT * 4); t.dslot_sorted = (uint32_t*)take((size_t)MAX_DISTINCT * 4);
+    t.slot = (uint32_t*)take(n * 4);
+    t.count = (uint32_t*)take(256);
     return off;
+}
+
+static int table_reset(const Table& t, hipStream_t st) {
+    if (hipMemsetAsync(t.keys, 0xff, (size_t)TABLE_SLOTS * 8, st) != hipSuccess) return LHVI_E_LAUNCH;
+    if (hipMemsetAsync(t.dkeys, 0xff, (size_t)MAX_DISTINCT * 8, st) != hipSuccess) return LHVI_E_LAUNCH;
+    if (hipMemsetAsync(t.count, 0, 2 * sizeof(uint32_t), st) != hipSuccess) return LHVI_E_LAUNCH;
+    return LHVI_OK;
+}
+
+// distinct keys -> ranks -> colours (the list beyond the count holds EMPTY_KEY, which sorts last)
+static int table_rank_and_assign(Workspace& w, int n, int32_t* color_out, int32_t* result, hipStream_t st) {
+    Table& t = w.table;
+    size_t tb = w.temp_bytes;
+    if (rocprim::radix_sort_pairs(w.temp, tb, t.dkeys, t.dkeys_sorted, t.dslot, t.dslot_sorted, (size_t)MAX_DISTINCT, 0, 64, st) != hipSuccess)
+        return LHVI_E_LAUNCH;
+    hipLaunchKernelGGL(slot_rank_kernel, dim3(grid_for(MAX_DISTINCT)), dim3(BLOCK), 0, st, t);
+    hipLaunchKernelGGL(assign_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, st, n, t, w.h2, color_out, result);
+    return check_launch();
 }
 
 static int rank_and_scatter(Workspace& w, int n, int32_t* color_out, int32_t* result, hipStream_t st) {
@@ -193,19 +350,27 @@ size_t lhvi_color_workspace_bytes(const lhvi_graph_t* g) {
     return carve(&w, nullptr, n < 1 ? 1 : n);
 }
 
-// n_colors_out: device int32[2] = {number of colours, collision flag (retry with another seed if 1)}
+// result: device int32[4] = {number of colours, collision flag (retry with another seed if 1), table overflow (repeat the
+// half round with method 1), 0}
 int lhvi_color_refine_factors(const lhvi_graph_t* g, const uint8_t* symmetric, const int32_t* rv_color,
                               const int32_t* f_color, int32_t* f_color_out, int32_t* n_colors_out,
-                              void* ws, size_t ws_bytes, void* stream) {
-    if (!g || !rv_color || !f_color || !f_color_out || !n_colors_out || !ws) return LHVI_E_ARG;
+                              void* ws, size_t ws_bytes, int32_t method, void* stream) {
+    if (!g || !rv_color || !f_color || !f_color_out || !n_colors_out || !ws || method < 0 || method > 1) return LHVI_E_ARG;
     if (ws_bytes < lhvi_color_workspace_bytes(g)) return LHVI_E_ARG;
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(n_colors_out, 0, 2 * sizeof(int32_t), st) != hipSuccess) return LHVI_E_LAUNCH;
+    if (hipMemsetAsync(n_colors_out, 0, 4 * sizeof(int32_t), st) != hipSuccess) return LHVI_E_LAUNCH;
     if (g->F == 0) return LHVI_OK;
     Workspace w;
     size_t n = (size_t)(g->V > g->F ? g->V : g->F);
     carve(&w, ws, n);
     const uint64_t seed = 0;
+    if (method == 0) {
+        if (int rc = table_reset(w.table, st)) return rc;
+        hipLaunchKernelGGL(factor_insert_kernel, dim3(grid_for(g->F)), dim3(BLOCK), 0, st, *g, symmetric, rv_color, f_color, seed,
+                           w.h2, w.table);
+        if (int rc = check_launch()) return rc;
+        return table_rank_and_assign(w, g->F, f_color_out, n_colors_out, st);
+    }
     hipLaunchKernelGGL(factor_sig_kernel, dim3(grid_for(g->F)), dim3(BLOCK), 0, st, *g, symmetric, rv_color, f_color,
                        seed, w.h1, w.h2, w.idx);
     if (int rc = check_launch()) return rc;
@@ -213,16 +378,25 @@ int lhvi_color_refine_factors(const lhvi_graph_t* g, const uint8_t* symmetric, c
 }
 
 int lhvi_color_refine_rvs(const lhvi_graph_t* g, const int32_t* f_color, const int32_t* rv_color,
-                          int32_t* rv_color_out, int32_t* n_colors_out, void* ws, size_t ws_bytes, void* stream) {
-    if (!g || !rv_color || !f_color || !rv_color_out || !n_colors_out || !ws) return LHVI_E_ARG;
+                          int32_t* rv_color_out, int32_t* n_colors_out, void* ws, size_t ws_bytes, int32_t method, void* stream) {
+    if (!g || !rv_color || !f_color || !rv_color_out || !n_colors_out || !ws || method < 0 || method > 1) return LHVI_E_ARG;
     if (ws_bytes < lhvi_color_workspace_bytes(g)) return LHVI_E_ARG;
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(n_colors_out, 0, 2 * sizeof(int32_t), st) != hipSuccess) return LHVI_E_LAUNCH;
+    if (hipMemsetAsync(n_colors_out, 0, 4 * sizeof(int32_t), st) != hipSuccess) return LHVI_E_LAUNCH;
     if (g->V == 0) return LHVI_OK;
     Workspace w;
     size_t n = (size_t)(g->V > g->F ? g->V : g->F);
     carve(&w, ws, n);
     const uint64_t seed = 0;
+    if (method == 0) {
+        if (int rc = table_reset(w.table, st)) return rc;
+        hipLaunchKernelGGL(rv_insert_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, st, *g, f_color, rv_color, seed, w.h2, w.table);
+        const int64_t nh = g->hub_vars ? g->n_hubs : g->V;
+        if (nh > 0 && g->nnz > 0)
+            hipLaunchKernelGGL(rv_insert_hub_kernel, dim3(grid_for(nh * 64)), dim3(BLOCK), 0, st, *g, f_color, rv_color, seed, w.h2, w.table);
+        if (int rc = check_launch()) return rc;
+        return table_rank_and_assign(w, g->V, rv_color_out, n_colors_out, st);
+    }
     hipLaunchKernelGGL(rv_sig_init_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, st, g->V, rv_color, seed, w.h1, w.h2, w.idx);
     if (g->nnz > 0)
     {

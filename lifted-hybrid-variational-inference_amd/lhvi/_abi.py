@@ -82,6 +82,7 @@ PBP_CQ = 512
 PBP_SKIP_CQ = 1024
 ABI_VERSION = 8             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
 PBP_DESC_BYTES = 128
+COLOR_HASH, COLOR_SORT = 0, 1     # method of lhvi_color_refine_* (LHVI_COLOR_HASH / LHVI_COLOR_SORT)
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE
 
 _G, _P, _S, _VI = C.POINTER(GraphStruct), C.POINTER(PotsStruct), C.POINTER(PbpStruct), C.POINTER(ViStruct)
@@ -130,8 +131,8 @@ SIGNATURES = {
     'lhvi_adam_step': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64, _f64, _i32, _f64, _vp]),
     'lhvi_softmax_rows': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     'lhvi_color_workspace_bytes': (_sz, [_G]),
-    'lhvi_color_refine_factors': (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'lhvi_color_refine_rvs': (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'lhvi_color_refine_factors': (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
+    'lhvi_color_refine_rvs': (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
 }
 
 _lib = None

@@ -248,7 +248,7 @@ class CompressedGraph:
             torch = _abi.require_gpu()
             self._dev = dict(flat=flat, dg=dg, sym=_abi.to_dev(sym) if sym.size else None,
                              ws=torch.empty(ws_bytes, dtype=torch.uint8, device=dg.device), ws_bytes=ws_bytes,
-                             res=torch.zeros(2, dtype=torch.int32, device=dg.device))
+                             res=torch.zeros(4, dtype=torch.int32, device=dg.device))
         return self._dev
 
     def _upload_colors(self):
@@ -288,27 +288,37 @@ class CompressedGraph:
             out.append(float(np.var(values[(rv_color == c) & ~np.isnan(values)])))
         return out
 
-    def split_factors(self):
+    def _half_round(self, call, what):
+        """one refinement half round on the device: hash-table relabelling, repeated through the radix sort if the table
+        overflowed (more than half a million distinct colours); returns the number of colours"""
         d = self._upload_colors()
+        for method in (self.method, _abi.COLOR_SORT):
+            call(d, method)
+            n, collision, overflow = (int(x) for x in d['res'].cpu()[:3])
+            if collision:
+                raise _abi.LhviError('colour refinement fingerprint collision (%s side)' % what)
+            if not overflow:
+                return n
+        raise _abi.LhviError('colour refinement: table overflow reported by the sort path')
+
+    method = _abi.COLOR_HASH
+
+    def split_factors(self):
         l = _abi.lib()
-        _abi.check(l.lhvi_color_refine_factors(d['dg'].g, _abi.ptr(d['sym']), _abi.ptr(d['rvc']), _abi.ptr(d['fc']),
-                                               _abi.ptr(d['fc2']), _abi.ptr(d['res']), _abi.ptr(d['ws']),
-                                               d['ws_bytes'], _abi.stream_ptr()))
-        n, collision = (int(x) for x in d['res'].cpu())
-        if collision:
-            raise _abi.LhviError('colour refinement fingerprint collision (factor side)')
+        n = self._half_round(lambda d, m: _abi.check(l.lhvi_color_refine_factors(
+            d['dg'].g, _abi.ptr(d['sym']), _abi.ptr(d['rvc']), _abi.ptr(d['fc']), _abi.ptr(d['fc2']), _abi.ptr(d['res']),
+            _abi.ptr(d['ws']), d['ws_bytes'], m, _abi.stream_ptr())), 'factor')
+        d = self._dev
         d['fc'], d['fc2'] = d['fc2'], d['fc']
         self.num_factor_clusters = n
         self._objects = None
 
     def split_rvs(self):
-        d = self._upload_colors()
         l = _abi.lib()
-        _abi.check(l.lhvi_color_refine_rvs(d['dg'].g, _abi.ptr(d['fc']), _abi.ptr(d['rvc']), _abi.ptr(d['rvc2']),
-                                           _abi.ptr(d['res']), _abi.ptr(d['ws']), d['ws_bytes'], _abi.stream_ptr()))
-        n, collision = (int(x) for x in d['res'].cpu())
-        if collision:
-            raise _abi.LhviError('colour refinement fingerprint collision (variable side)')
+        n = self._half_round(lambda d, m: _abi.check(l.lhvi_color_refine_rvs(
+            d['dg'].g, _abi.ptr(d['fc']), _abi.ptr(d['rvc']), _abi.ptr(d['rvc2']), _abi.ptr(d['res']), _abi.ptr(d['ws']),
+            d['ws_bytes'], m, _abi.stream_ptr())), 'variable')
+        d = self._dev
         d['rvc'], d['rvc2'] = d['rvc2'], d['rvc']
         self.num_rv_clusters = n
         self._objects = None
@@ -468,35 +478,56 @@ def lift_flat(flat, rv_color, f_color):
         potentials=flat.potentials, domains=flat.domains)
 
 
-def refine_flat(flat, symmetric, rv_color, f_color, max_rounds=1000, dg=None, stats=None):
+def refine_flat(flat, symmetric, rv_color, f_color, max_rounds=1000, dg=None, stats=None, method=None, device_out=False):
     """Colour passing on flat arrays entirely on the device (the large-graph path: no Python objects).
-    Same loop as ``CompressedGraph.run``: factor half-round, rv half-round, until #rv colours is stable.
-    ``dg``: an already uploaded ``DeviceGraph`` of ``flat``; ``stats``: dict that receives the number of rounds."""
+    Same loop as ``CompressedGraph.run``: factor half-round, rv half-round, until #rv colours is stable; one host
+    synchronisation per round (both halves' result words are read together).
+    ``dg``: an already uploaded ``DeviceGraph`` of ``flat``; ``stats``: dict that receives the number of rounds;
+    ``method``: ``_abi.COLOR_HASH`` (default; a half round whose table overflows is repeated by sorting) or ``_abi.COLOR_SORT``;
+    ``device_out``: return the colour arrays as device tensors instead of NumPy arrays."""
     torch = _abi.require_gpu()
     dg = dg or _abi.DeviceGraph(flat)
     l = _abi.lib()
+    method = _abi.COLOR_HASH if method is None else method
     ws_bytes = int(l.lhvi_color_workspace_bytes(dg.g))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dg.device)
-    res = torch.zeros(2, dtype=torch.int32, device=dg.device)
+    res = torch.zeros(8, dtype=torch.int32, device=dg.device)          # [0:4] factor half, [4:8] variable half
+    res_f, res_v = res[:4], res[4:]
     sym = _abi.to_dev(np.asarray(symmetric, dtype=np.uint8))
-    rvc = _abi.to_dev(np.asarray(rv_color, dtype=np.int32))
-    fc = _abi.to_dev(np.asarray(f_color, dtype=np.int32))
+    rvc = rv_color if torch.is_tensor(rv_color) else _abi.to_dev(np.asarray(rv_color, dtype=np.int32))
+    fc = f_color if torch.is_tensor(f_color) else _abi.to_dev(np.asarray(f_color, dtype=np.int32))
     rvc2, fc2 = rvc.clone(), fc.clone()
     n_rv = int(rvc.max().item()) + 1 if flat.V else 0
     prev = -1
-    rounds = 0
+    rounds = sorted_halves = 0
+    st = _abi.stream_ptr()
+
+    def factors(m):
+        _abi.check(l.lhvi_color_refine_factors(dg.g, _abi.ptr(sym), _abi.ptr(rvc), _abi.ptr(fc), _abi.ptr(fc2),
+                                               _abi.ptr(res_f), _abi.ptr(ws), ws_bytes, m, st))
+
+    def rvs(m):
+        _abi.check(l.lhvi_color_refine_rvs(dg.g, _abi.ptr(fc2), _abi.ptr(rvc), _abi.ptr(rvc2), _abi.ptr(res_v),
+                                           _abi.ptr(ws), ws_bytes, m, st))
     while prev != n_rv and rounds < max_rounds:
         prev = n_rv
-        _abi.check(l.lhvi_color_refine_factors(dg.g, _abi.ptr(sym), _abi.ptr(rvc), _abi.ptr(fc), _abi.ptr(fc2),
-                                               _abi.ptr(res), _abi.ptr(ws), ws_bytes, _abi.stream_ptr()))
-        fc, fc2 = fc2, fc
-        _abi.check(l.lhvi_color_refine_rvs(dg.g, _abi.ptr(fc), _abi.ptr(rvc), _abi.ptr(rvc2), _abi.ptr(res),
-                                           _abi.ptr(ws), ws_bytes, _abi.stream_ptr()))
-        rvc, rvc2 = rvc2, rvc
-        n_rv, collision = (int(x) for x in res.cpu())
-        if collision:
+        factors(method)
+        rvs(method)
+        r = [int(x) for x in res.cpu()]
+        if r[2] or r[6]:                               # a table overflowed: the round again through the sort
+            sorted_halves += 2
+            factors(_abi.COLOR_SORT)
+            rvs(_abi.COLOR_SORT)
+            r = [int(x) for x in res.cpu()]
+        if r[1] or r[5]:
             raise _abi.LhviError('colour refinement fingerprint collision')
+        fc, fc2 = fc2, fc
+        rvc, rvc2 = rvc2, rvc
+        n_rv = r[4]
         rounds += 1
     if stats is not None:
         stats['rounds'] = rounds
+        stats['sorted_half_rounds'] = sorted_halves
+    if device_out:
+        return rvc, fc
     return rvc.cpu().numpy(), fc.cpu().numpy()

@@ -116,6 +116,31 @@ def test_color_refinement_large_random_vs_oracle(api):
     assert oracle.canonical_labels(f_color) == oracle.canonical_labels(of)
 
 
+def test_color_refinement_hash_table_equals_the_radix_sort(api):
+    """the two relabelling methods of lhvi_color_refine_* (fingerprints into a hash table and only the distinct keys sorted /
+    radix sort of every item's fingerprint) give the same colour ARRAYS, not just the same partition; a graph with more
+    distinct colours than the table holds falls back to the sort inside refine_flat and still agrees"""
+    from lhvi import synth, lifting, _abi
+    flat, sym, rv0, f0 = synth.rgm_flat(C=300, B=200, n_values=5, evidence_ratio=0.2, seed=2)
+    sa, sb = {}, {}
+    ra, fa = lifting.refine_flat(flat, sym, rv0, f0, method=_abi.COLOR_HASH, stats=sa)
+    rb, fb = lifting.refine_flat(flat, sym, rv0, f0, method=_abi.COLOR_SORT, stats=sb)
+    np.testing.assert_array_equal(ra, rb)
+    np.testing.assert_array_equal(fa, fb)
+    assert sa['rounds'] == sb['rounds'] and sa['sorted_half_rounds'] == 0 and int(ra.max()) + 1 < flat.V
+    # every variable its own initial colour: 600 k distinct keys > 512 k table entries
+    big = synth.random_gaussian_mrf(V=600_000, deg=4, seed=3)
+    rv1 = np.arange(big.V, dtype=np.int32)
+    f1 = np.zeros(big.F, dtype=np.int32)
+    symb = np.zeros(big.F, dtype=np.uint8)
+    st = {}
+    r1, g1 = lifting.refine_flat(big, symb, rv1, f1, stats=st)
+    r2, g2 = lifting.refine_flat(big, symb, rv1, f1, method=_abi.COLOR_SORT)
+    assert st['sorted_half_rounds'] > 0 and int(r1.max()) + 1 == big.V
+    np.testing.assert_array_equal(r1, r2)
+    np.testing.assert_array_equal(g1, g2)
+
+
 def test_flat_grounded_rgm_matches_object_path(api):
     """RelationalGraph.ground_flat -> GaBP on the arrays, against ground_graph -> GaBP on the objects (different rv /
     factor order because the object path keeps sets; same marginals)"""
