@@ -14,11 +14,10 @@
 // sorting and the atomics below are deterministic.
 //
 // Two ways to turn fingerprints into dense colours, with identical results (colour = rank of h1 among the distinct h1):
-//   method 0  hash table: the kernel that builds an item's fingerprint also finds-or-inserts it in an open-addressing table of
-//             TABLE_SLOTS 64-bit keys (the answer has few distinct keys: ~30 k at 10 M edges), the thread whose insertion
-//             succeeded appends (key, slot) to the list of distinct keys, only that list is sorted, and every item reads its
-//             colour through its slot.  More than TABLE_SLOTS / 2 distinct keys raise the overflow flag: the caller repeats the
-//             half round with method 1.
+//   method 0  hash table: the kernel that builds the fingerprints also inserts each wavefront's distinct keys in an
+//             open-addressing table of TABLE_SLOTS 64-bit keys (the answer has few distinct keys: ~30 k at 10 M edges), only the
+//             distinct keys are ranked (bucket counting, no general sort), and every item looks its colour up.  More than
+//             TABLE_SLOTS / 2 distinct keys raise the overflow flag: the caller repeats the half round with method 1.
 //   method 1  radix sort of all n keys + flag + scan + scatter (n log n traffic: ~120 B per edge per round).
 // Bound: HBM (the colour gathers of the signature kernels).
 #include "common.hpp"
@@ -133,76 +132,113 @@ __global__ void __launch_bounds__(BLOCK) rv_sig_accum_hub_kernel(lhvi_graph_t g,
 }
 
 // ---- method 0: hash table -------------------------------------------------------------------------------------------------
+// Per half round: (1) the signature kernels store every item's fingerprints and insert the DISTINCT keys of each wavefront
+// (neighbouring items of a relational graph mostly share their signature) with compare-and-swap -- no plain load ever probes
+// the table inside the kernel that fills it: per-XCD L2s are not coherent, a slot once read as empty would stay empty for that
+// XCD and every later item would fall back to the atomic; (2) the distinct keys are ranked without a general sort: counted
+// into 65 536 buckets by their top 16 bits while they are inserted, one block scans the counts, the keys are scattered into
+// their bucket's segment and each key counts the smaller keys of its segment (a handful) -- rank = numeric order of the
+// 64-bit keys, exactly what the radix sort of method 1 gives; (3) every item finds its key with plain loads (a new kernel:
+// the table is now read-only) and takes the slot's rank as its colour.
 constexpr int TABLE_BITS = 20;
 constexpr uint32_t TABLE_SLOTS = 1u << TABLE_BITS;          // 1 M slots: up to 512 k distinct colours per half round
 constexpr uint32_t MAX_DISTINCT = TABLE_SLOTS / 2;
-constexpr int MAX_PROBES = 4096;
+constexpr int MAX_PROBES = 8192;
+constexpr int BUCKETS = 1 << 16;
 
 struct Table {
     uint64_t* keys;         // [TABLE_SLOTS] EMPTY_KEY or a fingerprint h1
     uint64_t* h2;           // [TABLE_SLOTS] h2 of the item that inserted the key
     int32_t* rank;          // [TABLE_SLOTS] colour of the slot's key
-    uint64_t* dkeys;        // [MAX_DISTINCT] distinct keys in insertion order, EMPTY_KEY beyond the count
+    uint64_t* dkeys;        // [MAX_DISTINCT] distinct keys in insertion order
     uint32_t* dslot;        // [MAX_DISTINCT] their slots
-    uint64_t* dkeys_sorted;
-    uint32_t* dslot_sorted;
-    uint32_t* slot;         // [n] slot of every item
+    uint64_t* skeys;        // [MAX_DISTINCT] the same, grouped by bucket
+    uint32_t* sslot;
+    uint32_t* bucket;       // [BUCKETS] keys per bucket | [BUCKETS + 1] segment starts | [BUCKETS] scatter cursors
     uint32_t* count;        // [2] number of distinct keys, overflow flag
 };
+__device__ __forceinline__ uint32_t* bucket_count(const Table& t) { return t.bucket; }
+__device__ __forceinline__ uint32_t* bucket_start(const Table& t) { return t.bucket + BUCKETS; }
+__device__ __forceinline__ uint32_t* bucket_cursor(const Table& t) { return t.bucket + 2 * BUCKETS + 1; }
+__device__ __forceinline__ uint32_t home_slot(uint64_t key) { return (uint32_t)(key >> 17) & (TABLE_SLOTS - 1); }
 
-// slot of `key`, inserting it if absent.  Slots only ever go from EMPTY_KEY to a key, so a plain (possibly stale) load that
-// shows another key or this key is final, and one that shows EMPTY_KEY is settled by the compare-and-swap.
-__device__ __forceinline__ uint32_t find_or_insert(const Table& t, uint64_t key, uint64_t h2) {
-    uint32_t s = (uint32_t)(key >> 17) & (TABLE_SLOTS - 1);
+// make sure `key` is in the table (called by one lane per distinct key of a wavefront)
+__device__ __forceinline__ void insert_key(const Table& t, uint64_t key, uint64_t h2) {
+    uint32_t s = home_slot(key);
     for (int probe = 0; probe < MAX_PROBES; ++probe) {
-        uint64_t cur = t.keys[s];
-        if (cur == EMPTY_KEY) {
-            cur = atomicCAS((unsigned long long*)&t.keys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-            if (cur == EMPTY_KEY) {                     // this thread inserted the key: it owns the slot's h2 and the list entry
-                t.h2[s] = h2;
-                const uint32_t pos = atomicAdd(&t.count[0], 1u);
-                if (pos < MAX_DISTINCT) { t.dkeys[pos] = key; t.dslot[pos] = s; }
-                else t.count[1] = 1;
-                return s;
-            }
+        const uint64_t cur = atomicCAS((unsigned long long*)&t.keys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+        if (cur == EMPTY_KEY) {                         // this lane inserted the key: it owns the slot's h2 and the list entry
+            t.h2[s] = h2;
+            const uint32_t pos = atomicAdd(&t.count[0], 1u);
+            if (pos < MAX_DISTINCT) {
+                t.dkeys[pos] = key; t.dslot[pos] = s;
+                atomicAdd(&bucket_count(t)[key >> 48], 1u);
+            } else t.count[1] = 1;
+            return;
         }
-        if (cur == key) return s;
+        if (cur == key) return;
         s = (s + 1) & (TABLE_SLOTS - 1);
     }
     t.count[1] = 1;                                     // a probe sequence this long means the table is (nearly) full
-    return 0;
+}
+
+// one insertion per distinct key of the wavefront: a lane inserts its key unless a lower active lane holds the same one
+__device__ __forceinline__ void wave_insert(const Table& t, uint64_t key, uint64_t h2, bool active) {
+    const uint64_t live = __ballot(active);
+    if (!live) return;
+    const int first = __builtin_ctzll(live);
+    const int klo = (int)(uint32_t)key, khi = (int)(uint32_t)(key >> 32);
+    const int flo = __builtin_amdgcn_readlane(klo, first), fhi = __builtin_amdgcn_readlane(khi, first);
+    const int lane = threadIdx.x & 63;
+    bool leader = active;
+    if (__ballot(active && (klo != flo || khi != fhi)) == 0) {
+        leader = lane == first;                          // every live lane holds the same key (the common case)
+    } else {
+        for (uint64_t rest = live; rest; rest &= rest - 1) {
+            const int l = __builtin_ctzll(rest);
+            const int llo = __builtin_amdgcn_readlane(klo, l), lhi = __builtin_amdgcn_readlane(khi, l);
+            if (l < lane && llo == klo && lhi == khi) leader = false;
+        }
+    }
+    if (leader) insert_key(t, key, h2);
 }
 
 __global__ void __launch_bounds__(BLOCK) factor_insert_kernel(lhvi_graph_t g, const uint8_t* __restrict__ symmetric,
                                                              const int32_t* __restrict__ rv_color,
                                                              const int32_t* __restrict__ f_color, uint64_t seed,
-                                                             uint64_t* __restrict__ h2, Table t) {
+                                                             uint64_t* __restrict__ h1, uint64_t* __restrict__ h2, Table t) {
     const int f = blockIdx.x * BLOCK + threadIdx.x;
-    if (f >= g.F) return;
-    uint64_t a1, a2;
-    factor_sig(g, symmetric, rv_color, f_color, seed, f, a1, a2);
-    h2[f] = a2;
-    t.slot[f] = find_or_insert(t, a1, a2);
+    uint64_t a1 = 0, a2 = 0;
+    if (f < g.F) {
+        factor_sig(g, symmetric, rv_color, f_color, seed, f, a1, a2);
+        h1[f] = a1; h2[f] = a2;
+    }
+    wave_insert(t, a1, a2, f < g.F);
 }
 
 __global__ void __launch_bounds__(BLOCK) rv_insert_kernel(lhvi_graph_t g, const int32_t* __restrict__ f_color,
                                                          const int32_t* __restrict__ rv_color, uint64_t seed,
-                                                         uint64_t* __restrict__ h2, Table t) {
+                                                         uint64_t* __restrict__ h1, uint64_t* __restrict__ h2, Table t) {
     const int v = blockIdx.x * BLOCK + threadIdx.x;
-    if (v >= g.V) return;
-    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
-    if (hi - lo > HUB_DEGREE) return;
-    uint64_t a = mix64((uint64_t)(uint32_t)rv_color[v] ^ seed ^ SEED2);
-    uint64_t b = mix64(((uint64_t)(uint32_t)rv_color[v] + seed) * 0xA24BAED4963EE407ull + SEED1);
-    for (int k = lo; k < hi; ++k) sig_terms(g, f_color, seed, k, a, b);
-    a = key_of(a);
-    h2[v] = b;
-    t.slot[v] = find_or_insert(t, a, b);
+    uint64_t a = 0, b = 0;
+    bool mine = false;
+    if (v < g.V) {
+        const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+        if (hi - lo <= HUB_DEGREE) {
+            mine = true;
+            a = mix64((uint64_t)(uint32_t)rv_color[v] ^ seed ^ SEED2);
+            b = mix64(((uint64_t)(uint32_t)rv_color[v] + seed) * 0xA24BAED4963EE407ull + SEED1);
+            for (int k = lo; k < hi; ++k) sig_terms(g, f_color, seed, k, a, b);
+            a = key_of(a);
+            h1[v] = a; h2[v] = b;
+        }
+    }
+    wave_insert(t, a, b, mine);
 }
 
 __global__ void __launch_bounds__(BLOCK) rv_insert_hub_kernel(lhvi_graph_t g, const int32_t* __restrict__ f_color,
                                                              const int32_t* __restrict__ rv_color, uint64_t seed,
-                                                             uint64_t* __restrict__ h2, Table t) {
+                                                             uint64_t* __restrict__ h1, uint64_t* __restrict__ h2, Table t) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (i >= (g.hub_vars ? g.n_hubs : g.V)) return;
@@ -218,25 +254,68 @@ __global__ void __launch_bounds__(BLOCK) rv_insert_hub_kernel(lhvi_graph_t g, co
     if (lane == 0) {
         a = key_of(a + mix64((uint64_t)(uint32_t)rv_color[v] ^ seed ^ SEED2));
         b += mix64(((uint64_t)(uint32_t)rv_color[v] + seed) * 0xA24BAED4963EE407ull + SEED1);
-        h2[v] = b;
-        t.slot[v] = find_or_insert(t, a, b);
+        h1[v] = a; h2[v] = b;
+        insert_key(t, a, b);
     }
 }
 
-// colour of a slot = position of its key among the sorted distinct keys
-__global__ void __launch_bounds__(BLOCK) slot_rank_kernel(Table t) {
+// exclusive scan of the bucket counts by one workgroup (BUCKETS / 1024 = 64 counts per thread)
+__global__ void __launch_bounds__(1024) bucket_scan_kernel(Table t) {
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    constexpr int PER = BUCKETS / 1024;
+    const uint32_t* cnt = bucket_count(t);
+    uint32_t* start = bucket_start(t);
+    uint32_t sum = 0;
+    for (int k = 0; k < PER; ++k) sum += cnt[tid * PER + k];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    for (int k = 0; k < PER; ++k) { start[tid * PER + k] = run; run += cnt[tid * PER + k]; }
+    if (tid == 1023) start[BUCKETS] = run;
+}
+
+__global__ void __launch_bounds__(BLOCK) bucket_scatter_kernel(Table t) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t n = min(t.count[0], MAX_DISTINCT);
-    if (i < n) t.rank[t.dslot_sorted[i]] = (int32_t)i;
+    if (i >= min(t.count[0], MAX_DISTINCT)) return;
+    const uint64_t key = t.dkeys[i];
+    const uint32_t b = (uint32_t)(key >> 48);
+    const uint32_t p = bucket_start(t)[b] + atomicAdd(&bucket_cursor(t)[b], 1u);
+    t.skeys[p] = key; t.sslot[p] = t.dslot[i];
+}
+
+// colour of a key = keys of lower buckets + smaller keys of its own bucket = its position in numeric order
+__global__ void __launch_bounds__(BLOCK) bucket_rank_kernel(Table t) {
+    const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= min(t.count[0], MAX_DISTINCT)) return;
+    const uint64_t key = t.skeys[p];
+    const uint32_t b = (uint32_t)(key >> 48);
+    const uint32_t lo = bucket_start(t)[b], hi = bucket_start(t)[b + 1];
+    uint32_t smaller = 0;
+    for (uint32_t q = lo; q < hi; ++q) smaller += t.skeys[q] < key;
+    t.rank[t.sslot[p]] = (int32_t)(lo + smaller);
 }
 
 // result: [0] number of colours, [1] fingerprint collision, [2] table overflow
-__global__ void __launch_bounds__(BLOCK) assign_kernel(int n, Table t, const uint64_t* __restrict__ h2,
+__global__ void __launch_bounds__(BLOCK) assign_kernel(int n, Table t, const uint64_t* __restrict__ h1, const uint64_t* __restrict__ h2,
                                                       int32_t* __restrict__ color_out, int32_t* __restrict__ result) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i == 0) { result[0] = (int32_t)min(t.count[0], MAX_DISTINCT); if (t.count[1]) result[2] = 1; }
-    if (i >= n) return;
-    const uint32_t s = t.slot[i];
+    if (i >= n || t.count[1]) return;
+    const uint64_t key = h1[i];
+    uint32_t s = home_slot(key);
+    for (int probe = 0; probe < MAX_PROBES; ++probe) {
+        const uint64_t cur = t.keys[s];
+        if (cur == key) break;
+        if (cur == EMPTY_KEY) { result[2] = 1; return; }    // cannot happen: every key was inserted
+        s = (s + 1) & (TABLE_SLOTS - 1);
+    }
     color_out[i] = t.rank[s];
     if (t.h2[s] != h2[i]) result[1] = 1;               // equal h1, different h2: the host retries with another seed
 }
@@ -281,11 +360,7 @@ static size_t temp_bytes_for(size_t n) {
     (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                               (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
     (void)rocprim::inclusive_scan(nullptr, b, (int32_t*)nullptr, (int32_t*)nullptr, n, rocprim::plus<int32_t>(), (hipStream_t)0);
-    size_t c = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, c, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                              (uint32_t*)nullptr, (size_t)MAX_DISTINCT, 0, 64, (hipStream_t)0);
-    a = a > b ? a : b;
-    return align_up(a > c ? a : c);
+    return align_up(a > b ? a : b);
 }
 
 static size_t carve(Workspace* w, void* base, size_t n) {
@@ -300,28 +375,27 @@ static size_t carve(Workspace* w, void* base, size_t n) {
     Table& t = w->table;
     t.keys = (uint64_t*)take((size_t)TABLE_SLOTS * 8); t.h2 = (uint64_t*)take((size_t)TABLE_SLOTS * 8);
     t.rank = (int32_t*)take((size_t)TABLE_SLOTS * 4);
-    t.dkeys = (uint64_t*)take((size_t)MAX_DISTINCT * 8); t.dkeys_sorted = (uint64_t*)take((size_t)MAX_DISTINCT * 8);
-    t.dslot = (uint32_t*)take((size_t)MAX_DISTINCT * 4); t.dslot_sorted = (uint32_t*)take((size_t)MAX_DISTINCT * 4);
-    t.slot = (uint32_t*)take(n * 4);
+    t.dkeys = (uint64_t*)take((size_t)MAX_DISTINCT * 8); t.skeys = (uint64_t*)take((size_t)MAX_DISTINCT * 8);
+    t.dslot = (uint32_t*)take((size_t)MAX_DISTINCT * 4); t.sslot = (uint32_t*)take((size_t)MAX_DISTINCT * 4);
+    t.bucket = (uint32_t*)take((size_t)(3 * BUCKETS + 1) * 4);
     t.count = (uint32_t*)take(256);
     return off;
 }
 
 static int table_reset(const Table& t, hipStream_t st) {
     if (hipMemsetAsync(t.keys, 0xff, (size_t)TABLE_SLOTS * 8, st) != hipSuccess) return LHVI_E_LAUNCH;
-    if (hipMemsetAsync(t.dkeys, 0xff, (size_t)MAX_DISTINCT * 8, st) != hipSuccess) return LHVI_E_LAUNCH;
+    if (hipMemsetAsync(t.bucket, 0, (size_t)(3 * BUCKETS + 1) * 4, st) != hipSuccess) return LHVI_E_LAUNCH;
     if (hipMemsetAsync(t.count, 0, 2 * sizeof(uint32_t), st) != hipSuccess) return LHVI_E_LAUNCH;
     return LHVI_OK;
 }
 
-// distinct keys -> ranks -> colours (the list beyond the count holds EMPTY_KEY, which sorts last)
+// distinct keys -> ranks -> colours
 static int table_rank_and_assign(Workspace& w, int n, int32_t* color_out, int32_t* result, hipStream_t st) {
     Table& t = w.table;
-    size_t tb = w.temp_bytes;
-    if (rocprim::radix_sort_pairs(w.temp, tb, t.dkeys, t.dkeys_sorted, t.dslot, t.dslot_sorted, (size_t)MAX_DISTINCT, 0, 64, st) != hipSuccess)
-        return LHVI_E_LAUNCH;
-    hipLaunchKernelGGL(slot_rank_kernel, dim3(grid_for(MAX_DISTINCT)), dim3(BLOCK), 0, st, t);
-    hipLaunchKernelGGL(assign_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, st, n, t, w.h2, color_out, result);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, t);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(grid_for(MAX_DISTINCT)), dim3(BLOCK), 0, st, t);
+    hipLaunchKernelGGL(bucket_rank_kernel, dim3(grid_for(MAX_DISTINCT)), dim3(BLOCK), 0, st, t);
+    hipLaunchKernelGGL(assign_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, st, n, t, w.h1, w.h2, color_out, result);
     return check_launch();
 }
 
@@ -367,7 +441,7 @@ int lhvi_color_refine_factors(const lhvi_graph_t* g, const uint8_t* symmetric, c
     if (method == 0) {
         if (int rc = table_reset(w.table, st)) return rc;
         hipLaunchKernelGGL(factor_insert_kernel, dim3(grid_for(g->F)), dim3(BLOCK), 0, st, *g, symmetric, rv_color, f_color, seed,
-                           w.h2, w.table);
+                           w.h1, w.h2, w.table);
         if (int rc = check_launch()) return rc;
         return table_rank_and_assign(w, g->F, f_color_out, n_colors_out, st);
     }
@@ -390,10 +464,10 @@ int lhvi_color_refine_rvs(const lhvi_graph_t* g, const int32_t* f_color, const i
     const uint64_t seed = 0;
     if (method == 0) {
         if (int rc = table_reset(w.table, st)) return rc;
-        hipLaunchKernelGGL(rv_insert_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, st, *g, f_color, rv_color, seed, w.h2, w.table);
+        hipLaunchKernelGGL(rv_insert_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, st, *g, f_color, rv_color, seed, w.h1, w.h2, w.table);
         const int64_t nh = g->hub_vars ? g->n_hubs : g->V;
         if (nh > 0 && g->nnz > 0)
-            hipLaunchKernelGGL(rv_insert_hub_kernel, dim3(grid_for(nh * 64)), dim3(BLOCK), 0, st, *g, f_color, rv_color, seed, w.h2, w.table);
+            hipLaunchKernelGGL(rv_insert_hub_kernel, dim3(grid_for(nh * 64)), dim3(BLOCK), 0, st, *g, f_color, rv_color, seed, w.h1, w.h2, w.table);
         if (int rc = check_launch()) return rc;
         return table_rank_and_assign(w, g->V, rv_color_out, n_colors_out, st);
     }

@@ -121,7 +121,7 @@ def test_color_refinement_hash_table_equals_the_radix_sort(api):
     radix sort of every item's fingerprint) give the same colour ARRAYS, not just the same partition; a graph with more
     distinct colours than the table holds falls back to the sort inside refine_flat and still agrees"""
     from lhvi import synth, lifting, _abi
-    flat, sym, rv0, f0 = synth.rgm_flat(C=300, B=200, n_values=5, evidence_ratio=0.2, seed=2)
+    flat, sym, rv0, f0 = synth.rgm_structured_flat(400, 250)          # the 1/25 twin of cfg 5: 9 956 rv clusters
     sa, sb = {}, {}
     ra, fa = lifting.refine_flat(flat, sym, rv0, f0, method=_abi.COLOR_HASH, stats=sa)
     rb, fb = lifting.refine_flat(flat, sym, rv0, f0, method=_abi.COLOR_SORT, stats=sb)
