@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(BLOCK) rv_sig_accum_hub_kernel(lhvi_graph_t g,
 // (neighbouring items of a relational graph mostly share their signature) with compare-and-swap -- no plain load ever probes
 // the table inside the kernel that fills it: per-XCD L2s are not coherent, a slot once read as empty would stay empty for that
 // XCD and every later item would fall back to the atomic; (2) the distinct keys are ranked without a general sort: counted
-// into 65 536 buckets by their top 16 bits while they are inserted, one block scans the counts, the keys are scattered into
+// into 8 192 buckets by their top 13 bits while they are inserted, one block scans the counts, the keys are scattered into
 // their bucket's segment and each key counts the smaller keys of its segment (a handful) -- rank = numeric order of the
 // 64-bit keys, exactly what the radix sort of method 1 gives; (3) every item finds its key with plain loads (a new kernel:
 // the table is now read-only) and takes the slot's rank as its colour.
@@ -144,7 +144,8 @@ constexpr int TABLE_BITS = 20;
 constexpr uint32_t TABLE_SLOTS = 1u << TABLE_BITS;          // 1 M slots: up to 512 k distinct colours per half round
 constexpr uint32_t MAX_DISTINCT = TABLE_SLOTS / 2;
 constexpr int MAX_PROBES = 8192;
-constexpr int BUCKETS = 1 << 16;
+constexpr int BUCKET_BITS = 13;
+constexpr int BUCKETS = 1 << BUCKET_BITS;        // by the keys' top bits: ~4 keys per bucket at 30 k colours, 64 at the table's limit
 
 struct Table {
     uint64_t* keys;         // [TABLE_SLOTS] EMPTY_KEY or a fingerprint h1
@@ -162,19 +163,25 @@ __device__ __forceinline__ uint32_t* bucket_start(const Table& t) { return t.buc
 __device__ __forceinline__ uint32_t* bucket_cursor(const Table& t) { return t.bucket + 2 * BUCKETS + 1; }
 __device__ __forceinline__ uint32_t home_slot(uint64_t key) { return (uint32_t)(key >> 17) & (TABLE_SLOTS - 1); }
 
-// make sure `key` is in the table (called by one lane per distinct key of a wavefront)
+// make sure `key` is in the table.  The probe reads slots with agent-scope (sc1) loads: per-XCD L2s are not coherent, and a
+// slot a plain load once showed empty would stay empty for that XCD, sending every later item of the key to the atomic;
+// slots only ever go from EMPTY_KEY to a key, so whatever key a load shows is final, and only an empty slot is settled by
+// the compare-and-swap.
 __device__ __forceinline__ void insert_key(const Table& t, uint64_t key, uint64_t h2) {
     uint32_t s = home_slot(key);
     for (int probe = 0; probe < MAX_PROBES; ++probe) {
-        const uint64_t cur = atomicCAS((unsigned long long*)&t.keys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-        if (cur == EMPTY_KEY) {                         // this lane inserted the key: it owns the slot's h2 and the list entry
-            t.h2[s] = h2;
-            const uint32_t pos = atomicAdd(&t.count[0], 1u);
-            if (pos < MAX_DISTINCT) {
-                t.dkeys[pos] = key; t.dslot[pos] = s;
-                atomicAdd(&bucket_count(t)[key >> 48], 1u);
-            } else t.count[1] = 1;
-            return;
+        uint64_t cur = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == EMPTY_KEY) {
+            cur = atomicCAS((unsigned long long*)&t.keys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (cur == EMPTY_KEY) {                     // this lane inserted the key: it owns the slot's h2 and the list entry
+                t.h2[s] = h2;
+                const uint32_t pos = atomicAdd(&t.count[0], 1u);
+                if (pos < MAX_DISTINCT) {
+                    t.dkeys[pos] = key; t.dslot[pos] = s;
+                    atomicAdd(&bucket_count(t)[key >> (64 - BUCKET_BITS)], 1u);
+                } else t.count[1] = 1;
+                return;
+            }
         }
         if (cur == key) return;
         s = (s + 1) & (TABLE_SLOTS - 1);
@@ -182,43 +189,49 @@ __device__ __forceinline__ void insert_key(const Table& t, uint64_t key, uint64_
     t.count[1] = 1;                                     // a probe sequence this long means the table is (nearly) full
 }
 
-// one insertion per distinct key of the wavefront: a lane inserts its key unless a lower active lane holds the same one
-__device__ __forceinline__ void wave_insert(const Table& t, uint64_t key, uint64_t h2, bool active) {
-    const uint64_t live = __ballot(active);
-    if (!live) return;
-    const int first = __builtin_ctzll(live);
-    const int klo = (int)(uint32_t)key, khi = (int)(uint32_t)(key >> 32);
-    const int flo = __builtin_amdgcn_readlane(klo, first), fhi = __builtin_amdgcn_readlane(khi, first);
-    const int lane = threadIdx.x & 63;
-    bool leader = active;
-    if (__ballot(active && (klo != flo || khi != fhi)) == 0) {
-        leader = lane == first;                          // every live lane holds the same key (the common case)
-    } else {
-        for (uint64_t rest = live; rest; rest &= rest - 1) {
-            const int l = __builtin_ctzll(rest);
-            const int llo = __builtin_amdgcn_readlane(klo, l), lhi = __builtin_amdgcn_readlane(khi, l);
-            if (l < lane && llo == klo && lhi == khi) leader = false;
-        }
+// Neighbouring items of a relational graph mostly share their signature, so a workgroup filters its keys through a small
+// direct-mapped LDS table before going to memory: a lane publishes (key with its low 8 bits replaced by its thread id) in
+// the key's LDS slot -- one 8-byte store, the last writer wins whole -- and reads the slot back: the winner inserts the key
+// for everyone, lanes that find another thread's entry for the same key are done, lanes that lost the slot to a different key
+// insert theirs themselves.  Later waves of the workgroup find the entry and skip without writing.  (Keys equal in all but
+// their low 8 bits would share an entry, 2^-56 per pair; the key then missing from the table shows up in assign_kernel as
+// an empty slot, which is reported as overflow and sends the half round through the sort.)
+constexpr int FILTER_SLOTS = 512;
+__device__ __forceinline__ void block_insert(const Table& t, uint64_t* __restrict__ filter, uint64_t key, uint64_t h2, bool active) {
+    const uint64_t tag = key & ~0xFFull, mine = tag | threadIdx.x;
+    uint64_t* slot = filter + ((key >> 9) & (FILTER_SLOTS - 1));
+    bool go = active && (*slot & ~0xFFull) != tag;
+    if (go) *slot = mine;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (go) {
+        const uint64_t now = *slot;
+        go = now == mine || (now & ~0xFFull) != tag;
     }
-    if (leader) insert_key(t, key, h2);
+    if (go) insert_key(t, key, h2);
 }
 
 __global__ void __launch_bounds__(BLOCK) factor_insert_kernel(lhvi_graph_t g, const uint8_t* __restrict__ symmetric,
                                                              const int32_t* __restrict__ rv_color,
                                                              const int32_t* __restrict__ f_color, uint64_t seed,
                                                              uint64_t* __restrict__ h1, uint64_t* __restrict__ h2, Table t) {
+    __shared__ uint64_t filter[FILTER_SLOTS];
+    for (int i = threadIdx.x; i < FILTER_SLOTS; i += BLOCK) filter[i] = EMPTY_KEY;
+    __syncthreads();
     const int f = blockIdx.x * BLOCK + threadIdx.x;
     uint64_t a1 = 0, a2 = 0;
     if (f < g.F) {
         factor_sig(g, symmetric, rv_color, f_color, seed, f, a1, a2);
         h1[f] = a1; h2[f] = a2;
     }
-    wave_insert(t, a1, a2, f < g.F);
+    block_insert(t, filter, a1, a2, f < g.F);
 }
 
 __global__ void __launch_bounds__(BLOCK) rv_insert_kernel(lhvi_graph_t g, const int32_t* __restrict__ f_color,
                                                          const int32_t* __restrict__ rv_color, uint64_t seed,
                                                          uint64_t* __restrict__ h1, uint64_t* __restrict__ h2, Table t) {
+    __shared__ uint64_t filter[FILTER_SLOTS];
+    for (int i = threadIdx.x; i < FILTER_SLOTS; i += BLOCK) filter[i] = EMPTY_KEY;
+    __syncthreads();
     const int v = blockIdx.x * BLOCK + threadIdx.x;
     uint64_t a = 0, b = 0;
     bool mine = false;
@@ -233,25 +246,32 @@ __global__ void __launch_bounds__(BLOCK) rv_insert_kernel(lhvi_graph_t g, const 
             h1[v] = a; h2[v] = b;
         }
     }
-    wave_insert(t, a, b, mine);
+    block_insert(t, filter, a, b, mine);
 }
 
+// hubs (template variables with thousands of incident factors): a workgroup per hub, the four wavefronts' partial sums
+// combined through LDS (integer sums: any order gives the same bits)
 __global__ void __launch_bounds__(BLOCK) rv_insert_hub_kernel(lhvi_graph_t g, const int32_t* __restrict__ f_color,
                                                              const int32_t* __restrict__ rv_color, uint64_t seed,
                                                              uint64_t* __restrict__ h1, uint64_t* __restrict__ h2, Table t) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    __shared__ uint64_t part[2 * (BLOCK / 64)];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int i = blockIdx.x;
     if (i >= (g.hub_vars ? g.n_hubs : g.V)) return;
     const int v = g.hub_vars ? g.hub_vars[i] : i;
     const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
     if (hi - lo <= HUB_DEGREE) return;
     uint64_t a = 0, b = 0;
-    for (int k = lo + lane; k < hi; k += 64) sig_terms(g, f_color, seed, k, a, b);
+    for (int k = lo + threadIdx.x; k < hi; k += BLOCK) sig_terms(g, f_color, seed, k, a, b);
     for (int off = 32; off > 0; off >>= 1) {
         a += ((uint64_t)(uint32_t)__shfl_xor((int)(a >> 32), off) << 32) | (uint32_t)__shfl_xor((int)a, off);
         b += ((uint64_t)(uint32_t)__shfl_xor((int)(b >> 32), off) << 32) | (uint32_t)__shfl_xor((int)b, off);
     }
-    if (lane == 0) {
+    if (lane == 0) { part[2 * wid] = a; part[2 * wid + 1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = 0; b = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) { a += part[2 * w]; b += part[2 * w + 1]; }
         a = key_of(a + mix64((uint64_t)(uint32_t)rv_color[v] ^ seed ^ SEED2));
         b += mix64(((uint64_t)(uint32_t)rv_color[v] + seed) * 0xA24BAED4963EE407ull + SEED1);
         h1[v] = a; h2[v] = b;
@@ -259,7 +279,7 @@ __global__ void __launch_bounds__(BLOCK) rv_insert_hub_kernel(lhvi_graph_t g, co
     }
 }
 
-// exclusive scan of the bucket counts by one workgroup (BUCKETS / 1024 = 64 counts per thread)
+// exclusive scan of the bucket counts by one workgroup (BUCKETS / 1024 = 8 counts per thread)
 __global__ void __launch_bounds__(1024) bucket_scan_kernel(Table t) {
     __shared__ uint32_t part[1024];
     const int tid = threadIdx.x;
@@ -285,7 +305,7 @@ __global__ void __launch_bounds__(BLOCK) bucket_scatter_kernel(Table t) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= min(t.count[0], MAX_DISTINCT)) return;
     const uint64_t key = t.dkeys[i];
-    const uint32_t b = (uint32_t)(key >> 48);
+    const uint32_t b = (uint32_t)(key >> (64 - BUCKET_BITS));
     const uint32_t p = bucket_start(t)[b] + atomicAdd(&bucket_cursor(t)[b], 1u);
     t.skeys[p] = key; t.sslot[p] = t.dslot[i];
 }
@@ -295,7 +315,7 @@ __global__ void __launch_bounds__(BLOCK) bucket_rank_kernel(Table t) {
     const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= min(t.count[0], MAX_DISTINCT)) return;
     const uint64_t key = t.skeys[p];
-    const uint32_t b = (uint32_t)(key >> 48);
+    const uint32_t b = (uint32_t)(key >> (64 - BUCKET_BITS));
     const uint32_t lo = bucket_start(t)[b], hi = bucket_start(t)[b + 1];
     uint32_t smaller = 0;
     for (uint32_t q = lo; q < hi; ++q) smaller += t.skeys[q] < key;
@@ -467,7 +487,7 @@ int lhvi_color_refine_rvs(const lhvi_graph_t* g, const int32_t* f_color, const i
         hipLaunchKernelGGL(rv_insert_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, st, *g, f_color, rv_color, seed, w.h1, w.h2, w.table);
         const int64_t nh = g->hub_vars ? g->n_hubs : g->V;
         if (nh > 0 && g->nnz > 0)
-            hipLaunchKernelGGL(rv_insert_hub_kernel, dim3(grid_for(nh * 64)), dim3(BLOCK), 0, st, *g, f_color, rv_color, seed, w.h1, w.h2, w.table);
+            hipLaunchKernelGGL(rv_insert_hub_kernel, dim3((unsigned)nh), dim3(BLOCK), 0, st, *g, f_color, rv_color, seed, w.h1, w.h2, w.table);
         if (int rc = check_launch()) return rc;
         return table_rank_and_assign(w, g->V, rv_color_out, n_colors_out, st);
     }

@@ -401,12 +401,9 @@ class _OrderedSet(list):
         return any(x is y for y in self)
 
 
-def lift_flat(flat, rv_color, f_color):
-    """Lifted ``FlatGraph`` straight from a ground ``FlatGraph`` and a partition, without Python objects
-    (vectorised; the 10M-edge path).  Representative of a cluster = its first ground member; lifted edges
-    are the representative factor's incidences; ``count`` comes from the representative variable's
-    incident factor colours (``SuperRV.update_nb``, ``CompressedGraphWithObs.py:41-45``)."""
-    from .flat import FlatGraph
+def _lift_reduce_host(flat, rv_color, f_color):
+    """the O(V + F) part of ``lift_flat`` in NumPy: representatives, cluster sizes, evidence means, and the factor colours
+    along the representatives' adjacency rows"""
     rv_color = np.asarray(rv_color, dtype=np.int64)
     f_color = np.asarray(f_color, dtype=np.int64)
     nV, nF = int(rv_color.max()) + 1, int(f_color.max()) + 1
@@ -414,6 +411,72 @@ def lift_flat(flat, rv_color, f_color):
     np.minimum.at(rep_v, rv_color, np.arange(flat.V))
     rep_f = np.full(nF, flat.F, dtype=np.int64)
     np.minimum.at(rep_f, f_color, np.arange(flat.F))
+    mult_v = np.bincount(rv_color, minlength=nV).astype(np.float64)
+    mult_f = np.bincount(f_color, minlength=nF).astype(np.float64)
+    # evidence value of a cluster: running sum of member values / size (SuperRV.get_value)
+    val = flat.var_value[rep_v].copy()
+    obs = ~np.isnan(val)
+    if obs.any():
+        sums = np.zeros(nV)
+        vv = np.where(np.isnan(flat.var_value), 0.0, flat.var_value)
+        np.add.at(sums, rv_color, vv)      # sequential accumulation in ground order
+        val[obs] = sums[obs] / mult_v[obs]
+    deg = (flat.var_ptr[rep_v + 1] - flat.var_ptr[rep_v]).astype(np.int64)
+    start = np.zeros(nV + 1, dtype=np.int64)
+    np.cumsum(deg, out=start[1:])
+    slots = np.repeat(flat.var_ptr[rep_v].astype(np.int64) - start[:-1], deg) + np.arange(int(start[-1]), dtype=np.int64)
+    fcol = f_color[flat.edge_fac[flat.var_edge[slots]]]
+    return dict(nV=nV, nF=nF, rep_v=rep_v, rep_f=rep_f, mult_v=mult_v, mult_f=mult_f, val=val, deg=deg, fcol=fcol,
+                color_of_edge_var=lambda g_edge: rv_color[flat.edge_var[g_edge]])
+
+
+def _lift_reduce_device(flat, dg, rvc, fc):
+    """the same reductions on the device, for colour arrays that are already there (``refine_flat(device_out=True)``): only
+    lifted-size arrays come back to the host.  Evidence sums run over each cluster's observed members in ground order (one
+    thread per cluster segment), i.e. in the order of the host path."""
+    torch = _abi.require_gpu()
+    dev = rvc.device
+    rl, fl = rvc.long(), fc.long()
+    nV, nF = int(rl.max().item()) + 1, int(fl.max().item()) + 1
+    rep_v = torch.full((nV,), flat.V, dtype=torch.int64, device=dev).scatter_reduce_(0, rl, torch.arange(flat.V, device=dev), 'amin')
+    rep_f = torch.full((nF,), flat.F, dtype=torch.int64, device=dev).scatter_reduce_(0, fl, torch.arange(flat.F, device=dev), 'amin')
+    mult_v = torch.bincount(rl, minlength=nV).to(torch.float64)
+    mult_f = torch.bincount(fl, minlength=nF).to(torch.float64)
+    value = dg.t['var_value']
+    val = value[rep_v].clone()
+    obs_members = torch.nonzero(~torch.isnan(value)).flatten()
+    if obs_members.numel():
+        oc = rl[obs_members]
+        order = torch.sort(oc, stable=True).indices                   # members grouped by cluster, ground order inside
+        lengths = torch.bincount(oc, minlength=nV)
+        sums = torch.segment_reduce(value[obs_members][order], 'sum', lengths=lengths, unsafe=True)
+        ob = ~torch.isnan(val)
+        val[ob] = sums[ob] / mult_v[ob]
+    var_ptr = dg.t['var_ptr'].long()
+    deg = var_ptr[rep_v + 1] - var_ptr[rep_v]
+    start = torch.zeros(nV + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg, 0, out=start[1:])
+    total = int(start[-1].item())
+    slots = torch.repeat_interleave(var_ptr[rep_v] - start[:-1], deg, output_size=total) + torch.arange(total, device=dev)
+    fcol = fl[dg.t['edge_fac'].long()[dg.t['var_edge'].long()[slots]]]
+    edge_var_d = dg.t['edge_var']
+    host = lambda t: t.cpu().numpy()
+    return dict(nV=nV, nF=nF, rep_v=host(rep_v), rep_f=host(rep_f), mult_v=host(mult_v), mult_f=host(mult_f), val=host(val),
+                deg=host(deg), fcol=host(fcol),
+                color_of_edge_var=lambda g_edge: host(rl[edge_var_d[_abi.to_dev(np.asarray(g_edge, dtype=np.int64))].long()]))
+
+
+def lift_flat(flat, rv_color, f_color, dg=None):
+    """Lifted ``FlatGraph`` straight from a ground ``FlatGraph`` and a partition, without Python objects
+    (vectorised; the 10M-edge path).  Representative of a cluster = its first ground member; lifted edges
+    are the representative factor's incidences; ``count`` comes from the representative variable's
+    incident factor colours (``SuperRV.update_nb``, ``CompressedGraphWithObs.py:41-45``).
+    With device colour tensors (``refine_flat(..., device_out=True)``) and the graph's ``DeviceGraph`` the reductions over
+    the ground graph run on the device and only lifted-size arrays reach the host."""
+    from .flat import FlatGraph
+    on_device = dg is not None and not isinstance(rv_color, np.ndarray) and hasattr(rv_color, 'device')
+    R = _lift_reduce_device(flat, dg, rv_color, f_color) if on_device else _lift_reduce_host(flat, rv_color, f_color)
+    nV, nF, rep_v, rep_f = R['nV'], R['nF'], R['rep_v'], R['rep_f']
     arity = (flat.fac_ptr[1:] - flat.fac_ptr[:-1])[rep_f]
     fac_ptr = np.zeros(nF + 1, dtype=np.int32)
     np.cumsum(arity, out=fac_ptr[1:])
@@ -421,27 +484,21 @@ def lift_flat(flat, rv_color, f_color):
     edge_fac = np.repeat(np.arange(nF, dtype=np.int32), arity)
     edge_pos = (np.arange(E) - fac_ptr[edge_fac]).astype(np.int32)
     g_edge = flat.fac_ptr[rep_f][edge_fac] + edge_pos
-    edge_var = rv_color[flat.edge_var[g_edge]].astype(np.int32)
+    edge_var = R['color_of_edge_var'](g_edge).astype(np.int32)
     # canonical edge of each (factor, variable) pair
     pair = edge_fac.astype(np.int64) * nV + edge_var
     order = np.argsort(pair, kind='stable')
     first = np.ones(E, dtype=bool)
     first[1:] = pair[order][1:] != pair[order][:-1]
-    canon_sorted = np.maximum.accumulate(np.where(first, order, 0))
     # within a run the first element (stable sort) is the smallest edge id
     run_start = np.maximum.accumulate(np.where(first, np.arange(E), 0))
     edge_canon = np.empty(E, dtype=np.int32)
     edge_canon[order] = order[run_start]
-    del canon_sorted
     # variable side: the representative ground rv's incident factors, grouped by factor colour in first-seen order
     # (vectorised: one pass over the representatives' adjacency rows instead of a Python loop per cluster)
-    deg = (flat.var_ptr[rep_v + 1] - flat.var_ptr[rep_v]).astype(np.int64)
-    start = np.zeros(nV + 1, dtype=np.int64)
-    np.cumsum(deg, out=start[1:])
-    slots = np.repeat(flat.var_ptr[rep_v].astype(np.int64) - start[:-1], deg) + np.arange(int(start[-1]), dtype=np.int64)
+    deg = R['deg']
     owner = np.repeat(np.arange(nV, dtype=np.int64), deg)
-    fcol = f_color[flat.edge_fac[flat.var_edge[slots]]]
-    key = owner * nF + fcol                                   # (cluster, factor colour) pairs along the rows
+    key = owner * nF + R['fcol']                              # (cluster, factor colour) pairs along the rows
     uniq, first, cnt = np.unique(key, return_index=True, return_counts=True)
     order = np.argsort(first, kind='stable')                  # first-seen order (rows are contiguous per cluster)
     uniq, cnt = uniq[order], cnt[order]
@@ -458,22 +515,12 @@ def lift_flat(flat, rv_color, f_color):
     var_ptr = np.zeros(nV + 1, dtype=np.int32)
     np.cumsum(np.bincount(pc, minlength=nV), out=var_ptr[1:])
     edge_count = counts[edge_canon]
-    mult_v = np.bincount(rv_color, minlength=nV).astype(np.float64)
-    mult_f = np.bincount(f_color, minlength=nF).astype(np.float64)
-    # evidence value of a cluster: running sum of member values / size (SuperRV.get_value)
-    val = flat.var_value[rep_v].copy()
-    obs = ~np.isnan(val)
-    if obs.any():
-        sums = np.zeros(nV)
-        vv = np.where(np.isnan(flat.var_value), 0.0, flat.var_value)
-        np.add.at(sums, rv_color, vv)      # sequential accumulation in ground order
-        val[obs] = sums[obs] / mult_v[obs]
     return FlatGraph(
         V=nV, F=nF, E=E, fac_ptr=fac_ptr, edge_var=edge_var, edge_fac=edge_fac, edge_pos=edge_pos,
         edge_canon=edge_canon, var_ptr=var_ptr, var_edge=var_edge.reshape(-1),
         edge_count=edge_count, lifted=True, fac_pot=flat.fac_pot[rep_f].astype(np.int32),
         pot_kind=flat.pot_kind, pot_off=flat.pot_off, pot_param=flat.pot_param,
-        var_value=val, var_dom=flat.var_dom[rep_v].astype(np.int32), var_mult=mult_v, fac_mult=mult_f,
+        var_value=R['val'], var_dom=flat.var_dom[rep_v].astype(np.int32), var_mult=R['mult_v'], fac_mult=R['mult_f'],
         dom_cont=flat.dom_cont, dom_lo=flat.dom_lo, dom_hi=flat.dom_hi, dom_ptr=flat.dom_ptr, dom_val=flat.dom_val,
         potentials=flat.potentials, domains=flat.domains)
 

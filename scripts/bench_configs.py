@@ -192,13 +192,25 @@ if 'cfg5' in which:
     torch.cuda.synchronize()
     st5 = {}
     t0 = time.perf_counter()
-    rvc, fc = lifting.refine_flat(flat, sym, rv0, f0, dg=dg5, stats=st5)
+    rvc_d, fc_d = lifting.refine_flat(flat, sym, rv0, f0, dg=dg5, stats=st5, device_out=True)
     torch.cuda.synchronize()
     t_ref = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rvc_s, fc_s = lifting.refine_flat(flat, sym, rv0, f0, dg=dg5, method=_abi.COLOR_SORT, device_out=True)
+    torch.cuda.synchronize()
+    t_ref_sort = time.perf_counter() - t0
+    assert bool((rvc_s == rvc_d).all()) and bool((fc_s == fc_d).all())
+    lifting.lift_flat(flat, rvc_d, fc_d, dg=dg5)     # warm-up of the torch kernels it uses
+    t0 = time.perf_counter()
+    lflat = lifting.lift_flat(flat, rvc_d, fc_d, dg=dg5)
+    t_lift_dev = time.perf_counter() - t0
+    rvc, fc = rvc_d.cpu().numpy(), fc_d.cpu().numpy()
     del dg5
     t0 = time.perf_counter()
-    lflat = lifting.lift_flat(flat, rvc, fc)
+    lflat_h = lifting.lift_flat(flat, rvc, fc)
     t_lift = time.perf_counter() - t0
+    assert all(np.array_equal(getattr(lflat, k), getattr(lflat_h, k), equal_nan=True) for k in
+               ('fac_ptr', 'edge_var', 'var_ptr', 'var_edge', 'edge_count', 'var_value', 'var_mult', 'fac_mult', 'fac_pot'))
     from lhvi.vi import VarInference
     vi = VarInference(None, 2, 3)
     vi._setup_flat(lflat)
@@ -213,8 +225,8 @@ if 'cfg5' in which:
     dt = time.perf_counter() - t0
     out(config='cfg5 RGM 10M ground edges -> colour refinement -> LVI K=2 T=3', ground_edges=flat.E,
         rv_clusters=int(rvc.max()) + 1, f_clusters=int(fc.max()) + 1, lifted_edges=lflat.E, colour_refinement_s=t_ref, colour_rounds=st5.get('rounds'),
-        colour_GBs_at_120B_per_edge_round=120.0 * flat.E * st5.get('rounds', 0) / t_ref / 1e9,
-        lift_flat_host_s=t_lift, adam_iterations_per_s=20 / dt, fe_start=fe0, fe_after_20=vi.free_energy())
+        colour_ms_per_round=1e3 * t_ref / max(st5.get('rounds', 1), 1), colour_GBs_at_120B_per_edge_round=120.0 * flat.E * st5.get('rounds', 0) / t_ref / 1e9,
+        colour_refinement_by_radix_sort_s=t_ref_sort, lift_flat_device_assisted_s=t_lift_dev, lift_flat_host_s=t_lift, adam_iterations_per_s=20 / dt, fe_start=fe0, fe_after_20=vi.free_energy())
 
 if 'vi_ground' in which:
     # the variational step on a GROUND graph: RGM template C=1000, B=500 (1.0 M pairwise Gaussian factors), K=2, T=3

@@ -138,6 +138,14 @@ def test_cfg5_rgm_at_10m_ground_edges_lifts_to_10k_clusters():
     assert np.unique(np.stack([rvc, rv0], 1), axis=0).shape[0] == n_rv and np.unique(np.stack([fc, f0], 1), axis=0).shape[0] == n_f
     lflat = lifting.lift_flat(flat, rvc, fc)
     assert lflat.V == n_rv and lflat.F == n_f
+    # the same lifted graph when the O(V + F) reductions run on the device from device-resident colours
+    dg = _abi.DeviceGraph(flat)
+    rvc_d, fc_d = lifting.refine_flat(flat, sym, rv0, f0, dg=dg, device_out=True)
+    ld = lifting.lift_flat(flat, rvc_d, fc_d, dg=dg)
+    del dg
+    for name in ('fac_ptr', 'edge_var', 'edge_canon', 'var_ptr', 'var_edge', 'edge_count', 'var_value', 'var_dom', 'var_mult',
+                 'fac_mult', 'fac_pot'):
+        np.testing.assert_array_equal(getattr(ld, name), getattr(lflat, name), err_msg=name)
     # count / N bookkeeping: a cluster's counts add up to its representative's ground degree, and over all clusters to E
     deg = np.diff(flat.var_ptr)
     rep = np.full(n_rv, flat.V, dtype=np.int64)

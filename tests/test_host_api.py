@@ -58,10 +58,10 @@ def test_mln_ops_and_tracing():
     assert pot.get((1, 2.0, 3.5)) == pytest.approx(np.e ** (-2.25 * 0.5))
     rng = np.random.default_rng(0)
     for name, f in modelio.FORMULAS.items():
-        arity = 3 if name in ('x0_eq12', 'any3') else 2 if name in ('x0_eq1c', 'nand') else 1
+        arity = 5 if name == 'rm_aligned' else 3 if name in ('x0_eq12', 'any3') else 2 if name in ('nand',) or name.startswith('x0_eq') else 1
         prog = expr.trace(f, arity)
         for _ in range(20):
-            x = [float(rng.integers(0, 2)) if name in ('nand', 'any3') else float(rng.uniform(-3, 3)) for _ in range(arity)]
+            x = [float(rng.integers(0, 2)) if name in ('nand', 'any3', 'rm_aligned') else float(rng.uniform(-3, 3)) for _ in range(arity)]
             assert expr.run(prog, x) == pytest.approx(float(f(x)), rel=1e-15, abs=1e-15)
     with pytest.raises(expr.FormulaNotTraceable):
         expr.trace(lambda x: 1 if x[0] > 0 else 0, 1)
