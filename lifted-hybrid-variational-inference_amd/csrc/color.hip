@@ -262,7 +262,22 @@ __global__ void __launch_bounds__(BLOCK) rv_insert_hub_kernel(lhvi_graph_t g, co
     const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
     if (hi - lo <= HUB_DEGREE) return;
     uint64_t a = 0, b = 0;
-    for (int k = lo + threadIdx.x; k < hi; k += BLOCK) sig_terms(g, f_color, seed, k, a, b);
+    // four rows of the three-level gather f_color[edge_fac[var_edge[k]]] in flight per thread
+    int k = lo + threadIdx.x;
+    for (; k + 3 * BLOCK < hi; k += 4 * BLOCK) {
+        int e[4], f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = g.var_edge[k + u * BLOCK];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f[u] = g.edge_fac[e[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t c = (uint64_t)(uint32_t)f_color[f[u]];
+            a += mix64(c ^ seed ^ SEED1);
+            b += mix64((c + 0x7Full) * 0xC2B2AE3D27D4EB4Full + seed);
+        }
+    }
+    for (; k < hi; k += BLOCK) sig_terms(g, f_color, seed, k, a, b);
     for (int off = 32; off > 0; off >>= 1) {
         a += ((uint64_t)(uint32_t)__shfl_xor((int)(a >> 32), off) << 32) | (uint32_t)__shfl_xor((int)a, off);
         b += ((uint64_t)(uint32_t)__shfl_xor((int)(b >> 32), off) << 32) | (uint32_t)__shfl_xor((int)b, off);

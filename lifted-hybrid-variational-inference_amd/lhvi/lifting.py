@@ -426,7 +426,10 @@ def _lift_reduce_host(flat, rv_color, f_color):
     np.cumsum(deg, out=start[1:])
     slots = np.repeat(flat.var_ptr[rep_v].astype(np.int64) - start[:-1], deg) + np.arange(int(start[-1]), dtype=np.int64)
     fcol = f_color[flat.edge_fac[flat.var_edge[slots]]]
-    return dict(nV=nV, nF=nF, rep_v=rep_v, rep_f=rep_f, mult_v=mult_v, mult_f=mult_f, val=val, deg=deg, fcol=fcol,
+    owner = np.repeat(np.arange(nV, dtype=np.int64), deg)
+    key = owner * nF + fcol                                   # (cluster, factor colour) pairs along the rows
+    uniq, first, cnt = np.unique(key, return_index=True, return_counts=True)
+    return dict(nV=nV, nF=nF, rep_v=rep_v, rep_f=rep_f, mult_v=mult_v, mult_f=mult_f, val=val, pairs=(uniq, first, cnt),
                 color_of_edge_var=lambda g_edge: rv_color[flat.edge_var[g_edge]])
 
 
@@ -459,10 +462,13 @@ def _lift_reduce_device(flat, dg, rvc, fc):
     total = int(start[-1].item())
     slots = torch.repeat_interleave(var_ptr[rep_v] - start[:-1], deg, output_size=total) + torch.arange(total, device=dev)
     fcol = fl[dg.t['edge_fac'].long()[dg.t['var_edge'].long()[slots]]]
+    owner = torch.repeat_interleave(torch.arange(nV, device=dev), deg, output_size=total)
+    uniq, inv, cnt = torch.unique(owner * nF + fcol, return_inverse=True, return_counts=True)
+    first = torch.full((uniq.numel(),), total, dtype=torch.int64, device=dev).scatter_reduce_(0, inv, torch.arange(total, device=dev), 'amin')
     edge_var_d = dg.t['edge_var']
     host = lambda t: t.cpu().numpy()
     return dict(nV=nV, nF=nF, rep_v=host(rep_v), rep_f=host(rep_f), mult_v=host(mult_v), mult_f=host(mult_f), val=host(val),
-                deg=host(deg), fcol=host(fcol),
+                pairs=(host(uniq), host(first), host(cnt)),
                 color_of_edge_var=lambda g_edge: host(rl[edge_var_d[_abi.to_dev(np.asarray(g_edge, dtype=np.int64))].long()]))
 
 
@@ -496,10 +502,7 @@ def lift_flat(flat, rv_color, f_color, dg=None):
     edge_canon[order] = order[run_start]
     # variable side: the representative ground rv's incident factors, grouped by factor colour in first-seen order
     # (vectorised: one pass over the representatives' adjacency rows instead of a Python loop per cluster)
-    deg = R['deg']
-    owner = np.repeat(np.arange(nV, dtype=np.int64), deg)
-    key = owner * nF + R['fcol']                              # (cluster, factor colour) pairs along the rows
-    uniq, first, cnt = np.unique(key, return_index=True, return_counts=True)
+    uniq, first, cnt = R['pairs']                             # distinct (cluster, factor colour) pairs along the rows
     order = np.argsort(first, kind='stable')                  # first-seen order (rows are contiguous per cluster)
     uniq, cnt = uniq[order], cnt[order]
     pc, pf = uniq // nF, uniq % nF
