@@ -249,44 +249,25 @@ __global__ void __launch_bounds__(BLOCK) rv_insert_kernel(lhvi_graph_t g, const 
     block_insert(t, filter, a, b, mine);
 }
 
-// hubs (template variables with thousands of incident factors): a workgroup per hub, the four wavefronts' partial sums
-// combined through LDS (integer sums: any order gives the same bits)
+// hubs (template variables with thousands of incident factors): a wavefront per hub.  (A workgroup per hub, also with four
+// gathers in flight per thread, measured slower: 64 / 77 us against 48 us on the 10 M-edge cfg-5 graph -- the rows of the
+// revenue hubs stride through the factor-major edge arrays, and more requests in flight only thrash the sectors.)
 __global__ void __launch_bounds__(BLOCK) rv_insert_hub_kernel(lhvi_graph_t g, const int32_t* __restrict__ f_color,
                                                              const int32_t* __restrict__ rv_color, uint64_t seed,
                                                              uint64_t* __restrict__ h1, uint64_t* __restrict__ h2, Table t) {
-    __shared__ uint64_t part[2 * (BLOCK / 64)];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int i = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (i >= (g.hub_vars ? g.n_hubs : g.V)) return;
     const int v = g.hub_vars ? g.hub_vars[i] : i;
     const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
     if (hi - lo <= HUB_DEGREE) return;
     uint64_t a = 0, b = 0;
-    // four rows of the three-level gather f_color[edge_fac[var_edge[k]]] in flight per thread
-    int k = lo + threadIdx.x;
-    for (; k + 3 * BLOCK < hi; k += 4 * BLOCK) {
-        int e[4], f[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = g.var_edge[k + u * BLOCK];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) f[u] = g.edge_fac[e[u]];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint64_t c = (uint64_t)(uint32_t)f_color[f[u]];
-            a += mix64(c ^ seed ^ SEED1);
-            b += mix64((c + 0x7Full) * 0xC2B2AE3D27D4EB4Full + seed);
-        }
-    }
-    for (; k < hi; k += BLOCK) sig_terms(g, f_color, seed, k, a, b);
+    for (int k = lo + lane; k < hi; k += 64) sig_terms(g, f_color, seed, k, a, b);
     for (int off = 32; off > 0; off >>= 1) {
         a += ((uint64_t)(uint32_t)__shfl_xor((int)(a >> 32), off) << 32) | (uint32_t)__shfl_xor((int)a, off);
         b += ((uint64_t)(uint32_t)__shfl_xor((int)(b >> 32), off) << 32) | (uint32_t)__shfl_xor((int)b, off);
     }
-    if (lane == 0) { part[2 * wid] = a; part[2 * wid + 1] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        a = 0; b = 0;
-        for (int w = 0; w < BLOCK / 64; ++w) { a += part[2 * w]; b += part[2 * w + 1]; }
+    if (lane == 0) {
         a = key_of(a + mix64((uint64_t)(uint32_t)rv_color[v] ^ seed ^ SEED2));
         b += mix64(((uint64_t)(uint32_t)rv_color[v] + seed) * 0xA24BAED4963EE407ull + SEED1);
         h1[v] = a; h2[v] = b;
@@ -502,7 +483,7 @@ int lhvi_color_refine_rvs(const lhvi_graph_t* g, const int32_t* f_color, const i
         hipLaunchKernelGGL(rv_insert_kernel, dim3(grid_for(g->V)), dim3(BLOCK), 0, st, *g, f_color, rv_color, seed, w.h1, w.h2, w.table);
         const int64_t nh = g->hub_vars ? g->n_hubs : g->V;
         if (nh > 0 && g->nnz > 0)
-            hipLaunchKernelGGL(rv_insert_hub_kernel, dim3((unsigned)nh), dim3(BLOCK), 0, st, *g, f_color, rv_color, seed, w.h1, w.h2, w.table);
+            hipLaunchKernelGGL(rv_insert_hub_kernel, dim3(grid_for(nh * 64)), dim3(BLOCK), 0, st, *g, f_color, rv_color, seed, w.h1, w.h2, w.table);
         if (int rc = check_launch()) return rc;
         return table_rank_and_assign(w, g->V, rv_color_out, n_colors_out, st);
     }
