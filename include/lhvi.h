@@ -30,7 +30,7 @@ extern "C" {
 #define LHVI_ABI_VERSION 8   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
                               * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t;  7: lhvi_pbp_t gained pair_desc;
                               * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq; the colour
-                              *    refinement calls take a method and return four result words */
+                              *    refinement calls take a method and return four result words; lhvi_vi_t gained var_N; lhvi_vi_opt_t, lhvi_vi_adam_run */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -342,7 +342,26 @@ typedef struct lhvi_vi {
     const double* obs_var;      /* [V] or NULL.  C2FVarInference.py:120-136,253-261: obs_var[v] > 0 makes the evidence cluster v
                                  * a Gaussian observation N(var_value[v], obs_var[v]) -- T quadrature nodes in every expectation,
                                  * its pdf in every belief, no parameters; 0 = exact evidence (or not evidence at all) */
+    const double* var_N;        /* [V] or NULL: rv.N = number of incident ground factors (the sum of the row's edge_count on a
+                                 * lifted graph, LiftedVarInference.py:64-67).  NULL: every (variable, k) thread sums its row itself,
+                                 * which serialises on the template variables of a relational model (thousands of entries) */
 } lhvi_vi_t;
+
+/* state of the optimiser for lhvi_vi_adam_run: the arrays ADAM_update (VarInference.py:249-287) reads and writes.  w, eta_c and
+ * eta_d must be the arrays the lhvi_vi_t passed alongside points to (the step must see what it updates). */
+typedef struct lhvi_vi_opt {
+    double* w_tau;              /* [K] mixture logits */
+    double* w;                  /* [K] softmax(w_tau) */
+    double* eta_c;              /* [V][K][2] */
+    double* tau_d;              /* [V][K][Dmax] category logits */
+    double* eta_d;              /* [V][K][Dmax] softmax(tau_d) over each hidden discrete variable's states */
+    double *m_w, *s_w, *m_c, *s_c, *m_d, *s_d;   /* ADAM moments, shaped like w_tau / eta_c / tau_d */
+    double *g_w, *g_c, *g_d;    /* gradient scratch, same shapes */
+    double* fe;                 /* [1] scratch for the free energy of passes that are not logged */
+    double lr, b1, b2, eps;     /* VarInference.py:252-254: 0.9, 0.999, 1e-8 */
+    double var_min;             /* var_threshold: variances are clipped from below (VarInference.py:11,277) */
+    int32_t t;                  /* updates done before this call (bias correction uses t + i + 1) */
+} lhvi_vi_opt_t;
 
 /* gradient_w_tau / gradient_mu_var / gradient_category_tau / free_energy: VarInference.py:57-195,
  * LiftedVarInference.py:59-199.  Outputs: g_w [K] (already softmax-projected), g_c [V][K][2],
@@ -350,6 +369,12 @@ typedef struct lhvi_vi {
 size_t lhvi_vi_workspace_bytes(const lhvi_graph_t* g, const lhvi_vi_t* p);
 int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t* p,
                  double* g_w, double* g_c, double* g_d, double* fe, void* ws, size_t ws_bytes, void* stream);
+/* `iterations` rounds of ADAM_update (VarInference.py:249-300) enqueued back to back, no host work in between: per round one
+ * lhvi_vi_grad and ONE update launch for all three parameter arrays (ADAM step, variance clip, both softmaxes).  fe_log: device
+ * [iterations] or NULL -- fe_log[i] = the free energy after update i + 1, which is what the next round's gradient pass computes
+ * anyway (one extra pass after the last update).  Results equal the per-array calls below bit for bit. */
+int lhvi_vi_adam_run(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t* p, const lhvi_vi_opt_t* o, int32_t iterations,
+                     double* fe_log, void* ws, size_t ws_bytes, void* stream);
 /* ADAM_update body: VarInference.py:255-287.  theta/m/s/g are flat arrays of `count` doubles;
  * clip_stride>0 clamps every element with index % clip_stride == clip_stride-1 to >= clip_min (variances). */
 int lhvi_adam_step(double* theta, double* m, double* s, const double* g, int64_t count, int32_t t,

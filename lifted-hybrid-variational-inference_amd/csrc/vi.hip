@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(BLOCK) vi_var_kernel(lhvi_graph_t g, lhvi_vi_t
     if (i >= (int64_t)g.V * p.K) return;
     const int v = (int)(i / p.K), k = (int)(i % p.K);
     double N = (double)(g.var_ptr[v + 1] - g.var_ptr[v]);          // ground graph: the degree (sum of ones is exact)
-    if (g.edge_count) {
+    if (p.var_N) N = p.var_N[v];                                   // (the caller's sum: a hub cluster's row has thousands of entries)
+    else if (g.edge_count) {
         N = 0.0;
         for (int j = g.var_ptr[v]; j < g.var_ptr[v + 1]; ++j) N += g.edge_count[g.var_edge[j]];
     }
@@ -541,6 +542,48 @@ __global__ void __launch_bounds__(BLOCK) softmax_rows_kernel(const double* __res
     for (int c = 0; c < cols; ++c) out[r * stride + c] = exp(tau[r * stride + c]) / z;
 }
 
+// ADAM_update body for all three parameter arrays in one launch (VI:255-287): thread i < K updates w_tau[i] (thread 0 then
+// forms w = softmax(w_tau) -- it waits for nobody: K <= 64 elements are its own loop); the next V * K threads own one
+// (variable, k) each: a hidden continuous variable's (mu, var) with var clipped at var_min, or a hidden discrete variable's
+// category logits followed by that row's softmax.  Rows of observed variables never move (the Python path multiplies their
+// gradients by a zero mask: m and s stay 0 and the step is 0).
+__device__ __forceinline__ double adam_one(double theta, double& m, double& s, double gr, const lhvi_vi_opt_t& o, double c1, double c2) {
+    m = m * o.b1 + (1 - o.b1) * gr;
+    s = s * o.b2 + (1 - o.b2) * gr * gr;
+    return theta - (o.lr * (m / c1)) / (sqrt(s / c2) + o.eps);
+}
+
+__global__ void __launch_bounds__(BLOCK) vi_update_kernel(lhvi_graph_t g, lhvi_vi_t p, lhvi_vi_opt_t o, double c1, double c2) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0) {
+        double z = 0.0;
+        for (int k = 0; k < p.K; ++k) {
+            o.w_tau[k] = adam_one(o.w_tau[k], o.m_w[k], o.s_w[k], o.g_w[k], o, c1, c2);
+            z += exp(o.w_tau[k]);
+        }
+        for (int k = 0; k < p.K; ++k) o.w[k] = exp(o.w_tau[k]) / z;       // e ** x / sum (VI:32-38): no max shift
+    }
+    if (i >= (int64_t)g.V * p.K) return;
+    const int v = (int)(i / p.K);
+    if (!is_hidden(g.var_value[v])) return;
+    if (v_cont(g, v)) {
+        double* th = o.eta_c + i * 2;
+        th[0] = adam_one(th[0], o.m_c[i * 2], o.s_c[i * 2], o.g_c[i * 2], o, c1, c2);
+        const double var = adam_one(th[1], o.m_c[i * 2 + 1], o.s_c[i * 2 + 1], o.g_c[i * 2 + 1], o, c1, c2);
+        th[1] = var < o.var_min ? o.var_min : var;
+    } else {
+        const int D = v_nstates(g, v);
+        double* tau = o.tau_d + i * p.Dmax;
+        double* eta = o.eta_d + i * p.Dmax;
+        double z = 0.0;
+        for (int d = 0; d < D; ++d) {
+            tau[d] = adam_one(tau[d], o.m_d[i * p.Dmax + d], o.s_d[i * p.Dmax + d], o.g_d[i * p.Dmax + d], o, c1, c2);
+            z += exp(tau[d]);
+        }
+        for (int d = 0; d < D; ++d) eta[d] = exp(tau[d]) / z;
+    }
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace lhvi
@@ -591,6 +634,27 @@ int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t
     const int nblocks = (int)(nred < VI_RED_BLOCKS ? (nred > 0 ? nred : 1) : VI_RED_BLOCKS);
     hipLaunchKernelGGL(vi_weights_partial_kernel, dim3(nblocks), dim3(BLOCK), 0, st, (int64_t)g->V, (int64_t)g->F, *p, rvterm, ef, partial);
     hipLaunchKernelGGL(vi_weights_kernel, dim3(1), dim3(BLOCK), 0, st, nblocks, *p, partial, g_w, fe);
+    return check_launch();
+}
+
+int lhvi_vi_adam_run(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t* p, const lhvi_vi_opt_t* o, int32_t iterations,
+                     double* fe_log, void* ws, size_t ws_bytes, void* stream) {
+    if (!g || !pots || !p || !o || iterations < 0) return LHVI_E_ARG;
+    if (!o->w_tau || !o->w || !o->eta_c || !o->tau_d || !o->eta_d || !o->m_w || !o->s_w || !o->m_c || !o->s_c || !o->m_d || !o->s_d ||
+        !o->g_w || !o->g_c || !o->g_d || !o->fe) return LHVI_E_ARG;
+    if (o->w != p->w || o->eta_c != p->eta_c || o->eta_d != p->eta_d) return LHVI_E_ARG;      // the step must see what it updates
+    hipStream_t st = as_stream(stream);
+    for (int i = 0; i < iterations; ++i) {
+        // the free energy the reference logs after update i - 1 is the one this gradient pass computes (same parameters)
+        double* fe = (fe_log && i > 0) ? fe_log + (i - 1) : o->fe;
+        if (int rc = lhvi_vi_grad(g, pots, p, o->g_w, o->g_c, o->g_d, fe, ws, ws_bytes, stream)) return rc;
+        const int t = o->t + i + 1;
+        const double c1 = 1 - pow(o->b1, (double)t), c2 = 1 - pow(o->b2, (double)t);
+        const int64_t n = (int64_t)g->V * p->K;
+        hipLaunchKernelGGL(vi_update_kernel, dim3(grid_for(n > 1 ? n : 1)), dim3(BLOCK), 0, st, *g, *p, *o, c1, c2);
+    }
+    if (fe_log && iterations > 0)
+        if (int rc = lhvi_vi_grad(g, pots, p, o->g_w, o->g_c, o->g_d, fe_log + (iterations - 1), ws, ws_bytes, stream)) return rc;
     return check_launch();
 }
 

@@ -65,8 +65,14 @@ class ViStruct(C.Structure):
     _fields_ = [
         ('K', C.c_int32), ('T', C.c_int32), ('Dmax', C.c_int32), ('quirks', C.c_int32),
         ('gh_x', C.c_void_p), ('gh_w', C.c_void_p), ('w', C.c_void_p), ('eta_c', C.c_void_p), ('eta_d', C.c_void_p),
-        ('obs_var', C.c_void_p),
+        ('obs_var', C.c_void_p), ('var_N', C.c_void_p),
     ]
+
+
+class ViOptStruct(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('w_tau', 'w', 'eta_c', 'tau_d', 'eta_d', 'm_w', 's_w', 'm_c', 's_c', 'm_d', 's_d',
+                                          'g_w', 'g_c', 'g_d', 'fe')] + \
+               [(n, C.c_double) for n in ('lr', 'b1', 'b2', 'eps', 'var_min')] + [('t', C.c_int32)]
 
 
 PBP_EP = 1
@@ -128,6 +134,7 @@ SIGNATURES = {
     'lhvi_pbp_belief_points': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     'lhvi_vi_workspace_bytes': (_sz, [_G, _VI]),
     'lhvi_vi_grad': (C.c_int, [_G, _P, _VI, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'lhvi_vi_adam_run': (C.c_int, [_G, _P, _VI, C.POINTER(ViOptStruct), _i32, _vp, _vp, _sz, _vp]),
     'lhvi_adam_step': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64, _f64, _i32, _f64, _vp]),
     'lhvi_softmax_rows': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     'lhvi_color_workspace_bytes': (_sz, [_G]),

@@ -29,6 +29,7 @@ class _Variational:
     var_threshold = 0.1
     reference_quirks = True
     verbose = False
+    fused_loop = True           # ADAM_update enqueues its whole loop through lhvi_vi_adam_run (else: one call per array and step)
 
     def _init_common(self, num_mixtures, num_quadrature_points):
         self.K = num_mixtures
@@ -58,6 +59,11 @@ class _Variational:
         for name in ('w_tau', 'eta_c', 'tau_d'):
             d['m_' + name] = torch.zeros_like(d[name])
             d['s_' + name] = torch.zeros_like(d[name])
+        # rv.N per variable (LVI:64-67): the sum of the row's counts, in row order like the kernel's own loop
+        if flat.lifted and flat.var_edge.size:
+            n_row = np.zeros(flat.V)
+            np.add.at(n_row, np.repeat(np.arange(flat.V), np.diff(flat.var_ptr)), flat.edge_count[flat.var_edge])
+            d['var_N'] = _abi.to_dev(n_row)
         self._dev = d
         ws_bytes = int(_abi.lib().lhvi_vi_workspace_bytes(dg.g, self._struct()))
         d['ws'] = torch.empty(ws_bytes, dtype=torch.uint8, device=dg.device)
@@ -78,7 +84,18 @@ class _Variational:
         p.K, p.T, p.Dmax, p.quirks = self.K, self.T, self.Dmax, 1 if self.reference_quirks else 0
         p.gh_x, p.gh_w, p.w = _abi.ptr(d['gh_x']), _abi.ptr(d['gh_w']), _abi.ptr(d['w'])
         p.eta_c, p.eta_d = _abi.ptr(d['eta_c']), _abi.ptr(d['eta_d'])
+        p.var_N = _abi.ptr(d.get('var_N'))
         return p
+
+    def _opt_struct(self):
+        d = self._dev
+        o = _abi.ViOptStruct()
+        for field, name in (('w_tau', 'w_tau'), ('w', 'w'), ('eta_c', 'eta_c'), ('tau_d', 'tau_d'), ('eta_d', 'eta_d'),
+                            ('m_w', 'm_w_tau'), ('s_w', 's_w_tau'), ('m_c', 'm_eta_c'), ('s_c', 's_eta_c'), ('m_d', 'm_tau_d'),
+                            ('s_d', 's_tau_d'), ('g_w', 'g_w'), ('g_c', 'g_c'), ('g_d', 'g_d'), ('fe', 'fe')):
+            setattr(o, field, _abi.ptr(d[name]))
+        o.lr, o.b1, o.b2, o.eps, o.var_min, o.t = float(self.alpha), self.b1, self.b2, self.eps, float(self.var_threshold), int(self.t)
+        return o
 
     def _refresh(self):
         """w = softmax(w_tau); eta[drv] = softmax(eta_tau[drv], 1) (VI:211-213)"""
@@ -175,6 +192,22 @@ class _Variational:
         log_dev = bool(self.is_log and self.log_fe)
         fe_buf = torch.empty(max(iteration, 1), dtype=torch.float64, device=self.dg.device) if log_dev else None
         start = time.process_time()
+        if self.fused_loop and (log_dev or not self.is_log):
+            # the whole loop enqueued by one call: per update one gradient pass and one launch for the three ADAM steps, the
+            # variance clip and the softmaxes (lhvi_vi_adam_run) -- same arithmetic as the per-array calls below
+            _abi.check(l.lhvi_vi_adam_run(self.dg.g, self.dg.p, self._struct(), self._opt_struct(), int(iteration),
+                                          _abi.ptr(fe_buf) if log_dev else None, _abi.ptr(d['ws']), d['ws_bytes'], _abi.stream_ptr()))
+            self.t += iteration
+            self._cache = {}
+            if log_dev and iteration > 0:
+                fes = fe_buf.cpu().numpy()
+                elapsed = time.process_time() - start
+                for i in range(iteration):
+                    self.total_time += elapsed / iteration
+                    if self.verbose:
+                        print(float(fes[i]), self.total_time)
+                    self.time_log.append([self.total_time, float(fes[i])])
+            return
         for i in range(iteration):
             self.t += 1
             self._grad()
