@@ -214,3 +214,23 @@ def test_c2f_var_inference_matches_reference(api, golden_dir, name):
             assert vi.map(rv) == pytest.approx(z['map'][i], abs=1e-4)
         elif i % 16 == 0 or len(rvs) < 200:
             assert vi.map(rv) == rv.value
+
+
+@pytest.mark.parametrize('name', ['hybrid_k2', 'lifted_hybrid_k2', 'lifted_rgm_small_k2'])
+def test_fused_adam_loop_equals_the_per_array_calls(api, golden_dir, name):
+    """lhvi_vi_adam_run (one gradient pass + one update launch per iteration, enqueued by a single call) against the loop of
+    lhvi_vi_grad / masked lhvi_adam_step x 3 / lhvi_softmax_rows: parameters, ADAM moments and logged free energies bit for bit"""
+    from lhvi.vi import LiftedVarInference, VarInference
+    z, meta = load_vi(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    runs = []
+    for fused in (True, False):
+        vi = (LiftedVarInference if meta['lifted'] else VarInference)(g, meta['K'], meta['T'])
+        vi.fused_loop = fused
+        np.random.seed(5)
+        vi.run(7, lr=0.15)
+        runs.append(vi)
+    a, b = runs
+    for key in ('w_tau', 'w', 'eta_c', 'tau_d', 'eta_d', 'm_w_tau', 's_w_tau', 'm_eta_c', 's_eta_c', 'm_tau_d', 's_tau_d'):
+        np.testing.assert_array_equal(a._dev[key].cpu().numpy(), b._dev[key].cpu().numpy(), err_msg=key)
+    assert [fe for _, fe in a.time_log] == [fe for _, fe in b.time_log] and a.t == b.t == 7
