@@ -519,16 +519,25 @@ __global__ void __launch_bounds__(BLOCK) loglik_final_kernel(int nblocks, const 
     if (threadIdx.x == 0) out[0] = red[0] == -__builtin_huge_val() ? -__builtin_huge_val() : -red[0];
 }
 
+// one ADAM step of one element (VI:255-287).  Every operation is pinned (no contraction), so that the per-array kernel below and
+// the fused update kernel give the same bits whatever the compiler does around them.
+struct AdamConst { double lr, b1, b2, eps, c1, c2; };
+__device__ __forceinline__ double adam_one(double theta, double& m, double& s, double gr, const AdamConst& o) {
+    m = __dadd_rn(__dmul_rn(m, o.b1), __dmul_rn(1 - o.b1, gr));                     // the reference's expressions, one rounding per operation
+    s = __dadd_rn(__dmul_rn(s, o.b2), __dmul_rn(__dmul_rn(1 - o.b2, gr), gr));
+    const double step = __ddiv_rn(__dmul_rn(o.lr, __ddiv_rn(m, o.c1)), __dadd_rn(sqrt(__ddiv_rn(s, o.c2)), o.eps));
+    return __dsub_rn(theta, step);
+}
+
 __global__ void __launch_bounds__(BLOCK) adam_kernel(double* __restrict__ theta, double* __restrict__ m, double* __restrict__ s,
                                                     const double* __restrict__ grad, int64_t count, double c1, double c2, double lr,
                                                     double b1, double b2, double eps, int clip_stride, double clip_min) {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= count) return;
-    const double gr = grad[i];
-    const double mi = m[i] * b1 + (1 - b1) * gr;
-    const double si = s[i] * b2 + (1 - b2) * gr * gr;
+    const AdamConst o = {lr, b1, b2, eps, c1, c2};
+    double mi = m[i], si = s[i];
+    double th = adam_one(theta[i], mi, si, grad[i], o);
     m[i] = mi; s[i] = si;
-    double th = theta[i] - (lr * (mi / c1)) / (sqrt(si / c2) + eps);
     if (clip_stride > 0 && (i % clip_stride) == clip_stride - 1 && th < clip_min) th = clip_min;
     theta[i] = th;
 }
@@ -547,18 +556,13 @@ __global__ void __launch_bounds__(BLOCK) softmax_rows_kernel(const double* __res
 // (variable, k) each: a hidden continuous variable's (mu, var) with var clipped at var_min, or a hidden discrete variable's
 // category logits followed by that row's softmax.  Rows of observed variables never move (the Python path multiplies their
 // gradients by a zero mask: m and s stay 0 and the step is 0).
-__device__ __forceinline__ double adam_one(double theta, double& m, double& s, double gr, const lhvi_vi_opt_t& o, double c1, double c2) {
-    m = m * o.b1 + (1 - o.b1) * gr;
-    s = s * o.b2 + (1 - o.b2) * gr * gr;
-    return theta - (o.lr * (m / c1)) / (sqrt(s / c2) + o.eps);
-}
-
 __global__ void __launch_bounds__(BLOCK) vi_update_kernel(lhvi_graph_t g, lhvi_vi_t p, lhvi_vi_opt_t o, double c1, double c2) {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const AdamConst ac = {o.lr, o.b1, o.b2, o.eps, c1, c2};
     if (i == 0) {
         double z = 0.0;
         for (int k = 0; k < p.K; ++k) {
-            o.w_tau[k] = adam_one(o.w_tau[k], o.m_w[k], o.s_w[k], o.g_w[k], o, c1, c2);
+            o.w_tau[k] = adam_one(o.w_tau[k], o.m_w[k], o.s_w[k], o.g_w[k], ac);
             z += exp(o.w_tau[k]);
         }
         for (int k = 0; k < p.K; ++k) o.w[k] = exp(o.w_tau[k]) / z;       // e ** x / sum (VI:32-38): no max shift
@@ -568,8 +572,8 @@ __global__ void __launch_bounds__(BLOCK) vi_update_kernel(lhvi_graph_t g, lhvi_v
     if (!is_hidden(g.var_value[v])) return;
     if (v_cont(g, v)) {
         double* th = o.eta_c + i * 2;
-        th[0] = adam_one(th[0], o.m_c[i * 2], o.s_c[i * 2], o.g_c[i * 2], o, c1, c2);
-        const double var = adam_one(th[1], o.m_c[i * 2 + 1], o.s_c[i * 2 + 1], o.g_c[i * 2 + 1], o, c1, c2);
+        th[0] = adam_one(th[0], o.m_c[i * 2], o.s_c[i * 2], o.g_c[i * 2], ac);
+        const double var = adam_one(th[1], o.m_c[i * 2 + 1], o.s_c[i * 2 + 1], o.g_c[i * 2 + 1], ac);
         th[1] = var < o.var_min ? o.var_min : var;
     } else {
         const int D = v_nstates(g, v);
@@ -577,7 +581,7 @@ __global__ void __launch_bounds__(BLOCK) vi_update_kernel(lhvi_graph_t g, lhvi_v
         double* eta = o.eta_d + i * p.Dmax;
         double z = 0.0;
         for (int d = 0; d < D; ++d) {
-            tau[d] = adam_one(tau[d], o.m_d[i * p.Dmax + d], o.s_d[i * p.Dmax + d], o.g_d[i * p.Dmax + d], o, c1, c2);
+            tau[d] = adam_one(tau[d], o.m_d[i * p.Dmax + d], o.s_d[i * p.Dmax + d], o.g_d[i * p.Dmax + d], ac);
             z += exp(tau[d]);
         }
         for (int d = 0; d < D; ++d) eta[d] = exp(tau[d]) / z;
