@@ -216,10 +216,12 @@ def test_c2f_var_inference_matches_reference(api, golden_dir, name):
             assert vi.map(rv) == rv.value
 
 
-@pytest.mark.parametrize('name', ['hybrid_k2', 'lifted_hybrid_k2', 'lifted_rgm_small_k2'])
+@pytest.mark.parametrize('name', ['hybrid_k2', 'lifted_hybrid_k2', 'lifted_rgm_small_k2', 'kalman_k3', 'lifted_robot_k2'])
 def test_fused_adam_loop_equals_the_per_array_calls(api, golden_dir, name):
     """lhvi_vi_adam_run (one gradient pass + one update launch per iteration, enqueued by a single call) against the loop of
-    lhvi_vi_grad / masked lhvi_adam_step x 3 / lhvi_softmax_rows: parameters, ADAM moments and logged free energies bit for bit"""
+    lhvi_vi_grad / masked lhvi_adam_step x 3 / lhvi_softmax_rows: parameters, ADAM moments and logged free energies bit for bit
+    (the hybrid fixtures mix binary and three-state variables, for which the per-array path forms its softmax with torch's exp
+    and sum instead of the device's: there the two runs agree to rounding)"""
     from lhvi.vi import LiftedVarInference, VarInference
     z, meta = load_vi(golden_dir, name)
     g, rvs, factors = modelio.load_model(meta['model'], API)
@@ -231,6 +233,11 @@ def test_fused_adam_loop_equals_the_per_array_calls(api, golden_dir, name):
         vi.run(7, lr=0.15)
         runs.append(vi)
     a, b = runs
+    exact = bool(a._uniform_states or not a._has_disc)
     for key in ('w_tau', 'w', 'eta_c', 'tau_d', 'eta_d', 'm_w_tau', 's_w_tau', 'm_eta_c', 's_eta_c', 'm_tau_d', 's_tau_d'):
-        np.testing.assert_array_equal(a._dev[key].cpu().numpy(), b._dev[key].cpu().numpy(), err_msg=key)
-    assert [fe for _, fe in a.time_log] == [fe for _, fe in b.time_log] and a.t == b.t == 7
+        if exact:
+            np.testing.assert_array_equal(a._dev[key].cpu().numpy(), b._dev[key].cpu().numpy(), err_msg=key)
+        else:
+            np.testing.assert_allclose(a._dev[key].cpu().numpy(), b._dev[key].cpu().numpy(), rtol=1e-11, atol=1e-13, err_msg=key)
+    fa, fb = [fe for _, fe in a.time_log], [fe for _, fe in b.time_log]
+    assert (fa == fb if exact else np.allclose(fa, fb, rtol=1e-12)) and a.t == b.t == 7
