@@ -519,14 +519,14 @@ __global__ void __launch_bounds__(BLOCK) loglik_final_kernel(int nblocks, const 
     if (threadIdx.x == 0) out[0] = red[0] == -__builtin_huge_val() ? -__builtin_huge_val() : -red[0];
 }
 
-// one ADAM step of one element (VI:255-287).  Every operation is pinned (no contraction), so that the per-array kernel below and
+// one ADAM step of one element (VI:255-287).  Contraction is off inside, so that the per-array kernel below and
 // the fused update kernel give the same bits whatever the compiler does around them.
 struct AdamConst { double lr, b1, b2, eps, c1, c2; };
 __device__ __forceinline__ double adam_one(double theta, double& m, double& s, double gr, const AdamConst& o) {
-    m = __dadd_rn(__dmul_rn(m, o.b1), __dmul_rn(1 - o.b1, gr));                     // the reference's expressions, one rounding per operation
-    s = __dadd_rn(__dmul_rn(s, o.b2), __dmul_rn(__dmul_rn(1 - o.b2, gr), gr));
-    const double step = __ddiv_rn(__dmul_rn(o.lr, __ddiv_rn(m, o.c1)), __dadd_rn(sqrt(__ddiv_rn(s, o.c2)), o.eps));
-    return __dsub_rn(theta, step);
+#pragma clang fp contract(off)
+    m = m * o.b1 + (1 - o.b1) * gr;                       // the reference's expressions, one rounding per operation
+    s = s * o.b2 + (1 - o.b2) * gr * gr;
+    return theta - (o.lr * (m / o.c1)) / (sqrt(s / o.c2) + o.eps);
 }
 
 __global__ void __launch_bounds__(BLOCK) adam_kernel(double* __restrict__ theta, double* __restrict__ m, double* __restrict__ s,
