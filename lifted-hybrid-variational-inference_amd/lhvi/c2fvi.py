@@ -180,6 +180,177 @@ def run_c2fvi(g, engine, refiner, K, iteration, lr, opts, init=None, observer=No
     return dict(rvc=rvc, fc=fc, flat=flat, cg=cg, stage=stage, params=P, fe_log=fe_log, obs_var=obs_var, t=t)
 
 
+# ---- the same schedule on arrays (ground FlatGraph in, no Python object per ground atom) ---------------------------------------
+def _kmeans_vec(vals, k, iteration):
+    """``lifting.kmeans_assign`` vectorised over the distinct values (same seeds -- the first k distinct values in member
+    order --, same accumulation order: ``np.bincount`` adds its weights in input order like the reference's loop over its
+    Counter), for clusters with many distinct values.  Returns the piece of every member or None."""
+    if vals.size <= 1:
+        return None
+    distinct, first, inv, cnt = np.unique(vals, return_index=True, return_inverse=True, return_counts=True)
+    order = np.argsort(first, kind='stable')            # distinct values in first-appearance (member) order
+    distinct, cnt = distinct[order], cnt[order].astype(np.float64)
+    kk = min(k, distinct.size)
+    if kk <= 1:
+        return None
+    cen = distinct[:kk].copy()
+    for _ in range(iteration):
+        idx = np.abs(cen[None, :] - distinct[:, None]).argmin(axis=1)
+        tot = np.bincount(idx, weights=distinct * cnt, minlength=kk)
+        num = np.bincount(idx, weights=cnt, minlength=kk)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            cen = tot / num
+    return np.abs(cen[None, :] - vals[:, None]).argmin(axis=1)
+
+
+def _group(rvc, mask):
+    """members of every colour among `mask`: (sorted member indices, colour of each group, group boundaries)"""
+    idx = np.flatnonzero(mask)
+    order = idx[np.argsort(rvc[idx], kind='stable')]
+    cols, start = np.unique(rvc[order], return_index=True)
+    return order, cols, np.append(start, order.size)
+
+
+def _variances_flat(values, rvc, obs):
+    """{colour: np.var of its observed members}, two passes with per-colour sums"""
+    nc = int(rvc.max()) + 1
+    c = rvc[obs]
+    n = np.bincount(c, minlength=nc).astype(np.float64)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        mean = np.bincount(c, weights=values[obs], minlength=nc) / n
+        var = np.bincount(c, weights=(values[obs] - mean[c]) ** 2, minlength=nc) / n
+    return var, n
+
+
+def split_evidence_flat(values, rvc, tracked, k, iteration, epsilon):
+    """``split_evidence`` on arrays: `tracked` is a boolean array over the colours; members are grouped once per pass"""
+    obs = ~np.isnan(values)
+    while True:
+        nc = int(rvc.max()) + 1
+        var, _ = _variances_flat(values, rvc, obs)
+        todo = np.flatnonzero(tracked[:nc] & (np.sqrt(np.nan_to_num(var)) > epsilon))
+        if todo.size == 0:
+            return rvc, tracked
+        order, cols, bounds = _group(rvc, obs & np.isin(rvc, todo))
+        rvc = rvc.copy()
+        nxt = nc
+        grown = list(tracked[:nc])
+        for gi, c in enumerate(cols):
+            members = order[bounds[gi]:bounds[gi + 1]]
+            vals = values[members]
+            assign = _kmeans_vec(vals, k, iteration)
+            if assign is None:
+                if members.size == 1:
+                    grown[c] = False
+                continue
+            for piece in range(1, int(assign.max()) + 1):     # piece 0 keeps the colour and stays tracked (CGWO:240-245 only adds)
+                sel = members[assign == piece]
+                if sel.size:
+                    rvc[sel] = nxt
+                    nxt += 1
+                    grown.append(bool(np.var(values[sel]) > epsilon))      # (variance here, its square root above: CGWO:239,244)
+        tracked = np.array(grown, dtype=bool)
+        if nxt == nc:
+            return rvc, tracked
+
+
+def cp_run_flat(flat, sym, dg, values, rvc, fc, tracked):
+    """``cp_run`` with the refinement run to its fixed point on the device (``lifting.refine_flat``: the same sequence of
+    half rounds).  ``clustered_evidence`` after the loop in closed form: an evidence cluster is tracked iff it has more than
+    one member and its ancestor at the start of the loop was tracked or ended up with several descendants (C2FVI:39-67: pieces
+    of a split enter the set, a cluster that stays whole leaves it when it is a singleton -- and the loop's last pass splits
+    nothing)."""
+    from .lifting import refine_flat
+    new_rvc, new_fc = refine_flat(flat, sym, rvc, fc, dg=dg)
+    n_new, n_old = int(new_rvc.max()) + 1, int(rvc.max()) + 1
+    rep = _first_member(new_rvc, n_new)
+    parent = rvc[rep]
+    nchild = np.bincount(parent, minlength=n_old)
+    size = np.bincount(new_rvc, minlength=n_new)
+    is_obs = ~np.isnan(values[rep])
+    out = is_obs & (size > 1) & (tracked[parent] | (nchild[parent] > 1))
+    return new_rvc.astype(np.int32), new_fc.astype(np.int32), out
+
+
+def run_c2fvi_flat(flat, engine, K, iteration, lr, opts, init=None, observer=None, dg=None):
+    """``run_c2fvi`` for a ground ``FlatGraph`` (e.g. ``RelationalGraph.ground_flat``): colours as arrays, every refinement to
+    its fixed point and every re-lift (``lifting.lift_flat``) on the device, parameters kept per CLUSTER and handed down
+    through the parent colour of each new cluster (clusters only split, children inherit: C2FVI:39-60).  ``init``: optional
+    (eta_c [V, K, 2], tau_d [V, K, D]) per ground variable.  Returns dict(rvc, fc, flat (lifted), stage, params (per cluster),
+    fe_log, obs_var, t, relift_s (seconds spent re-lifting, per round))."""
+    import time as _time
+    from .lifting import initial_colors_flat, lift_flat
+    torch = _abi.require_gpu()
+    dg = dg or _abi.DeviceGraph(flat)
+    values = flat.var_value
+    obs = ~np.isnan(values)
+    hid_d = flat.var_hidden & ~flat.var_cont
+    D = int(flat.var_nstates[hid_d].max()) if hid_d.any() else 1
+    rvc, fc, sym = initial_colors_flat(flat, is_split_cont_evidence=False)         # C2FVI:302
+    nc = int(rvc.max()) + 1
+    tracked = np.zeros(nc, dtype=bool)
+    tracked[np.unique(rvc[obs & flat.var_cont])] = True                            # CGWO:204-210
+    rep0 = _first_member(rvc, nc)
+    P = dict(w_tau=np.zeros(K), eta_c=np.ones((nc, K, 2)), tau_d=np.zeros((nc, K, D)))
+    if init is not None:
+        P['eta_c'] = np.nan_to_num(np.asarray(init[0], dtype=np.float64)[rep0], nan=1.0)
+        src = np.nan_to_num(np.asarray(init[1], dtype=np.float64)[rep0], nan=0.0)
+        P['tau_d'][:, :, :min(D, src.shape[2])] = src[:, :, :D]
+    else:                                                                          # one draw per coarse hidden cluster
+        for c in np.flatnonzero(flat.var_hidden[rep0]):
+            if flat.var_cont[rep0[c]]:
+                P['eta_c'][c, :, 0] = np.random.rand(K) * 3 - 1.5
+            else:
+                d = int(flat.var_nstates[rep0[c]])
+                P['tau_d'][c, :, :d] = np.random.rand(K, d) * 10
+    for name in ('w_tau', 'eta_c', 'tau_d'):
+        P['m_' + name] = np.zeros_like(P[name])
+        P['s_' + name] = np.zeros_like(P[name])
+
+    def inherit(old_rvc, new_rvc):
+        parent = old_rvc[_first_member(new_rvc, int(new_rvc.max()) + 1)]
+        for name in list(P):
+            if not name.endswith('w_tau'):
+                P[name] = P[name][parent]
+    t = 0
+    prev = rvc
+    rvc, fc, tracked = cp_run_flat(flat, sym, dg, values, rvc, fc, tracked)        # C2FVI:324
+    inherit(prev, rvc)
+    var, _ = _variances_flat(values, rvc, obs)
+    epsilon = float(np.sqrt(np.nanmax(var))) if obs.any() else 0.0                 # C2FVI:326-331
+    d_eps = epsilon * opts['update_obs_its'] / (iteration - opts['output_its'])
+    epsilon -= d_eps
+    fe_log, relift = [], []
+    stage = lflat = obs_var = None
+    for rnd in range(int(iteration / opts['update_obs_its'])):                      # C2FVI:338-345
+        t0 = _time.perf_counter()
+        prev = rvc
+        rvc, tracked = split_evidence_flat(values, rvc, tracked, opts['k_mean_k'], opts['k_mean_its'], epsilon)
+        rvc, fc, tracked = cp_run_flat(flat, sym, dg, values, rvc, fc, tracked)
+        inherit(prev, rvc)
+        epsilon = max(epsilon - d_eps, opts['min_obs_var'])
+        lflat = lift_flat(flat, _abi.to_dev(rvc), _abi.to_dev(fc), dg=dg)
+        var, _ = _variances_flat(values, rvc, obs)
+        obs_var = np.zeros(lflat.V)
+        if opts['gaussian_obs']:
+            ev = np.flatnonzero(~np.isnan(var) & (var > opts['min_obs_var']))
+            obs_var[ev] = var[ev]
+        torch.cuda.synchronize()
+        relift.append(_time.perf_counter() - t0)
+        if observer is not None:
+            observer(rnd, dict(rvc=rvc, fc=fc, tracked=set(np.flatnonzero(tracked).tolist()), flat=lflat, obs_var=obs_var, params=P, t=t))
+        stage = engine.stage(lflat, obs_var)
+        stage.load(P)
+        fe_log += stage.adam(opts['update_obs_its'], t, lr)
+        t += opts['update_obs_its']
+        for name, a in stage.dump().items():
+            if name.endswith('w_tau'):
+                P[name] = np.array(a, dtype=np.float64)
+            else:
+                P[name][..., :a.shape[-1]] = a
+    return dict(rvc=rvc, fc=fc, flat=lflat, stage=stage, params=P, fe_log=fe_log, obs_var=obs_var, t=t, relift_s=relift)
+
+
 class _DeviceStage(_Variational):
     """one round of the schedule on the device: the lifted graph of the round, Gaussian observations, ADAM"""
 

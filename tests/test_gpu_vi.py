@@ -241,3 +241,35 @@ def test_fused_adam_loop_equals_the_per_array_calls(api, golden_dir, name):
             np.testing.assert_allclose(a._dev[key].cpu().numpy(), b._dev[key].cpu().numpy(), rtol=1e-11, atol=1e-13, err_msg=key)
     fa, fb = [fe for _, fe in a.time_log], [fe for _, fe in b.time_log]
     assert (fa == fb if exact else np.allclose(fa, fb, rtol=1e-12)) and a.t == b.t == 7
+
+
+@pytest.mark.parametrize('name', ['c2f_rgm_k2', 'c2f_hmln_k2'])
+def test_c2fvi_on_arrays_equals_the_object_path(api, golden_dir, name):
+    """``run_c2fvi_flat`` (ground FlatGraph in: refinement to the fixed point and re-lifting on the device, clustered_evidence in
+    closed form, parameters per cluster) against ``run_c2fvi`` on the objects and through it against the reference's run:
+    every round's partition and Gaussian observations, the free energy after every update, the final parameters"""
+    from lhvi import c2fvi
+    from lhvi.flat import flatten
+    from oracle import oracle
+    z, meta = load_vi(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    vi = c2fvi.VarInference(g, meta['K'], meta['T'])
+    opts = dict(vi._options(), update_obs_its=meta['update_obs_its'])
+    rounds = []
+    res = c2fvi.run_c2fvi_flat(flatten(g, require_device_potentials=True), c2fvi._DeviceEngine(vi), meta['K'], meta['iterations'],
+                               meta['lr'], opts, init=(z['eta_c0'], z['tau_d0']), observer=lambda r, st: rounds.append(st))
+    assert len(rounds) == meta['iterations'] // meta['update_obs_its']
+    ev = np.array([rv.value is not None for rv in rvs])
+    for r, st in enumerate(rounds):
+        assert oracle.canonical_labels(st['rvc']) == z['round_rv_label'][r].tolist(), 'rv partition of round %d' % r
+        assert oracle.canonical_labels(st['fc']) == z['round_f_label'][r].tolist(), 'factor partition of round %d' % r
+        np.testing.assert_allclose(st['obs_var'][st['rvc']][ev], z['round_variance'][r][ev], rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(st['flat'].var_value[st['rvc']][ev], z['round_value'][r][ev], rtol=1e-14)
+        live = ev & (z['round_variance'][r] > 0)
+        tracked = np.array([int(st['rvc'][i]) in st['tracked'] for i in range(len(rvs))], dtype=np.int8)
+        assert (tracked[live] == z['round_tracked'][r][live]).all()
+    assert oracle.canonical_labels(res['rvc']) == z['final_rv_label'].tolist()
+    np.testing.assert_allclose(res['fe_log'], z['fe_log'], rtol=1e-8)
+    cont = np.array([rv.value is None and rv.domain.continuous for rv in rvs])
+    np.testing.assert_allclose(res['params']['eta_c'][res['rvc']][cont], z['final_eta_c'][cont], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(res['params']['w_tau'], z['final_w_tau'], rtol=1e-7, atol=1e-10)
