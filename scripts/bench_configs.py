@@ -228,6 +228,28 @@ if 'cfg5' in which:
         colour_ms_per_round=1e3 * t_ref / max(st5.get('rounds', 1), 1), colour_GBs_at_120B_per_edge_round=120.0 * flat.E * st5.get('rounds', 0) / t_ref / 1e9,
         colour_refinement_by_radix_sort_s=t_ref_sort, lift_flat_device_assisted_s=t_lift_dev, lift_flat_host_s=t_lift, adam_iterations_per_s=20 / dt, fe_start=fe0, fe_after_20=vi.free_energy())
 
+if 'c2fvi' in which:
+    # C2FVarInference on the 10 M-edge RGM of cfg 5, on arrays: coarse start, evidence split by k-means under a shrinking threshold,
+    # re-lift every 10 ADAM updates (C2FVarInference.py:301-352).  Reported: what a round spends re-lifting (evidence split, colour
+    # refinement to the fixed point, lift_flat, Gaussian-observation variances) and what it spends in its 10 ADAM updates.
+    from lhvi import c2fvi
+    flat, sym, rv0, f0 = synth.rgm_structured_flat()
+    dgc = _abi.DeviceGraph(flat)
+    owner = c2fvi.VarInference.__new__(c2fvi.VarInference)
+    owner._init_common(2, 3)
+    np.random.seed(0)
+    opts = dict(k_mean_k=2, k_mean_its=10, update_obs_its=10, output_its=0, min_obs_var=0, gaussian_obs=True)
+    seen = []
+    t0 = time.perf_counter()
+    res = c2fvi.run_c2fvi_flat(flat, c2fvi._DeviceEngine(owner), 2, 30, 0.2, opts, dg=dgc,
+                               observer=lambda r, st: seen.append((int(st['rvc'].max()) + 1, int((st['obs_var'] > 0).sum()))))
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    out(config='C2FVarInference K=2 T=3, 30 updates in 3 rounds, RGM 10M ground edges (arrays)', ground_edges=int(flat.E),
+        rv_clusters_per_round=[a for a, _ in seen], gaussian_observation_clusters_per_round=[b for _, b in seen],
+        relift_ms_per_round=[1e3 * x for x in res['relift_s']], total_s=total, fe_first=res['fe_log'][0], fe_last=res['fe_log'][-1])
+    del dgc
+
 if 'vi_ground' in which:
     # the variational step on a GROUND graph: RGM template C=1000, B=500 (1.0 M pairwise Gaussian factors), K=2, T=3
     from lhvi.vi import VarInference
