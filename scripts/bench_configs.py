@@ -250,6 +250,29 @@ if 'c2fvi' in which:
         relift_ms_per_round=[1e3 * x for x in res['relift_s']], total_s=total, fe_first=res['fe_log'][0], fe_last=res['fe_log'][-1])
     del dgc
 
+if 'lifted_pbp' in which:
+    # the counted particle sweep (HybridLBP semantics) on array-lifted graphs: the cfg-5 graph (10 M ground edges -> 39 260 lifted)
+    # and a 10 M-edge graph that lifts to ~1 M edges; n = 10 as in Demo/RGM/demo.py:19-20, the RGM's 100 integral points
+    from lhvi.pbp import HybridLBP
+    for label, args in (('cfg5 lifted', (2000, 1250, 400, 250)), ('10M ground -> ~1M lifted edges', (2000, 1250, 2000, 250))):
+        flat, sym, rv0, f0 = synth.rgm_structured_flat(*args)
+        dgl = _abi.DeviceGraph(flat)
+        rd, fd = lifting.refine_flat(flat, sym, rv0, f0, dg=dgl, device_out=True)
+        lf = lifting.lift_flat(flat, rd, fd, dg=dgl)
+        del dgl
+        for n_ in (10, 64):
+            bp = HybridLBP.on_flat(lf, n=n_, proposal_approximation='simple', sampler='device', seed=1)
+            bp._setup(None, flat=lf)
+            _abi.check(_abi.lib().lhvi_pbp_init(bp.dg.g, bp._struct(), _abi.ptr(bp.eta), _abi.ptr(bp.q_dev), _abi.ptr(bp.f2v),
+                                                _abi.ptr(bp.v2f), _abi.stream_ptr()))
+            bp._generate_sample()
+            t = ev_time(lambda: bp.sweep(last=False))
+            out(config='lifted particle sweep (HybridLBP semantics, simple proposals), %s, n=%d T=%d' % (label, n_, bp.T), ground_edges=int(flat.E),
+                lifted_edges=int(lf.E), rv_clusters=int(lf.V), max_count=float(lf.edge_count.max()), max_lifted_degree=int(np.diff(lf.var_ptr).max()),
+                sweep_ms=t, sweeps_per_s=1e3 / t, ground_edge_messages_per_s=2e3 * flat.E / t, heavy_edges=bp.n_heavy,
+                fast_edges=int(bp.fast_edges.numel()), generic_edges=int(bp.generic_edges.numel()), finite=bool(torch.isfinite(bp.f2v).all().item()))
+            del bp
+
 if 'vi_ground' in which:
     # the variational step on a GROUND graph: RGM template C=1000, B=500 (1.0 M pairwise Gaussian factors), K=2, T=3
     from lhvi.vi import VarInference

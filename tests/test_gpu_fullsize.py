@@ -188,3 +188,90 @@ def test_cfg5_rgm_at_10m_ground_edges_lifts_to_10k_clusters():
     lv.ADAM_update(5)
     gv._upload_params(lv._dev['w_tau'].cpu().numpy(), lv._dev['eta_c'].cpu().numpy()[rs], lv._dev['tau_d'].cpu().numpy()[rs])
     assert lv.free_energy() == pytest.approx(gv.free_energy(), rel=1e-8) and lv.free_energy() < fl
+
+
+def _lifted_sweeps(lflat, n, sweeps, sampler='device', seed=3):
+    from lhvi import _abi
+    from lhvi.pbp import HybridLBP
+    bp = HybridLBP.on_flat(lflat, n=n, proposal_approximation='simple', sampler=sampler, seed=seed)
+    bp._setup(None, flat=lflat)
+    _abi.check(_abi.lib().lhvi_pbp_init(bp.dg.g, bp._struct(), _abi.ptr(bp.eta), _abi.ptr(bp.q_dev), _abi.ptr(bp.f2v),
+                                        _abi.ptr(bp.v2f), _abi.stream_ptr()))
+    bp._generate_sample()
+    for _ in range(sweeps):
+        bp.sweep(last=False)
+    return bp
+
+
+def test_lifted_particle_sweep_at_scale():
+    """The counted sweep of HybridLBP (HLBP:182-215: count-weighted sums, the own factor with count - 1; Demo/RGM/demo.py:19-20
+    runs it with n = 10) on array-lifted graphs:
+    (a) the 1/25 twin of cfg 5 (400 k ground edges -> 39 260 lifted): with the same particles per cluster the lifted run equals the
+        GROUND run of the same semantics (every variable its own cluster, all counts 1) member for member -- the partition is a
+        fixed point of colour refinement, so lifting is exact;
+    (b) the cfg-5 graph itself (10.0 M ground edges -> the same 39 260 lifted edges with 25 x larger multiplicities, counts up to
+        2 000) and a 10 M-edge graph that lifts to ~1 M edges: finite tables, balanced messages, clamped sites, determinism."""
+    import torch
+    from lhvi import _abi, lifting, synth
+    _abi.require_gpu()
+    n, sweeps = 10, 3
+    # ---- (a) lifted == ground on the twin
+    small, sym, rv0, f0 = synth.rgm_structured_flat(400, 250)
+    rvc, fc = lifting.refine_flat(small, sym, rv0, f0)
+    lflat = lifting.lift_flat(small, rvc, fc)
+    assert lflat.E == 39260 and lflat.edge_count.max() > 1
+    ground = lifting.lift_flat(small, np.arange(small.V), np.arange(small.F))       # HLBP semantics, nothing merged
+    rng = np.random.default_rng(4)
+    draws = []
+
+    def lifted_sampler(k, flat, q):
+        cont = flat.var_hidden & flat.var_cont
+        out = np.zeros((flat.V, n))
+        lo, hi = flat.dom_lo[flat.var_dom], flat.dom_hi[flat.var_dom]
+        out[cont] = np.clip(rng.standard_normal((int(cont.sum()), n)) * np.sqrt(q[cont, 1:2]) + q[cont, 0:1], lo[cont, None], hi[cont, None])
+        draws.append(out)
+        return out
+    bl = _lifted_sweeps(lflat, n, sweeps, sampler=lifted_sampler)
+    assert bl.n_heavy > 0 and bl.T == 100                       # the RGM's 100 integral points: n + T = 110 output points per edge
+    bg = _lifted_sweeps(ground, n, sweeps, sampler=lambda k, flat, q: draws[k][rvc])
+    hid = small.var_hidden
+    ql, qg = bl.q_dev.cpu().numpy(), bg.q_dev.cpu().numpy()
+    np.testing.assert_allclose(qg[hid], ql[rvc][hid], rtol=1e-9, atol=1e-11)
+    # log-beliefs at the particles: sum over a ground variable's factors == count-weighted sum over its cluster's edges
+    gb = bg.belief_rv_all(bg.particles).cpu().numpy()
+    bl._stable_partition = True
+    lb = bl.belief_rv_all(bl.particles).cpu().numpy()
+    np.testing.assert_allclose(gb[hid], lb[rvc][hid], rtol=1e-9, atol=1e-7)
+    del bg, bl
+    # ---- (b) invariants at scale
+    for name, args, lifted_edges in (('cfg5', (2000, 1250, 400, 250), 39260), ('1M lifted edges', (2000, 1250, 2000, 250), None)):
+        flat, sym, rv0, f0 = synth.rgm_structured_flat(*args)
+        dg = _abi.DeviceGraph(flat)
+        rd, fd = lifting.refine_flat(flat, sym, rv0, f0, dg=dg, device_out=True)
+        lf = lifting.lift_flat(flat, rd, fd, dg=dg)
+        del dg
+        assert lifted_edges is None or lf.E == lifted_edges
+        assert lf.E < flat.E / 5 and float((lf.edge_count[lf.var_edge] * lf.var_mult[np.repeat(np.arange(lf.V), np.diff(lf.var_ptr))]).sum()) == flat.E
+        bp = _lifted_sweeps(lf, n, sweeps)
+        dev = bp.dg.device
+        edge_var = bp.dg.t['edge_var'].long()
+        hid_e = torch.from_numpy(lf.var_hidden).to(dev)[edge_var]
+        assert bool(torch.isfinite(bp.f2v[hid_e]).all()) and bool(torch.isfinite(bp.v2f[hid_e]).all())
+        cont = torch.from_numpy(lf.var_hidden & lf.var_cont).to(dev)
+        q = bp.q_dev[cont]
+        assert bool(torch.isfinite(q).all()) and float(q[:, 1].min()) > 0
+        # sites clamped from below by var_threshold * (number of ground factors of a member) (HLBP:104)
+        N = torch.from_numpy(np.add.reduceat(lf.edge_count[lf.var_edge], lf.var_ptr[:-1])).to(dev)
+        ce = cont[edge_var]
+        assert bool((bp.eta[ce][:, 1] >= 5.0 * N[edge_var][ce] - 1e-9).all())
+        # v -> f messages balanced over the distinct particles (HLBP:225-236) unless the max - 700 branch fired
+        uq_old = torch.empty_like(bp.uniq)
+        _abi.check(_abi.lib().lhvi_pbp_uniq(bp.dg.g, n, _abi.ptr(bp.old_particles), _abi.ptr(bp.np_dev), _abi.ptr(uq_old), _abi.stream_ptr()))
+        uq = uq_old[edge_var].bool() & (torch.arange(n, device=dev)[None, :] < bp.np_dev.long()[edge_var][:, None])
+        mean = (bp.v2f * uq).sum(1) / uq.sum(1).clamp_min(1)
+        mx = torch.where(uq, bp.v2f, torch.full_like(bp.v2f, -1e300)).max(1).values
+        by_mean = hid_e & ~((mx - 700.0).abs() < 1e-9)
+        assert float(mean[by_mean].abs().max()) < 1e-7
+        bp2 = _lifted_sweeps(lf, n, sweeps)
+        assert torch.equal(bp2.q_dev, bp.q_dev) and torch.equal(bp2.f2v, bp.f2v), name
+        del bp, bp2
