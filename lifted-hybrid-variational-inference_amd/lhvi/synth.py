@@ -113,13 +113,15 @@ def rgm_flat(C=100, B=50, n_values=0, evidence_ratio=0.2, seed=0):
     return flat, sym, rv_color, fac_pot.copy()
 
 
-def rgm_structured_flat(C=2000, B=1250, A=400, R=250):
+def rgm_structured_flat(C=2000, B=1250, A=400, R=250, distinct=False):
     """cfg 5 (BASELINE.json: "10 M ground / ~10 k lifted clusters"): the RGM template with evidence that is a function of
     (c mod A, b mod R) only -- a third of the market classes and a quarter of the revenue classes observed from small value
     pools, a tenth of the loss atoms observed on a lattice of the two class indices.  Colour passing then converges to a
     partition whose size depends on (A, R) but not on (C, B) as long as A | C and R | B: the defaults give 9 956 rv clusters
     and 19 630 factor clusters at any scale, 10.0 M ground edges at C = 2 000, B = 1 250.
-    Returns (flat, symmetric, rv_color0, f_color0) like ``rgm_flat``."""
+    ``distinct``: every observed market / revenue class gets a value of its own (instead of one from a pool of 11 / 9), so the
+    partition has about one loss cluster per (market class, revenue class) pair: A = 2 000, R = 250 lifts the 10 M-edge graph
+    to ~1 M edges.  Returns (flat, symmetric, rv_color0, f_color0) like ``rgm_flat``."""
     if C % A or B % R:
         raise ValueError('A must divide C and R must divide B')
     flat, sym, _, f0 = rgm_flat(C=C, B=B, n_values=0, evidence_ratio=0.0, seed=0)
@@ -129,9 +131,9 @@ def rgm_structured_flat(C=2000, B=1250, A=400, R=250):
     c, b = np.arange(C), np.arange(B)
     ac, rb = c % A, b % R
     mo = ac % 3 == 0
-    val[market + c[mo]] = (ac[mo] % 11).astype(float) - 5.0
+    val[market + c[mo]] = ac[mo].astype(float) * 0.01 - 5.0 if distinct else (ac[mo] % 11).astype(float) - 5.0
     ro = rb % 4 == 0
-    val[revenue + b[ro]] = (rb[ro] % 9).astype(float) * 1.5
+    val[revenue + b[ro]] = rb[ro].astype(float) * 0.02 if distinct else (rb[ro] % 9).astype(float) * 1.5
     acc, rbb = np.repeat(ac, B), np.tile(rb, C)
     lo = (acc * 7 + rbb * 3) % 10 == 0
     val[loss + np.flatnonzero(lo)] = ((acc + 2 * rbb) % 6)[lo].astype(float) - 2.5

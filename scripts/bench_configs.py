@@ -254,7 +254,7 @@ if 'lifted_pbp' in which:
     # the counted particle sweep (HybridLBP semantics) on array-lifted graphs: the cfg-5 graph (10 M ground edges -> 39 260 lifted)
     # and a 10 M-edge graph that lifts to ~1 M edges; n = 10 as in Demo/RGM/demo.py:19-20, the RGM's 100 integral points
     from lhvi.pbp import HybridLBP
-    for label, args in (('cfg5 lifted', (2000, 1250, 400, 250)), ('10M ground -> ~1M lifted edges', (2000, 1250, 2000, 250))):
+    for label, args in (('cfg5 lifted', (2000, 1250, 400, 250)), ('10M ground -> ~1M lifted edges', (2000, 1250, 1000, 250, True))):
         flat, sym, rv0, f0 = synth.rgm_structured_flat(*args)
         dgl = _abi.DeviceGraph(flat)
         rd, fd = lifting.refine_flat(flat, sym, rv0, f0, dg=dgl, device_out=True)

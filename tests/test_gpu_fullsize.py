@@ -238,20 +238,20 @@ def test_lifted_particle_sweep_at_scale():
     ql, qg = bl.q_dev.cpu().numpy(), bg.q_dev.cpu().numpy()
     np.testing.assert_allclose(qg[hid], ql[rvc][hid], rtol=1e-9, atol=1e-11)
     # log-beliefs at the particles: sum over a ground variable's factors == count-weighted sum over its cluster's edges
+    bg._stable_partition = bl._stable_partition = True
     gb = bg.belief_rv_all(bg.particles).cpu().numpy()
-    bl._stable_partition = True
     lb = bl.belief_rv_all(bl.particles).cpu().numpy()
     np.testing.assert_allclose(gb[hid], lb[rvc][hid], rtol=1e-9, atol=1e-7)
     del bg, bl
     # ---- (b) invariants at scale
-    for name, args, lifted_edges in (('cfg5', (2000, 1250, 400, 250), 39260), ('1M lifted edges', (2000, 1250, 2000, 250), None)):
+    for name, args, lifted_edges in (('cfg5', (2000, 1250, 400, 250), 39260), ('1M lifted edges', (2000, 1250, 1000, 250, True), None)):
         flat, sym, rv0, f0 = synth.rgm_structured_flat(*args)
         dg = _abi.DeviceGraph(flat)
         rd, fd = lifting.refine_flat(flat, sym, rv0, f0, dg=dg, device_out=True)
         lf = lifting.lift_flat(flat, rd, fd, dg=dg)
         del dg
         assert lifted_edges is None or lf.E == lifted_edges
-        assert lf.E < flat.E / 5 and float((lf.edge_count[lf.var_edge] * lf.var_mult[np.repeat(np.arange(lf.V), np.diff(lf.var_ptr))]).sum()) == flat.E
+        assert lf.E < flat.E / 5 and (lifted_edges is not None or lf.E > 500_000) and float((lf.edge_count[lf.var_edge] * lf.var_mult[np.repeat(np.arange(lf.V), np.diff(lf.var_ptr))]).sum()) == flat.E
         bp = _lifted_sweeps(lf, n, sweeps)
         dev = bp.dg.device
         edge_var = bp.dg.t['edge_var'].long()
