@@ -119,7 +119,8 @@ def rgm_structured_flat(C=2000, B=1250, A=400, R=250, distinct=False):
     pools, a tenth of the loss atoms observed on a lattice of the two class indices.  Colour passing then converges to a
     partition whose size depends on (A, R) but not on (C, B) as long as A | C and R | B: the defaults give 9 956 rv clusters
     and 19 630 factor clusters at any scale, 10.0 M ground edges at C = 2 000, B = 1 250.
-    ``distinct``: every observed market / revenue class gets a value of its own (instead of one from a pool of 11 / 9), so the
+    ``distinct``: every observed market / revenue class and every observed (market class, revenue class) pair of loss atoms gets a
+    value of its own (instead of one from a pool of 11 / 9 / 6), so the
     partition has about one loss cluster per (market class, revenue class) pair: A = 2 000, R = 250 lifts the 10 M-edge graph
     to ~1 M edges.  Returns (flat, symmetric, rv_color0, f_color0) like ``rgm_flat``."""
     if C % A or B % R:
@@ -136,7 +137,7 @@ def rgm_structured_flat(C=2000, B=1250, A=400, R=250, distinct=False):
     val[revenue + b[ro]] = rb[ro].astype(float) * 0.02 if distinct else (rb[ro] % 9).astype(float) * 1.5
     acc, rbb = np.repeat(ac, B), np.tile(rb, C)
     lo = (acc * 7 + rbb * 3) % 10 == 0
-    val[loss + np.flatnonzero(lo)] = ((acc + 2 * rbb) % 6)[lo].astype(float) - 2.5
+    val[loss + np.flatnonzero(lo)] = (acc * R + rbb)[lo].astype(float) * 1e-4 - 2.5 if distinct else ((acc + 2 * rbb) % 6)[lo].astype(float) - 2.5
     flat.var_value = val
     rv_color = np.zeros(V, dtype=np.int32)
     ob = ~np.isnan(val)
