@@ -49,22 +49,33 @@ def algorithmic_bytes_per_edge(n, T):
             'sweep': 32 * n + 16 * T + 16 + 12}
 
 
+TRAFFIC_PROFILE = 'profiles/r03_final_traffic.json'     # the PMC summary of THIS round's build (scripts/profile_round.sh r03_final)
+
+
 def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/*_traffic.json, written by scripts/summarize_pmc.py with the gfx950 FETCH_SIZE correction) and the file it
-    came from; (None, None) if absent.  PMC passes cannot be collected inside a timed run, so this number is read, not
-    measured live."""
-    import glob
-    best = src = None
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json'))):
-        try:
-            d = json.load(open(path))
-        except Exception:
-            continue
-        for k, v in d.items():
-            if k.endswith(kernel):
-                best, src = v['hbm_bytes'], os.path.relpath(path, ROOT)
-    return best, src
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command -- exactly the file
+    named above (written by scripts/summarize_pmc.py with the gfx950 FETCH_SIZE correction), never "whichever file sorts
+    last" -- and that file's name; (None, None) if it is absent or does not list the kernel.  PMC passes cannot be collected
+    inside a timed run, so this number is read, not measured live."""
+    path = os.path.join(ROOT, TRAFFIC_PROFILE)
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None, None
+    for k, v in d.items():
+        if k.endswith(kernel):
+            return v['hbm_bytes'], TRAFFIC_PROFILE
+    return None, None
+
+
+def progress(msg):
+    """one flushed line per phase on stderr (with the time since start), so that a run that does not finish shows where it
+    stopped; stdout carries only the JSON line"""
+    sys.stderr.write('[bench %8.2f s] %s\n' % (time.perf_counter() - _T0, msg))
+    sys.stderr.flush()
+
+
+_T0 = time.perf_counter()
 
 
 def cpu_baseline(n, T, seconds_target=15.0):
@@ -98,12 +109,13 @@ def cpu_baseline(n, T, seconds_target=15.0):
 
 def python_baseline(n, T, budget_s=10.0):
     """The reference-equivalent pure-Python path (oracle/pyref.py: dict-of-dicts restatement of EPBPLogVersion.py:225-289,
-    pinned against the reference's golden vectors in the CPU suite), single thread, on 1e3- and 1e4-edge graphs of the same
-    generator; the f -> rv half is bounded to `budget_s` seconds of factors and extrapolated linearly (labelled)."""
+    pinned against the reference's golden vectors in the CPU suite), single thread, on 1e3-, 1e4- and 1e5-edge graphs of the
+    same generator; the f -> rv half is bounded to `budget_s` seconds of factors and extrapolated linearly
+    (labelled)."""
     from lhvi import graph, potentials, synth
     from oracle import pyref
     out = []
-    for V, budget in ((250, budget_s), (2500, budget_s * 0.6)):
+    for V, budget in ((250, budget_s), (2500, budget_s * 0.6), (25000, budget_s * 0.5)):
         flat = synth.hybrid_mrf_flat(V=V, deg=4, seed=123, T=T)
         out.append(pyref.time_sweep(flat, n, graph, potentials, budget_s=budget))
     return out
@@ -112,13 +124,10 @@ def python_baseline(n, T, budget_s=10.0):
 def self_launch(n_ranks):
     """`--gpus N` without a launcher: start N ranks of this file under torch.distributed.run from a parent that has not
     touched the GPU (and never will); returns the launcher's exit code (non-zero if any rank failed)"""
-    import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(('127.0.0.1', 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_ranks),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher picks and binds its own rendezvous port (no bind / close / reuse race with other processes)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           '--nproc-per-node', str(n_ranks), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, LHVI_BENCH_SELF_LAUNCHED='1')
     return subprocess.call(cmd, env=env)
 
@@ -165,6 +174,7 @@ def main():
         else:
             td.init_process_group(backend)
 
+    progress('rank %d of %d on device %d' % (rank, world, device_index))
     n, T = args.particles, args.grid
     deg = 4
     V = args.edges // deg
@@ -181,6 +191,7 @@ def main():
         runner = dist.ShardedRunner(flat, n=n, seed=1, rank=rank, world=world,
                                     fac_owner=dist.broadcast_partition(flat, rank, world))
     del flat
+    progress('graph on the device, work lists built')
     runner.init()
 
     def barrier():
@@ -193,12 +204,16 @@ def main():
     for _ in range(args.warmup):
         runner.sweep()
     barrier()
+    progress('%d warm-up sweeps done' % args.warmup)
+    if hasattr(runner, 'record_phases'):
+        runner.record_phases = True
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
         runner.sweep(f2v_events=ev[i])
     barrier()
     elapsed = time.perf_counter() - t0
+    progress('%d timed sweeps done in %.3f s' % (args.steps, elapsed))
     t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if os.environ.get('LHVI_DIST_BACKEND', 'nccl') == 'nccl' else 'cpu')
     if world > 1:
         import torch.distributed as td
@@ -223,6 +238,15 @@ def main():
         # the terms at the particles cost exactly that; the terms at the integral points of edges the kernel serves by the
         # grid recurrence cost FLOP_PER_GRID_TERM (the rest of them take the direct form, 16)
         grid_terms = runner.heavy_grid_terms()
+        # ... as counted by the kernel itself: words 8 / 9 of the ticket buffer hold the edges of the last launch that went through
+        # the recurrence / failed its range guard (the guard is data dependent)
+        grid_edges = fallback_edges = None
+        ticket = getattr(getattr(runner, 'bp', None), 'f2v_ticket', None)
+        if ticket is not None and world == 1:
+            stat = ticket.cpu().numpy()
+            grid_edges, fallback_edges = int(stat[8]), int(stat[9])
+            if grid_edges + fallback_edges > 0:
+                grid_terms = int(round(grid_terms * grid_edges / float(grid_edges + fallback_edges)))
         f2v_tflops = terms * FLOP_PER_TERM / (f2v_ms * 1e-3) / 1e12
         exec_tflops = ((terms - grid_terms) * FLOP_PER_TERM + grid_terms * FLOP_PER_GRID_TERM) / (f2v_ms * 1e-3) / 1e12
         sweep_gbs = bytes_e['sweep'] * E_local / (ms * 1e-3) / 1e9
@@ -244,6 +268,7 @@ def main():
                          'unit': 'TFLOP/s', 'frac': f2v_tflops / FP64_PEAK_TFLOPS,
                          'executed': {'achieved': exec_tflops, 'frac': exec_tflops / FP64_PEAK_TFLOPS,
                                       'grid_terms_per_launch': grid_terms, 'flop_per_grid_term': FLOP_PER_GRID_TERM,
+                                      'grid_edges_counted_by_the_kernel': grid_edges, 'guard_fallback_edges': fallback_edges,
                                       'note': 'flops the kernel really issues: 16 per term at the particles, %.2f per term at '
                                               'the integral points tabulated by the grid recurrence' % FLOP_PER_GRID_TERM},
                          'traffic': traffic, 'traffic_source': ('from_committed_profile: ' + traffic_src) if traffic_src else None,
@@ -262,8 +287,12 @@ def main():
                                             'for n = 64 particles by arithmetic intensity, not by wasted traffic'},
             'hidden_edge_fraction': hidden_frac,
         }
+        if getattr(runner, 'phase_ms', None):
+            out['phases_ms'] = runner.phase_ms()      # sharded runs: HIP-event times of pack / interior / exchange wait / boundary
         if not args.no_cpu_baseline and world == 1:
+            progress('CPU baseline: C oracle on a bounded sample')
             Es, sw, dt, edge_rate, cores = cpu_baseline(n, T)
+            progress('CPU baseline: pure-Python restatement at 1e3 / 1e4 / 1e5 edges')
             py = python_baseline(n, T)
             out['cpu_baseline'] = {'value': edge_rate / (2.0 * E_total), 'unit': 'sweeps/s', 'cores': cores, 'kind': 'port',
                                    'edge_messages_per_sec': edge_rate,
@@ -274,12 +303,13 @@ def main():
                                               'kind': 'port (pure-Python dict-of-dicts restatement of EPBPLogVersion.py:225-289, '
                                                       'oracle/pyref.py; the reference itself cannot travel to this box)',
                                               'edge_messages_per_sec': py[0]['edge_messages_per_sec'],
-                                              'sample': 'one sweep at n = %d, T = %d on %d- and %d-edge graphs of the same generator; '
-                                                        'the f -> rv half timed on the first %d / %d hidden edges and extrapolated '
+                                              'sample': 'one sweep at n = %d, T = %d on %d-, %d- and %d-edge graphs of the same generator; '
+                                                        'the f -> rv half timed on the first %d / %d / %d hidden edges and extrapolated '
                                                         'linearly; value = edge-message rate of the first / (2 * %d edges)'
-                                                        % (n, T, py[0]['edges'], py[1]['edges'], py[0]['f2v_edges_done'],
-                                                           py[1]['f2v_edges_done'], E_total),
+                                                        % (n, T, py[0]['edges'], py[1]['edges'], py[2]['edges'], py[0]['f2v_edges_done'],
+                                                           py[1]['f2v_edges_done'], py[2]['f2v_edges_done'], E_total),
                                               'runs': py}}
+        progress('done')
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as td

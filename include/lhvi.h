@@ -219,7 +219,8 @@ typedef struct lhvi_pbp {
      * cuts its work list into one contiguous range per XCD (each XCD has its own L2) and hands each range out in chunks of
      * consecutive entries through an atomic counter, which the call resets on its stream: a wave's descriptors are then
      * neighbours in memory, and a workgroup dispatched late finds less left to do instead of owing a full static share
-     * (13.4 -> 12.0 ms per launch on the 10 M-edge benchmark).  NULL: every wave strides over the list. */
+     * (13.4 -> 12.0 ms per launch on the 10 M-edge benchmark).  NULL: every wave strides over the list.  Words 8 and 9 come
+     * back with the launch's grid-recurrence statistics (LHVI_PBP_TICKET_COUNTERS). */
     uint32_t* f2v_ticket;
     /* optional, lhvi_pbp_proposal only: one record of eight 32-bit words per hidden CONTINUOUS variable, host-built --
      *   0 variable   1 degree (entries of its var_edge row)   2 grid base in dom_val   3 T   4-7 the first four incident
@@ -245,7 +246,9 @@ typedef struct lhvi_pbp {
 } lhvi_pbp_t;
 
 #define LHVI_PBP_DESC_BYTES 128
-#define LHVI_PBP_TICKET_WORDS 8
+#define LHVI_PBP_TICKET_WORDS 16     /* the work counters, then two words of statistics of the last lhvi_pbp_f2v call */
+#define LHVI_PBP_TICKET_COUNTERS 8   /* words 0-7: one work counter per XCD range; word 8: heavy edges whose integral points were tabulated by the
+                                      * uniform-grid recurrence; word 9: eligible edges that failed its range guard and took the direct form */
 /* static per-edge descriptors of the fast work list: lets the persistent f2v kernels fetch everything about an edge with
  * scalar loads.  Must be rebuilt when np / the graph / the potentials change.  Layout (32-bit words unless noted):
  *   0 edge   1 target variable   2 partner variable   3 partner's canonical edge   4 class (lhvi_pbp_classify)

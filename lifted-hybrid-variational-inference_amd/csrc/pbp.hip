@@ -609,7 +609,7 @@ struct WorkCursor {
         left = 0; pending = 0; lo = 0; limit = nitems;
         ticket = base;
         if (ticket) {
-            const int parts = min((int)gridDim.x, LHVI_PBP_TICKET_WORDS);
+            const int parts = min((int)gridDim.x, LHVI_PBP_TICKET_COUNTERS);
             const int part = blockIdx.x % parts;
             const int per = ((nitems + parts - 1) / parts + WORK_CHUNK - 1) / WORK_CHUNK * WORK_CHUNK;
             lo = min(part * per, nitems);
@@ -733,7 +733,7 @@ __device__ __forceinline__ HeavyData heavy_fetch(const FastDesc& d, const lhvi_g
 
 __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI_HEAVY_WAVES, LHVI_HEAVY_WAVES))) pbp_f2v_heavy_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
                                                              double* __restrict__ f2v, const FastDesc* __restrict__ descs,
-                                                             int nitems) {
+                                                             int nitems, uint32_t* __restrict__ stats) {
     __shared__ AB sh_all[HEAVY_BLOCK / WAVE][WAVE];
     __shared__ double sh_tab[EXP_TAB_N];
     __shared__ LogRec sh_log[LOG_TAB_N];
@@ -748,6 +748,7 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
     const int n = s.n, S = s.n + s.T;
     WorkCursor<8, HEAVY_BLOCK / WAVE> cur;
     if (!cur.start(s.f2v_ticket, nitems, lane)) return;
+    int n_grid = 0, n_direct = 0;          // edges of this wave whose integral points went through the recurrence / fell back
     // pipeline: the loads of edge k+1 are issued as soon as edge k has been staged into LDS (its registers are free
     // then, so nothing has to be rotated) and stay in flight through the term loops of edge k; `dn` is the full
     // descriptor of edge k+1, fetched one edge ahead, `d` the seven words the arithmetic of edge k needs
@@ -783,6 +784,7 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
             const double X = fmax(fabs(d.gx0), fabs(fma((double)(d.T - 1), d.gh, d.gx0)));
             const double bound = fma(fabs(mine.b) + fabs(kconst) * X, X, fabs(mine.a));
             grid_path = __ballot(lane < nj && !(bound < GRID_MAX_EXPONENT)) == 0;
+            if (grid_path) ++n_grid; else ++n_direct;
         }
         const int npts = eligible ? np : np + d.T;          // eligible: the integral points are handled after the particle rounds
         const double x0 = h.x0, x1 = h.x1;
@@ -831,6 +833,7 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
         if (!more) break;
         cur.advance(nxt, lane);
     }
+    if (stats && lane == 0) { atomicAdd(stats, (uint32_t)n_grid); atomicAdd(stats + 1, (uint32_t)n_direct); }
 }
 
 // LIGHT edges: HybridQuadratic(1 discrete, 1 continuous) with a binary (or observed) discrete side -- the edges between
@@ -1751,12 +1754,13 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     const int heavy_grid = min((s->n_heavy + HWPB - 1) / HWPB, max(cus * heavy_blocks - spare * (BLOCK / WAVE) / HWPB, 1));
     lhvi_pbp_t sh = *s;
     if (sh.f2v_ticket && (int64_t)s->n_heavy < (int64_t)heavy_grid * HWPB * 8 * 4) sh.f2v_ticket = nullptr;
-    if (sh.f2v_ticket && run_heavy && hipMemsetAsync(sh.f2v_ticket, 0, LHVI_PBP_TICKET_WORDS * sizeof(uint32_t), as_stream(stream)) != hipSuccess)
+    if (s->f2v_ticket && run_heavy && hipMemsetAsync(s->f2v_ticket, 0, LHVI_PBP_TICKET_WORDS * sizeof(uint32_t), as_stream(stream)) != hipSuccess)
         return LHVI_E_LAUNCH;
     if (!(s->flags & LHVI_PBP_SKIP_FAST)) {
         if (s->heavy_desc && s->n_heavy > 0 && !(s->flags & LHVI_PBP_SKIP_HEAVY))
             hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(heavy_grid), dim3(HEAVY_BLOCK), 0, as_stream(stream),
-                               *g, sh, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy);
+                               *g, sh, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy,
+                               s->f2v_ticket ? s->f2v_ticket + LHVI_PBP_TICKET_COUNTERS : (uint32_t*)nullptr);
         if (s->pair_desc && s->n_pair > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT)) {
             static const int pair_per_cu = blocks_per_cu((const void*)pbp_f2v_pair_kernel);
             hipLaunchKernelGGL(pbp_f2v_pair_kernel, dim3(min((s->n_pair + 3) / 4, max(cus * min(pair_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0,

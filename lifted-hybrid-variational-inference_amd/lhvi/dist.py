@@ -273,6 +273,8 @@ class ShardedRunner:
         # two-part schedule: needs both parts non-empty and the fused resample kernel (n <= 64), which takes a range
         self.overlap = bool(overlap) and world > 1 and nb > 0 and self.n_int > 0 and n <= 64
         self.f2v_extra = []                 # event pairs around the second heavy-kernel launch of a sweep (bench)
+        self.record_phases = False          # sweep() records HIP events at its phase boundaries (bench.py --gpus N)
+        self._phase_events = []
         self.ph = torch.zeros(plan.flat.V, 2, dtype=torch.float64, device=dev)
         # exchange rows, packed back to back in peer-major order: n + 2 doubles for a continuous boundary variable, its
         # np states for a discrete one (nothing else of a discrete variable is exchanged)
@@ -418,16 +420,47 @@ class ShardedRunner:
             self.post(recv, f2v_events)
             return
         import torch
+        marks = []
+
+        def mark():
+            if self.record_phases:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
+        mark()
         send = self.pre(part=1)                             # boundary rows first: the exchange starts as early as it can
+        mark()
         recv, work = self.exchange(send, async_op=True)
         extra = None
         if f2v_events:
             extra = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.f2v_extra.append(extra)
         self.interior(extra)
+        mark()
         if work is not None:
             work.wait()                                     # the compute stream waits for the collective
+        mark()
         self.boundary(recv, f2v_events)
+        mark()
+        if marks:
+            self._phase_events.append(marks)
+
+    def phase_ms(self):
+        """mean HIP-event time of each phase of the two-part schedule on this rank's compute stream (call after a
+        synchronisation): boundary partials + pack, the interior part, the wait for the collective that is NOT hidden behind
+        it, the boundary part"""
+        if not self._phase_events:
+            return None
+        names = ('pack', 'interior', 'exchange_wait', 'boundary')
+        acc = {k: 0.0 for k in names}
+        for m in self._phase_events:
+            for k, a, b in zip(names, m[:-1], m[1:]):
+                acc[k] += a.elapsed_time(b)
+        n = len(self._phase_events)
+        out = {k: v / n for k, v in acc.items()}
+        out.update(sweeps=n, boundary_variables=int(self.nb), interior_variables=int(self.n_int),
+                   exchanged_MB_per_sweep=8e-6 * self.n_elems)
+        return out
 
     def local_edges(self):
         return self.plan.flat.E

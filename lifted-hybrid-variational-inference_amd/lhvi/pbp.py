@@ -63,7 +63,7 @@ class _ParticleSweep:
         self.particles = dg.zeros(flat.V, n)
         self.old_particles = dg.zeros(flat.V, n)
         self.uniq = torch.zeros(flat.V, n, dtype=torch.uint8, device=dg.device)
-        self.f2v_ticket = torch.zeros(8, dtype=torch.int32, device=dg.device)     # work counters of the heavy f2v kernel (LHVI_PBP_TICKET_WORDS)
+        self.f2v_ticket = torch.zeros(16, dtype=torch.int32, device=dg.device)    # work counters + statistics of the heavy f2v kernel (LHVI_PBP_TICKET_WORDS)
         self.flags = (_abi.PBP_EP if self.proposal_approximation == 'EP' else 0) | \
                      (_abi.PBP_EPBP_DISCRETE if self._epbp_discrete else 0) | \
                      (_abi.PBP_CQ if self.cq_routing and bool((flat.pot_kind == 8).any()) else 0)

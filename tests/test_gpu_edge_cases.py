@@ -240,3 +240,16 @@ def test_random_shapes_against_oracle(api, seed):
         np.testing.assert_allclose(bp.v2f.cpu().numpy()[hid_e][:, :n], o.v2f[hid_e], rtol=1e-9, atol=1e-7)
         np.testing.assert_allclose(bp.f2v.cpu().numpy()[hid_e], o.f2v[hid_e], rtol=1e-9, atol=1e-7)
         np.testing.assert_allclose(bp.q_dev.cpu().numpy()[flat.var_hidden], o.q[flat.var_hidden], rtol=1e-9, atol=1e-10)
+
+
+def test_build_then_smoke_in_one_fresh_process():
+    """``__graft_entry__.build()`` followed by ``smoke()`` in ONE process that has not imported torch before: ``build()`` loads
+    liblhvi.so, and unless PyTorch's own HIP runtime is in the process first the library binds to the system's copy and the first
+    launch fails with hipErrorNoDevice (seen in round 2; ``lhvi/_abi.py::lib`` imports torch before ``dlopen``)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; assert 'torch' not in sys.modules; import __graft_entry__ as g; g.build(); g.smoke(); print('BUILD+SMOKE OK')")
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and 'BUILD+SMOKE OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
