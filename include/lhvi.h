@@ -140,6 +140,16 @@ int lhvi_gabp_pull(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_ga
 int lhvi_gabp_run_pull(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_gabp_plan_t* plan, double* f2v, double* v2f,
                        int iterations, void* ws, size_t ws_bytes, void* stream);
 
+/* The whole of GaBP.run + the marginals (lhvi_gabp_run_pull, then lhvi_gabp_marginals into mu_var [V][2]) recorded once as a
+ * hipGraph over the caller's buffers and replayed with ONE launch: on template-sized graphs (BASELINE cfg 2: 20 k edges, 23
+ * launches) the launches are the run.  The handle owns only the executable graph; rebuild it when the graph, the plan, a
+ * buffer or `iterations` changes.  Evidence values are read from g->var_value at replay time, so new evidence in the same
+ * buffer needs no rebuild. */
+int lhvi_gabp_graph_create(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_gabp_plan_t* plan, double* f2v, double* v2f,
+                           double* mu_var, int iterations, void* ws, size_t ws_bytes, void** handle_out);
+int lhvi_gabp_graph_launch(void* handle, void* stream);
+int lhvi_gabp_graph_destroy(void* handle);
+
 /* per-variable product of incoming messages -> mu_var [V][2]; evidence rows get (value, 0):
  * GaBP.get_belief_params GaBP.py:187-200, GaLBP.map GaLBP.py:201-217 */
 int lhvi_gabp_marginals(const lhvi_graph_t* g, const double* f2v, double* mu_var, void* stream);

@@ -289,7 +289,10 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_kernel(lhvi_graph_t g, lhvi_p
     }
     for (int j = lo_ext + threadIdx.x; j < hi_ext; j += BLOCK) {
         // first sweep: every f -> v message still is its initial value (0, 1) (GaBP.py:143-150)
-        const bool hid = is_hidden(g.var_value[g.slot_var[j]]);
+        const int vj = g.slot_var[j];
+        // (slots of a hub row are never read from LDS: gabp_pull_hub_kernel serves the whole row)
+        if (g.n_hubs > 0 && g.var_ptr[vj + 1] - g.var_ptr[vj] > GABP_HUB_DEGREE) continue;
+        const bool hid = is_hidden(g.var_value[vj]);
         const double2 m = (hid && !first) ? pull_incoming(g, pots, pl, vprev, j) : make_double2(0.0, 1.0);
         // staged in information form (p * mu, p), p = 1 / var -- the products every slot of the row would form anyway, so
         // the row sums below are additions only; a `None` variance (NaN) keeps (mu, NaN)
@@ -326,15 +329,18 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_hub_kernel(lhvi_graph_t g, lh
     const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
     if (hi - lo <= GABP_HUB_DEGREE || !is_hidden(g.var_value[v])) return;     // observed rows: written by gabp_pull_kernel
     double H = 0.0, P = 0.0;
+    // pass 1: the row's total; every slot's incoming message (one random gather + the closed form) is parked in the slot's own
+    // output cell, which the same lane reads back in pass 2 -- one gather per slot and sweep instead of two
     for (int j = lo + lane; j < hi; j += 64) {
         const double c = pl.count ? pl.count[j] : 1.0;
         const double2 m = first ? make_double2(0.0, 1.0) : pull_incoming(g, pots, pl, vprev, j);
+        st2(vnext, j, m.x, m.y);
         if (m.y != m.y) H -= m.x * c;
         else { const double p = 1.0 / m.y; H += p * m.x * c; P += p * c; }
     }
     H = dpp_wave_reduce(H, SumOp()); P = dpp_wave_reduce(P, SumOp());
     for (int j = lo + lane; j < hi; j += 64) {
-        const double2 m = first ? make_double2(0.0, 1.0) : pull_incoming(g, pots, pl, vprev, j);
+        const double2 m = ld2(vnext, j);
         double h = H, p = P;
         if (m.y != m.y) h += m.x;
         else { const double q = 1.0 / m.y; h -= q * m.x; p -= q; }
@@ -450,6 +456,47 @@ int lhvi_gabp_run_pull(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhv
     }
     hipLaunchKernelGGL(gabp_unpack_kernel, grid, dim3(BLOCK), 0, as_stream(stream), *g, a, v2f);
     return check_launch();
+}
+
+// A whole run -- `iterations` pull sweeps, the conversion to edge order and the marginals -- recorded once as a hipGraph and
+// replayed with one launch: on a template-sized graph (cfg 2: 20 k edges, 23 launches of a few microseconds each) the launches
+// are the run.  The handle owns nothing but the executable graph; every buffer stays the caller's and is baked in.
+struct GabpGraph { hipGraph_t graph; hipGraphExec_t exec; };
+
+int lhvi_gabp_graph_create(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_gabp_plan_t* plan, double* f2v, double* v2f,
+                           double* mu_var, int iterations, void* ws, size_t ws_bytes, void** handle_out) {
+    if (!handle_out || !mu_var) return LHVI_E_ARG;
+    *handle_out = nullptr;
+    hipStream_t cap;
+    if (hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) return LHVI_E_LAUNCH;
+    int rc = LHVI_OK;
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipStreamDestroy(cap); return LHVI_E_LAUNCH; }
+    rc = lhvi_gabp_run_pull(g, pots, plan, f2v, v2f, iterations, ws, ws_bytes, cap);
+    if (rc == LHVI_OK) rc = lhvi_gabp_marginals(g, f2v, mu_var, cap);
+    const hipError_t end = hipStreamEndCapture(cap, &graph);
+    (void)hipStreamDestroy(cap);
+    if (rc != LHVI_OK || end != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); return rc != LHVI_OK ? rc : LHVI_E_LAUNCH; }
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(graph); return LHVI_E_LAUNCH; }
+    GabpGraph* h = new GabpGraph{graph, exec};
+    *handle_out = h;
+    return LHVI_OK;
+}
+
+int lhvi_gabp_graph_launch(void* handle, void* stream) {
+    if (!handle) return LHVI_E_ARG;
+    if (hipGraphLaunch(static_cast<GabpGraph*>(handle)->exec, as_stream(stream)) != hipSuccess) { g_last_hip_error = (int)hipGetLastError(); return LHVI_E_LAUNCH; }
+    return LHVI_OK;
+}
+
+int lhvi_gabp_graph_destroy(void* handle) {
+    if (!handle) return LHVI_OK;
+    GabpGraph* h = static_cast<GabpGraph*>(handle);
+    (void)hipGraphExecDestroy(h->exec);
+    (void)hipGraphDestroy(h->graph);
+    delete h;
+    return LHVI_OK;
 }
 
 int lhvi_gabp_marginals(const lhvi_graph_t* g, const double* f2v, double* mu_var, void* stream) {

@@ -109,6 +109,9 @@ SIGNATURES = {
     'lhvi_gabp_pull_workspace_bytes': (C.c_size_t, [_G]),
     'lhvi_gabp_pull': (C.c_int, [_G, _P, _GP, _vp, _vp, C.c_int, _vp]),
     'lhvi_gabp_run_pull': (C.c_int, [_G, _P, _GP, _vp, _vp, C.c_int, _vp, C.c_size_t, _vp]),
+    'lhvi_gabp_graph_create': (C.c_int, [_G, _P, _GP, _vp, _vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_void_p)]),
+    'lhvi_gabp_graph_launch': (C.c_int, [_vp, _vp]),
+    'lhvi_gabp_graph_destroy': (C.c_int, [_vp]),
     'lhvi_pbp_uniq': (C.c_int, [_G, _i32, _vp, _vp, _vp, _vp]),
     'lhvi_pbp_classify': (C.c_int, [_G, _P, _S, _vp, _vp]),
     'lhvi_pbp_describe': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _vp]),

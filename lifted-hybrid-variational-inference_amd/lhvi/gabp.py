@@ -58,35 +58,91 @@ class _GaussianSweep:
         if np.any(hidden & (incoming <= 1) & (np.diff(flat.var_ptr) > 0)):
             raise ZeroDivisionError('0.0 cannot be raised to a negative power')
 
+    graph_replay_slots = 1 << 20   # runs on graphs of up to this many variable-side slots are recorded as a hipGraph and replayed
+
+    @staticmethod
+    def _same_graph(a, b):
+        """same structure and potentials (evidence may differ: it lives in one device buffer that is refreshed)"""
+        if (a.V, a.F, a.E, a.lifted) != (b.V, b.F, b.E, b.lifted) or a.var_edge.size != b.var_edge.size:
+            return False
+        return all(np.array_equal(getattr(a, k), getattr(b, k)) for k in
+                   ('fac_ptr', 'edge_var', 'var_edge', 'fac_pot', 'pot_kind', 'pot_off', 'pot_param', 'edge_count', 'var_dom',
+                    'dom_ptr', 'dom_val')) and np.array_equal(np.isnan(a.var_value), np.isnan(b.var_value))
+
+    def _device_state(self, flat):
+        """graph, pull plan, message buffers and workspace on the device, built once per graph and kept on the solver: a
+        second ``run()`` on the same graph (same structure, potentials and hidden / observed pattern) only refreshes the
+        evidence values"""
+        st = getattr(self, '_state', None)
+        if st is not None and self._same_graph(st['flat'], flat):
+            if not np.array_equal(st['flat'].var_value, flat.var_value, equal_nan=True):
+                st['dg'].t['var_value'].copy_(_abi.to_dev(flat.var_value))
+                if st['dg'].t['edge_value'] is not None:
+                    st['dg'].t['edge_value'].copy_(_abi.to_dev(np.ascontiguousarray(flat.var_value[flat.edge_var])))
+            st['flat'] = flat
+            st['dg'].flat = flat
+            return st
+        if st is not None:
+            for h in st['graphs'].values():
+                _abi.lib().lhvi_gabp_graph_destroy(h)
+        torch = _abi.require_gpu()
+        l = _abi.lib()
+        dg = _abi.DeviceGraph(flat)
+        st = dict(flat=flat, dg=dg, f2v=dg.empty(flat.E, 2), v2f=dg.empty(flat.E, 2), mv=dg.empty(flat.V, 2), plan=None, graphs={})
+        if self.pull and flat.var_edge.size:
+            host = pull_plan(flat)
+            st['plan_dev'] = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
+            plan = _abi.GabpPlanStruct()
+            plan.pslot, plan.info, plan.count = (_abi.ptr(st['plan_dev'][k]) for k in ('pslot', 'info', 'count'))
+            st['plan'] = plan
+            st['ws_bytes'] = int(l.lhvi_gabp_pull_workspace_bytes(dg.g))
+            st['ws'] = torch.empty(st['ws_bytes'], dtype=torch.uint8, device=dg.device)
+        self._state = st
+        return st
+
     def _sweep(self, graph_like, iteration):
+        import ctypes
         flat = flatten(graph_like)
         self._check_degrees(flat)
-        dg = _abi.DeviceGraph(flat)
-        f2v = dg.empty(flat.E, 2)
-        v2f = dg.empty(flat.E, 2)
-        mv = dg.empty(flat.V, 2)
+        st = self._device_state(flat)
+        dg, f2v, v2f, mv = st['dg'], st['f2v'], st['v2f'], st['mv']
         l = _abi.lib()
         s = _abi.stream_ptr()
-        if self.pull and flat.var_edge.size:
-            torch = _abi.require_gpu()
-            host = pull_plan(flat)
-            dev = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
-            plan = _abi.GabpPlanStruct()
-            plan.pslot, plan.info, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'count'))
-            nbytes = int(l.lhvi_gabp_pull_workspace_bytes(dg.g))
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dg.device)
-            _abi.check(l.lhvi_gabp_run_pull(dg.g, dg.p, plan, _abi.ptr(f2v), _abi.ptr(v2f), int(iteration), _abi.ptr(ws),
-                                            nbytes, s))
-            self._plan_dev = dev
+        if st['plan'] is not None:
+            if flat.var_edge.size <= self.graph_replay_slots:
+                # launch-bound sizes: the whole run (sweeps, conversion to edge order, marginals) is one graph launch
+                h = st['graphs'].get(int(iteration))
+                if h is None:
+                    out = ctypes.c_void_p()
+                    _abi.check(l.lhvi_gabp_graph_create(dg.g, dg.p, st['plan'], _abi.ptr(f2v), _abi.ptr(v2f), _abi.ptr(mv), int(iteration),
+                                                        _abi.ptr(st['ws']), st['ws_bytes'], ctypes.byref(out)))
+                    h = st['graphs'][int(iteration)] = out
+                    if len(st['graphs']) > 8:             # (a caller sweeping over iteration counts: keep the cache small)
+                        old = next(iter(st['graphs']))
+                        l.lhvi_gabp_graph_destroy(st['graphs'].pop(old))
+                _abi.check(l.lhvi_gabp_graph_launch(h, s))
+            else:
+                _abi.check(l.lhvi_gabp_run_pull(dg.g, dg.p, st['plan'], _abi.ptr(f2v), _abi.ptr(v2f), int(iteration), _abi.ptr(st['ws']),
+                                                st['ws_bytes'], s))
+                _abi.check(l.lhvi_gabp_marginals(dg.g, _abi.ptr(f2v), _abi.ptr(mv), s))
         else:
             _abi.check(l.lhvi_gabp_run(dg.g, dg.p, _abi.ptr(f2v), _abi.ptr(v2f), int(iteration), s))
-        _abi.check(l.lhvi_gabp_marginals(dg.g, _abi.ptr(f2v), _abi.ptr(mv), s))
+            _abi.check(l.lhvi_gabp_marginals(dg.g, _abi.ptr(f2v), _abi.ptr(mv), s))
         self.flat, self.dg = flat, dg
         self.f2v_dev, self.v2f_dev, self.mu_var_dev = f2v, v2f, mv
         self._f2v = f2v.cpu().numpy()
         self._v2f = v2f.cpu().numpy()
         self._mu_var = mv.cpu().numpy()
         self._message = None
+
+    def __del__(self):
+        st = getattr(self, '_state', None)
+        if st:
+            try:
+                for h in st['graphs'].values():
+                    _abi.lib().lhvi_gabp_graph_destroy(h)
+            except Exception:
+                pass
 
     @property
     def message(self):

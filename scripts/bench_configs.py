@@ -83,6 +83,52 @@ if 'cfg2' in which:
     out(config='cfg2 RGM lifted GaLBP', ground_edges=flat.E, rv_clusters=int(rvc.max()) + 1, f_clusters=int(fc.max()) + 1,
         lifted_edges=lflat.E, colour_passing_s=t_ref, ms_20_sweeps=t, max_abs_mu_diff_vs_ground=err)
 
+if 'cfg2' in which:
+    # cfg 2 through the solver API: the first run() builds the device state and records the run, the second replays it
+    from lhvi.gabp import GaBP
+    flat2, _, _, _ = synth.rgm_flat(C=100, B=50, n_values=0, evidence_ratio=0.2, seed=0)
+    bp2 = GaBP(flat2)
+    t0 = time.perf_counter(); bp2.run(20); torch.cuda.synchronize(); t_first = time.perf_counter() - t0
+    st2 = bp2._state
+    h2 = st2['graphs'][20]
+    t_replay = ev_time(lambda: _abi.check(_abi.lib().lhvi_gabp_graph_launch(h2, _abi.stream_ptr())), reps=20)
+    t0 = time.perf_counter(); bp2.run(20); torch.cuda.synchronize(); t_second = time.perf_counter() - t0
+    out(config='cfg2 RGM C=100 B=50 ground GaBP.run(20): recorded run replayed', edges=int(flat2.E), first_run_s=t_first,
+        second_run_wall_ms_incl_readback=1e3 * t_second, ms_20_sweeps_and_marginals_device=t_replay, sweeps_per_s=20e3 / t_replay)
+
+if 'gauss_rel' in which:
+    # the Gaussian sweep (pull form) on the reference's own structures at scale: the 10 M-edge RGM ground graph of cfg 5 and a
+    # 22.8 M-edge Kalman-filter graph (KalmanFilter.grounded_flat, n = 30, T = 20 000)
+    from lhvi.gabp import pull_plan
+    from lhvi import kalman
+    from lhvi.graph import Domain
+    graphs = [('RGM 10M ground edges (cfg 5 before lifting)', synth.rgm_structured_flat()[0])]
+    rng = np.random.default_rng(0)
+    nk, Tk = 30, int(os.environ.get('KALMAN_T', 20000))
+    A = rng.normal(size=(nk, nk)) * (rng.random((nk, nk)) < 0.4) * 0.2 + np.eye(nk) * 0.5
+    data = rng.normal(size=(nk, Tk))
+    data[rng.random(data.shape) < 0.3] = kalman.MISSING
+    dom = Domain((-20, 20), continuous=True, integral_points=np.linspace(-20, 20, 8))
+    graphs.append(('Kalman n=30 T=%d' % Tk, kalman.KalmanFilter(dom, A, 0.7, np.eye(nk), 0.4).grounded_flat(Tk, data)[0]))
+    for label, flat in graphs:
+        dg = _abi.DeviceGraph(flat)
+        l, st = _abi.lib(), _abi.stream_ptr()
+        host = pull_plan(flat)
+        dev = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
+        plan = _abi.GabpPlanStruct()
+        plan.pslot, plan.info, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'count'))
+        nnz = int(flat.var_edge.size)
+        va, vb = dg.empty(nnz, 2), dg.empty(nnz, 2)
+        _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 1, st))
+        _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(vb), _abi.ptr(va), 0, st))
+        t_p = ev_time(lambda: _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 0, st)))
+        bytes_sweep = 76.0 * flat.E
+        out(config='gaussian sweep, pull form, ' + label, edges=int(flat.E), hubs=int((np.diff(flat.var_ptr) > 512).sum()),
+            max_degree=int(np.diff(flat.var_ptr).max()), sweep_ms=t_p, sweeps_per_s=1e3 / t_p,
+            algorithmic_GBs=bytes_sweep / (t_p * 1e-3) / 1e9, hbm_frac=bytes_sweep / (t_p * 1e-3) / 8e12,
+            finite=bool(torch.isfinite(vb[torch.from_numpy(flat.var_hidden[flat.edge_var[flat.var_edge]]).to(vb.device)]).all().item()))
+        del dg, va, vb, dev
+
 if 'cfg3' in which:
     # cfg 3: paper-popularity HMLN (300 papers x 10 topics) through the object API, HybridLBP n=10, 10 sweeps
     from lhvi.graph import Domain

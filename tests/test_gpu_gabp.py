@@ -259,3 +259,48 @@ def test_pull_form_equals_the_kernel_pair_bit_for_bit(api, case):
     for a, b in ((f_a, f_b), (v_a, v_b), (m_a, m_b)):
         assert a.tobytes() == b.tobytes()
     assert np.isfinite(m_a[flat.var_hidden]).all() or case == 'no_sweep'
+
+
+def test_recorded_run_equals_the_direct_run_and_follows_new_evidence(api):
+    """GaBP.run on a small graph records its launches once (lhvi_gabp_graph_create) and replays them: same bits as the direct
+    call sequence; a second run() on the same solver after the evidence VALUES changed reuses the device state and the recorded
+    graph and equals a fresh solver; a changed hidden / observed pattern rebuilds"""
+    from lhvi import synth
+    from lhvi.gabp import GaBP
+    flat, sym, rv0, f0 = synth.rgm_flat(C=60, B=40, n_values=3, evidence_ratio=0.2, seed=4)
+    a = GaBP(flat)
+    a.run(12)
+    b = GaBP(flat)
+    b.graph_replay_slots = 0
+    b.run(12)
+    assert len(a._state['graphs']) == 1 and not b._state['graphs']
+    np.testing.assert_array_equal(a._f2v, b._f2v)
+    np.testing.assert_array_equal(a._v2f, b._v2f)
+    np.testing.assert_array_equal(a._mu_var, b._mu_var)
+    # new evidence values, same pattern
+    import copy
+    flat2 = copy.copy(flat)
+    flat2.__dict__.pop('_view_cache', None)
+    flat2.var_value = np.where(np.isnan(flat.var_value), np.nan, flat.var_value * 0.5 + 1.0)
+    state = a._state
+    a.g = flat2
+    a.run(12)
+    assert a._state is state and len(state['graphs']) == 1
+    c = GaBP(flat2)
+    c.graph_replay_slots = 0
+    c.run(12)
+    np.testing.assert_array_equal(a._mu_var, c._mu_var)
+    np.testing.assert_array_equal(a._f2v, c._f2v)
+    # another pattern: everything rebuilt
+    flat3 = copy.copy(flat)
+    flat3.__dict__.pop('_view_cache', None)
+    v = flat.var_value.copy()
+    v[np.flatnonzero(np.isnan(v))[5]] = 0.25
+    flat3.var_value = v
+    a.g = flat3
+    a.run(12)
+    assert a._state is not state
+    d = GaBP(flat3)
+    d.graph_replay_slots = 0
+    d.run(12)
+    np.testing.assert_array_equal(a._mu_var, d._mu_var)
