@@ -129,6 +129,8 @@ typedef struct lhvi_gabp_plan {
     const int32_t* pslot;
     const int32_t* info;
     const double* count;
+    int32_t n_hub_rows;     /* variables with more than 512 incident edges (served by the wave-parallel hub kernel); 0 skips that
+                             * launch, -1 = not counted (the kernel is launched whenever the graph lists hub_vars) */
 } lhvi_gabp_plan_t;
 size_t lhvi_gabp_pull_workspace_bytes(const lhvi_graph_t* g);
 /* one sweep: v_next[k] = message_rv_to_f of slot k given the f -> v messages implied by v_prev (first != 0: given the

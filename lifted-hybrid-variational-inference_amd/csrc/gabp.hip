@@ -428,7 +428,7 @@ int lhvi_gabp_pull(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_ga
     PullPlan pl;
     pl.pslot = plan->pslot; pl.info = plan->info; pl.count = plan->count;
     hipLaunchKernelGGL(gabp_pull_kernel, dim3(grid_for(g->nnz)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, pl, v_prev, v_next, first);
-    if (g->hub_vars && g->n_hubs > 0)
+    if (g->hub_vars && g->n_hubs > 0 && plan->n_hub_rows != 0)
         hipLaunchKernelGGL(gabp_pull_hub_kernel, dim3(grid_for((int64_t)g->n_hubs * 64)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, pl,
                            v_prev, v_next, first);
     return check_launch();

@@ -94,6 +94,7 @@ class _GaussianSweep:
             st['plan_dev'] = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
             plan = _abi.GabpPlanStruct()
             plan.pslot, plan.info, plan.count = (_abi.ptr(st['plan_dev'][k]) for k in ('pslot', 'info', 'count'))
+            plan.n_hub_rows = int((np.diff(flat.var_ptr) > 512).sum())
             st['plan'] = plan
             st['ws_bytes'] = int(l.lhvi_gabp_pull_workspace_bytes(dg.g))
             st['ws'] = torch.empty(st['ws_bytes'], dtype=torch.uint8, device=dg.device)

@@ -42,6 +42,7 @@ if 'gauss' in which:
     dev = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
     plan = _abi.GabpPlanStruct()
     plan.pslot, plan.info, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'count'))
+    plan.n_hub_rows = int((np.diff(flat.var_ptr) > 512).sum())
     nnz = int(flat.var_edge.size)
     va, vb = dg.empty(nnz, 2), dg.empty(nnz, 2)
     _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 1, st))
@@ -64,6 +65,7 @@ if 'cfg2' in which:
     dev = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
     plan = _abi.GabpPlanStruct()
     plan.pslot, plan.info, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'count'))
+    plan.n_hub_rows = int((np.diff(flat.var_ptr) > 512).sum())
     nb = int(l.lhvi_gabp_pull_workspace_bytes(dg.g))
     ws = torch.empty(nb, dtype=torch.uint8, device=dg.device)
     t = ev_time(lambda: _abi.check(l.lhvi_gabp_run_pull(dg.g, dg.p, plan, _abi.ptr(f2v), _abi.ptr(v2f), 20, _abi.ptr(ws), nb, st)))
@@ -117,6 +119,7 @@ if 'gauss_rel' in which:
         dev = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
         plan = _abi.GabpPlanStruct()
         plan.pslot, plan.info, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'count'))
+        plan.n_hub_rows = int((np.diff(flat.var_ptr) > 512).sum())
         nnz = int(flat.var_edge.size)
         va, vb = dg.empty(nnz, 2), dg.empty(nnz, 2)
         _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 1, st))

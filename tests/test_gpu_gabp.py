@@ -214,6 +214,7 @@ def _run_both_forms(api, flat, iterations):
     dev = {k: (api.to_dev(a) if a is not None else None) for k, a in host.items()}
     plan = api.GabpPlanStruct()
     plan.pslot, plan.info, plan.count = (api.ptr(dev[k]) for k in ('pslot', 'info', 'count'))
+    plan.n_hub_rows = int((np.diff(flat.var_ptr) > 512).sum())
     nbytes = int(l.lhvi_gabp_pull_workspace_bytes(dg.g))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dg.device)
     for pull in (False, True):
