@@ -30,7 +30,8 @@ extern "C" {
 #define LHVI_ABI_VERSION 8   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
                               * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t;  7: lhvi_pbp_t gained pair_desc;
                               * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq; the colour
-                              *    refinement calls take a method and return four result words; lhvi_vi_t gained var_N; lhvi_vi_opt_t, lhvi_vi_adam_run */
+                              *    refinement calls take a method and return four result words; lhvi_vi_t gained var_N; lhvi_vi_opt_t, lhvi_vi_adam_run;
+                              *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow; 16 ticket words */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -255,6 +256,14 @@ typedef struct lhvi_pbp {
      * partners of a discrete target); served by their own kernel. */
     const void* cq_desc;
     int32_t n_cq;
+    /* optional, lhvi_pbp_v2f only (single-GPU runs: not with bslot or a variable range): the hidden variables split by particle
+     * count -- v2f_wide: more than four particles, one wavefront each; v2f_narrow: at most four (binary variables, boolean
+     * atoms), sixteen per wavefront.  Both or neither; together they must list every hidden variable once.  NULL: one wavefront
+     * per variable of the range. */
+    const int32_t* v2f_wide;
+    int32_t n_v2f_wide;
+    const int32_t* v2f_narrow;
+    int32_t n_v2f_narrow;
 } lhvi_pbp_t;
 
 #define LHVI_PBP_DESC_BYTES 128

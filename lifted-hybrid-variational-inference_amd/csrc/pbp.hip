@@ -105,8 +105,15 @@ constexpr int V2F_CACHE = 4;
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                        double* __restrict__ v2f) {
     const int lane = threadIdx.x & 63;
-    const int v = __builtin_amdgcn_readfirstlane(var_first(s) + blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
-    if (v >= var_limit(g, s)) return;
+    int v;
+    if (s.v2f_wide) {                                      // the caller's list: hidden variables with more than four particles
+        const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+        if (item >= s.n_v2f_wide) return;
+        v = s.v2f_wide[item];
+    } else {
+        v = __builtin_amdgcn_readfirstlane(var_first(s) + blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+        if (v >= var_limit(g, s)) return;
+    }
     if (!is_hidden(g.var_value[v])) return;
     const int n = s.n, S = s.n + s.T;
     const int np = s.np[v];
@@ -191,6 +198,55 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
                 if (j < np) v2f[(int64_t)e * n + j] -= shift;
             }
         }
+    }
+}
+
+// Variables with at most four particles -- the binary variables of a hybrid model, the boolean atoms of an MLN -- would
+// leave 60 of a wavefront's lanes idle in the kernel above, and every such wave still costs its chain of dependent loads.
+// Here a wavefront serves sixteen of them, four lanes each (lane & 3 = particle); the balance step's mean and max are quad
+// reductions.  Same expressions per message as above (total minus own; mean over the distinct particles; max - 700 rule).
+__global__ void __launch_bounds__(BLOCK) pbp_v2f_narrow_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
+                                                              double* __restrict__ v2f) {
+    const int lane = threadIdx.x & 63;
+    const int64_t slot = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * 16 + (lane >> 2);
+    const int j = lane & 3;
+    const int v = slot < s.n_v2f_narrow ? s.v2f_narrow[slot] : -1;
+    const int n = s.n, S = s.n + s.T;
+    const bool on = v >= 0 && is_hidden(g.var_value[v]);
+    const int np = on ? s.np[v] : 0;
+    const bool valid = j < np;
+    const int lo = on ? g.var_ptr[v] : 0, deg = on ? g.var_ptr[v + 1] - lo : 0;
+    const bool lifted = g.edge_count != nullptr;
+    double total = 0.0;
+    for (int k = 0; k < deg; ++k) {
+        const int e = g.var_edge[lo + k];
+        const double m = valid ? f2v[(int64_t)e * S + j] : 0.0;
+        total += lifted ? m * g.edge_count[e] : m;
+    }
+    double logw = 0.0;
+    bool uq = false;
+    if (valid) {
+        const int d = g.var_dom[v];
+        const double sd = sqrt_pos(s.q[2 * v + 1]);
+        logw = log_importance(g, s, v, d, s.particles[(int64_t)v * n + j], s.q[2 * v], rcp_newton(sd), log_pos(2.506628274631 * sd));
+        uq = s.uniq[(int64_t)v * n + j] != 0;
+    }
+    auto quad_sum = [](double x) { x += dpp_move<0xb1>(x); return x + dpp_move<0x4e>(x); };
+    auto quad_max = [](double x) { x = fmax(x, dpp_move<0xb1>(x)); return fmax(x, dpp_move<0x4e>(x)); };
+    const double rcnt = rcp_newton(fmax(quad_sum(uq ? 1.0 : 0.0), 1.0));     // (the kernel above multiplies by the same reciprocal)
+    // every lane of the wave runs the longest row of its sixteen variables (the reductions are wave-wide instructions)
+    int maxdeg = deg;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
+    for (int k = 0; k < maxdeg; ++k) {
+        const bool live = k < deg;
+        const int e = live ? g.var_edge[lo + k] : 0;
+        const double m = (live && valid) ? f2v[(int64_t)e * S + j] : 0.0;
+        const double res = (total - m) + logw;
+        const double mean = quad_sum(uq ? res : 0.0) * rcnt;
+        const double mx = quad_max(uq ? res : -__builtin_huge_val());
+        const double shift = (mx - mean > s.max_log_value) ? mx - s.max_log_value : mean;
+        if (live && valid) v2f[(int64_t)e * n + j] = res - shift;
     }
 }
 
@@ -1725,6 +1781,16 @@ int lhvi_pbp_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, 
     if (int rc = validate_pbp(g, s)) return rc;
     if (!f2v || !v2f || !s->uniq || !s->q) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
+    if (s->v2f_wide || s->v2f_narrow) {
+        // the caller's split of the hidden variables: one wavefront per variable / sixteen variables per wavefront
+        if (!s->v2f_wide || !s->v2f_narrow || s->n_v2f_wide < 0 || s->n_v2f_narrow < 0 || s->bslot || s->var_hi > s->var_lo) return LHVI_E_ARG;
+        if (s->n_v2f_wide > 0)
+            hipLaunchKernelGGL(pbp_v2f_kernel, dim3(grid_for((int64_t)s->n_v2f_wide * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, v2f);
+        if (s->n_v2f_narrow > 0)
+            hipLaunchKernelGGL(pbp_v2f_narrow_kernel, dim3(grid_for(((int64_t)s->n_v2f_narrow + 15) / 16 * WAVE)), dim3(BLOCK), 0,
+                               as_stream(stream), *g, *s, f2v, v2f);
+        return check_launch();
+    }
     hipLaunchKernelGGL(pbp_v2f_kernel, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0, as_stream(stream),
                        *g, *s, f2v, v2f);
     return check_launch();

@@ -34,6 +34,7 @@ class _ParticleSweep:
     dynamic_f2v = True              # the persistent f2v kernels claim their work in chunks (else static striding)
     paired_light = True             # the light edges are served per factor (pair_desc) instead of per edge (light_desc)
     cq_routing = True               # conditionally quadratic MLN formulas go to the quadratic-family kernels (else: generic kernel)
+    packed_v2f = True               # variables with at most four particles share a wavefront in the v -> f half (sixteen each)
 
     # ---- set-up ------------------------------------------------------------------------------
     def _setup(self, graph_like, flat=None, edge_key=None):
@@ -109,6 +110,13 @@ class _ParticleSweep:
                 pd[:, 4 + k] = flat.var_edge[np.minimum(pbase + np.minimum(k, np.maximum(pdeg - 1, 0)), flat.var_edge.size - 1)]
         self.prop_desc = _abi.to_dev(pd) if pv.size else None
         self.n_prop_desc = int(pv.size)
+        # the v -> f half's split of the hidden variables (include/lhvi.h, lhvi_pbp_t.v2f_wide / v2f_narrow)
+        hidden_v = np.flatnonzero(flat.var_hidden)
+        narrow = self.np_host[hidden_v] <= 4
+        self.v2f_lists = None
+        if self.packed_v2f and hidden_v.size and narrow.any():
+            pad = lambda a: _abi.to_dev(a.astype(np.int32) if a.size else np.zeros(1, dtype=np.int32))
+            self.v2f_lists = (pad(hidden_v[~narrow]), int((~narrow).sum()), pad(hidden_v[narrow]), int(narrow.sum()))
         self.fast_desc = self.heavy_desc = self.light_desc = self.pair_desc = None
         self.n_heavy = self.n_light = self.n_pair = 0
         self.cq_terms = 0
@@ -221,6 +229,9 @@ class _ParticleSweep:
         if self.paired_light and getattr(self, 'pair_desc', None) is not None:
             s.pair_desc, s.n_pair = _abi.ptr(self.pair_desc), int(self.n_pair)
         s.cq_desc, s.n_cq = _abi.ptr(getattr(self, 'cq_desc', None)), int(getattr(self, 'n_cq', 0))
+        if getattr(self, 'v2f_lists', None) is not None:
+            w, nw, nr, nn = self.v2f_lists
+            s.v2f_wide, s.n_v2f_wide, s.v2f_narrow, s.n_v2f_narrow = _abi.ptr(w), nw, _abi.ptr(nr), nn
         s.f2v_ticket = _abi.ptr(self.f2v_ticket) if self.dynamic_f2v else None
         if self.listed_proposal and getattr(self, 'prop_desc', None) is not None:
             s.prop_desc, s.n_prop_desc = _abi.ptr(self.prop_desc), self.n_prop_desc

@@ -756,3 +756,34 @@ def test_pair_records_do_not_change_results(api, frac_discrete, evidence):
         assert bool(torch.isfinite(bp.f2v).all())
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('solver', ['epbp', 'hlbp'])
+def test_packed_v2f_kernel_does_not_change_results(api, solver):
+    """variables with at most four particles (binary variables, boolean atoms) served sixteen per wavefront by
+    pbp_v2f_narrow_kernel against one wavefront each: whole sweeps agree bit for bit (hybrid MRF with binary and observed
+    variables for EPBP; the paper-popularity HMLN, lifted with counts, for HybridLBP)"""
+    import torch
+    from lhvi import synth
+    from lhvi.pbp import EPBP, HybridLBP
+    runs = []
+    for packed in (True, False):
+        if solver == 'epbp':
+            flat = synth.hybrid_mrf_flat(V=9000, deg=4, seed=31, frac_discrete=0.4)
+            bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=6)
+            bp.packed_v2f = packed
+            bp._setup(None, flat=flat)
+            _init(api, bp)
+            for _ in range(4):
+                bp.sweep(last=False)
+        else:
+            g, table = paper_popularity(30, 4, seed=9)
+            np.random.seed(3)
+            bp = HybridLBP(g, n=12, proposal_approximation='simple')
+            bp.packed_v2f = packed
+            bp.run(4)
+        runs.append(bp)
+    a, b = runs
+    assert a.v2f_lists is not None and a.v2f_lists[3] > 0 and b.v2f_lists is None
+    for name in ('v2f', 'f2v', 'q_dev', 'eta', 'particles'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
