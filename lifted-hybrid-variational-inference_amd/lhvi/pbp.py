@@ -115,8 +115,8 @@ class _ParticleSweep:
         narrow = self.np_host[hidden_v] <= 4
         self.v2f_lists = None
         if self.packed_v2f and hidden_v.size and narrow.any():
-            pad = lambda a: _abi.to_dev(a.astype(np.int32) if a.size else np.zeros(1, dtype=np.int32))
-            self.v2f_lists = (pad(hidden_v[~narrow]), int((~narrow).sum()), pad(hidden_v[narrow]), int(narrow.sum()))
+            up = lambda a: _abi.to_dev(a.astype(np.int32) if a.size else np.zeros(1, dtype=np.int32))
+            self.v2f_lists = (up(hidden_v[~narrow]), int((~narrow).sum()), up(hidden_v[narrow]), int(narrow.sum()))
         self.fast_desc = self.heavy_desc = self.light_desc = self.pair_desc = None
         self.n_heavy = self.n_light = self.n_pair = 0
         self.cq_terms = 0
