@@ -264,6 +264,10 @@ typedef struct lhvi_pbp {
     int32_t n_v2f_wide;
     const int32_t* v2f_narrow;
     int32_t n_v2f_narrow;
+    const int32_t* v2f_hub;     /* optional third part of the split: variables with 5..64 particles and more than 64 incident edges
+                                 * (template variables of relational models), a workgroup each; such variables are then NOT in
+                                 * v2f_wide */
+    int32_t n_v2f_hub;
 } lhvi_pbp_t;
 
 #define LHVI_PBP_DESC_BYTES 128

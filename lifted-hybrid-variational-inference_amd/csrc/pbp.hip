@@ -201,6 +201,63 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
     }
 }
 
+// Template variables of relational models touch hundreds or thousands of factors (a topic of the paper-popularity model: one
+// factor per paper).  One wavefront walking such a row is a chain of a few hundred dependent row loads, and the launch lasts as
+// long as its longest chain.  Here a workgroup shares the row: wavefront w takes the entries k = w (mod 4), four row loads in
+// flight each; the four partial totals are added in wavefront order (fixed, so the result is deterministic; it differs from the
+// one-wave sum by rounding, like any other summation order), then every wavefront emits the messages of its own entries.
+constexpr int V2F_HUB_DEGREE = 64;
+__global__ void __launch_bounds__(BLOCK) pbp_v2f_hub_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
+                                                           double* __restrict__ v2f) {
+    __shared__ double part[BLOCK / WAVE][WAVE];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int v = s.v2f_hub[blockIdx.x];
+    const int n = s.n, S = s.n + s.T;
+    const int np = s.np[v];                                 // <= 64 (the caller's list)
+    const int lo = g.var_ptr[v], deg = g.var_ptr[v + 1] - lo;
+    const bool lifted = g.edge_count != nullptr;
+    const bool valid = lane < np;
+    constexpr int NW = BLOCK / WAVE;
+    double acc = 0.0;
+    int k = wid;
+    for (; k + 3 * NW < deg; k += 4 * NW) {
+        int e[4];
+        double m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = g.var_edge[lo + k + u * NW];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m[u] = valid ? f2v[(int64_t)e[u] * S + lane] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += lifted ? m[u] * g.edge_count[e[u]] : m[u];
+    }
+    for (; k < deg; k += NW) {
+        const int e = g.var_edge[lo + k];
+        const double m = valid ? f2v[(int64_t)e * S + lane] : 0.0;
+        acc += lifted ? m * g.edge_count[e] : m;
+    }
+    part[wid][lane] = acc;
+    __syncthreads();
+    double total = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) total += part[w][lane];
+    const int d = g.var_dom[v];
+    const double mu = s.q[2 * v], sd = sqrt_pos(s.q[2 * v + 1]), rsd = rcp_newton(sd);
+    const double log_norm = log_pos(2.506628274631 * sd);
+    const double x = valid ? s.particles[(int64_t)v * n + lane] : 0.0;
+    const bool uq = valid && s.uniq[(int64_t)v * n + lane];
+    const double logw = valid ? log_importance(g, s, v, d, x, mu, rsd, log_norm) : 0.0;
+    const double rcnt = rcp_newton((double)__builtin_popcountll(__ballot(uq)));
+    for (k = wid; k < deg; k += NW) {
+        const int e = g.var_edge[lo + k];
+        const double m = valid ? f2v[(int64_t)e * S + lane] : 0.0;      // second touch: out of L2
+        const double res = (total - m) + logw;
+        const double mean = wave_sum(uq ? res : 0.0) * rcnt;
+        double shift = mean;
+        if (__ballot(uq && (res - mean > s.max_log_value))) shift = wave_max(uq ? res : -__builtin_huge_val()) - s.max_log_value;
+        if (valid) v2f[(int64_t)e * n + lane] = res - shift;
+    }
+}
+
 // Variables with at most four particles -- the binary variables of a hybrid model, the boolean atoms of an MLN -- would
 // leave 60 of a wavefront's lanes idle in the kernel above, and every such wave still costs its chain of dependent loads.
 // Here a wavefront serves sixteen of them, four lanes each (lane & 3 = particle); the balance step's mean and max are quad
@@ -1786,6 +1843,8 @@ int lhvi_pbp_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, 
         if (!s->v2f_wide || !s->v2f_narrow || s->n_v2f_wide < 0 || s->n_v2f_narrow < 0 || s->bslot || s->var_hi > s->var_lo) return LHVI_E_ARG;
         if (s->n_v2f_wide > 0)
             hipLaunchKernelGGL(pbp_v2f_kernel, dim3(grid_for((int64_t)s->n_v2f_wide * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, v2f);
+        if (s->v2f_hub && s->n_v2f_hub > 0)
+            hipLaunchKernelGGL(pbp_v2f_hub_kernel, dim3((unsigned)s->n_v2f_hub), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, v2f);
         if (s->n_v2f_narrow > 0)
             hipLaunchKernelGGL(pbp_v2f_narrow_kernel, dim3(grid_for(((int64_t)s->n_v2f_narrow + 15) / 16 * WAVE)), dim3(BLOCK), 0,
                                as_stream(stream), *g, *s, f2v, v2f);

@@ -303,7 +303,7 @@ class ShardedRunner:
         s.brow_ptr, s.brow_off, s.brow_peer = _abi.ptr(self.brow_ptr), _abi.ptr(self.brow_off), _abi.ptr(self.brow_peer)
         s.recv, s.rank = _abi.ptr(self.recv), int(self.rank)
         s.prop_desc, s.n_prop_desc = None, 0                 # the sharded proposal addresses variables by range
-        s.v2f_wide, s.n_v2f_wide, s.v2f_narrow, s.n_v2f_narrow = None, 0, None, 0     # ... and so does the sharded v -> f half
+        s.v2f_wide, s.n_v2f_wide, s.v2f_narrow, s.n_v2f_narrow, s.v2f_hub, s.n_v2f_hub = None, 0, None, 0, None, 0     # ... and so does the sharded v -> f half
         if part is not None:
             s.var_lo, s.var_hi = (0, self.n_int) if part == 0 else (self.n_int, self.plan.flat.V)
         return s

@@ -784,6 +784,44 @@ def test_packed_v2f_kernel_does_not_change_results(api, solver):
             bp.run(4)
         runs.append(bp)
     a, b = runs
-    assert a.v2f_lists is not None and a.v2f_lists[3] > 0 and b.v2f_lists is None
+    assert a.v2f_lists is not None and a.v2f_lists[3] > 0 and a.v2f_lists[5] == 0 and b.v2f_lists is None
     for name in ('v2f', 'f2v', 'q_dev', 'eta', 'particles'):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
+def test_v2f_hub_kernel_matches_the_one_wave_path(api):
+    """template variables (more than 64 incident factors: the topics of the paper-popularity model) are swept by a workgroup
+    each (pbp_v2f_hub_kernel: four partial totals added in a fixed order) instead of one wavefront walking the row: the same
+    messages to rounding, and deterministic"""
+    import torch
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    flat, keys = synth.paper_popularity_flat(150, 4, seed=2)
+    assert np.diff(flat.var_ptr).max() > 64
+    n = 16
+    rng = np.random.default_rng(1)
+    draws = []
+
+    def sampler(k, fl, q):
+        if k == len(draws):
+            cont = fl.var_hidden & fl.var_cont
+            out = np.zeros((fl.V, n))
+            out[cont] = np.clip(rng.standard_normal((int(cont.sum()), n)) * np.sqrt(q[cont, 1:2]) + q[cont, 0:1], -15, 15)
+            draws.append(out)
+        return draws[k]
+    runs = []
+    for packed in (True, False, True):
+        bp = EPBP(None, n=n, proposal_approximation='simple', sampler=sampler, seed=6)
+        bp.packed_v2f = packed
+        bp._setup(None, flat=flat)
+        _init(api, bp)
+        for _ in range(3):
+            bp.sweep(last=False)
+        runs.append(bp)
+    a, b, c = runs
+    assert a.v2f_lists[5] > 0
+    hid = flat.var_hidden[flat.edge_var]
+    live = hid[:, None] & (np.arange(n)[None, :] < a.np_host[flat.edge_var][:, None])
+    np.testing.assert_allclose(a.v2f.cpu().numpy()[live], b.v2f.cpu().numpy()[live], rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(a.q_dev.cpu().numpy(), b.q_dev.cpu().numpy(), rtol=1e-10, atol=1e-12, equal_nan=True)
+    assert torch.equal(a.v2f, c.v2f) and torch.equal(a.f2v, c.f2v)
