@@ -206,7 +206,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
 // long as its longest chain.  Here a workgroup shares the row: wavefront w takes the entries k = w (mod 4), four row loads in
 // flight each; the four partial totals are added in wavefront order (fixed, so the result is deterministic; it differs from the
 // one-wave sum by rounding, like any other summation order), then every wavefront emits the messages of its own entries.
-constexpr int V2F_HUB_DEGREE = 64;
 __global__ void __launch_bounds__(BLOCK) pbp_v2f_hub_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                            double* __restrict__ v2f) {
     __shared__ double part[BLOCK / WAVE][WAVE];
@@ -1136,7 +1135,7 @@ struct CqDesc {
     int32_t e, tv, type, S;          // edge, target variable, 1 = MIX / 2 = JOINT, coefficient sets
     int32_t np, T, gb, yv;           // target particles (JOINT: = S states), grid points, grid base; staged partner's variable
     int32_t yce, ny, zv, zce;        // staged partner's v2f row and particles (1: observed / absent); z: variable and v2f row (MIX: -1 = none)
-    int32_t nz, pad;                 // MIX: states of z; JOINT: particles of the lane-side partner
+    int32_t nz, pad;                 // MIX: states of z; JOINT: particles of the lane-side partner;  pad: 1 = the target's integral points are a uniform grid
     double yval;                     // NaN: the staged partner is hidden
     double coef[LHVI_CQ_MAX_STATES][6];   // per set (ay, by, c, axy, bx, kx)
 };
@@ -1159,6 +1158,14 @@ __global__ void __launch_bounds__(BLOCK) pbp_describe_cq_kernel(lhvi_graph_t g, 
     d.gb = g.dom_ptr[dom];
     d.T = g.dom_cont[dom] ? g.dom_ptr[dom + 1] - d.gb : 0;
     d.yv = ci.yv; d.yce = ci.yce; d.ny = ci.ny; d.zv = ci.zv; d.zce = ci.zce; d.nz = ci.nz; d.pad = 0;
+    if (d.type == 1 && d.T >= 2) {                        // uniform integral-point grid (as in make_fast_desc): word 13 = 1
+        const double x0 = g.dom_val[d.gb], xl = g.dom_val[d.gb + d.T - 1];
+        const double h = (xl - x0) / (double)(d.T - 1);
+        const double tol = 1.8e-15 * fmax(fabs(x0), fabs(xl));
+        bool uniform = h > 0.0 && h < __builtin_huge_val();
+        for (int t = 0; t < d.T && uniform; ++t) uniform = fabs(g.dom_val[d.gb + t] - fma((double)t, h, x0)) <= tol;
+        d.pad = uniform ? 1 : 0;
+    }
     d.yval = ci.yval;
     for (int k = 0; k < LHVI_CQ_MAX_STATES; ++k) {
         const bool on = d.type != 0 && k < ci.S;
@@ -1190,7 +1197,25 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
         double y = d.yval, my = 0.0;
         if (is_hidden(d.yval)) { y = 0.0; if (lane < ny) { y = s.old_particles[(int64_t)d.yv * n + lane]; my = v2f[(int64_t)d.yce * n + lane]; } }
         if (type == 1) {
-            const int np = d.np, npts = d.np + d.T;
+            const int np = d.np;
+            double mz = 0.0;                                  // the discrete partner's message at its states (lane = state)
+            if (d.zce >= 0 && lane < nst) mz = v2f[(int64_t)d.zce * n + lane];
+            // integral points by the uniform-grid recurrence (as in the heavy kernel), once per state, when every exponent of
+            // every state stays far inside the double range over the whole grid; otherwise they join the direct rounds
+            bool grid_path = grid_eligible(d.pad, ny, d.T) && !(s.flags & (LHVI_PBP_SKIP_TERMS | LHVI_PBP_NO_GRID));
+            double gx0 = 0.0, gh = 0.0;
+            if (grid_path) {
+                gx0 = g.dom_val[d.gb];
+                gh = (g.dom_val[d.gb + d.T - 1] - gx0) / (double)(d.T - 1);
+                const double X = fmax(fabs(gx0), fabs(fma((double)(d.T - 1), gh, gx0)));
+                for (int st = 0; st < nst; ++st) {
+                    const double a = (d.coef[st][0] * y + d.coef[st][1]) * y + d.coef[st][2] + my + readlane_f64(mz, st);
+                    const double b = d.coef[st][3] * y + d.coef[st][4];
+                    const double bound = fma(fabs(b) + fabs(d.coef[st][5]) * X, X, fabs(a));
+                    if (__ballot(lane < ny && !(bound < GRID_MAX_EXPONENT))) grid_path = false;
+                }
+            }
+            const int npts = grid_path ? np : np + d.T;       // output points of the direct rounds
             // this lane's output points of the (at most two) rounds
             double xr[2] = {0.0, 0.0};
 #pragma unroll
@@ -1201,9 +1226,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
                     if (pl < rem) xr[r] = pp < np ? s.particles[(int64_t)d.tv * n + pp] : g.dom_val[d.gb + pp - np];
                 }
             }
-            double mz = 0.0;                                  // the discrete partner's message at its states (lane = state)
-            if (d.zce >= 0 && lane < nst) mz = v2f[(int64_t)d.zce * n + lane];
             double tot[2] = {0.0, 0.0};
+            double totg[2] = {0.0, 0.0};                      // grid path: sums at this lane's point of each batch of 32 points
             for (int st = 0; st < nst; ++st) {
                 const double ay = d.coef[st][0], by = d.coef[st][1], c = d.coef[st][2], axy = d.coef[st][3], bx = d.coef[st][4],
                              kx = d.coef[st][5];
@@ -1214,6 +1238,18 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
                 LHVI_WAVE_SYNC();
                 sh[lane] = mine;
                 LHVI_WAVE_SYNC();
+                if (grid_path) {
+                    double gv = exp_core(fma(mine.b, gx0, mine.a), sh_tab);
+                    const double q = exp_core(mine.b * gh, sh_tab);
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb) {
+                        if (32 * tb < d.T) {
+                            const double sum = grid_sums32(gv, q, lane);
+                            const double xt = fma((double)(32 * tb + grid_owned_point(lane)), gh, gx0);
+                            totg[tb] = fma(sum, exp_core(kx * xt * xt, sh_tab), totg[tb]);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int rem = npts - 64 * r;
@@ -1235,6 +1271,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
                     const int lw = round_log2_width(rem);
                     const int sub = lane >> lw, pl = lane & ((1 << lw) - 1), p = 64 * r + pl;
                     if (pl < rem && sub == 0) out[p < np ? p : n + (p - np)] = tot[r] > 0.0 ? log_table(tot[r], sh_log) : -700.0;
+                }
+            }
+            if (grid_path) {
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) {
+                    const int t = 32 * tb + grid_owned_point(lane);
+                    if (t < d.T && !(lane & 1)) out[n + t] = totg[tb] > 0.0 ? log_table(totg[tb], sh_log) : -700.0;
                 }
             }
         } else {
