@@ -1739,7 +1739,16 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
     const int vend = var_limit(g, s);
     for (int v = __builtin_amdgcn_readfirstlane(var_first(s) + blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)); v < vend; v += nwaves) {
         const int cnt = s.np[v];
+        if (cnt == 0) {                                        // observed: no particles; the mask row is all zero
+            if (lane < n) uniq[(int64_t)v * n + lane] = 0;
+            continue;
+        }
         const int d = g.var_dom[v];
+        if (!g.dom_cont[d]) {                                  // discrete: the particles are the (distinct) states, no draw, no duplicates
+            if (lane < cnt) out[(int64_t)v * n + lane] = g.dom_val[g.dom_ptr[d] + lane];
+            if (lane < n) uniq[(int64_t)v * n + lane] = (uint8_t)(lane < cnt);
+            continue;
+        }
         double x = 0.0;
         if (lane < cnt) {
             if (!g.dom_cont[d]) x = g.dom_val[g.dom_ptr[d] + lane];
