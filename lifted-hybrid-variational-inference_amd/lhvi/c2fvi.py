@@ -38,10 +38,19 @@ def _parents(old, new):
     return old[_first_member(new, n)]
 
 
+def _members_by_colour(rvc, mask):
+    """members of every colour among `mask`, grouped once: yields (colour, member indices in ground order)"""
+    idx = np.flatnonzero(mask)
+    order = idx[np.argsort(rvc[idx], kind='stable')]
+    cols, start = np.unique(rvc[order], return_index=True)
+    bounds = np.append(start, order.size)
+    for i, c in enumerate(cols):
+        yield int(c), order[bounds[i]:bounds[i + 1]]
+
+
 def evidence_variances(values, rvc):
     """{cluster: np.var of its members' values} for the evidence clusters (``SuperRV.get_variance``, CGWO:38-39)"""
-    obs = ~np.isnan(values)
-    return {int(c): float(np.var(values[(rvc == c) & obs])) for c in np.unique(rvc[obs])}
+    return {c: float(np.var(values[m])) for c, m in _members_by_colour(rvc, ~np.isnan(values))}
 
 
 def split_rvs_tracked(refiner, values, rvc, fc, tracked):
@@ -79,8 +88,7 @@ def split_evidence_pass(values, rvc, tracked, k, iteration, epsilon, member_orde
     rvc = rvc.copy()
     tracked = set(tracked)
     nxt = int(rvc.max()) + 1
-    for c in sorted(tracked):
-        members = np.flatnonzero(rvc == c)
+    for c, members in list(_members_by_colour(rvc, np.isin(rvc, sorted(tracked)))):     # (one grouping per pass, not one scan per cluster)
         vals = values[members]
         if not (np.sqrt(np.var(vals)) > epsilon):
             continue
@@ -132,8 +140,7 @@ def run_c2fvi(g, engine, refiner, K, iteration, lr, opts, init=None, observer=No
         src = np.nan_to_num(np.array(init[1], dtype=np.float64), nan=0.0)
         P['tau_d'][:, :, :min(D, src.shape[2])] = src[:, :, :D]
     else:                                                                           # one draw per coarse hidden cluster
-        for c in np.unique(rvc[gflat.var_hidden]):
-            members = np.flatnonzero(rvc == c)
+        for c, members in _members_by_colour(rvc, gflat.var_hidden):
             if gflat.var_cont[members[0]]:
                 P['eta_c'][members, :, 0] = np.random.rand(K) * 3 - 1.5
             else:
@@ -381,6 +388,9 @@ class _DeviceStage(_Variational):
                 d[pre + name].copy_(_abi.to_dev(dst))
 
     def adam(self, n, t, lr):
+        # (a round always logs the free energy after each update -- what the schedule's caller gets back -- whatever ``run`` was
+        # asked to log: the reference's other log, -log phi at the current MAP (C2FVI:393-404), needs the ground graph's MAP
+        # queries between updates and is not produced by the coarse-to-fine run)
         self.is_log, self.log_fe = True, True
         self.time_log, self.total_time = [], 0
         self.alpha, self.b1, self.b2, self.eps, self.t = lr, 0.9, 0.999, 1e-8, t
