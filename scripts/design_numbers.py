@@ -114,6 +114,14 @@ def block(tag):
             d = json.loads(line)
             cfg = d.pop('config')
             L.append('* %s: %s' % (cfg, ', '.join('%s = %s' % (k, ('%.4g' % v) if isinstance(v, float) else v) for k, v in d.items())))
+    for extra, what in (('_cfg3_configs.jsonl', 'scaled cfg 3 under rocprofv3 (`scripts/profile_cfg3.sh`)'),
+                        ('_cfg3_routed_vs_generic.jsonl', 'scaled cfg 3, plain run, conditional-quadratic routing against the generic kernel')):
+        path = os.path.join(PROF, tag + extra)
+        if os.path.exists(path):
+            d = _json_line(path)
+            cfg = d.pop('config')
+            L.append('* (`profiles/%s%s`: %s) %s: %s' % (tag, extra, what, cfg, ', '.join(
+                '%s = %s' % (k, ('%.4g' % v) if isinstance(v, float) else v) for k, v in d.items())))
     sec = os.path.join(PROF, tag + '_secondary_traffic.json')
     if os.path.exists(sec):
         t = {_short(k): v for k, v in json.load(open(sec)).items()}
