@@ -230,32 +230,41 @@ def _variances_flat(values, rvc, obs):
 
 
 def split_evidence_flat(values, rvc, tracked, k, iteration, epsilon):
-    """``split_evidence`` on arrays: `tracked` is a boolean array over the colours; members are grouped once per pass"""
-    obs = ~np.isnan(values)
+    """``split_evidence`` on arrays: `tracked` is a boolean array over the colours.  Everything runs on the observed members
+    only (a fifth of the variables of the RGM), grouped once per pass by a stable sort of their colours."""
+    obs_idx = np.flatnonzero(~np.isnan(values))
+    ovals = values[obs_idx]
     while True:
         nc = int(rvc.max()) + 1
-        var, _ = _variances_flat(values, rvc, obs)
-        todo = np.flatnonzero(tracked[:nc] & (np.sqrt(np.nan_to_num(var)) > epsilon))
-        if todo.size == 0:
+        oc = rvc[obs_idx]
+        n = np.bincount(oc, minlength=nc).astype(np.float64)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            mean = np.bincount(oc, weights=ovals, minlength=nc) / n
+            var = np.bincount(oc, weights=(ovals - mean[oc]) ** 2, minlength=nc) / n
+        todo = tracked[:nc] & (np.sqrt(np.nan_to_num(var)) > epsilon)
+        if not todo.any():
             return rvc, tracked
-        order, cols, bounds = _group(rvc, obs & np.isin(rvc, todo))
+        sel = np.flatnonzero(todo[oc])                        # observed members of the clusters to split
+        order = sel[np.argsort(oc[sel], kind='stable')]       # grouped by colour, ground order inside a group
+        cols, start = np.unique(oc[order], return_index=True)
+        bounds = np.append(start, order.size)
         rvc = rvc.copy()
         nxt = nc
         grown = list(tracked[:nc])
         for gi, c in enumerate(cols):
-            members = order[bounds[gi]:bounds[gi + 1]]
-            vals = values[members]
+            loc = order[bounds[gi]:bounds[gi + 1]]
+            vals = ovals[loc]
             assign = _kmeans_vec(vals, k, iteration)
             if assign is None:
-                if members.size == 1:
+                if loc.size == 1:
                     grown[c] = False
                 continue
             for piece in range(1, int(assign.max()) + 1):     # piece 0 keeps the colour and stays tracked (CGWO:240-245 only adds)
-                sel = members[assign == piece]
-                if sel.size:
-                    rvc[sel] = nxt
+                part = loc[assign == piece]
+                if part.size:
+                    rvc[obs_idx[part]] = nxt
                     nxt += 1
-                    grown.append(bool(np.var(values[sel]) > epsilon))      # (variance here, its square root above: CGWO:239,244)
+                    grown.append(bool(np.var(ovals[part]) > epsilon))      # (variance here, its square root above: CGWO:239,244)
         tracked = np.array(grown, dtype=bool)
         if nxt == nc:
             return rvc, tracked

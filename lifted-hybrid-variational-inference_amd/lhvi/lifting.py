@@ -146,10 +146,12 @@ def initial_colors_flat(flat, is_split_cont_evidence=True):
     val = np.where(hidden, 0.0, flat.var_value)
     if not is_split_cont_evidence:
         val = np.where(flat.var_cont, 0.0, val)
-    keys = np.stack([dom.astype(np.float64), (~hidden).astype(np.float64), val], axis=1)
-    _, first, inv = np.unique(keys, axis=0, return_index=True, return_inverse=True)
-    order = np.argsort(np.argsort(first))                  # colours numbered in order of first appearance, like the dict
-    rv_color = order[inv.ravel()].astype(np.int32)
+    # colours numbered in order of first appearance, like the reference's dict: hash-based factorisation (O(V), no sort), first
+    # of the values, then of the (value code, domain, observed) triples
+    import pandas as pd
+    vcode = pd.factorize(val + 0.0)[0].astype(np.int64)    # (+ 0.0: -0.0 and 0.0 are one evidence value)
+    nd = int(dom.max()) + 1 if dom.size else 1
+    rv_color = pd.factorize((vcode * nd + dom) * 2 + (~hidden))[0].astype(np.int32)
     pots = list(getattr(flat, 'potentials', []) or [])
     row_color = np.arange(int(flat.pot_kind.size), dtype=np.int32)
     sym_row = np.zeros(int(flat.pot_kind.size), dtype=np.uint8)
