@@ -210,45 +210,23 @@ def _kmeans_vec(vals, k, iteration):
     return np.abs(cen[None, :] - vals[:, None]).argmin(axis=1)
 
 
-def _group(rvc, mask):
-    """members of every colour among `mask`: (sorted member indices, colour of each group, group boundaries)"""
-    idx = np.flatnonzero(mask)
-    order = idx[np.argsort(rvc[idx], kind='stable')]
-    cols, start = np.unique(rvc[order], return_index=True)
-    return order, cols, np.append(start, order.size)
-
-
-def _variances_flat(values, rvc, obs):
-    """{colour: np.var of its observed members}, two passes with per-colour sums"""
-    nc = int(rvc.max()) + 1
-    c = rvc[obs]
-    n = np.bincount(c, minlength=nc).astype(np.float64)
-    with np.errstate(invalid='ignore', divide='ignore'):
-        mean = np.bincount(c, weights=values[obs], minlength=nc) / n
-        var = np.bincount(c, weights=(values[obs] - mean[c]) ** 2, minlength=nc) / n
-    return var, n
-
-
-def split_evidence_flat(values, rvc, tracked, k, iteration, epsilon):
-    """``split_evidence`` on arrays: `tracked` is a boolean array over the colours.  Everything runs on the observed members
-    only (a fifth of the variables of the RGM), grouped once per pass by a stable sort of their colours."""
-    obs_idx = np.flatnonzero(~np.isnan(values))
-    ovals = values[obs_idx]
+def split_evidence_observed(ovals, oc, nc, tracked, k, iteration, epsilon):
+    """``split_evidence`` on the OBSERVED members only (`ovals` their values, `oc` their colours, both in ground order; `nc`
+    colours in all; `tracked` a boolean array over the colours): members are grouped once per pass by a stable sort of their
+    colours.  Returns (oc, nc, tracked) with piece 0 of every split keeping its colour and the other pieces numbered from `nc` up."""
     while True:
-        nc = int(rvc.max()) + 1
-        oc = rvc[obs_idx]
         n = np.bincount(oc, minlength=nc).astype(np.float64)
         with np.errstate(invalid='ignore', divide='ignore'):
             mean = np.bincount(oc, weights=ovals, minlength=nc) / n
             var = np.bincount(oc, weights=(ovals - mean[oc]) ** 2, minlength=nc) / n
         todo = tracked[:nc] & (np.sqrt(np.nan_to_num(var)) > epsilon)
         if not todo.any():
-            return rvc, tracked
+            return oc, nc, tracked
         sel = np.flatnonzero(todo[oc])                        # observed members of the clusters to split
         order = sel[np.argsort(oc[sel], kind='stable')]       # grouped by colour, ground order inside a group
         cols, start = np.unique(oc[order], return_index=True)
         bounds = np.append(start, order.size)
-        rvc = rvc.copy()
+        oc = oc.copy()
         nxt = nc
         grown = list(tracked[:nc])
         for gi, c in enumerate(cols):
@@ -262,51 +240,58 @@ def split_evidence_flat(values, rvc, tracked, k, iteration, epsilon):
             for piece in range(1, int(assign.max()) + 1):     # piece 0 keeps the colour and stays tracked (CGWO:240-245 only adds)
                 part = loc[assign == piece]
                 if part.size:
-                    rvc[obs_idx[part]] = nxt
+                    oc[part] = nxt
                     nxt += 1
                     grown.append(bool(np.var(ovals[part]) > epsilon))      # (variance here, its square root above: CGWO:239,244)
         tracked = np.array(grown, dtype=bool)
         if nxt == nc:
-            return rvc, tracked
+            return oc, nc, tracked
+        nc = nxt
 
 
-def cp_run_flat(flat, sym, dg, values, rvc, fc, tracked):
+def cp_run_device(flat, sym, dg, rvc_d, fc_d, tracked, obs_mask_d):
     """``cp_run`` with the refinement run to its fixed point on the device (``lifting.refine_flat``: the same sequence of
-    half rounds).  ``clustered_evidence`` after the loop in closed form: an evidence cluster is tracked iff it has more than
-    one member and its ancestor at the start of the loop was tracked or ended up with several descendants (C2FVI:39-67: pieces
-    of a split enter the set, a cluster that stays whole leaves it when it is a singleton -- and the loop's last pass splits
-    nothing)."""
+    half rounds) on device-resident colours.  ``clustered_evidence`` after the loop in closed form: an evidence cluster is
+    tracked iff it has more than one member and its ancestor at the start of the loop was tracked or ended up with several
+    descendants (C2FVI:39-67: pieces of a split enter the set, a cluster that stays whole leaves it when it is a singleton --
+    and the loop's last pass splits nothing).  Returns (rvc_d, fc_d, tracked [new colours], parent [new colour -> old colour])."""
     from .lifting import refine_flat
-    new_rvc, new_fc = refine_flat(flat, sym, rvc, fc, dg=dg)
-    n_new, n_old = int(new_rvc.max()) + 1, int(rvc.max()) + 1
-    rep = _first_member(new_rvc, n_new)
-    parent = rvc[rep]
-    nchild = np.bincount(parent, minlength=n_old)
-    size = np.bincount(new_rvc, minlength=n_new)
-    is_obs = ~np.isnan(values[rep])
-    out = is_obs & (size > 1) & (tracked[parent] | (nchild[parent] > 1))
-    return new_rvc.astype(np.int32), new_fc.astype(np.int32), out
+    torch = _abi.require_gpu()
+    new_r, new_f = refine_flat(flat, sym, rvc_d, fc_d, dg=dg, device_out=True)
+    nl, ol = new_r.long(), rvc_d.long()
+    n_new, n_old = int(nl.max().item()) + 1, int(ol.max().item()) + 1
+    rep = torch.full((n_new,), flat.V, dtype=torch.int64, device=nl.device).scatter_reduce_(0, nl, torch.arange(flat.V, device=nl.device), 'amin')
+    parent = ol[rep]
+    nchild = torch.bincount(parent, minlength=n_old)
+    size = torch.bincount(nl, minlength=n_new)
+    tr = torch.from_numpy(np.ascontiguousarray(tracked[:n_old])).to(nl.device)
+    out = obs_mask_d[rep] & (size > 1) & (tr[parent] | (nchild[parent] > 1))
+    return new_r, new_f, out.cpu().numpy(), parent.cpu().numpy()
 
 
 def run_c2fvi_flat(flat, engine, K, iteration, lr, opts, init=None, observer=None, dg=None):
-    """``run_c2fvi`` for a ground ``FlatGraph`` (e.g. ``RelationalGraph.ground_flat``): colours as arrays, every refinement to
-    its fixed point and every re-lift (``lifting.lift_flat``) on the device, parameters kept per CLUSTER and handed down
-    through the parent colour of each new cluster (clusters only split, children inherit: C2FVI:39-60).  ``init``: optional
-    (eta_c [V, K, 2], tau_d [V, K, D]) per ground variable.  Returns dict(rvc, fc, flat (lifted), stage, params (per cluster),
-    fe_log, obs_var, t, relift_s (seconds spent re-lifting, per round))."""
+    """``run_c2fvi`` for a ground ``FlatGraph`` (e.g. ``RelationalGraph.ground_flat``).  The colour arrays live on the device:
+    every refinement runs there to its fixed point, ``lifting.lift_flat`` re-lifts from them, and what reaches the host per
+    round is the colours of the OBSERVED members (the k-means evidence splits run there, vectorised) and lifted-size arrays.
+    Parameters are kept per CLUSTER and handed down through the parent colour of each new cluster (clusters only split,
+    children inherit: C2FVI:39-60).  ``init``: optional (eta_c [V, K, 2], tau_d [V, K, D]) per ground variable.  Returns
+    dict(rvc, fc (host arrays), flat (lifted), stage, params (per cluster), fe_log, obs_var, t, relift_s (seconds per round))."""
     import time as _time
     from .lifting import initial_colors_flat, lift_flat
     torch = _abi.require_gpu()
     dg = dg or _abi.DeviceGraph(flat)
     values = flat.var_value
     obs = ~np.isnan(values)
+    obs_idx = np.flatnonzero(obs)
+    ovals = values[obs_idx]
+    obs_idx_d, obs_mask_d = _abi.to_dev(obs_idx), _abi.to_dev(obs)
     hid_d = flat.var_hidden & ~flat.var_cont
     D = int(flat.var_nstates[hid_d].max()) if hid_d.any() else 1
-    rvc, fc, sym = initial_colors_flat(flat, is_split_cont_evidence=False)         # C2FVI:302
-    nc = int(rvc.max()) + 1
+    rvc0, fc0, sym = initial_colors_flat(flat, is_split_cont_evidence=False)       # C2FVI:302
+    nc = int(rvc0.max()) + 1
     tracked = np.zeros(nc, dtype=bool)
-    tracked[np.unique(rvc[obs & flat.var_cont])] = True                            # CGWO:204-210
-    rep0 = _first_member(rvc, nc)
+    tracked[np.unique(rvc0[obs & flat.var_cont])] = True                           # CGWO:204-210
+    rep0 = _first_member(rvc0, nc)
     P = dict(w_tau=np.zeros(K), eta_c=np.ones((nc, K, 2)), tau_d=np.zeros((nc, K, D)))
     if init is not None:
         P['eta_c'] = np.nan_to_num(np.asarray(init[0], dtype=np.float64)[rep0], nan=1.0)
@@ -323,16 +308,22 @@ def run_c2fvi_flat(flat, engine, K, iteration, lr, opts, init=None, observer=Non
         P['m_' + name] = np.zeros_like(P[name])
         P['s_' + name] = np.zeros_like(P[name])
 
-    def inherit(old_rvc, new_rvc):
-        parent = old_rvc[_first_member(new_rvc, int(new_rvc.max()) + 1)]
+    def inherit(parent):
         for name in list(P):
             if not name.endswith('w_tau'):
                 P[name] = P[name][parent]
+
+    def observed_variances(oc, n_colours):
+        n = np.bincount(oc, minlength=n_colours).astype(np.float64)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            mean = np.bincount(oc, weights=ovals, minlength=n_colours) / n
+            return np.bincount(oc, weights=(ovals - mean[oc]) ** 2, minlength=n_colours) / n
     t = 0
-    prev = rvc
-    rvc, fc, tracked = cp_run_flat(flat, sym, dg, values, rvc, fc, tracked)        # C2FVI:324
-    inherit(prev, rvc)
-    var, _ = _variances_flat(values, rvc, obs)
+    rvc_d, fc_d = _abi.to_dev(rvc0), _abi.to_dev(fc0)
+    rvc_d, fc_d, tracked, parent = cp_run_device(flat, sym, dg, rvc_d, fc_d, tracked, obs_mask_d)     # C2FVI:324
+    inherit(parent)
+    oc = rvc_d[obs_idx_d].cpu().numpy().astype(np.int64)
+    var = observed_variances(oc, tracked.size)
     epsilon = float(np.sqrt(np.nanmax(var))) if obs.any() else 0.0                 # C2FVI:326-331
     d_eps = epsilon * opts['update_obs_its'] / (iteration - opts['output_its'])
     epsilon -= d_eps
@@ -340,13 +331,20 @@ def run_c2fvi_flat(flat, engine, K, iteration, lr, opts, init=None, observer=Non
     stage = lflat = obs_var = None
     for rnd in range(int(iteration / opts['update_obs_its'])):                      # C2FVI:338-345
         t0 = _time.perf_counter()
-        prev = rvc
-        rvc, tracked = split_evidence_flat(values, rvc, tracked, opts['k_mean_k'], opts['k_mean_its'], epsilon)
-        rvc, fc, tracked = cp_run_flat(flat, sym, dg, values, rvc, fc, tracked)
-        inherit(prev, rvc)
+        n_before = tracked.size
+        new_oc, n_split, tracked = split_evidence_observed(ovals, oc, n_before, tracked, opts['k_mean_k'], opts['k_mean_its'], epsilon)
+        moved = np.flatnonzero(new_oc != oc)                                       # the pieces that got fresh colours
+        split_parent = np.arange(n_split)
+        if moved.size:
+            rvc_d = rvc_d.clone()
+            rvc_d[obs_idx_d[_abi.to_dev(moved)]] = _abi.to_dev(new_oc[moved].astype(np.int32))
+            split_parent[new_oc[moved]] = oc[moved]                                # a fresh colour's parent: the colour it left
+        rvc_d, fc_d, tracked, parent = cp_run_device(flat, sym, dg, rvc_d, fc_d, tracked, obs_mask_d)
+        inherit(split_parent[parent])
         epsilon = max(epsilon - d_eps, opts['min_obs_var'])
-        lflat = lift_flat(flat, _abi.to_dev(rvc), _abi.to_dev(fc), dg=dg)
-        var, _ = _variances_flat(values, rvc, obs)
+        lflat = lift_flat(flat, rvc_d, fc_d, dg=dg)
+        oc = rvc_d[obs_idx_d].cpu().numpy().astype(np.int64)
+        var = observed_variances(oc, lflat.V)
         obs_var = np.zeros(lflat.V)
         if opts['gaussian_obs']:
             ev = np.flatnonzero(~np.isnan(var) & (var > opts['min_obs_var']))
@@ -354,7 +352,8 @@ def run_c2fvi_flat(flat, engine, K, iteration, lr, opts, init=None, observer=Non
         torch.cuda.synchronize()
         relift.append(_time.perf_counter() - t0)
         if observer is not None:
-            observer(rnd, dict(rvc=rvc, fc=fc, tracked=set(np.flatnonzero(tracked).tolist()), flat=lflat, obs_var=obs_var, params=P, t=t))
+            observer(rnd, dict(rvc=rvc_d.cpu().numpy(), fc=fc_d.cpu().numpy(), tracked=set(np.flatnonzero(tracked).tolist()), flat=lflat,
+                               obs_var=obs_var, params=P, t=t))
         stage = engine.stage(lflat, obs_var)
         stage.load(P)
         fe_log += stage.adam(opts['update_obs_its'], t, lr)
@@ -364,7 +363,8 @@ def run_c2fvi_flat(flat, engine, K, iteration, lr, opts, init=None, observer=Non
                 P[name] = np.array(a, dtype=np.float64)
             else:
                 P[name][..., :a.shape[-1]] = a
-    return dict(rvc=rvc, fc=fc, flat=lflat, stage=stage, params=P, fe_log=fe_log, obs_var=obs_var, t=t, relift_s=relift)
+    return dict(rvc=rvc_d.cpu().numpy(), fc=fc_d.cpu().numpy(), flat=lflat, stage=stage, params=P, fe_log=fe_log, obs_var=obs_var,
+                t=t, relift_s=relift)
 
 
 class _DeviceStage(_Variational):
