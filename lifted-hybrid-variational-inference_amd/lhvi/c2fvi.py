@@ -257,13 +257,16 @@ def cp_run_device(flat, sym, dg, rvc_d, fc_d, tracked, obs_mask_d):
     and the loop's last pass splits nothing).  Returns (rvc_d, fc_d, tracked [new colours], parent [new colour -> old colour])."""
     from .lifting import refine_flat
     torch = _abi.require_gpu()
+    ol = rvc_d.long()
     new_r, new_f = refine_flat(flat, sym, rvc_d, fc_d, dg=dg, device_out=True)
-    nl, ol = new_r.long(), rvc_d.long()
+    nl = new_r.long()
     n_new, n_old = int(nl.max().item()) + 1, int(ol.max().item()) + 1
     rep = torch.full((n_new,), flat.V, dtype=torch.int64, device=nl.device).scatter_reduce_(0, nl, torch.arange(flat.V, device=nl.device), 'amin')
     parent = ol[rep]
     nchild = torch.bincount(parent, minlength=n_old)
     size = torch.bincount(nl, minlength=n_new)
+    if tracked.size < n_old:
+        raise _abi.LhviError('cp_run_device: the tracked flags do not cover the colours')
     tr = torch.from_numpy(np.ascontiguousarray(tracked[:n_old])).to(nl.device)
     out = obs_mask_d[rep] & (size > 1) & (tr[parent] | (nchild[parent] > 1))
     return new_r, new_f, out.cpu().numpy(), parent.cpu().numpy()
