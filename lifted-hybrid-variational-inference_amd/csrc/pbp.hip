@@ -1422,7 +1422,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8
                                                             double* __restrict__ ph_out) {
     const int lane = threadIdx.x & 63;
     const int n = s.n, S = s.n + s.T;
-    int v, gb, T, lo, hi;
+    int v, gb, T, lo, hi, slot = -1;
     int e4[4] = {0, 0, 0, 0};                              // the first four incident edges (descriptor path)
     const bool listed = s.prop_desc != nullptr;
     if (listed) {
@@ -1432,10 +1432,18 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8
         if (item >= s.n_prop_desc) return;
         const int32_t* rec = s.prop_desc + 8 * (int64_t)item;
         v = rec[0]; gb = rec[2]; T = rec[3];
-        // (the row's position in var_edge is needed only when one pass of four edge groups does not cover it)
-        lo = (rec[1] > 4 || T > 32 || g.edge_count) ? g.var_ptr[v] : 0;       // (a lifted graph sums the row's counts below)
-        hi = lo + rec[1];
-        e4[0] = rec[4]; e4[1] = rec[5]; e4[2] = rec[6]; e4[3] = rec[7];
+        if (rec[1] < 0) {
+            // a slice of a hub variable's row: -rec[1] entries from position rec[4] of the row; the slice's information-form
+            // sums go to slot rec[5] of prop_partial and pbp_proposal_hub_finish_kernel adds the slices up
+            slot = rec[5];
+            lo = g.var_ptr[v] + rec[4];
+            hi = lo - rec[1];
+        } else {
+            // (the row's position in var_edge is needed only when one pass of four edge groups does not cover it)
+            lo = (rec[1] > 4 || T > 32 || g.edge_count) ? g.var_ptr[v] : 0;       // (a lifted graph sums the row's counts below)
+            hi = lo + rec[1];
+            e4[0] = rec[4]; e4[1] = rec[5]; e4[2] = rec[6]; e4[3] = rec[7];
+        }
     } else {
         v = __builtin_amdgcn_readfirstlane(var_first(s) + blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
         if (v >= var_limit(g, s)) return;
@@ -1446,7 +1454,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8
     }
     double total = 0.0;
     if (s.var_degree) total = s.var_degree[v];
-    else for (int k = lo; k < hi; ++k) total += g.edge_count ? g.edge_count[g.var_edge[k]] : 1.0;
+    else {
+        const int r0 = slot >= 0 ? g.var_ptr[v] : lo, r1 = slot >= 0 ? g.var_ptr[v + 1] : hi;      // (a slice: the whole row's total)
+        if (g.edge_count) for (int k = r0; k < r1; ++k) total += g.edge_count[g.var_edge[k]];
+        else total = (double)(r1 - r0);
+    }
     const double min_sig = total * s.var_threshold;
     const double q0 = s.q[2 * v], q1 = s.q[2 * v + 1];
     // lane groups of 16 / 32 / 64 lanes, one incident edge per group and pass: with T <= 32 integral points a degree-4
@@ -1459,7 +1471,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8
         const int k = k0 + grp;
         const bool live = k < hi;
         int e;
-        if (listed && k0 == lo && groups == 4) {           // first pass of four groups: the edges are in the record
+        if (listed && slot < 0 && k0 == lo && groups == 4) {           // first pass of four groups: the edges are in the record
             e = grp == 0 ? e4[0] : (grp == 1 ? e4[1] : (grp == 2 ? e4[2] : e4[3]));
             if (!live) e = e4[0];
         } else {
@@ -1499,8 +1511,20 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8
     }
     for (int off = width; off < 64; off <<= 1) { ps += __shfl_xor(ps, off); pm += __shfl_xor(pm, off); }
     if (ph_out) { if (lane == 0) { ph_out[2 * v] = ps; ph_out[2 * v + 1] = pm; } return; }
+    if (slot >= 0) { if (lane == 0) { s.prop_partial[2 * slot] = ps; s.prop_partial[2 * slot + 1] = pm; } return; }
     ps = 1.0 / ps;
     if (lane == 0) { q[2 * v] = ps * pm; q[2 * v + 1] = ps; }
+}
+
+// q of the hub variables from their slices' sums, slices in row order (lhvi_pbp_t.prop_hub)
+__global__ void __launch_bounds__(BLOCK) pbp_proposal_hub_finish_kernel(lhvi_pbp_t s, double* __restrict__ q) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= s.n_prop_hub) return;
+    const int v = s.prop_hub[4 * i], first = s.prop_hub[4 * i + 1], count = s.prop_hub[4 * i + 2];
+    double ps = 0.0, pm = 0.0;
+    for (int k = 0; k < count; ++k) { ps += s.prop_partial[2 * (first + k)]; pm += s.prop_partial[2 * (first + k) + 1]; }
+    ps = 1.0 / ps;
+    q[2 * v] = ps * pm; q[2 * v + 1] = ps;
 }
 
 // q[v] from the local information-form sums plus the other ranks' (lhvi_pbp_proposal_finish)
@@ -1968,6 +1992,7 @@ int lhvi_pbp_proposal(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* 
     if (int rc = validate_pbp(g, s)) return rc;
     if (!f2v || !eta || !q) return LHVI_E_ARG;
     if (s->prop_desc && (s->n_prop_desc < 0 || s->var_hi > s->var_lo)) return LHVI_E_ARG;    // the list replaces the variable range
+    if (s->n_prop_hub < 0 || (s->n_prop_hub > 0 && (!s->prop_desc || !s->prop_hub || !s->prop_partial))) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
     if (s->prop_desc) {
         if (s->n_prop_desc == 0) return LHVI_OK;
@@ -1976,6 +2001,8 @@ int lhvi_pbp_proposal(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* 
             hipLaunchKernelGGL(pbp_proposal_kernel<true>, grid, dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, eta, q, (double*)nullptr);
         else
             hipLaunchKernelGGL(pbp_proposal_kernel<false>, grid, dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, eta, q, (double*)nullptr);
+        if (s->n_prop_hub > 0)
+            hipLaunchKernelGGL(pbp_proposal_hub_finish_kernel, dim3(grid_for(s->n_prop_hub)), dim3(BLOCK), 0, as_stream(stream), *s, q);
         return check_launch();
     }
     if (s->flags & LHVI_PBP_EP)

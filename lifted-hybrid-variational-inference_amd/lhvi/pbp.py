@@ -34,6 +34,8 @@ class _ParticleSweep:
     dynamic_f2v = True              # the persistent f2v kernels claim their work in chunks (else static striding)
     paired_light = True             # the light edges are served per factor (pair_desc) instead of per edge (light_desc)
     cq_routing = True               # conditionally quadratic MLN formulas go to the quadratic-family kernels (else: generic kernel)
+    sliced_proposal = True          # rows of more than prop_slice incident edges are cut into slices, a wavefront per slice
+    prop_slice = 64
     packed_v2f = True               # variables with at most four particles share a wavefront in the v -> f half (sixteen each)
 
     # ---- set-up ------------------------------------------------------------------------------
@@ -108,8 +110,27 @@ class _ParticleSweep:
         for k in range(4):
             if flat.var_edge.size:
                 pd[:, 4 + k] = flat.var_edge[np.minimum(pbase + np.minimum(k, np.maximum(pdeg - 1, 0)), flat.var_edge.size - 1)]
-        self.prop_desc = _abi.to_dev(pd) if pv.size else None
-        self.n_prop_desc = int(pv.size)
+        # rows longer than prop_slice entries go in as slices of that length, a wavefront each, ahead of the ordinary records
+        self.prop_hub = self.prop_partial = None
+        self.n_prop_hub = 0
+        hubs = np.flatnonzero(pdeg > self.prop_slice) if self.sliced_proposal else np.zeros(0, dtype=np.int64)
+        if hubs.size:
+            L = int(self.prop_slice)
+            nsl = (pdeg[hubs] + L - 1) // L
+            first = np.concatenate([[0], np.cumsum(nsl)[:-1]])
+            owner = np.repeat(np.arange(hubs.size), nsl)
+            within = np.arange(int(nsl.sum())) - first[owner]
+            sl = np.zeros((owner.size, 8), dtype=np.int32)
+            sl[:, 0], sl[:, 2], sl[:, 3] = pd[hubs[owner], 0], pd[hubs[owner], 2], pd[hubs[owner], 3]
+            sl[:, 1] = -np.minimum(L, pdeg[hubs][owner] - within * L)
+            sl[:, 4], sl[:, 5] = within * L, np.arange(owner.size)
+            ph = np.zeros((hubs.size, 4), dtype=np.int32)
+            ph[:, 0], ph[:, 1], ph[:, 2] = pv[hubs], first, nsl
+            pd = np.concatenate([sl, np.delete(pd, hubs, axis=0)])
+            self.prop_hub, self.n_prop_hub = _abi.to_dev(ph), int(hubs.size)
+            self.prop_partial = dg.zeros(owner.size, 2)
+        self.prop_desc = _abi.to_dev(np.ascontiguousarray(pd)) if pv.size else None
+        self.n_prop_desc = int(pd.shape[0])
         # the v -> f half's split of the hidden variables (include/lhvi.h, lhvi_pbp_t.v2f_wide / v2f_narrow)
         hidden_v = np.flatnonzero(flat.var_hidden)
         narrow = self.np_host[hidden_v] <= 4
@@ -239,6 +260,8 @@ class _ParticleSweep:
         s.f2v_ticket = _abi.ptr(self.f2v_ticket) if self.dynamic_f2v else None
         if self.listed_proposal and getattr(self, 'prop_desc', None) is not None:
             s.prop_desc, s.n_prop_desc = _abi.ptr(self.prop_desc), self.n_prop_desc
+            if getattr(self, 'prop_hub', None) is not None:
+                s.prop_hub, s.n_prop_hub, s.prop_partial = _abi.ptr(self.prop_hub), self.n_prop_hub, _abi.ptr(self.prop_partial)
         return s
 
     # ---- sampling ----------------------------------------------------------------------------

@@ -825,3 +825,49 @@ def test_v2f_hub_kernel_matches_the_one_wave_path(api):
     np.testing.assert_allclose(a.v2f.cpu().numpy()[live], b.v2f.cpu().numpy()[live], rtol=1e-11, atol=1e-10)
     np.testing.assert_allclose(a.q_dev.cpu().numpy(), b.q_dev.cpu().numpy(), rtol=1e-10, atol=1e-12, equal_nan=True)
     assert torch.equal(a.v2f, c.v2f) and torch.equal(a.f2v, c.f2v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rule', ['simple', 'EP'])
+@pytest.mark.parametrize('lifted', [False, True])
+def test_sliced_proposal_matches_the_one_wave_path(api, rule, lifted):
+    """rows of more than 64 incident edges are handed to the proposal kernel in slices (lhvi_pbp_t.prop_hub): the sites are the
+    same bit for bit, the proposals equal to the rounding of a differently ordered sum, and a repeat gives the same bits"""
+    import torch
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    flat, keys = synth.paper_popularity_flat(150, 4, seed=2)
+    if lifted:
+        flat.edge_count = 1.0 + (np.arange(flat.E) % 3).astype(np.float64)
+        flat.lifted = True
+    deg = np.diff(flat.var_ptr)
+    assert deg.max() > 130
+    n = 16
+    rng = np.random.default_rng(1)
+    draws = []
+
+    def sampler(k, fl, q):
+        if k == len(draws):
+            cont = fl.var_hidden & fl.var_cont
+            out = np.zeros((fl.V, n))
+            out[cont] = np.clip(rng.standard_normal((int(cont.sum()), n)) * np.sqrt(q[cont, 1:2]) + q[cont, 0:1], -15, 15)
+            draws.append(out)
+        return draws[k]
+    runs = []
+    for sliced in (True, False, True):
+        bp = EPBP(None, n=n, proposal_approximation=rule, sampler=sampler, seed=6)
+        bp.sliced_proposal = sliced
+        bp._setup(None, flat=flat)
+        _init(api, bp)
+        for _ in range(3):
+            bp.sweep(last=False)
+        runs.append(bp)
+    a, b, c = runs
+    hubs = int(((deg > 64) & flat.var_hidden & flat.var_cont).sum())
+    assert a.n_prop_hub == hubs and hubs > 0 and b.n_prop_hub == 0
+    assert a.n_prop_desc > b.n_prop_desc
+    qa, qb = a.q_dev.cpu().numpy(), b.q_dev.cpu().numpy()
+    assert np.isfinite(qa).all()
+    np.testing.assert_allclose(qa, qb, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(a.eta.cpu().numpy(), b.eta.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    assert torch.equal(a.q_dev, c.q_dev) and torch.equal(a.eta, c.eta) and torch.equal(a.f2v, c.f2v)
