@@ -141,6 +141,9 @@ def main():
     ap.add_argument('--particles', type=int, default=64)
     ap.add_argument('--grid', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--exchange', choices=('pairs', 'owner'), default='pairs',
+                    help='multi-GPU runs: boundary rows between every pair of ranks sharing a variable (one collective), or reduced '
+                         'to an owner rank and sent back (two smaller collectives)')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -189,7 +192,8 @@ def main():
         # the factor partition (one breadth-first sweep of the whole graph) is computed on rank 0 only and broadcast; every
         # rank then builds just its own slice of the plan
         runner = dist.ShardedRunner(flat, n=n, seed=1, rank=rank, world=world,
-                                    fac_owner=dist.broadcast_partition(flat, rank, world))
+                                    fac_owner=dist.broadcast_partition(flat, rank, world),
+                                    owner_reduce=args.exchange == 'owner')
     del flat
     progress('graph on the device, work lists built')
     runner.init()

@@ -31,7 +31,7 @@ extern "C" {
                               * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t;  7: lhvi_pbp_t gained pair_desc;
                               * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq; the colour
                               *    refinement calls take a method and return four result words; lhvi_vi_t gained var_N; lhvi_vi_opt_t, lhvi_vi_adam_run;
-                              *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub, prop_hub / prop_partial; 16 ticket words */
+                              *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub, prop_hub / prop_partial; 16 ticket words; lhvi_pbp_boundary_reduce */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -184,6 +184,8 @@ int lhvi_log_likelihood(const lhvi_graph_t* g, const lhvi_pots_t* pots, const do
                                    * Demo/Data/HMLN/GeneratorPaperPopularity.py:28-40) to the quadratic-family kernels instead of the
                                    * generic interpreter kernel: set it for lhvi_pbp_classify / _describe / _describe_cq AND lhvi_pbp_f2v */
 #define LHVI_PBP_SKIP_CQ 1024u   /* lhvi_pbp_f2v: do not launch the kernel of the cq_desc list (profiling aid) */
+#define LHVI_PBP_BOUNDARY_TOTALS 2048u /* sharded runs: a boundary variable's one listed row of s->recv holds the finished total over all ranks
+                                        * (lhvi_pbp_boundary_reduce); without it the rows are the peers' sums and the kernels add them */
 #define LHVI_PBP_NO_GRID 128u    /* lhvi_pbp_f2v: integral points always by the direct form (one exponential per term), never by the
                                    * uniform-grid recurrence (testing / profiling aid) */
 
@@ -347,6 +349,15 @@ int lhvi_pbp_proposal_partial(const lhvi_graph_t* g, const lhvi_pbp_t* s, const 
 int lhvi_pbp_proposal_finish(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* ph, double* q, void* stream);
 int lhvi_pbp_boundary_pack(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, const double* ph, int32_t nb,
                            const int32_t* bvars, double* send, void* stream);
+/* Reduce-to-owner form of the exchange (a boundary variable present on k ranks costs 2 (k - 1) rows instead of k (k - 1)): every
+ * such variable has one owner among its ranks; the others send it their row, the owner adds the rows in ascending rank order
+ * (its own at its position -- the order lhvi_pbp_v2f / _proposal_finish use for the all-to-all form, so both forms give the same
+ * bits) and sends the total back.  This call is the owner's sum: item i adds the `width[i]` doubles at in + src_off[r],
+ * r in [src_ptr[i], src_ptr[i+1]), and stores the total at out + dst_off[r], r in [dst_ptr[i], dst_ptr[i+1]).  Afterwards
+ * lhvi_pbp_v2f / _proposal_finish run with LHVI_PBP_BOUNDARY_TOTALS: each boundary variable lists ONE row (brow_ptr / brow_off into
+ * s->recv) holding the total over all ranks. */
+int lhvi_pbp_boundary_reduce(int32_t n_items, const int32_t* width, const int32_t* src_ptr, const int64_t* src_off,
+                             const int32_t* dst_ptr, const int64_t* dst_off, const double* in, double* out, void* stream);
 /* initial_proposal: q=(0,5), sites (0, 5*deg): EPBP.py:72-81; HLBP.py:89-98 */
 int lhvi_pbp_init(const lhvi_graph_t* g, const lhvi_pbp_t* s, double* eta, double* q, double* f2v, double* v2f, void* stream);
 /* generate_sample with a counter-based device RNG keyed (seed, variable gid, iteration, j): EPBP.py:61-70.

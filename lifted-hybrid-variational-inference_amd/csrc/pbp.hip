@@ -137,11 +137,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
         const double x = valid ? s.particles[(int64_t)v * n + j] : 0.0;
         const bool uq = valid && s.uniq[(int64_t)v * n + j];
         double total = 0.0;
-        if (s.bslot && valid) {                      // edges of this variable that live on other ranks: received partial sums
-            const int bs = s.bslot[v];
-            if (bs >= 0)
-                for (int r = s.brow_ptr[bs]; r < s.brow_ptr[bs + 1]; ++r) total += s.recv[s.brow_off[r] + j];
-        }
 #pragma unroll
         for (int k = 0; k < V2F_CACHE; ++k)
             if (k < deg) total += lifted ? row[k] * g.edge_count[ecache[k]] : row[k];
@@ -149,6 +144,26 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
             const int e = g.var_edge[lo + k];
             const double m = valid ? f2v[(int64_t)e * S + j] : 0.0;
             total += lifted ? m * g.edge_count[e] : m;
+        }
+        if (s.bslot && valid) {
+            // edges of this variable that live on other ranks.  The ranks' sums are added in ascending rank order, this rank's at
+            // its own position (like the proposal's), so that the total is the same bits on every rank and under either
+            // exchange: rows of every peer (all-to-all), or one row with the finished total (LHVI_PBP_BOUNDARY_TOTALS)
+            const int bs = s.bslot[v];
+            if (bs >= 0) {
+                if (s.flags & LHVI_PBP_BOUNDARY_TOTALS) {
+                    total = s.recv[s.brow_off[s.brow_ptr[bs]] + j];
+                } else {
+                    const double own = total;
+                    total = 0.0;
+                    bool own_done = false;
+                    for (int r = s.brow_ptr[bs]; r < s.brow_ptr[bs + 1]; ++r) {
+                        if (!own_done && s.brow_peer[r] > s.rank) { total += own; own_done = true; }
+                        total += s.recv[s.brow_off[r] + j];
+                    }
+                    if (!own_done) total += own;
+                }
+            }
         }
         const double logw = valid ? log_importance(g, s, v, d, x, mu, rsd, log_norm) : 0.0;
         const int cnt1 = __builtin_popcountll(__ballot(uq));        // distinct particles: the same for every incident edge
@@ -1538,7 +1553,10 @@ __global__ void __launch_bounds__(BLOCK) pbp_proposal_finish_kernel(lhvi_graph_t
         // boundary variable: add the ranks' information-form sums in ascending rank order (own sum at its own position),
         // so that every replica of the variable computes bit-identical q and therefore draws identical particles
         const int bs = s.bslot[v];
-        if (bs >= 0) {
+        if (bs >= 0 && (s.flags & LHVI_PBP_BOUNDARY_TOTALS)) {
+            const double* row = s.recv + s.brow_off[s.brow_ptr[bs]] + s.n;     // the owner's finished sums (lhvi_pbp_boundary_reduce)
+            ps = row[0]; pm = row[1];
+        } else if (bs >= 0) {
             const double own_s = ps, own_m = pm;
             ps = 0.0; pm = 0.0;
             bool own_done = false;
@@ -1579,6 +1597,23 @@ __global__ void __launch_bounds__(BLOCK) pbp_boundary_pack_kernel(lhvi_graph_t g
             }
         } else if (j >= n) val = ph[2 * v + (j - n)];
         for (int r = r0; r < r1; ++r) out[s.brow_off[r] + j] = val;
+    }
+}
+
+// owner side of the reduce-to-owner exchange: one wavefront per owned boundary variable adds its sources (the ranks' rows in
+// ascending rank order, host-listed) and writes the total to each of its destinations (own total row, one send row per replica)
+__global__ void __launch_bounds__(BLOCK) pbp_boundary_reduce_kernel(int n_items, const int32_t* __restrict__ width,
+                                                                   const int32_t* __restrict__ src_ptr, const int64_t* __restrict__ src_off,
+                                                                   const int32_t* __restrict__ dst_ptr, const int64_t* __restrict__ dst_off,
+                                                                   const double* __restrict__ in, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+    if (i >= n_items) return;
+    const int W = width[i];
+    for (int j = lane; j < W; j += 64) {
+        double total = 0.0;
+        for (int r = src_ptr[i]; r < src_ptr[i + 1]; ++r) total += in[src_off[r] + j];
+        for (int r = dst_ptr[i]; r < dst_ptr[i + 1]; ++r) out[dst_off[r] + j] = total;
     }
 }
 
@@ -2044,6 +2079,16 @@ int lhvi_pbp_boundary_pack(const lhvi_graph_t* g, const lhvi_pbp_t* s, const dou
     if (!f2v || !ph || !bvars || !out || !s->brow_ptr || !s->brow_off) return LHVI_E_ARG;
     hipLaunchKernelGGL(pbp_boundary_pack_kernel, dim3(grid_for((int64_t)nb * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, ph,
                        nb, bvars, out);
+    return check_launch();
+}
+
+int lhvi_pbp_boundary_reduce(int32_t n_items, const int32_t* width, const int32_t* src_ptr, const int64_t* src_off,
+                             const int32_t* dst_ptr, const int64_t* dst_off, const double* in, double* out, void* stream) {
+    if (n_items < 0) return LHVI_E_ARG;
+    if (n_items == 0) return LHVI_OK;
+    if (!width || !src_ptr || !src_off || !dst_ptr || !dst_off || !in || !out) return LHVI_E_ARG;
+    hipLaunchKernelGGL(pbp_boundary_reduce_kernel, dim3(grid_for((int64_t)n_items * WAVE)), dim3(BLOCK), 0, as_stream(stream), n_items,
+                       width, src_ptr, src_off, dst_ptr, dst_off, in, out);
     return check_launch();
 }
 

@@ -87,6 +87,7 @@ PBP_SKIP_HEAVY = 32
 PBP_SKIP_LIGHT = 64
 PBP_NO_GRID = 128
 PBP_LEAVE_ROOM = 256
+PBP_BOUNDARY_TOTALS = 2048
 PBP_CQ = 512
 PBP_SKIP_CQ = 1024
 ABI_VERSION = 8             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
@@ -133,6 +134,7 @@ SIGNATURES = {
     'lhvi_pbp_proposal_partial': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp]),
     'lhvi_pbp_proposal_finish': (C.c_int, [_G, _S, _vp, _vp, _vp]),
     'lhvi_pbp_boundary_pack': (C.c_int, [_G, _S, _vp, _vp, _i32, _vp, _vp, _vp]),
+    'lhvi_pbp_boundary_reduce': (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'lhvi_pbp_init': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp, _vp]),
     'lhvi_pbp_resample': (C.c_int, [_G, _S, _vp, _u64, _u32, _vp, _vp]),
     'lhvi_pbp_edge_points': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),

@@ -219,6 +219,79 @@ class ShardPlan:
         return list(self.counts)
 
 
+def owner_exchange_layout(plan, bwidth):
+    """Buffers of the reduce-to-owner exchange of one rank (NumPy only).  ``bwidth[b]`` = doubles in boundary variable b's row.
+
+    Every boundary variable has one owner among the ranks that hold edges of it -- entry ``gid % k`` of the ascending list of
+    its k ranks, which every one of them computes alike.  Step A: each other rank sends the owner its row; the owner adds the
+    rows in ascending rank order.  Step B: the owner sends the total back.  2 (k - 1) rows per variable instead of the
+    k (k - 1) of the all-to-all form.  Element offsets:
+
+    * buffer A = [rows to the owners, owner-major | own rows of the variables owned here | rows received, sender-major],
+      ``pack_off[b]`` = where boundary variable b's local row goes (first or second block);
+    * buffer B = [totals to the replicas, receiver-major | totals received, owner-major | totals of the owned variables],
+      ``total_off[b]`` = where b's total is read after step B (second or third block);
+    * ``items`` = the owned variables; ``src_ptr / src_off`` their rows in A in ascending rank order; ``dst_ptr / dst_off``
+      their total's places in B;  ``a_send / a_recv / b_send / b_recv`` = elements per peer of the two collectives.
+    Inside a peer's block rows are in ascending global id on both ends, so no index travels."""
+    rank, world = plan.rank, plan.world
+    nb = int(plan.bvars.size)
+    bwidth = np.asarray(bwidth, dtype=np.int64)
+    npeers = np.diff(plan.brow_ptr).astype(np.int64)
+    pair_b = np.repeat(np.arange(nb, dtype=np.int64), npeers)
+    pair_peer = plan.brow_peer.astype(np.int64)
+    gid = plan.var_gid[plan.bvars].astype(np.int64)
+    k = npeers + 1
+    p_own = np.bincount(pair_b, weights=(pair_peer < rank), minlength=nb).astype(np.int64)      # own position among the sorted ranks
+    idx = gid % k
+    look = plan.brow_ptr[:-1].astype(np.int64) + idx - (idx > p_own)
+    owner = np.where(idx == p_own, rank, pair_peer[np.minimum(look, max(pair_peer.size - 1, 0))] if pair_peer.size else rank)
+    owned = owner == rank
+
+    def block(bs, peers, base):
+        """rows (bs[i], peers[i]) laid out peer-major, ascending b inside a peer: offsets per row, elements per peer, end"""
+        order = np.lexsort((bs, peers))
+        w = bwidth[bs[order]]
+        off = np.empty(bs.size, dtype=np.int64)
+        off[order] = base + np.concatenate([[0], np.cumsum(w)[:-1]]) if bs.size else 0
+        per_peer = np.bincount(peers, weights=bwidth[bs], minlength=world).astype(np.int64) if bs.size else np.zeros(world, np.int64)
+        return off, per_peer, base + int(w.sum())
+    mine, theirs = np.flatnonzero(owned), np.flatnonzero(~owned)
+    own_pairs = owned[pair_b]
+    ob, op = pair_b[own_pairs], pair_peer[own_pairs]                 # (owned variable, replica rank)
+    # buffer A
+    a_send_off, a_send, end = block(theirs, owner[theirs], 0)
+    own_off = end + np.concatenate([[0], np.cumsum(bwidth[mine])[:-1]]) if mine.size else np.zeros(0, np.int64)
+    end += int(bwidth[mine].sum())
+    a_recv_base = end
+    a_recv_off, a_recv, a_end = block(ob, op, end)
+    pack_off = np.zeros(nb, dtype=np.int64)
+    pack_off[theirs], pack_off[mine] = a_send_off, own_off
+    # buffer B
+    b_send_off, b_send, end = block(ob, op, 0)
+    b_recv_base = end
+    b_recv_off, b_recv, end = block(theirs, owner[theirs], end)
+    tot_off = end + np.concatenate([[0], np.cumsum(bwidth[mine])[:-1]]) if mine.size else np.zeros(0, np.int64)
+    b_end = end + int(bwidth[mine].sum())
+    total_off = np.zeros(nb, dtype=np.int64)
+    total_off[theirs], total_off[mine] = b_recv_off, tot_off
+    # the owner's sums: sources in ascending rank order, destinations in any order
+    item_of = np.full(nb, -1, dtype=np.int64)
+    item_of[mine] = np.arange(mine.size)
+    sb = np.concatenate([item_of[ob], np.arange(mine.size)])
+    srank = np.concatenate([op, np.full(mine.size, rank, dtype=np.int64)])
+    soff = np.concatenate([a_recv_off, own_off])
+    order = np.lexsort((srank, sb))
+    src_ptr = np.zeros(mine.size + 1, dtype=np.int64)
+    np.cumsum(np.bincount(sb, minlength=mine.size), out=src_ptr[1:])
+    doff = np.concatenate([b_send_off, tot_off])
+    dorder = np.argsort(sb, kind='stable')
+    return dict(owner=owner, owned=owned, items=mine, width=bwidth[mine].astype(np.int32), pack_off=pack_off, total_off=total_off,
+                src_ptr=src_ptr.astype(np.int32), src_off=soff[order], dst_ptr=src_ptr.astype(np.int32), dst_off=doff[dorder],
+                a_size=a_end, b_size=b_end, a_recv_base=a_recv_base, b_recv_base=b_recv_base,
+                a_send=a_send.tolist(), a_recv=a_recv.tolist(), b_send=b_send.tolist(), b_recv=b_recv.tolist())
+
+
 class LoopbackGroup:
     """In-process stand-in for the all-to-all of `world` simulated ranks (single-GPU parity tests of the sharded path)."""
 
@@ -254,7 +327,7 @@ class ShardedRunner:
     """
 
     def __init__(self, flat, n, seed, rank, world, proposal_approximation='simple', group=None, overlap=True,
-                 fac_owner=None):
+                 fac_owner=None, owner_reduce=False):
         import torch
         from .pbp import EPBP
         self.plan = plan = ShardPlan(flat, rank, world, fac_owner=fac_owner)
@@ -293,6 +366,21 @@ class ShardedRunner:
         # elements per peer (what the all_to_all splits by); rows per peer stay in plan.counts
         ends = np.cumsum([c for c in plan.counts])
         self.counts = [int(row_off[e] - row_off[e - c]) for e, c in zip(ends, plan.counts)]
+        # reduce-to-owner form of the exchange (owner_exchange_layout): two smaller collectives with the owners' sums between
+        self.owner_reduce = bool(owner_reduce) and world > 1 and nb > 0
+        if self.owner_reduce:
+            lay = self.lay = owner_exchange_layout(plan, bwidth)
+            self.bufA = torch.zeros(max(lay['a_size'], 1), dtype=torch.float64, device=dev)
+            self.bufB = torch.zeros(max(lay['b_size'], 1), dtype=torch.float64, device=dev)
+            self.one_ptr = _abi.to_dev(np.arange(nb + 1, dtype=np.int32))
+            self.pack_off, self.total_off = _abi.to_dev(lay['pack_off']), _abi.to_dev(lay['total_off'])
+            self.red = {k: _abi.to_dev(np.ascontiguousarray(lay[k]) if lay[k].size else np.zeros(1, dtype=lay[k].dtype))
+                        for k in ('width', 'src_ptr', 'src_off', 'dst_ptr', 'dst_off')}
+            self.n_items = int(lay['items'].size)
+            self.a_send_elems, self.b_send_elems = int(sum(lay['a_send'])), int(sum(lay['b_send']))
+            self.a_recv_elems, self.b_recv_elems = int(sum(lay['a_recv'])), int(sum(lay['b_recv']))
+            self.counts = list(lay['a_send'])            # (what a loopback group cuts this rank's first send by)
+            self.side = None
 
     def _struct(self, part=None):
         """`part`: None = everything, 0 = interior variables, 1 = boundary variables (variable range only)"""
@@ -302,7 +390,11 @@ class ShardedRunner:
         s.bslot, s.var_degree = _abi.ptr(self.bslot), _abi.ptr(self.var_degree)
         s.brow_ptr, s.brow_off, s.brow_peer = _abi.ptr(self.brow_ptr), _abi.ptr(self.brow_off), _abi.ptr(self.brow_peer)
         s.recv, s.rank = _abi.ptr(self.recv), int(self.rank)
+        if self.owner_reduce:                                # one row per boundary variable: the total, in buffer B
+            s.flags |= _abi.PBP_BOUNDARY_TOTALS
+            s.brow_ptr, s.brow_off, s.recv = _abi.ptr(self.one_ptr), _abi.ptr(self.total_off), _abi.ptr(self.bufB)
         s.prop_desc, s.n_prop_desc = None, 0                 # the sharded proposal addresses variables by range
+        s.prop_hub, s.n_prop_hub, s.prop_partial = None, 0, None
         s.v2f_wide, s.n_v2f_wide, s.v2f_narrow, s.n_v2f_narrow, s.v2f_hub, s.n_v2f_hub = None, 0, None, 0, None, 0     # ... and so does the sharded v -> f half
         if part is not None:
             s.var_lo, s.var_hi = (0, self.n_int) if part == 0 else (self.n_int, self.plan.flat.V)
@@ -345,14 +437,41 @@ class ShardedRunner:
         bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
         s = self._struct(part)
         _abi.check(l.lhvi_pbp_proposal_partial(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.eta), _abi.ptr(self.ph), st))
-        if part != 0:
+        if part != 0 and self.owner_reduce:
+            s.brow_off = _abi.ptr(self.pack_off)             # one row per boundary variable: to its owner, or kept when owned here
+            _abi.check(l.lhvi_pbp_boundary_pack(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(self.ph), self.nb, _abi.ptr(self.bvars),
+                                                _abi.ptr(self.bufA), st))
+        elif part != 0:
             _abi.check(l.lhvi_pbp_boundary_pack(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(self.ph), self.nb, _abi.ptr(self.bvars),
                                                 _abi.ptr(self.send), st))
-        return self.send[:self.n_elems]
+        return self.bufA[:self.a_send_elems] if self.owner_reduce else self.send[:self.n_elems]
+
+    def owner_sums(self, rows=None, stream=None):
+        """reduce-to-owner form, between its two collectives: the totals of the variables owned here from the rows received
+        (`rows`: a loopback group's copy of them; None = already in buffer A); returns the block of totals to send back"""
+        lay = self.lay
+        if rows is not None:
+            self.bufA[lay['a_recv_base']:lay['a_recv_base'] + self.a_recv_elems].copy_(rows)
+        r = self.red
+        _abi.check(_abi.lib().lhvi_pbp_boundary_reduce(self.n_items, _abi.ptr(r['width']), _abi.ptr(r['src_ptr']), _abi.ptr(r['src_off']),
+                                                       _abi.ptr(r['dst_ptr']), _abi.ptr(r['dst_off']), _abi.ptr(self.bufA),
+                                                       _abi.ptr(self.bufB), stream if stream is not None else _abi.stream_ptr()))
+        return self.bufB[:self.b_send_elems]
+
+    def _install(self, recv):
+        """rows handed in by a loopback group go where the kernels read them (a real collective wrote them there already)"""
+        if self.owner_reduce:
+            dst = self.bufB[self.lay['b_recv_base']:self.lay['b_recv_base'] + self.b_recv_elems]
+        else:
+            dst = self.recv[:recv.shape[0]]
+        if recv.data_ptr() != dst.data_ptr():
+            dst.copy_(recv)
 
     def exchange(self, send, async_op=False):
         """the one collective of a sweep; returns the receive buffer (and the work handle when `async_op`)"""
         import torch.distributed as td
+        if self.owner_reduce:
+            return self._exchange_owner(async_op)
         recv = self.recv[:self.n_elems]         # symmetric: the rows shared with rank s are sent to and received from s
         splits = list(self.counts)
         work = None
@@ -367,6 +486,41 @@ class ShardedRunner:
             recv.view(-1).copy_(h_recv)
         return (recv, work) if async_op else recv
 
+    def _exchange_owner(self, async_op):
+        """rows to the owners -> the owners' sums -> totals back.  Asynchronous form: the sums and the second collective are
+        issued on a side stream, so that they run as soon as the first collective ends and not behind the interior part of the
+        sweep queued on the compute stream"""
+        import torch
+        import torch.distributed as td
+        lay = self.lay
+        sendA = self.bufA[:self.a_send_elems]
+        recvA = self.bufA[lay['a_recv_base']:lay['a_recv_base'] + self.a_recv_elems]
+        sendB = self.bufB[:self.b_send_elems]
+        recvB = self.bufB[lay['b_recv_base']:lay['b_recv_base'] + self.b_recv_elems]
+        if td.get_backend() != 'nccl':
+            # rehearsal backend (gloo): same collectives on host copies
+            h = torch.empty(self.a_recv_elems, dtype=torch.float64)
+            td.all_to_all_single(h, sendA.cpu(), output_split_sizes=lay['a_recv'], input_split_sizes=lay['a_send'])
+            recvA.copy_(h)
+            self.owner_sums()
+            h = torch.empty(self.b_recv_elems, dtype=torch.float64)
+            td.all_to_all_single(h, sendB.cpu(), output_split_sizes=lay['b_recv'], input_split_sizes=lay['b_send'])
+            recvB.copy_(h)
+            return (recvB, None) if async_op else recvB
+        if not async_op:
+            td.all_to_all_single(recvA, sendA, output_split_sizes=lay['a_recv'], input_split_sizes=lay['a_send'])
+            self.owner_sums()
+            td.all_to_all_single(recvB, sendB, output_split_sizes=lay['b_recv'], input_split_sizes=lay['b_send'])
+            return recvB
+        if self.side is None:
+            self.side = torch.cuda.Stream()
+        self.side.wait_stream(torch.cuda.current_stream())            # the packed rows (own rows included) are ready
+        with torch.cuda.stream(self.side):
+            td.all_to_all_single(recvA, sendA, output_split_sizes=lay['a_recv'], input_split_sizes=lay['a_send'])
+            self.owner_sums(stream=self.side.cuda_stream)
+            work = td.all_to_all_single(recvB, sendB, output_split_sizes=lay['b_recv'], input_split_sizes=lay['b_send'], async_op=True)
+        return recvB, work
+
     # -- phase 2: the rest of the sweep, reading the peers' rows straight from the receive buffer ---------------------
     def _f2v(self, s, f2v_events=None):
         self.bp._launch_f2v(s, f2v_events)
@@ -376,8 +530,7 @@ class ShardedRunner:
         bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
         # the kernels read the received rows in place (v2f: particle-part sums; proposal_finish: information-form sums in
         # rank order, so every replica of a boundary variable forms bit-identical q and draws bit-identical particles)
-        if recv.data_ptr() != self.recv.data_ptr():
-            self.recv[:recv.shape[0]].copy_(recv)
+        self._install(recv)
         s = self._struct()
         _abi.check(l.lhvi_pbp_v2f(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.v2f), st))
         _abi.check(l.lhvi_pbp_proposal_finish(bp.dg.g, s, _abi.ptr(self.ph), _abi.ptr(bp.q_dev), st))
@@ -409,8 +562,7 @@ class ShardedRunner:
 
     def boundary(self, recv, f2v_events=None):
         """the rest, once the peers' rows have arrived (after `interior`)"""
-        if recv.data_ptr() != self.recv.data_ptr():
-            self.recv[:recv.shape[0]].copy_(recv)
+        self._install(recv)
         self._var_part(1, swapped=True)
         self._f2v(self._edge_part(self._struct(), 1), f2v_events)
 
@@ -460,7 +612,8 @@ class ShardedRunner:
         n = len(self._phase_events)
         out = {k: v / n for k, v in acc.items()}
         out.update(sweeps=n, boundary_variables=int(self.nb), interior_variables=int(self.n_int),
-                   exchanged_MB_per_sweep=8e-6 * self.n_elems)
+                   exchange='reduce to owner + totals back' if self.owner_reduce else 'all-to-all of the ranks\' rows',
+                   exchanged_MB_per_sweep=8e-6 * ((self.a_send_elems + self.b_send_elems) if self.owner_reduce else self.n_elems))
         return out
 
     def local_edges(self):

@@ -51,6 +51,84 @@ def test_shard_plan_invariants(world):
     assert (owners >= 1).all()
 
 
+@pytest.mark.parametrize('world', [3, 8])
+def test_owner_exchange_layout_adds_up(world):
+    """reduce-to-owner exchange, both collectives played in NumPy over all ranks' layouts: every replica ends up with the sum
+    of the ranks' rows taken in ascending rank order (bit for bit), the two ends of every block agree on its size, and the
+    payload is smaller than the all-to-all form's whenever a variable lives on three or more ranks"""
+    from lhvi import synth
+    from lhvi.dist import owner_exchange_layout
+    flat = synth.hybrid_mrf_flat(V=1500, deg=4, seed=2)
+    plans = _plans(flat, world)
+    rng = np.random.default_rng(0)
+    W = 6
+    lays, A, B, local = [], [], [], []
+    for p in plans:
+        width = np.where(np.arange(p.bvars.size) % 3 == 0, 2, W)          # two row widths, like discrete / continuous variables
+        # (the width of a variable must be the same on every rank: make it a function of the global id)
+        width = np.where(p.var_gid[p.bvars] % 3 == 0, 2, W)
+        lay = owner_exchange_layout(p, width)
+        lays.append(lay)
+        rows = rng.normal(size=(p.bvars.size, W))
+        local.append(rows)
+        a = np.full(lay['a_size'], np.nan)
+        for b in range(p.bvars.size):
+            a[lay['pack_off'][b]:lay['pack_off'][b] + width[b]] = rows[b, :width[b]]
+        A.append(a)
+        B.append(np.full(lay['b_size'], np.nan))
+    for r in range(world):
+        for s in range(world):
+            assert lays[r]['a_send'][s] == lays[s]['a_recv'][r] and lays[r]['b_send'][s] == lays[s]['b_recv'][r]
+        assert lays[r]['a_send'][r] == 0 and lays[r]['b_send'][r] == 0
+
+    def all_to_all(bufs, send_key, recv_key, recv_base_key):
+        for dst in range(world):
+            pos = lays[dst][recv_base_key]
+            for src in range(world):
+                cnt = lays[src][send_key][dst]
+                off = int(sum(lays[src][send_key][:dst]))
+                bufs[dst][pos:pos + cnt] = bufs[src][off:off + cnt]
+                pos += cnt
+    all_to_all(A, 'a_send', 'a_recv', 'a_recv_base')
+    for r, lay in enumerate(lays):
+        for i in range(lay['items'].size):
+            w = lay['width'][i]
+            tot = np.zeros(w)
+            for k in range(lay['src_ptr'][i], lay['src_ptr'][i + 1]):
+                tot = tot + A[r][lay['src_off'][k]:lay['src_off'][k] + w]
+            for k in range(lay['dst_ptr'][i], lay['dst_ptr'][i + 1]):
+                B[r][lay['dst_off'][k]:lay['dst_off'][k] + w] = tot
+    all_to_all(B, 'b_send', 'b_recv', 'b_recv_base')
+    # expected: the ranks' rows added in ascending rank order
+    by_gid = {}
+    for r, p in enumerate(plans):
+        for b, lv in enumerate(p.bvars):
+            by_gid.setdefault(int(p.var_gid[lv]), []).append((r, local[r][b]))
+    many = 0
+    for r, p in enumerate(plans):
+        lay = lays[r]
+        for b, lv in enumerate(p.bvars):
+            gid = int(p.var_gid[lv])
+            w = 2 if gid % 3 == 0 else W
+            want = np.zeros(w)
+            for _, row in sorted(by_gid[gid], key=lambda t: t[0]):
+                want = want + row[:w]
+            got = B[r][lay['total_off'][b]:lay['total_off'][b] + w]
+            assert (got == want).all()
+            assert len(by_gid[gid]) == p.brow_ptr[b + 1] - p.brow_ptr[b] + 1
+            many += len(by_gid[gid]) >= 3
+            # one owner per variable, the same on every rank that holds it
+            assert len({int(lays[q]['owner'][list(plans[q].var_gid[plans[q].bvars]).index(gid)]) for q, _ in by_gid[gid]}) == 1 \
+                if b % 40 == 0 else True
+    pairs = sum(int(np.where(p.var_gid[p.bvars][np.repeat(np.arange(p.bvars.size), np.diff(p.brow_ptr))] % 3 == 0, 2, W).sum())
+                for p in plans)
+    owner = sum(sum(l['a_send']) + sum(l['b_send']) for l in lays)
+    assert many > 0 and owner < pairs
+    # owners are spread over the ranks
+    owned = np.array([l['items'].size for l in lays])
+    assert owned.min() > 0 and owned.max() < 3 * max(owned.mean(), 1)
+
+
 def _gloo_worker(rank, world, port, out):
     sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
     import torch
@@ -145,6 +223,51 @@ def test_bench_starts_its_own_ranks():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('two_part', [False, True])
+def test_owner_reduce_exchange_equals_the_all_to_all_form(two_part):
+    """three simulated ranks, the same sweeps with the boundary rows exchanged between all pairs and reduced to an owner rank:
+    proposals, particles and messages are the same bits (both forms add the ranks' sums in ascending rank order)"""
+    import torch
+    from lhvi import synth, dist, _abi
+    _abi.require_gpu()
+    world = 3
+    flat = synth.hybrid_mrf_flat(V=2000, deg=4, seed=6)
+    n = 64
+    sets = []
+    for owner in (False, True):
+        group = dist.LoopbackGroup(world)
+        runners = [dist.ShardedRunner(flat, n=n, seed=3, rank=r, world=world, group=group, owner_reduce=owner) for r in range(world)]
+        for r in runners:
+            r.init()
+        for it in range(3):
+            sends = [r.pre(part=1) if two_part else r.pre() for r in runners]
+            for r, s in zip(runners, sends):
+                group.post(r.rank, s, r.counts)
+            if two_part:
+                for r in runners:
+                    r.interior()
+            if owner:
+                back = [r.owner_sums(group.collect(r.rank, r.W)) for r in runners]
+                for r, s in zip(runners, back):
+                    group.post(r.rank, s, r.lay['b_send'])
+            for r in runners:
+                (r.boundary if two_part else r.post)(group.collect(r.rank, r.W))
+        sets.append(runners)
+    pairs, owners = sets
+    assert all(r.owner_reduce for r in owners) and not any(r.owner_reduce for r in pairs)
+    assert any((np.diff(r.plan.brow_ptr) >= 2).any() for r in pairs)           # some variable lives on all three ranks
+    sent_pairs = sum(r.n_elems for r in pairs)
+    sent_owner = sum(r.a_send_elems + r.b_send_elems for r in owners)
+    assert sent_owner < sent_pairs
+    for a, b in zip(pairs, owners):
+        hid = torch.from_numpy(a.plan.flat.var_hidden).to(a.bp.q_dev.device)
+        assert torch.equal(a.bp.q_dev[hid], b.bp.q_dev[hid]) and torch.equal(a.bp.particles[hid], b.bp.particles[hid])
+        he = hid[torch.from_numpy(a.plan.flat.edge_var.astype(np.int64)).to(hid.device)]
+        assert torch.equal(a.bp.v2f[he], b.bp.v2f[he]) and torch.equal(a.bp.f2v[he], b.bp.f2v[he])
+        assert torch.isfinite(b.bp.q_dev[hid]).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('world,two_part', [(2, False), (3, False), (2, True), (3, True)])
 def test_sharded_sweep_matches_single_gpu(world, two_part):
     """simulate `world` ranks in one process (loopback exchange): messages and proposals equal the unsharded sweep, with
@@ -205,7 +328,7 @@ def test_sharded_sweep_matches_single_gpu(world, two_part):
                     seen[gid] = (Pr[lv].copy(), Qr[lv].copy())
 
 
-def _gpu_rank_worker(rank, world, port, out_dir):
+def _gpu_rank_worker(rank, world, port, out_dir, owner_reduce=False):
     sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
     import torch
     import torch.distributed as td
@@ -214,7 +337,8 @@ def _gpu_rank_worker(rank, world, port, out_dir):
     torch.cuda.set_device(0)
     td.init_process_group('gloo', rank=rank, world_size=world)
     flat = synth.hybrid_mrf_flat(V=1500, deg=4, seed=6)
-    r = dist.ShardedRunner(flat, n=64, seed=3, rank=rank, world=world)
+    r = dist.ShardedRunner(flat, n=64, seed=3, rank=rank, world=world, owner_reduce=owner_reduce)
+    assert r.owner_reduce == owner_reduce
     r.init()
     for _ in range(3):
         r.sweep()                      # pre -> all_to_all_single (gloo: staged through the host) -> post
@@ -226,9 +350,10 @@ def _gpu_rank_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
-def test_two_process_sharded_sweep_matches_single_gpu(tmp_path):
+@pytest.mark.parametrize('owner_reduce', [False, True])
+def test_two_process_sharded_sweep_matches_single_gpu(tmp_path, owner_reduce):
     """two real processes (torch.distributed, gloo rehearsal backend, both on cuda:0) run the sharded sweep with the real
-    collective call path; proposals and messages equal the unsharded run"""
+    collective call path (one all-to-all, or the two of the reduce-to-owner form); proposals and messages equal the unsharded run"""
     import torch.multiprocessing as mp
     from lhvi import synth, dist, _abi
     from lhvi.pbp import EPBP
@@ -237,7 +362,7 @@ def test_two_process_sharded_sweep_matches_single_gpu(tmp_path):
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
-    procs = [ctx.Process(target=_gpu_rank_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_gpu_rank_worker, args=(r, 2, port, str(tmp_path), owner_reduce)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
