@@ -590,6 +590,37 @@ __device__ __forceinline__ double fast_accumulate_uniform(const AB* __restrict__
     return (acc0 + acc1) * sft.scale;
 }
 
+// The MODE_CONST loop on records pre-divided by the table step (a_j / step, b_j / step): exp_accumulate_floor, one fp64 operation
+// less per term (fastmath.hpp).  The fp64 rounding mode is round-down between the two mode writes.
+template <int UNROLL = 4>
+__device__ __forceinline__ double fast_accumulate_floor(const AB* __restrict__ sh, const double* __restrict__ tab, int jn_, double X1,
+                                                        double C) {
+    const int jn = __builtin_amdgcn_readfirstlane(jn_);
+    const ExpShiftFloor sft = exp_shift_floor(C);
+    double acc0 = 0.0, acc1 = 0.0;
+    int j = 0;
+    round_down_on();
+    if (UNROLL == 4) {
+        double acc2 = 0.0, acc3 = 0.0;
+        for (; j + 4 <= jn; j += 4) {
+            const AB r0 = sh[j], r1 = sh[j + 1], r2 = sh[j + 2], r3 = sh[j + 3];
+            acc0 = exp_accumulate_floor(acc0, fma(r0.b, X1, r0.a), sft.magic, tab);
+            acc1 = exp_accumulate_floor(acc1, fma(r1.b, X1, r1.a), sft.magic, tab);
+            acc2 = exp_accumulate_floor(acc2, fma(r2.b, X1, r2.a), sft.magic, tab);
+            acc3 = exp_accumulate_floor(acc3, fma(r3.b, X1, r3.a), sft.magic, tab);
+        }
+        acc0 += acc2; acc1 += acc3;
+    }
+    for (; j + 2 <= jn; j += 2) {
+        const AB r0 = sh[j], r1 = sh[j + 1];
+        acc0 = exp_accumulate_floor(acc0, fma(r0.b, X1, r0.a), sft.magic, tab);
+        acc1 = exp_accumulate_floor(acc1, fma(r1.b, X1, r1.a), sft.magic, tab);
+    }
+    if (j < jn) { const AB r0 = sh[j]; acc0 = exp_accumulate_floor(acc0, fma(r0.b, X1, r0.a), sft.magic, tab); }
+    round_down_off();
+    return (acc0 + acc1) * sft.scale;
+}
+
 // FAST edges: persistent kernel, one wavefront per edge at a time (each wave strides over the work list).
 // Partner coefficients are staged in wave-private LDS in tiles of 64; each lane owns one output point per round and
 // accumulates sum_j exp(.).  A final partial round splits the partner range over idle lanes and folds the partial
@@ -775,6 +806,9 @@ struct HeavyData { double y, m, x0, x1; };
 #ifndef LHVI_HEAVY_UNROLL
 #define LHVI_HEAVY_UNROLL 4
 #endif
+#ifndef LHVI_HEAVY_FLOOR
+#define LHVI_HEAVY_FLOOR 1          // term loops in the floor form (exp_accumulate_floor); 0: the round-to-nearest form
+#endif
 constexpr int HEAVY_BLOCK = LHVI_HEAVY_BLOCK;
 
 // ---- integral points on a uniform grid: sum_j exp(a_j + b_j x_t) for t < 32 with lane = partner particle j ------------
@@ -904,7 +938,13 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
                 mine.a = (d.ay * y + d.by) * y + d.c + h.m;
                 mine.b = d.axy * y + d.bx;
             }
+#if LHVI_HEAVY_FLOOR
+            AB scaled;                                     // the term loops read the records in units of the table step
+            scaled.a = mine.a * LHVI_EXP_INV_STEP; scaled.b = mine.b * LHVI_EXP_INV_STEP;
+            sh[lane] = scaled;
+#else
             sh[lane] = mine;
+#endif
         }
         LHVI_WAVE_SYNC();
         if (grid_path) {
@@ -937,7 +977,11 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
                 const bool valid = pl < rem;
                 const double X1 = valid ? g.dom_val[d.gb + t0 + pl] : 0.0, C = kconst * X1 * X1;
                 const int chunk = (s.flags & LHVI_PBP_SKIP_TERMS) ? 0 : (nj + split - 1) >> (6 - lw);
+#if LHVI_HEAVY_FLOOR
+                double acc = fast_accumulate_floor<LHVI_HEAVY_UNROLL>(sh + sub * chunk, sh_tab, chunk, X1, C);
+#else
                 double acc = fast_accumulate_uniform<MODE_CONST, LHVI_HEAVY_UNROLL>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
+#endif
                 for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
                 if (valid && sub == 0) out[n + t0 + pl] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
             }
@@ -953,7 +997,11 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
             const double xv = r == 0 ? x0 : x1;
             const double X1 = valid ? xv : 0.0, C = kconst * X1 * X1;
             const int chunk = (s.flags & LHVI_PBP_SKIP_TERMS) ? 0 : (nj + split - 1) >> (6 - lw);   // flag 16: tuning aid, skips the term loop
+#if LHVI_HEAVY_FLOOR
+            double acc = fast_accumulate_floor<LHVI_HEAVY_UNROLL>(sh + sub * chunk, sh_tab, chunk, X1, C);
+#else
             double acc = fast_accumulate_uniform<MODE_CONST, LHVI_HEAVY_UNROLL>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
+#endif
             for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
             if (valid && sub == 0) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
         }
