@@ -75,12 +75,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
 __global__ void consistency_kernel(const double* __restrict__ s, int n, int* __restrict__ bad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double MAGIC = 6755399441055744.0;
+    const double MAGIC = 844424930131968.0;             // 1.5 * 2^49: ulp 1/8, floor(s) from bit 3 of the low word up
     round_down_on();
     double u;
     asm volatile("v_add_f64 %0, %1, %2" : "=v"(u) : "v"(s[i]), "v"(MAGIC));
     round_down_off();
-    const int nn = __double2loint(u);
+    const int nn = __double2loint(u) >> 3;
     const double f = __builtin_amdgcn_fract(s[i]);
     const double fl = floor(s[i]);
     if ((double)nn != fl || !(f >= 0.0 && f < 1.0) || fabs((fl + f) - s[i]) > 1e-9 * fabs(s[i]) + 1e-300) atomicAdd(bad, 1);
