@@ -322,6 +322,9 @@ int lhvi_pbp_refine_grid(const lhvi_graph_t* g, const lhvi_pbp_t* s, const doubl
 int lhvi_debug_exp(const double* x, double* y, int64_t n, void* stream);
 /* test hook: y[i] = exp(x[i] + c[i]) through the accumulating form the f2v term loop uses (c = the per-point constant) */
 int lhvi_debug_exp_acc(const double* x, const double* c, double* y, int64_t n, void* stream);
+/* the same value through the floor form of the term loop (heavy and cq kernels: records pre-divided by the table step, floor by a
+ * round-down addition, csrc/fastmath.hpp::exp_accumulate_floor) */
+int lhvi_debug_exp_acc_floor(const double* x, const double* c, double* y, int64_t n, void* stream);
 /* test hook: y[i] = log(x[i]), x > 0; which = 0 the table-driven log of the f2v epilogue, 1 the series log */
 int lhvi_debug_log(const double* x, double* y, int64_t n, int32_t which, void* stream);
 

@@ -1193,7 +1193,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_pair_kernel(lhvi_graph_t g, lhv
 //   type 2 (JOINT)  discrete target with S states, two hidden continuous partners x (lane = particle i) and y (staged):
 //                   exp(message)[s] = sum_i sum_j exp(a_sj + b_sj x_i + (k_s x_i^2 + m_x[i])) -- the heavy kernel's particle round
 //                   with the lane's own message folded into its per-point constant, then a wave reduction over i
-// Same term loop as the heavy kernel (fast_accumulate_uniform: 9 fp64 + 3 int32 VALU instructions per term).
+// Same term loop as the heavy kernel (fast_accumulate_floor: 8 fp64 + 2 int32 VALU instructions per term).
 struct CqDesc {
     int32_t e, tv, type, S;          // edge, target variable, 1 = MIX / 2 = JOINT, coefficient sets
     int32_t np, T, gb, yv;           // target particles (JOINT: = S states), grid points, grid base; staged partner's variable
@@ -1238,7 +1238,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_describe_cq_kernel(lhvi_graph_t g, 
     out[i] = d;
 }
 
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) pbp_f2v_cq_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) pbp_f2v_cq_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
                                                           double* __restrict__ f2v, const CqDesc* __restrict__ descs,
                                                           int nitems) {
     __shared__ AB sh_all[BLOCK / WAVE][WAVE];
@@ -1299,7 +1299,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
                 mine.a = -800.0; mine.b = 0.0;             // padding: exp(-800) underflows to exactly 0
                 if (lane < ny) { mine.a = (ay * y + by) * y + c + my + ms; mine.b = axy * y + bx; }
                 LHVI_WAVE_SYNC();
-                sh[lane] = mine;
+                {
+                    AB scaled;                             // the term loops read the records in units of the table step
+                    scaled.a = mine.a * LHVI_EXP_INV_STEP; scaled.b = mine.b * LHVI_EXP_INV_STEP;
+                    sh[lane] = scaled;
+                }
                 LHVI_WAVE_SYNC();
                 if (grid_path) {
                     double gv = exp_core(fma(mine.b, gx0, mine.a), sh_tab);
@@ -1321,7 +1325,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
                         const int width = 1 << lw, split = 64 >> lw, sub = lane >> lw, pl = lane & (width - 1);
                         const double X1 = pl < rem ? xr[r] : 0.0, C = kx * X1 * X1;
                         const int chunk = (ny + split - 1) >> (6 - lw);
-                        double acc = fast_accumulate_uniform<MODE_CONST, 4>(sh + sub * chunk, nullptr, sh_tab, chunk, X1, 0.0, C);
+                        double acc = fast_accumulate_floor<4>(sh + sub * chunk, sh_tab, chunk, X1, C);
                         for (int off = width; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
                         tot[r] += acc;
                     }
@@ -1354,10 +1358,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
                 AB mine;
                 mine.a = -800.0; mine.b = 0.0;
                 if (lane < ny) { mine.a = (ay * y + by) * y + c + my; mine.b = axy * y + bx; }
+                mine.a *= LHVI_EXP_INV_STEP; mine.b *= LHVI_EXP_INV_STEP;      // (records in units of the table step)
                 LHVI_WAVE_SYNC();
                 sh[lane] = mine;
                 LHVI_WAVE_SYNC();
-                double acc = fast_accumulate_uniform<MODE_CONST, 4>(sh, nullptr, sh_tab, ny, x, 0.0, fma(kx * x, x, mx));
+                double acc = fast_accumulate_floor<4>(sh, sh_tab, ny, x, fma(kx * x, x, mx));
                 acc = wave_sum(lane < nx ? acc : 0.0);
                 if (lane == st) res = acc;
             }
@@ -1392,6 +1397,22 @@ __global__ void __launch_bounds__(BLOCK) debug_exp_acc_kernel(const double* __re
     if (i < n) {
         const ExpShift sft = exp_shift(c[i]);
         y[i] = exp_accumulate(0.0, x[i], sft.magic, sh_tab) * sft.scale;
+    }
+}
+
+// test hook: the same through the floor form (s = x / step formed here, as the staging code does for a record)
+__global__ void __launch_bounds__(BLOCK) debug_exp_acc_floor_kernel(const double* __restrict__ x, const double* __restrict__ c,
+                                                                   double* __restrict__ y, int64_t n) {
+    __shared__ double sh_tab[EXP_TAB_N];
+    load_exp_table(sh_tab);
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) {
+        const ExpShiftFloor sft = exp_shift_floor(c[i]);
+        const double sv = x[i] * LHVI_EXP_INV_STEP;
+        round_down_on();
+        const double acc = exp_accumulate_floor(0.0, sv, sft.magic, sh_tab);
+        round_down_off();
+        y[i] = acc * sft.scale;
     }
 }
 
@@ -1983,6 +2004,13 @@ int lhvi_debug_log(const double* x, double* y, int64_t n, int32_t which, void* s
     if (!x || !y || n < 0 || which < 0 || which > 1) return LHVI_E_ARG;
     if (n == 0) return LHVI_OK;
     hipLaunchKernelGGL(debug_log_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, as_stream(stream), x, y, n, which);
+    return check_launch();
+}
+
+int lhvi_debug_exp_acc_floor(const double* x, const double* c, double* y, int64_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!x || !c || !y))) return LHVI_E_ARG;
+    if (n == 0) return LHVI_OK;
+    hipLaunchKernelGGL(debug_exp_acc_floor_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, as_stream(stream), x, c, y, n);
     return check_launch();
 }
 

@@ -128,6 +128,7 @@ SIGNATURES = {
     'lhvi_debug_exp': (C.c_int, [_vp, _vp, _i64, _vp]),
     'lhvi_debug_log': (C.c_int, [_vp, _vp, _i64, C.c_int32, _vp]),
     'lhvi_debug_exp_acc': (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    'lhvi_debug_exp_acc_floor': (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     'lhvi_pbp_v2f': (C.c_int, [_G, _S, _vp, _vp, _vp]),
     'lhvi_pbp_f2v': (C.c_int, [_G, _P, _S, _vp, _vp, _vp]),
     'lhvi_pbp_proposal': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp]),

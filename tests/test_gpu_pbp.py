@@ -395,6 +395,35 @@ def test_device_exp_accumulate_accuracy(api):
     assert (y[t + c < -760] == 0).all()
 
 
+def test_device_exp_accumulate_floor_form_accuracy(api):
+    """the heavy / cq kernels' term: s = t / step, floor(s) from an addition under round-down, v_fract as the polynomial
+    argument.  Relative error <= 1.2e-15 + 2.7e-16 |t| (the scaling by 1 / step rounds t once more than the round-to-nearest form
+    does), exact zero far below the double range, and no value off by a table step -- which is what an inconsistent floor / fract
+    pair would produce (3.4e-4 relative)"""
+    import torch
+    rng = np.random.default_rng(3)
+    step = np.log(2.0) / 2048
+    near = (rng.integers(-200000, 20000, 100000) + rng.choice([0.0, 1e-12, -1e-12, 0.5, 0.25, -0.5], 100000)) * step      # s next to integers / ties
+    t = np.concatenate([rng.uniform(-700, 50, 200000), rng.uniform(-20, 20, 200000), near, np.array([-800.0, -1e4, 0.0])])
+    c = np.concatenate([rng.uniform(-600, 30, 200000), rng.uniform(-20, 20, 200000), rng.uniform(-5, 5, 100000), np.array([0.0, 0.0, 0.0])])
+    keep = (t + c < 700)
+    t, c = t[keep], c[keep]
+    td, cd = api.to_dev(t), api.to_dev(c)
+    yd = torch.empty_like(td)
+    api.check(api.lib().lhvi_debug_exp_acc_floor(api.ptr(td), api.ptr(cd), api.ptr(yd), t.size, api.stream_ptr()))
+    y = yd.cpu().numpy()
+    want = np.exp(np.longdouble(t) + np.longdouble(c)).astype(np.float64)
+    fin = want > 1e-290
+    rel = np.abs(y[fin] - want[fin]) / want[fin]
+    bound = 1.2e-15 + 2.7e-16 * np.abs(t[fin])
+    assert (rel <= bound).all(), (rel / bound).max()
+    assert (y[t + c < -780] == 0).all()
+    # and the rounding mode is back to nearest afterwards: the round-to-nearest form still meets its own bound
+    api.check(api.lib().lhvi_debug_exp_acc(api.ptr(td), api.ptr(cd), api.ptr(yd), t.size, api.stream_ptr()))
+    rel = np.abs(yd.cpu().numpy()[fin] - want[fin]) / want[fin]
+    assert (rel <= 6e-16 + 3.8e-17 * np.abs(t[fin])).all()
+
+
 @pytest.mark.parametrize('name', C2F_CASES)
 def test_hlbp_coarse_to_fine_matches_reference(api, golden_dir, name):
     """c2f=0: coarse start, per-sweep refinement with message inheritance; partitions and proposals at every draw and the
