@@ -36,7 +36,9 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
 FP64_PEAK_TFLOPS = 78.6        # fp64 vector peak
 HBM_TARGET_FRAC = 0.40         # BASELINE.json: ">= 40 % of per-GPU HBM-read roofline"
-FLOP_PER_TERM = 16.0           # algorithmic: 7 fma + 1 add + 1 ldexp per (output point, partner particle) term
+FLOP_PER_TERM = 16.0           # algorithmic (SURVEY 8(d)): 7 fma + 1 add + 1 ldexp per (output point, partner particle) term
+# executed at the particles since the floor form of the term loop (round 3): 5 fma + 1 add + 1 fract + 1 ldexp
+FLOP_PER_PARTICLE_TERM = 13.0
 # executed cost of a term at the integral points when the heavy kernel tabulates them along the uniform grid: one
 # multiplication, 1.25 additions of the lane reduce-scatter (10 per lane and batch of 8 points) and the lane's two table
 # exponentials (2 x 16 flop) spread over its T = 32 points
@@ -239,8 +241,8 @@ def main():
         f2v_gbs = f2v_bytes / (f2v_ms * 1e-3) / 1e9
         hidden_frac = runner.work_fraction()
         # fp64 work.  Algorithmic: 16 flop per (output point, partner particle) term (SURVEY 8(d) / DESIGN 4.7).  Executed:
-        # the terms at the particles cost exactly that; the terms at the integral points of edges the kernel serves by the
-        # grid recurrence cost FLOP_PER_GRID_TERM (the rest of them take the direct form, 16)
+        # the terms at the particles cost FLOP_PER_PARTICLE_TERM; the terms at the integral points of edges the kernel serves by
+        # the grid recurrence cost FLOP_PER_GRID_TERM (the rest of them take the direct form, like the particles)
         grid_terms = runner.heavy_grid_terms()
         # ... as counted by the kernel itself: words 8 / 9 of the ticket buffer hold the edges of the last launch that went through
         # the recurrence / failed its range guard (the guard is data dependent)
@@ -252,7 +254,7 @@ def main():
             if grid_edges + fallback_edges > 0:
                 grid_terms = int(round(grid_terms * grid_edges / float(grid_edges + fallback_edges)))
         f2v_tflops = terms * FLOP_PER_TERM / (f2v_ms * 1e-3) / 1e12
-        exec_tflops = ((terms - grid_terms) * FLOP_PER_TERM + grid_terms * FLOP_PER_GRID_TERM) / (f2v_ms * 1e-3) / 1e12
+        exec_tflops = ((terms - grid_terms) * FLOP_PER_PARTICLE_TERM + grid_terms * FLOP_PER_GRID_TERM) / (f2v_ms * 1e-3) / 1e12
         sweep_gbs = bytes_e['sweep'] * E_local / (ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic('pbp_f2v_heavy_kernel') if world == 1 and args.edges == 10_000_000 else (None, None)
         out = {
@@ -273,13 +275,16 @@ def main():
                          'executed': {'achieved': exec_tflops, 'frac': exec_tflops / FP64_PEAK_TFLOPS,
                                       'grid_terms_per_launch': grid_terms, 'flop_per_grid_term': FLOP_PER_GRID_TERM,
                                       'grid_edges_counted_by_the_kernel': grid_edges, 'guard_fallback_edges': fallback_edges,
-                                      'note': 'flops the kernel really issues: 16 per term at the particles, %.2f per term at '
-                                              'the integral points tabulated by the grid recurrence' % FLOP_PER_GRID_TERM},
+                                      'flop_per_particle_term': FLOP_PER_PARTICLE_TERM,
+                                      'note': 'flops the kernel really issues: %d per term at the particles (5 fma, add, fract, '
+                                              'ldexp), %.2f per term at the integral points tabulated by the grid recurrence'
+                                              % (FLOP_PER_PARTICLE_TERM, FLOP_PER_GRID_TERM)},
                          'traffic': traffic, 'traffic_source': ('from_committed_profile: ' + traffic_src) if traffic_src else None,
                          'kernel_ms': f2v_ms, 'edges_per_launch': heavy_edges, 'joint_terms_per_launch': terms,
                          'note': 'achieved = algorithmic count, 16 flop per (output point, partner particle) term, over the HIP-event '
-                                 'time of the launch.  Terms at the particles cost 9 fp64 + 3 int32 issue slots + 2 LDS reads each '
-                                 '(issue ceiling 58 % of this peak); terms at the integral points are tabulated along the uniform '
+                                 'time of the launch.  Terms at the particles cost 8 fp64 + 2 int32 issue slots (36 cycles per '
+                                 'wave-term) + 2 LDS reads (36.8 LDS-pipe cycles per four wave-terms of a CU) each: both ceilings sit at '
+                                 '~0.88 of this peak in algorithmic flops; terms at the integral points are tabulated along the uniform '
                                  'grid by one multiplication each plus a lane reduce-scatter (DESIGN.md sections 4.3, 5)',
                          'hbm': {'achieved': f2v_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': f2v_gbs / HBM_PEAK_GBS,
                                  'algorithmic_bytes_per_launch': f2v_bytes},
