@@ -31,7 +31,7 @@ extern "C" {
                               * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t;  7: lhvi_pbp_t gained pair_desc;
                               * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq; the colour
                               *    refinement calls take a method and return four result words; lhvi_vi_t gained var_N; lhvi_vi_opt_t, lhvi_vi_adam_run;
-                              *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub, prop_hub / prop_partial; 16 ticket words; lhvi_pbp_boundary_reduce */
+                              *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub, prop_hub / prop_partial, resample_vars; 16 ticket words; lhvi_pbp_boundary_reduce */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -279,6 +279,13 @@ typedef struct lhvi_pbp {
     const int32_t* prop_hub;
     int32_t n_prop_hub;
     double* prop_partial;
+    /* optional, lhvi_pbp_resample_uniq only (n <= 64, not with a variable range): one record of eight 32-bit words per hidden
+     * CONTINUOUS variable -- 0 variable   1 its particle count np   2-3 dom_lo   4-5 dom_hi (doubles)   6-7 unused.  The call then
+     * draws for these only, two per wavefront, and touches no other row of particles_out / uniq_out -- the rows of discrete and
+     * observed variables never change, so the caller fills them once (one call without the list per particle buffer).  NULL:
+     * every variable of the range, neighbours two by two.  The draws do not depend on which form is used. */
+    const int32_t* resample_vars;
+    int32_t n_resample_vars;
 } lhvi_pbp_t;
 
 #define LHVI_PBP_DESC_BYTES 128
@@ -363,8 +370,9 @@ int lhvi_pbp_boundary_reduce(int32_t n_items, const int32_t* width, const int32_
                              const int32_t* dst_ptr, const int64_t* dst_off, const double* in, double* out, void* stream);
 /* initial_proposal: q=(0,5), sites (0, 5*deg): EPBP.py:72-81; HLBP.py:89-98 */
 int lhvi_pbp_init(const lhvi_graph_t* g, const lhvi_pbp_t* s, double* eta, double* q, double* f2v, double* v2f, void* stream);
-/* generate_sample with a counter-based device RNG keyed (seed, variable gid, iteration, j): EPBP.py:61-70.
- * var_gid may be NULL (gid = local index).  Parity runs inject host particles instead. */
+/* generate_sample with a counter-based device RNG: EPBP.py:61-70.  Philox4x32-10, key = seed, counter = (variable gid, block,
+ * iteration); a block yields two normals by Box-Muller, particle j takes block (j & 31) | (j >> 6 << 5) and the cosine (bit 5 of j
+ * clear) or the sine.  var_gid may be NULL (gid = local index).  Parity runs inject host particles instead. */
 int lhvi_pbp_resample(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int64_t* var_gid, uint64_t seed, uint32_t iteration, double* particles_out, void* stream);
 /* message_f_to_rv(x, f, rv, sample) for explicit (edge, point) pairs: qedge [nq] edge ids, x [nq][npts], out [nq][npts].
  * HybridLBP.belief_rv_query (HLBP.py:313-317) sums these over a ground variable's factors. */

@@ -1794,13 +1794,16 @@ __device__ __forceinline__ double cos_turns(double t) {
     return flip ? -p : p;
 }
 
-// standard normal draw for (variable gid, particle j, iteration): Box-Muller on two 53-bit uniforms of one Philox block.
+// Two standard normal draws from one Philox block (key = seed, counter = (variable gid, block, iteration)): Box-Muller on two
+// 53-bit uniforms gives r cos(2 pi u2) and r sin(2 pi u2).  Particle j of a variable takes block (j & 31) | (j >> 6 << 5) and the
+// cosine (bit 5 of j clear) or the sine (set): particles j and j + 32 share a block, so that a wavefront can draw for two variables
+// at once -- 32 blocks each -- whichever two they are (pbp_resample_uniq_kernel).
 // log / sqrt / cos are the short routines above (absolute error < 1e-15 on z): a sampler needs reproducibility -- every
 // rank runs this same code, so replicas of a boundary variable still draw identical particles -- not the last ulp.
 // `logtab` = LDS copy of the log table (load_log_table), or nullptr for the table-free series
-__device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t gid, uint32_t j, uint32_t iteration,
-                                                const LogRec* __restrict__ logtab) {
-    uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), j, iteration};
+__device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint64_t gid, uint32_t block, uint32_t iteration,
+                                                   const LogRec* __restrict__ logtab, double& zc, double& zs) {
+    uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), block, iteration};
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
@@ -1808,7 +1811,16 @@ __device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t gid, uin
     const double u1 = ((double)(r0 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
     const double u2 = ((double)(r1 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
     const double l = logtab ? log_table(u1, logtab) : log_pos(u1);
-    return sqrt_pos(-2.0 * l) * cos_turns(u2);
+    const double rad = sqrt_pos(-2.0 * l);
+    zc = rad * cos_turns(u2);
+    zs = rad * cos_turns(u2 - 0.25);                          // sin(2 pi t) = cos(2 pi (t - 1/4))
+}
+
+__device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t gid, uint32_t j, uint32_t iteration,
+                                                const LogRec* __restrict__ logtab) {
+    double zc, zs;
+    philox_normal_pair(seed, gid, (j & 31u) | ((j >> 6) << 5), iteration, logtab, zc, zs);
+    return (j & 32u) ? zs : zc;
 }
 
 // generate_sample (EPBP:61-70): clip(normal(q.mu, sqrt(q.var)), lo, hi); discrete rvs: the domain states
@@ -1863,75 +1875,137 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
     uint32_t* twice = bits + (1 << (UNIQ_HASH_BITS - 5));
     const int n = s.n;
     const int nwaves = gridDim.x * (BLOCK / WAVE);
-    // persistent waves (the table is loaded once per block, not once per four variables)
-    const int vend = var_limit(g, s);
-    for (int v = __builtin_amdgcn_readfirstlane(var_first(s) + blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)); v < vend; v += nwaves) {
-        const int cnt = s.np[v];
-        if (cnt == 0) {                                        // observed: no particles; the mask row is all zero
-            if (lane < n) uniq[(int64_t)v * n + lane] = 0;
-            continue;
+    // persistent waves (the table is loaded once per block), TWO variables per step: the Philox blocks and the Box-Muller radius are
+    // the expensive part of a draw and a block yields two normals, so lanes 0-31 run the 32 blocks of the first variable, lanes
+    // 32-63 those of the second, and one v_permlane32_swap per dword turns (cosines, sines) into the two variables' rows.
+    // The pairs are the caller's list of hidden continuous variables two by two (s.resample_vars: nothing else is touched),
+    // or neighbours of the variable range.
+    const bool listed = s.resample_vars != nullptr;
+    const int vfirst = var_first(s), vend = var_limit(g, s);
+    const int nvars = listed ? s.n_resample_vars : vend - vfirst;
+    const int nitems = (nvars + 1) >> 1;
+    constexpr int HALF_BITS = UNIQ_HASH_BITS - 1;           // each of the two rows of a step hashes into its own half of the bitsets
+    for (int item = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)); item < nitems; item += nwaves) {
+        int vv[2], cnt[2];
+        bool cont[2];
+        double lo[2] = {0.0, 0.0}, hi[2] = {0.0, 0.0}, mu[2] = {0.0, 0.0}, sd[2] = {0.0, 0.0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * item + h;
+            vv[h] = -1; cnt[h] = 0; cont[h] = false;
+            if (k < nvars) {
+                if (listed) {                                  // one 32-byte record instead of np -> var_dom -> dom_cont / dom_lo / dom_hi
+                    const int32_t* rec = s.resample_vars + 8 * (int64_t)k;
+                    vv[h] = rec[0]; cnt[h] = rec[1]; cont[h] = true;
+                    lo[h] = __hiloint2double(rec[3], rec[2]); hi[h] = __hiloint2double(rec[5], rec[4]);
+                } else {
+                    vv[h] = vfirst + k;
+                    cnt[h] = s.np[vv[h]];
+                    const int d = g.var_dom[vv[h]];
+                    cont[h] = cnt[h] > 0 && g.dom_cont[d];
+                    if (cont[h]) { lo[h] = g.dom_lo[d]; hi[h] = g.dom_hi[d]; }
+                }
+                if (cont[h]) { mu[h] = s.q[2 * vv[h]]; sd[h] = sqrt_pos(s.q[2 * vv[h] + 1]); }
+            }
         }
-        const int d = g.var_dom[v];
-        if (!g.dom_cont[d]) {                                  // discrete: the particles are the (distinct) states, no draw, no duplicates
-            if (lane < cnt) out[(int64_t)v * n + lane] = g.dom_val[g.dom_ptr[d] + lane];
-            if (lane < n) uniq[(int64_t)v * n + lane] = (uint8_t)(lane < cnt);
-            continue;
+        double row[2] = {0.0, 0.0};
+        if (cont[0] || cont[1]) {
+            // (a half whose own variable needs no draw repeats the other's blocks: the swap below then leaves that row intact)
+            const int mine = (lane >> 5) ? (cont[1] ? vv[1] : vv[0]) : (cont[0] ? vv[0] : vv[1]);
+            double zc, zs;
+#ifdef LHVI_DIAG_NO_PHILOX
+            zc = 1e-3 * lane + mine; zs = -zc;
+#else
+            philox_normal_pair(seed, gid ? (uint64_t)gid[mine] : (uint64_t)mine, (uint32_t)(lane & 31), iteration, sh_log, zc, zs);
+#endif
+            // v_permlane32_swap a, b: a's upper half <-> b's lower half: a = (cos | sin) of the first variable, b of the second
+            auto plo = __builtin_amdgcn_permlane32_swap(__double2loint(zc), __double2loint(zs), false, false);
+            auto phi = __builtin_amdgcn_permlane32_swap(__double2hiint(zc), __double2hiint(zs), false, false);
+            row[0] = __hiloint2double(phi[0], plo[0]);
+            row[1] = __hiloint2double(phi[1], plo[1]);
         }
-        double x = 0.0;
-        if (lane < cnt) {
-            if (!g.dom_cont[d]) x = g.dom_val[g.dom_ptr[d] + lane];
-            else {
-                const double z = philox_normal(seed, gid ? (uint64_t)gid[v] : (uint64_t)v, (uint32_t)lane, iteration, sh_log);
+        // the rows themselves
+        int xlo[2] = {0, 0}, xhi[2] = {0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int v = vv[h], cn = cnt[h];
+            if (v < 0) continue;
+            if (cn == 0) {                                         // observed: no particles; the mask row is all zero
+                if (lane < n) uniq[(int64_t)v * n + lane] = 0;
+            } else if (!cont[h]) {                                 // discrete: the particles are the (distinct) states, no draw, no duplicates
+                const int d = g.var_dom[v];
+                if (lane < cn) out[(int64_t)v * n + lane] = g.dom_val[g.dom_ptr[d] + lane];
+                if (lane < n) uniq[(int64_t)v * n + lane] = (uint8_t)(lane < cn);
+            } else if (lane < cn) {
                 // + 0.0: no -0, so that bitwise equality below is numeric equality
-                x = fmin(fmax(s.q[2 * v] + sqrt_pos(s.q[2 * v + 1]) * z, g.dom_lo[d]), g.dom_hi[d]) + 0.0;
-            }
-            out[(int64_t)v * n + lane] = x;
-        }
-        // first-occurrence mask.  Pass 1 only asks "can two live particles be equal at all?": every lane sets the bit its
-        // low word hashes to in a wave-private 16 Kbit LDS bitset with a returning atomic OR; equal particles always
-        // meet in the same bit, different ones do with probability 64^2 / 2 / 16384 = 12 % per variable (a false alarm
-        // costs the exact pass, nothing else).  The exact pass compares the 64-bit patterns particle by particle and
-        // in practice runs for the variables with draws clipped to a bound.  Each lane clears its own word afterwards.
-        const int xlo = __double2loint(x), xhi = __double2hiint(x);
-        const uint64_t live = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1);
-        // two independent hashes into the same bitset.  The first is decisive: of two equal particles the lane whose
-        // returning atomic OR executes second finds the bit set (whichever lane that is -- no ordering between lanes or
-        // between the two instructions is assumed).  The second only rejects false alarms, and order-independently: a
-        // lane that finds its second bit already set records it in the "twice" bitset, and after the wave has synchronised
-        // every lane asks whether its second bit was hit more than once -- for equal particles it always was.  Suspect =
-        // first bit found set AND second bit hit twice: different particles for 0.4 % of the variables (one hash: 12 %,
-        // and every false alarm costs the exact pass below)
-        const uint32_t hsh = ((uint32_t)xlo * 0x9E3779B1u) >> (32 - UNIQ_HASH_BITS);
-        const uint32_t hsh2 = (((uint32_t)xhi * 0x85EBCA6Bu) ^ ((uint32_t)xlo * 0xC2B2AE35u)) >> (32 - UNIQ_HASH_BITS);
-        uint32_t* word = bits + (hsh >> 5);
-        uint32_t* word2 = bits + (hsh2 >> 5);
-        uint32_t* tword2 = twice + (hsh2 >> 5);
-        const uint32_t bit = 1u << (hsh & 31), bit2 = 1u << (hsh2 & 31);
-        uint32_t old = 0;
-        if (lane < cnt) {
-            old = atomicOr(word, bit);
-            if (atomicOr(word2, bit2) & bit2) atomicOr(tword2, bit2);
-        }
-        LHVI_WAVE_SYNC();
-        uint64_t dup = __ballot(lane < cnt && (old & bit) && (*tword2 & bit2));
-        LHVI_WAVE_SYNC();
-        if (lane < cnt) { *word = 0; *word2 = 0; *tword2 = 0; }
-        LHVI_WAVE_SYNC();
-        if (dup) {
-            // every group of equal particles contains a suspect lane (the one whose atomics came later), so walking the
-            // suspects' values covers all groups: one step per distinct suspect value -- in practice the two domain bounds
-            uint64_t todo = dup & live;
-            dup = 0;
-            while (todo) {
-                const int k = __builtin_ctzll(todo);
-                const int klo = __builtin_amdgcn_readlane(xlo, k), khi = __builtin_amdgcn_readlane(xhi, k);
-                const uint64_t same = __ballot(xlo == klo && xhi == khi) & live;       // every lane holding this value
-                dup |= same & (same - 1);                                             // all but its first occurrence
-                todo &= ~same;
+                const double x = fmin(fmax(fma(sd[h], row[h], mu[h]), lo[h]), hi[h]) + 0.0;
+                out[(int64_t)v * n + lane] = x;
+                xlo[h] = __double2loint(x); xhi[h] = __double2hiint(x);
             }
         }
-        const int u = (lane < cnt) && !((dup >> lane) & 1);
-        if (lane < n) uniq[(int64_t)v * n + lane] = (uint8_t)u;
+#ifdef LHVI_DIAG_NO_UNIQ
+#pragma unroll
+        for (int h = 0; h < 2; ++h) if (cont[h] && lane < n) uniq[(int64_t)vv[h] * n + lane] = (uint8_t)(lane < cnt[h]);
+        continue;
+#endif
+        if (!(cont[0] || cont[1])) continue;
+        // first-occurrence masks of the (up to two) drawn rows, in step so that the LDS round trips are paid once.  Pass 1 only
+        // asks "can two live particles be equal at all?": every lane sets the bit its low word hashes to in a wave-private LDS
+        // bitset (8 Kbit per row) with a returning atomic OR; equal particles always meet in the same bit, different ones do with
+        // probability 64^2 / 2 / 8192 = 25 % per variable (a false alarm costs the exact pass, nothing else).  The exact pass
+        // compares the 64-bit patterns particle by particle and in practice runs for the variables with draws clipped to a bound.
+        // Each lane clears its own words afterwards.
+        // Two independent hashes into the same bitset.  The first is decisive: of two equal particles the lane whose returning
+        // atomic OR executes second finds the bit set (whichever lane that is -- no ordering between lanes or between the two
+        // instructions is assumed).  The second only rejects false alarms, and order-independently: a lane that finds its second
+        // bit already set records it in the "twice" bitset, and after the wave has synchronised every lane asks whether its
+        // second bit was hit more than once -- for equal particles it always was.  Suspect = first bit found set AND second bit
+        // hit twice: different particles for ~1.5 % of the variables (one hash: 25 %)
+        uint32_t *word[2], *word2[2], *tword2[2];
+        uint32_t bit[2], bit2[2], old[2] = {0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t hsh = (((uint32_t)xlo[h] * 0x9E3779B1u) >> (32 - HALF_BITS)) | ((uint32_t)h << HALF_BITS);
+            const uint32_t hsh2 = ((((uint32_t)xhi[h] * 0x85EBCA6Bu) ^ ((uint32_t)xlo[h] * 0xC2B2AE35u)) >> (32 - HALF_BITS)) | ((uint32_t)h << HALF_BITS);
+            word[h] = bits + (hsh >> 5); word2[h] = bits + (hsh2 >> 5); tword2[h] = twice + (hsh2 >> 5);
+            bit[h] = 1u << (hsh & 31); bit2[h] = 1u << (hsh2 & 31);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (cont[h] && lane < cnt[h]) {
+                old[h] = atomicOr(word[h], bit[h]);
+                if (atomicOr(word2[h], bit2[h]) & bit2[h]) atomicOr(tword2[h], bit2[h]);
+            }
+        LHVI_WAVE_SYNC();
+        uint64_t dup[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) dup[h] = __ballot(cont[h] && lane < cnt[h] && (old[h] & bit[h]) && (*tword2[h] & bit2[h]));
+        LHVI_WAVE_SYNC();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) if (cont[h] && lane < cnt[h]) { *word[h] = 0; *word2[h] = 0; *tword2[h] = 0; }
+        LHVI_WAVE_SYNC();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!cont[h]) continue;
+            const int cn = cnt[h];
+            const uint64_t live = cn >= 64 ? ~0ull : ((1ull << cn) - 1);
+            uint64_t dp = dup[h];
+            if (dp) {
+                // every group of equal particles contains a suspect lane (the one whose atomics came later), so walking the
+                // suspects' values covers all groups: one step per distinct suspect value -- in practice the two domain bounds
+                uint64_t todo = dp & live;
+                dp = 0;
+                while (todo) {
+                    const int k = __builtin_ctzll(todo);
+                    const int klo = __builtin_amdgcn_readlane(xlo[h], k), khi = __builtin_amdgcn_readlane(xhi[h], k);
+                    const uint64_t same = __ballot(xlo[h] == klo && xhi[h] == khi) & live;    // every lane holding this value
+                    dp |= same & (same - 1);                                                 // all but its first occurrence
+                    todo &= ~same;
+                }
+            }
+            const int u = (lane < cn) && !((dp >> lane) & 1);
+            if (lane < n) uniq[(int64_t)vv[h] * n + lane] = (uint8_t)u;
+        }
     }
 }
 
@@ -2212,7 +2286,10 @@ int lhvi_pbp_resample_uniq(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int
         if (int rc = lhvi_pbp_resample(g, s, var_gid, seed, iteration, particles_out, stream)) return rc;
         return lhvi_pbp_uniq(g, s->n, particles_out, s->np, uniq_out, stream);
     }
-    hipLaunchKernelGGL(pbp_resample_uniq_kernel, dim3(persistent_grid(var_limit(*g, *s) - var_first(*s), 8)), dim3(BLOCK), 0,
+    if (s->resample_vars && (s->n_resample_vars < 0 || s->var_hi > s->var_lo)) return LHVI_E_ARG;      // the list replaces the range
+    const int64_t nvars = s->resample_vars ? s->n_resample_vars : var_limit(*g, *s) - var_first(*s);
+    if (nvars == 0) return LHVI_OK;
+    hipLaunchKernelGGL(pbp_resample_uniq_kernel, dim3(persistent_grid((nvars + 1) / 2, 8)), dim3(BLOCK), 0,
                        as_stream(stream), *g, *s, var_gid, seed, iteration, particles_out, uniq_out);
     return check_launch();
 }

@@ -61,6 +61,7 @@ class PbpStruct(C.Structure):
         ('v2f_wide', C.c_void_p), ('n_v2f_wide', C.c_int32), ('v2f_narrow', C.c_void_p), ('n_v2f_narrow', C.c_int32),
         ('v2f_hub', C.c_void_p), ('n_v2f_hub', C.c_int32),
         ('prop_hub', C.c_void_p), ('n_prop_hub', C.c_int32), ('prop_partial', C.c_void_p),
+        ('resample_vars', C.c_void_p), ('n_resample_vars', C.c_int32),
     ]
 
 

@@ -34,6 +34,7 @@ class _ParticleSweep:
     dynamic_f2v = True              # the persistent f2v kernels claim their work in chunks (else static striding)
     paired_light = True             # the light edges are served per factor (pair_desc) instead of per edge (light_desc)
     cq_routing = True               # conditionally quadratic MLN formulas go to the quadratic-family kernels (else: generic kernel)
+    listed_resample = True          # the device sampler draws for the hidden continuous variables only, two per wavefront
     sliced_proposal = True          # rows of more than prop_slice incident edges are cut into slices, a wavefront per slice
     prop_slice = 64
     packed_v2f = True               # variables with at most four particles share a wavefront in the v -> f half (sixteen each)
@@ -110,6 +111,13 @@ class _ParticleSweep:
         for k in range(4):
             if flat.var_edge.size:
                 pd[:, 4 + k] = flat.var_edge[np.minimum(pbase + np.minimum(k, np.maximum(pdeg - 1, 0)), flat.var_edge.size - 1)]
+        # the device sampler's list (include/lhvi.h, lhvi_pbp_t.resample_vars); the other rows are filled once, by the first draw
+        rr = np.zeros((pv.size, 8), dtype=np.int32)
+        rr[:, 0], rr[:, 1] = pv, self.np_host[pv]
+        rr[:, 2:4] = np.ascontiguousarray(flat.dom_lo[pdom], dtype=np.float64).view(np.int32).reshape(-1, 2)
+        rr[:, 4:6] = np.ascontiguousarray(flat.dom_hi[pdom], dtype=np.float64).view(np.int32).reshape(-1, 2)
+        self.resample_vars = _abi.to_dev(rr) if pv.size else None
+        self._static_rows = False
         # rows longer than prop_slice entries go in as slices of that length, a wavefront each, ahead of the ordinary records
         self.prop_hub = self.prop_partial = None
         self.n_prop_hub = 0
@@ -296,8 +304,17 @@ class _ParticleSweep:
         if self.sampler == 'device':
             self.old_particles, self.particles = self.particles, self.old_particles
             s = self._struct()
-            _abi.check(l.lhvi_pbp_resample_uniq(self.dg.g, s, _abi.ptr(getattr(self, 'var_gid', None)), int(self.seed),
-                                                int(k), _abi.ptr(self.particles), _abi.ptr(self.uniq), st))
+            gid = _abi.ptr(getattr(self, 'var_gid', None))
+            if self.listed_resample and self.n <= 64 and getattr(self, 'resample_vars', None) is not None:
+                if not self._static_rows:
+                    # states of the discrete variables and the masks of the discrete / observed ones: once per buffer
+                    for buf in (self.old_particles, self.particles):
+                        _abi.check(l.lhvi_pbp_resample_uniq(self.dg.g, s, gid, int(self.seed), int(k), _abi.ptr(buf), _abi.ptr(self.uniq), st))
+                    self._static_rows = True
+                    self._views = {}
+                    return
+                s.resample_vars, s.n_resample_vars = _abi.ptr(self.resample_vars), int(self.resample_vars.shape[0])
+            _abi.check(l.lhvi_pbp_resample_uniq(self.dg.g, s, gid, int(self.seed), int(k), _abi.ptr(self.particles), _abi.ptr(self.uniq), st))
             self._views = {}
             return
         elif callable(self.sampler):

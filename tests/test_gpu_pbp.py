@@ -307,6 +307,47 @@ def test_device_sampler_statistics(api):
     assert (runs[0] == runs[1]).all()
 
 
+@pytest.mark.parametrize('n', [64, 40, 10])
+def test_device_sampler_draws_do_not_depend_on_the_pairing(api, n):
+    """the sampler draws for two variables per wavefront (one Philox block gives the cosine and the sine normal: particles j and
+    j + 32).  Which two variables share a wavefront -- the caller's list of hidden continuous variables two by two, or neighbours
+    of a variable range, or a range that starts one variable later -- must not change a single bit; rows of discrete and observed
+    variables are written once and then left alone by the listed form"""
+    import torch
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    flat = synth.hybrid_mrf_flat(V=3001, deg=4, seed=1)
+    bp = EPBP(None, n=n, proposal_approximation='simple', sampler='device', seed=9)
+    bp._setup(None, flat=flat)
+    _init(api, bp)                      # first draw: fills every row of both buffers
+    assert bp._static_rows and bp.resample_vars.shape[0] == int((flat.var_hidden & flat.var_cont).sum())
+    bp._generate_sample()               # second draw: the listed form
+    k = bp._draws - 1
+    l, st = api.lib(), api.stream_ptr()
+
+    def by_range(lo, hi):
+        s = bp._struct()
+        s.var_lo, s.var_hi = lo, hi
+        out, uq = torch.full_like(bp.particles, -77.0), torch.full_like(bp.uniq, 9)
+        api.check(l.lhvi_pbp_resample_uniq(bp.dg.g, s, None, int(bp.seed), int(k), api.ptr(out), api.ptr(uq), st))
+        return out, uq
+    whole, uw = by_range(0, 0)
+    live = torch.from_numpy(np.arange(n)[None, :] < bp.np_host[:, None]).to(whole.device)
+    assert torch.equal(torch.where(live, whole, 0.0), torch.where(live, bp.particles, 0.0)) and torch.equal(uw, bp.uniq)
+    shifted, us = by_range(1, flat.V)   # other neighbours share a wavefront now
+    assert torch.equal(torch.where(live, shifted, 0.0)[1:], torch.where(live, whole, 0.0)[1:]) and torch.equal(us[1:], uw[1:])
+    assert (shifted[0] == -77.0).all() and (us[0] == 9).all()           # outside the range: untouched
+    if n == 64:
+        cont = flat.var_hidden & flat.var_cont
+        x = bp.particles.cpu().numpy()[cont]
+        assert abs(x.mean()) < 0.02 and abs(x.var() - 5.0) < 0.1
+        a, b = x[:, :32].ravel(), x[:, 32:].ravel()                      # the two normals of a block are independent
+        assert abs(np.corrcoef(a, b)[0, 1]) < 0.01 and abs(np.corrcoef(a * a, b * b)[0, 1]) < 0.01
+        assert abs(a.var() - 5.0) < 0.1 and abs(b.var() - 5.0) < 0.1
+        z = x.ravel() / np.sqrt(5.0)
+        assert abs((z ** 4).mean() - 3.0) < 0.05                         # (clipping at 4.5 sigma removes ~1e-4 of it)
+
+
 @pytest.mark.parametrize('n', [64, 48])
 def test_device_sampler_first_occurrence_mask(api, n):
     """fused draw + mask against the stand-alone exact mask kernel: wide proposals on a narrow domain clip most draws to
