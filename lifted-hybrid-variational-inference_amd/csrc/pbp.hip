@@ -1862,6 +1862,8 @@ static int blocks_per_cu(const void* kernel, int block = BLOCK) {
 // the row never leaves registers and is broadcast lane by lane with v_readlane (exact equality test, like the dict keys)
 constexpr int UNIQ_HASH_BITS = 14;
 
+// LISTED: the caller's records (all hidden continuous: the paths for observed and discrete variables compile away)
+template <bool LISTED>
 __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g, lhvi_pbp_t s, const int64_t* __restrict__ gid,
                                                                  uint64_t seed, uint32_t iteration, double* __restrict__ out,
                                                                  uint8_t* __restrict__ uniq) {
@@ -1880,34 +1882,55 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
     // 32-63 those of the second, and one v_permlane32_swap per dword turns (cosines, sines) into the two variables' rows.
     // The pairs are the caller's list of hidden continuous variables two by two (s.resample_vars: nothing else is touched),
     // or neighbours of the variable range.
-    const bool listed = s.resample_vars != nullptr;
+    constexpr bool listed = LISTED;
     const int vfirst = var_first(s), vend = var_limit(g, s);
     const int nvars = listed ? s.n_resample_vars : vend - vfirst;
     const int nitems = (nvars + 1) >> 1;
     constexpr int HALF_BITS = UNIQ_HASH_BITS - 1;           // each of the two rows of a step hashes into its own half of the bitsets
-    for (int item = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)); item < nitems; item += nwaves) {
-        int vv[2], cnt[2];
-        bool cont[2];
-        double lo[2] = {0.0, 0.0}, hi[2] = {0.0, 0.0}, mu[2] = {0.0, 0.0}, sd[2] = {0.0, 0.0};
+    // what a step needs to know about its two variables, fetched one step ahead (scalar loads: one record each from the caller's
+    // list, or the chain np -> var_dom -> dom_cont / dom_lo / dom_hi) so that no step starts with a memory round trip
+    struct Pair { int vv[2], cnt[2]; bool cont[2]; double lo[2], hi[2], mu[2], var[2]; };
+    auto fetch = [&](int item) {
+        Pair p;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = 2 * item + h;
-            vv[h] = -1; cnt[h] = 0; cont[h] = false;
+            p.vv[h] = -1; p.cnt[h] = 0; p.cont[h] = false; p.lo[h] = 0.0; p.hi[h] = 0.0; p.mu[h] = 0.0; p.var[h] = 1.0;
             if (k < nvars) {
-                if (listed) {                                  // one 32-byte record instead of np -> var_dom -> dom_cont / dom_lo / dom_hi
+                if (listed) {
                     const int32_t* rec = s.resample_vars + 8 * (int64_t)k;
-                    vv[h] = rec[0]; cnt[h] = rec[1]; cont[h] = true;
-                    lo[h] = __hiloint2double(rec[3], rec[2]); hi[h] = __hiloint2double(rec[5], rec[4]);
+                    p.vv[h] = rec[0]; p.cnt[h] = rec[1]; p.cont[h] = true;
+                    p.lo[h] = __hiloint2double(rec[3], rec[2]); p.hi[h] = __hiloint2double(rec[5], rec[4]);
                 } else {
-                    vv[h] = vfirst + k;
-                    cnt[h] = s.np[vv[h]];
-                    const int d = g.var_dom[vv[h]];
-                    cont[h] = cnt[h] > 0 && g.dom_cont[d];
-                    if (cont[h]) { lo[h] = g.dom_lo[d]; hi[h] = g.dom_hi[d]; }
+                    p.vv[h] = vfirst + k;
+                    p.cnt[h] = s.np[p.vv[h]];
+                    const int d = g.var_dom[p.vv[h]];
+                    p.cont[h] = p.cnt[h] > 0 && g.dom_cont[d];
+                    if (p.cont[h]) { p.lo[h] = g.dom_lo[d]; p.hi[h] = g.dom_hi[d]; }
                 }
-                if (cont[h]) { mu[h] = s.q[2 * vv[h]]; sd[h] = sqrt_pos(s.q[2 * vv[h] + 1]); }
             }
         }
+        return p;
+    };
+    auto fetch_q = [&](Pair& p) {       // second level: the proposals (their addresses come out of the first)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) if (p.cont[h]) { p.mu[h] = s.q[2 * p.vv[h]]; p.var[h] = s.q[2 * p.vv[h] + 1]; }
+    };
+    int item = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+    if (item >= nitems) return;
+    Pair ahead = fetch(item);
+    fetch_q(ahead);
+    for (; item < nitems; item += nwaves) {
+        int vv[2], cnt[2];
+        bool cont[2];
+        double lo[2], hi[2], mu[2], sd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            vv[h] = ahead.vv[h]; cnt[h] = ahead.cnt[h]; cont[h] = ahead.cont[h]; lo[h] = ahead.lo[h]; hi[h] = ahead.hi[h];
+            mu[h] = ahead.mu[h]; sd[h] = sqrt_pos(ahead.var[h]);
+        }
+        const bool more = item + nwaves < nitems;
+        if (more) ahead = fetch(item + nwaves);
         double row[2] = {0.0, 0.0};
         if (cont[0] || cont[1]) {
             // (a half whose own variable needs no draw repeats the other's blocks: the swap below then leaves that row intact)
@@ -1924,15 +1947,16 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
             row[0] = __hiloint2double(phi[0], plo[0]);
             row[1] = __hiloint2double(phi[1], plo[1]);
         }
+        if (more) fetch_q(ahead);                              // (the records asked for at the top of the step have arrived by now)
         // the rows themselves
         int xlo[2] = {0, 0}, xhi[2] = {0, 0};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int v = vv[h], cn = cnt[h];
             if (v < 0) continue;
-            if (cn == 0) {                                         // observed: no particles; the mask row is all zero
+            if (!LISTED && cn == 0) {                              // observed: no particles; the mask row is all zero
                 if (lane < n) uniq[(int64_t)v * n + lane] = 0;
-            } else if (!cont[h]) {                                 // discrete: the particles are the (distinct) states, no draw, no duplicates
+            } else if (!LISTED && !cont[h]) {                      // discrete: the particles are the (distinct) states, no draw, no duplicates
                 const int d = g.var_dom[v];
                 if (lane < cn) out[(int64_t)v * n + lane] = g.dom_val[g.dom_ptr[d] + lane];
                 if (lane < n) uniq[(int64_t)v * n + lane] = (uint8_t)(lane < cn);
@@ -2289,8 +2313,12 @@ int lhvi_pbp_resample_uniq(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int
     if (s->resample_vars && (s->n_resample_vars < 0 || s->var_hi > s->var_lo)) return LHVI_E_ARG;      // the list replaces the range
     const int64_t nvars = s->resample_vars ? s->n_resample_vars : var_limit(*g, *s) - var_first(*s);
     if (nvars == 0) return LHVI_OK;
-    hipLaunchKernelGGL(pbp_resample_uniq_kernel, dim3(persistent_grid((nvars + 1) / 2, 8)), dim3(BLOCK), 0,
-                       as_stream(stream), *g, *s, var_gid, seed, iteration, particles_out, uniq_out);
+    if (s->resample_vars)
+        hipLaunchKernelGGL(pbp_resample_uniq_kernel<true>, dim3(persistent_grid((nvars + 1) / 2, 8)), dim3(BLOCK), 0,
+                           as_stream(stream), *g, *s, var_gid, seed, iteration, particles_out, uniq_out);
+    else
+        hipLaunchKernelGGL(pbp_resample_uniq_kernel<false>, dim3(persistent_grid((nvars + 1) / 2, 8)), dim3(BLOCK), 0,
+                           as_stream(stream), *g, *s, var_gid, seed, iteration, particles_out, uniq_out);
     return check_launch();
 }
 
