@@ -334,6 +334,17 @@ def test_device_sampler_draws_do_not_depend_on_the_pairing(api, n):
     whole, uw = by_range(0, 0)
     live = torch.from_numpy(np.arange(n)[None, :] < bp.np_host[:, None]).to(whole.device)
     assert torch.equal(torch.where(live, whole, 0.0), torch.where(live, bp.particles, 0.0)) and torch.equal(uw, bp.uniq)
+    # the list cut after an odd and after an even number of records: the last wavefront of the first works on one variable
+    for k in (bp.resample_vars.shape[0] - 1, bp.resample_vars.shape[0] - 2, 1):
+        s = bp._struct()
+        s.resample_vars, s.n_resample_vars = api.ptr(bp.resample_vars), int(k)
+        out, uq = torch.full_like(bp.particles, -77.0), torch.full_like(bp.uniq, 9)
+        api.check(l.lhvi_pbp_resample_uniq(bp.dg.g, s, None, int(bp.seed), int(bp._draws - 1), api.ptr(out), api.ptr(uq), st))
+        rows = bp.resample_vars[:k, 0].long()
+        rest = torch.ones(flat.V, dtype=torch.bool, device=out.device)
+        rest[rows] = False
+        assert torch.equal(torch.where(live, out, 0.0)[rows], torch.where(live, bp.particles, 0.0)[rows]) and torch.equal(uq[rows], bp.uniq[rows])
+        assert (out[rest] == -77.0).all() and (uq[rest] == 9).all()
     shifted, us = by_range(1, flat.V)   # other neighbours share a wavefront now
     assert torch.equal(torch.where(live, shifted, 0.0)[1:], torch.where(live, whole, 0.0)[1:]) and torch.equal(us[1:], uw[1:])
     assert (shifted[0] == -77.0).all() and (us[0] == 9).all()           # outside the range: untouched
@@ -898,15 +909,15 @@ def test_v2f_hub_kernel_matches_the_one_wave_path(api):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('rule', ['simple', 'EP'])
-@pytest.mark.parametrize('lifted', [False, True])
-def test_sliced_proposal_matches_the_one_wave_path(api, rule, lifted):
+@pytest.mark.parametrize('rule,lifted,points', [('simple', False, 32), ('EP', False, 32), ('simple', True, 32), ('EP', True, 32),
+                                               ('simple', False, 48), ('EP', True, 80)])
+def test_sliced_proposal_matches_the_one_wave_path(api, rule, lifted, points):
     """rows of more than 64 incident edges are handed to the proposal kernel in slices (lhvi_pbp_t.prop_hub): the sites are the
     same bit for bit, the proposals equal to the rounding of a differently ordered sum, and a repeat gives the same bits"""
     import torch
     from lhvi import synth
     from lhvi.pbp import EPBP
-    flat, keys = synth.paper_popularity_flat(150, 4, seed=2)
+    flat, keys = synth.paper_popularity_flat(150, 4, seed=2, points=points)      # (48 / 80 points: two / one edge per pass)
     if lifted:
         flat.edge_count = 1.0 + (np.arange(flat.E) % 3).astype(np.float64)
         flat.lifted = True
