@@ -208,7 +208,8 @@ typedef struct lhvi_pbp {
     int32_t generic_pts_log2;   /* ceil(log2(max output points of a generic edge)), clamped to [0, 6]: lanes per edge */
     const void* fast_desc;      /* [n_fast][LHVI_PBP_DESC_BYTES] from lhvi_pbp_describe, or NULL (built on the fly) */
     const void* heavy_desc;     /* [n_heavy][LHVI_PBP_DESC_BYTES] descriptors of the edges served by the specialised kernel:
-                                 * class 1, constant x^2 coefficient (kind != HYBRID_QUADRATIC), nj <= 64, np + T <= 128; disjoint from fast_edges */
+                                 * class 1, constant x^2 coefficient (kind != HYBRID_QUADRATIC), nj <= 64, and either np + T <= 128 or a uniform
+                                 * grid (word 15) of T <= 128 points with nj >= 24 and np <= 128; disjoint from fast_edges */
     int32_t n_heavy;
     const void* light_desc;     /* [n_light] descriptors with word 14 != 0: HybridQuadratic edges with a binary (or observed)
                                  * discrete side, served by their own kernel; disjoint from fast_edges and heavy_desc */

@@ -866,7 +866,8 @@ __device__ __forceinline__ double grid_sums32(double& g, double q, int lane) {
 }
 constexpr int GRID_MIN_NJ = 24;         // fewer partner particles: the direct loop is cheaper than 32 multiplications + 6 folds
 constexpr double GRID_MAX_EXPONENT = 600.0;
-__device__ __forceinline__ bool grid_eligible(int uniform_grid, int nj, int T) { return uniform_grid && nj >= GRID_MIN_NJ && T <= 64; }
+constexpr int GRID_MAX_T = 128;         // batches of 32 points; the recurrence carries ~t ulp (the reference's RGM domain has 100 points, Demo/Data/RGM/Generator.py:16)
+__device__ __forceinline__ bool grid_eligible(int uniform_grid, int nj, int T) { return uniform_grid && nj >= GRID_MIN_NJ && T <= GRID_MAX_T; }
 
 __device__ __forceinline__ int round_log2_width(int rem) {      // 64 lanes for a full round, else next pow2 >= rem
     int lw = 6;
@@ -1265,7 +1266,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
             if (d.zce >= 0 && lane < nst) mz = v2f[(int64_t)d.zce * n + lane];
             // integral points by the uniform-grid recurrence (as in the heavy kernel), once per state, when every exponent of
             // every state stays far inside the double range over the whole grid; otherwise they join the direct rounds
-            bool grid_path = grid_eligible(d.pad, ny, d.T) && !(s.flags & (LHVI_PBP_SKIP_TERMS | LHVI_PBP_NO_GRID));
+            bool grid_path = grid_eligible(d.pad, ny, d.T) && d.T <= 64 && !(s.flags & (LHVI_PBP_SKIP_TERMS | LHVI_PBP_NO_GRID));   // (two batches of sums per lane here)
             double gx0 = 0.0, gh = 0.0;
             if (grid_path) {
                 gx0 = g.dom_val[d.gb];

@@ -34,6 +34,7 @@ class _ParticleSweep:
     dynamic_f2v = True              # the persistent f2v kernels claim their work in chunks (else static striding)
     paired_light = True             # the light edges are served per factor (pair_desc) instead of per edge (light_desc)
     cq_routing = True               # conditionally quadratic MLN formulas go to the quadratic-family kernels (else: generic kernel)
+    long_grid_min_edges = 1 << 16   # edges with np + T > 128 join the heavy kernel's list (grid recurrence, T <= 128) from this many on
     listed_resample = True          # the device sampler draws for the hidden continuous variables only, two per wavefront
     sliced_proposal = True          # rows of more than prop_slice incident edges are cut into slices, a wavefront per slice
     prop_slice = 64
@@ -172,7 +173,12 @@ class _ParticleSweep:
                                                     _abi.ptr(desc), _abi.stream_ptr()))
             # split off the edges the specialised kernel serves (descriptor words: 4 = class, 6 = potential kind, 7 = nj, 8 = np, 9 = T)
             words = desc.view(torch.int32).view(nf, _abi.PBP_DESC_BYTES // 4)
-            heavy = (words[:, 4] == 1) & (words[:, 6] != 4) & (words[:, 7] <= 64) & (words[:, 8] + words[:, 9] <= 128)
+            # (a uniform grid of up to 128 integral points is tabulated by the recurrence, whatever np + T; otherwise two rounds of 64 points)
+            on_recurrence = (words[:, 15] == 1) & (words[:, 7] >= 24) & (words[:, 9] <= 128) & (words[:, 8] <= 128)
+            two_rounds = words[:, 8] + words[:, 9] <= 128
+            if int((on_recurrence & ~two_rounds).sum().item()) < self.long_grid_min_edges:
+                on_recurrence = two_rounds          # (a short list would only add a launch to a launch-bound sweep)
+            heavy = (words[:, 4] == 1) & (words[:, 6] != 4) & (words[:, 7] <= 64) & (two_rounds | on_recurrence)
             rows = desc.view(nf, _abi.PBP_DESC_BYTES)
             self.heavy_desc = rows[heavy].contiguous()
             self.n_heavy = int(self.heavy_desc.shape[0])
@@ -180,8 +186,8 @@ class _ParticleSweep:
             hw = words[heavy].to(torch.int64)
             self.heavy_terms = int(((hw[:, 8] + hw[:, 9]) * hw[:, 7]).sum().item())
             # of those, the terms at the integral points of edges served by the grid recurrence (word 15: uniform grid;
-            # at least 24 partner particles, T <= 64; the kernel's range guard is data dependent and assumed to pass)
-            on_grid = (hw[:, 15] == 1) & (hw[:, 7] >= 24) & (hw[:, 9] <= 64)
+            # at least 24 partner particles, T <= 128; the kernel's range guard is data dependent and assumed to pass)
+            on_grid = (hw[:, 15] == 1) & (hw[:, 7] >= 24) & (hw[:, 9] <= 128)
             self.heavy_grid_terms = int((hw[:, 9] * hw[:, 7])[on_grid].sum().item())
             light = ~heavy & (words[:, 14] != 0)          # word 14: set by lhvi_pbp_describe for the light kernel's edges
             self.light_desc = rows[light].contiguous()

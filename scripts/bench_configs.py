@@ -322,6 +322,27 @@ if 'lifted_pbp' in which:
                 fast_edges=int(bp.fast_edges.numel()), generic_edges=int(bp.generic_edges.numel()), finite=bool(torch.isfinite(bp.f2v).all().item()))
             del bp
 
+if 'grid100' in which:
+    # the headline generator with the 100 integral points of the reference's RGM domain (Demo/Data/RGM/Generator.py:16) instead of
+    # BASELINE's 32: n + T = 164 output points, more than the heavy kernel's two rounds -- its list takes these edges since round 3
+    # because the recurrence tabulates up to 128 grid points; before, the general kernel served them with one exponential per term
+    from lhvi.pbp import EPBP
+    flat = synth.hybrid_mrf_flat(V=500_000, deg=4, seed=0, T=100)
+    for label, min_edges in (('integral points by recurrence (heavy kernel)', 0), ('general kernel, direct form (round 2)', 1 << 30)):
+        bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=1)
+        bp.long_grid_min_edges = min_edges
+        bp._setup(None, flat=flat)
+        _abi.check(_abi.lib().lhvi_pbp_init(bp.dg.g, bp._struct(), _abi.ptr(bp.eta), _abi.ptr(bp.q_dev), _abi.ptr(bp.f2v),
+                                            _abi.ptr(bp.v2f), _abi.stream_ptr()))
+        bp._generate_sample()
+        for _ in range(2):
+            bp.sweep(last=False)
+        t = ev_time(lambda: bp.sweep(last=False))
+        out(config='cfg4 generator, 2 M edges, n=64, T=100 (the grid of the reference\'s RGM domain): ' + label, edges=int(flat.E), sweep_ms=t,
+            sweeps_per_s=1e3 / t, heavy_edges=bp.n_heavy, fast_edges=int(bp.fast_edges.numel()), q_checksum=float(bp.q_dev.nan_to_num().abs().sum().item()),
+            finite=bool(torch.isfinite(bp.f2v).all().item()))
+        del bp
+
 if 'vi_ground' in which:
     # the variational step on a GROUND graph: RGM template C=1000, B=500 (1.0 M pairwise Gaussian factors), K=2, T=3
     from lhvi.vi import VarInference

@@ -245,7 +245,7 @@ def _with_domain(flat, dom):
                       [dom, flat.domains[1]])
 
 
-@pytest.mark.parametrize('grid', ['uniform', 'uneven', 'T48', 'wide'])
+@pytest.mark.parametrize('grid', ['uniform', 'uneven', 'T48', 'wide', 'T100', 'T128'])
 def test_integral_points_by_grid_recurrence_match_the_direct_form(api, grid):
     """the heavy f2v kernel tabulates exp(a_j + b_j x_t) along a uniform integral-point grid by multiplication and
     reduce-scatters the sums over the lanes; LHVI_PBP_NO_GRID forces one exponential per term.  Same messages to 1e-12
@@ -256,12 +256,13 @@ def test_integral_points_by_grid_recurrence_match_the_direct_form(api, grid):
     from lhvi.graph import Domain
     from lhvi.pbp import EPBP
     lo, hi = (-40.0, 40.0) if grid == 'wide' else (-10.0, 10.0)
-    pts = np.linspace(lo, hi, 48 if grid == 'T48' else 32)
+    pts = np.linspace(lo, hi, {'T48': 48, 'T100': 100, 'T128': 128}.get(grid, 32))      # (100: the grid of the reference's RGM domain)
     if grid == 'uneven':
         pts = np.sign(pts) * np.abs(pts) ** 1.3 / 10 ** 0.3
     flat = _with_domain(synth.hybrid_mrf_flat(V=3000, deg=4, seed=11, frac_discrete=0.1),
                         Domain((lo, hi), continuous=True, integral_points=pts))
     bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=2)
+    bp.long_grid_min_edges = 0          # (100 / 128 points: more than two rounds of output points -- heavy kernel at any list length)
     bp._setup(None, flat=flat)
     _init(api, bp)
     for _ in range(2):
