@@ -690,6 +690,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
                         else            { r.a = (q.a00 * y + q.b0) * y + q.c + m; r.b = q.axy * y + q.b1; kk = q.a11; }
                     } else { r.a = m; r.b = y; }
                 }
+                if (mode == MODE_CONST) { r.a *= LHVI_EXP_INV_STEP; r.b *= LHVI_EXP_INV_STEP; }     // floor form: records in units of the table step
                 sh[lane] = r;
                 if (mode == MODE_VARK) shk[lane] = kk;
             }
@@ -730,7 +731,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
                 const int chunk = (jn + split - 1) >> (6 - lw);
                 const AB* base = sh + sub * chunk;
                 const double* basek = shk + sub * chunk;
-                if (mode == MODE_CONST) acc += fast_accumulate_uniform<MODE_CONST>(base, basek, sh_tab, chunk, X1, X2, C);
+                if (mode == MODE_CONST) acc += fast_accumulate_floor<2>(base, sh_tab, chunk, X1, C);
                 else if (mode == MODE_VARK) acc += fast_accumulate_uniform<MODE_VARK>(base, basek, sh_tab, chunk, X1, X2, C);
                 else acc += fast_accumulate_uniform<MODE_DISC>(base, basek, sh_tab, chunk, X1, X2, C);
             }
