@@ -9,7 +9,7 @@ from lhvi.pbp import EPBP
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 flat = synth.hybrid_mrf_flat(V=E // 4, deg=4, seed=0)
-bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=1)
+bp = EPBP(None, n=int(sys.argv[2]) if len(sys.argv) > 2 else 64, proposal_approximation='simple', sampler='device', seed=1)
 bp._setup(None, flat=flat)
 run = dist.SingleRunner(bp)
 run.init()
