@@ -31,7 +31,7 @@ extern "C" {
                               * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t;  7: lhvi_pbp_t gained pair_desc;
                               * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq; the colour
                               *    refinement calls take a method and return four result words; lhvi_vi_t gained var_N; lhvi_vi_opt_t, lhvi_vi_adam_run;
-                              *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub, prop_hub / prop_partial, resample_vars; 16 ticket words; lhvi_pbp_boundary_reduce */
+                              *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub, prop_hub / prop_partial, resample_vars, small16_desc / small32_desc; 16 ticket words; lhvi_pbp_boundary_reduce */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -287,6 +287,15 @@ typedef struct lhvi_pbp {
      * every variable of the range, neighbours two by two.  The draws do not depend on which form is used. */
     const int32_t* resample_vars;
     int32_t n_resample_vars;
+    /* optional, lhvi_pbp_f2v only: heavy-class descriptors (same rows as heavy_desc would hold, and NOT in heavy_desc) of the edges
+     * whose target AND partner have at most 16 / at most 32 particles (nj <= 16 and np <= 16; the rest with nj <= 32 and np <= 32);
+     * any number of integral points.  Served four / two edges per wavefront by their own kernel: with the particle counts of the
+     * reference's demos (10-20) an edge per wavefront is bound by its own latencies, not by its terms.  NULL: such edges stay in
+     * heavy_desc.  Skipped with LHVI_PBP_SKIP_HEAVY. */
+    const void* small16_desc;
+    int32_t n_small16;
+    const void* small32_desc;
+    int32_t n_small32;
 } lhvi_pbp_t;
 
 #define LHVI_PBP_DESC_BYTES 128

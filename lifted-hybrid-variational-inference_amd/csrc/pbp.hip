@@ -1013,6 +1013,72 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
     if (stats && lane == 0) { atomicAdd(stats, (uint32_t)n_grid); atomicAdd(stats + 1, (uint32_t)n_direct); }
 }
 
+// HEAVY-class edges with FEW particles (target and partner both at most W = 16 or 32: the particle counts of the reference's
+// demos), 64 / W edges per wavefront.  With one edge per wavefront such an edge keeps 64 lanes busy for a dozen terms and then
+// waits out the latencies of its own loads, LDS hand-off and stores (gfx950 counts loads and stores in one in-order counter, so
+// the wait for the next edge's operands includes this edge's store acknowledgements): ~10 us per edge whatever it holds.  Here a
+// lane group of W lanes owns an edge: lane = partner particle while the records are staged (wave-private LDS, one block of W
+// records per group), then lane = output point in rounds of W points (particles first, then the integral points); every lane runs
+// the same term loop over its group's records (padded to the longest list of the wave with terms that underflow to 0), so no
+// cross-lane reduction is needed at all, and every load, store and wait is shared by 64 / W edges.  Same term arithmetic as the
+// heavy kernel's direct form (fast_accumulate_floor): an edge gets the same message from either kernel up to the order of the sum
+// when the heavy kernel splits a short round across lane groups.
+template <int W>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) pbp_f2v_small_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
+                                                            double* __restrict__ f2v, const FastDesc* __restrict__ descs, int nitems) {
+    constexpr int G = WAVE / W;                              // edges per wavefront
+    __shared__ AB sh_all[BLOCK / WAVE][WAVE];
+    __shared__ double sh_tab[EXP_TAB_N];
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    load_log_table(sh_log);
+    load_exp_table(sh_tab);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / W, gl = lane % W;
+    AB* sh = sh_all[wid];
+    const AB* mine_recs = sh + grp * W;
+    const int n = s.n, S = s.n + s.T;
+    const int nsteps = (nitems + G - 1) / G;
+    const int nwaves = gridDim.x * (BLOCK / WAVE);
+    for (int step = blockIdx.x * (BLOCK / WAVE) + wid; step < nsteps; step += nwaves) {
+        const int idx = step * G + grp;
+        const bool live = idx < nitems;
+        const FastDesc& d = descs[live ? idx : nitems - 1];  // (a group past the end repeats the last entry and stores nothing)
+        const int e = d.e, tv = d.tv, nj = d.nj, np = d.np, T = d.T, gb = d.gb;
+        const double pval = d.pval, kx = d.kx;
+        // staging: lane = partner particle of its group's edge
+        AB rec;
+        rec.a = -800.0 * LHVI_EXP_INV_STEP; rec.b = 0.0;     // padding: exp(-800) underflows to exactly 0
+        if (gl < nj) {
+            double y = pval, m = 0.0;
+            if (is_hidden(pval)) { y = s.old_particles[(int64_t)d.pv * n + gl]; m = v2f[(int64_t)d.pce * n + gl]; }
+            rec.a = ((d.ay * y + d.by) * y + d.c + m) * LHVI_EXP_INV_STEP;        // (records in units of the table step: floor form)
+            rec.b = (d.axy * y + d.bx) * LHVI_EXP_INV_STEP;
+        }
+        LHVI_WAVE_SYNC();
+        sh[lane] = rec;
+        LHVI_WAVE_SYNC();
+        // the longest record list and the most output points of the wave's edges (wave-uniform loop bounds)
+        int jmax = 0, pmax = 0;
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            jmax = max(jmax, __builtin_amdgcn_readlane(nj, k * W));
+            pmax = max(pmax, __builtin_amdgcn_readlane(np + T, k * W));
+        }
+        if (s.flags & LHVI_PBP_SKIP_TERMS) jmax = 0;
+        const int npts = np + T;
+        double* out = f2v + (int64_t)e * S;
+        for (int p0 = 0; p0 < pmax; p0 += W) {
+            const int p = p0 + gl;
+            const bool valid = live && p < npts;
+            double x = 0.0;
+            if (valid) x = p < np ? s.particles[(int64_t)tv * n + p] : g.dom_val[gb + p - np];
+            const double acc = fast_accumulate_floor<4>(mine_recs, sh_tab, jmax, x, kx * x * x);
+            if (valid) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
+        }
+    }
+}
+
 // LIGHT edges: HybridQuadratic(1 discrete, 1 continuous) with a binary (or observed) discrete side -- the edges between
 // the continuous and the binary variables of the benchmark.  A handful of terms per output point, so the general
 // kernel's staging / splitting / shuffling is all overhead; here nothing goes through LDS but the two tables:
@@ -2146,6 +2212,7 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     if (int rc = validate_pbp(g, s)) return rc;
     if (!pots || !v2f || !f2v || !s->old_particles) return LHVI_E_ARG;
     if ((s->flags & LHVI_PBP_CQ) && (!s->fast_edges || !s->generic_edges)) return LHVI_E_ARG;   // (conditional-quadratic routing needs the work lists)
+    if (s->n_small16 < 0 || s->n_small32 < 0 || (s->n_small16 > 0 && !s->small16_desc) || (s->n_small32 > 0 && !s->small32_desc)) return LHVI_E_ARG;
     if (g->E == 0) return LHVI_OK;
     // persistent grids sized from the measured residency: CUs x resident workgroups per CU, every wave strides over its list
     const int nfast = s->fast_edges ? s->n_fast : g->E, ngen = s->generic_edges ? s->n_generic : g->E;
@@ -2173,6 +2240,18 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
             hipLaunchKernelGGL(pbp_f2v_heavy_kernel, dim3(heavy_grid), dim3(HEAVY_BLOCK), 0, as_stream(stream),
                                *g, sh, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy,
                                s->f2v_ticket ? s->f2v_ticket + LHVI_PBP_TICKET_COUNTERS : (uint32_t*)nullptr);
+        if (!(s->flags & LHVI_PBP_SKIP_HEAVY)) {
+            if (s->small16_desc && s->n_small16 > 0) {
+                static const int per_cu = blocks_per_cu((const void*)pbp_f2v_small_kernel<16>);
+                hipLaunchKernelGGL(pbp_f2v_small_kernel<16>, dim3(min((s->n_small16 + 15) / 16, max(cus * per_cu - spare, 1))), dim3(BLOCK), 0,
+                                   as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->small16_desc), s->n_small16);
+            }
+            if (s->small32_desc && s->n_small32 > 0) {
+                static const int per_cu = blocks_per_cu((const void*)pbp_f2v_small_kernel<32>);
+                hipLaunchKernelGGL(pbp_f2v_small_kernel<32>, dim3(min((s->n_small32 + 7) / 8, max(cus * per_cu - spare, 1))), dim3(BLOCK), 0,
+                                   as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->small32_desc), s->n_small32);
+            }
+        }
         if (s->pair_desc && s->n_pair > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT)) {
             static const int pair_per_cu = blocks_per_cu((const void*)pbp_f2v_pair_kernel);
             hipLaunchKernelGGL(pbp_f2v_pair_kernel, dim3(min((s->n_pair + 3) / 4, max(cus * min(pair_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0,

@@ -57,7 +57,7 @@ class SingleRunner:
 
     def heavy_stats(self):
         """(edges, joint terms) of the continuous x continuous kernel's work list"""
-        return self.bp.n_heavy, self.bp.heavy_terms
+        return int(getattr(self.bp, 'n_heavy_class', 0) or self.bp.n_heavy), self.bp.heavy_terms
 
     def heavy_grid_terms(self):
         """joint terms at the integral points of the edges the heavy kernel serves by the grid recurrence"""

@@ -34,6 +34,7 @@ class _ParticleSweep:
     dynamic_f2v = True              # the persistent f2v kernels claim their work in chunks (else static striding)
     paired_light = True             # the light edges are served per factor (pair_desc) instead of per edge (light_desc)
     cq_routing = True               # conditionally quadratic MLN formulas go to the quadratic-family kernels (else: generic kernel)
+    small_f2v = True                # heavy-class edges with at most 16 / 32 particles on both sides: four / two edges per wavefront
     long_grid_min_edges = 1 << 16   # edges with np + T > 128 join the heavy kernel's list (grid recurrence, T <= 128) from this many on
     listed_resample = True          # the device sampler draws for the hidden continuous variables only, two per wavefront
     sliced_proposal = True          # rows of more than prop_slice incident edges are cut into slices, a wavefront per slice
@@ -150,8 +151,8 @@ class _ParticleSweep:
             wide = ~narrow & ~hub
             self.v2f_lists = (up(hidden_v[wide]), int(wide.sum()), up(hidden_v[narrow]), int(narrow.sum()),
                               up(hidden_v[hub]), int(hub.sum()))
-        self.fast_desc = self.heavy_desc = self.light_desc = self.pair_desc = None
-        self.n_heavy = self.n_light = self.n_pair = 0
+        self.fast_desc = self.heavy_desc = self.light_desc = self.pair_desc = self.small16_desc = self.small32_desc = None
+        self.n_heavy = self.n_light = self.n_pair = self.n_small16 = self.n_small32 = self.n_heavy_class = 0
         self.cq_terms = 0
         ncq = int(self.cq_edges.numel())
         if ncq:
@@ -174,20 +175,31 @@ class _ParticleSweep:
             # split off the edges the specialised kernel serves (descriptor words: 4 = class, 6 = potential kind, 7 = nj, 8 = np, 9 = T)
             words = desc.view(torch.int32).view(nf, _abi.PBP_DESC_BYTES // 4)
             # (a uniform grid of up to 128 integral points is tabulated by the recurrence, whatever np + T; otherwise two rounds of 64 points)
+            base = (words[:, 4] == 1) & (words[:, 6] != 4)
+            # edges with few particles on both sides go four / two to a wavefront, whatever their number of integral points
+            # (include/lhvi.h, small16_desc)
+            small16 = small32 = torch.zeros_like(base)
+            if self.small_f2v and edge_key is None:
+                small16 = base & (words[:, 7] <= 16) & (words[:, 8] <= 16)
+                small32 = base & ~small16 & (words[:, 7] <= 32) & (words[:, 8] <= 32)
+            small = small16 | small32
             on_recurrence = (words[:, 15] == 1) & (words[:, 7] >= 24) & (words[:, 9] <= 128) & (words[:, 8] <= 128)
             two_rounds = words[:, 8] + words[:, 9] <= 128
-            if int((on_recurrence & ~two_rounds).sum().item()) < self.long_grid_min_edges:
+            if int((on_recurrence & ~two_rounds & ~small).sum().item()) < self.long_grid_min_edges:
                 on_recurrence = two_rounds          # (a short list would only add a launch to a launch-bound sweep)
-            heavy = (words[:, 4] == 1) & (words[:, 6] != 4) & (words[:, 7] <= 64) & (two_rounds | on_recurrence)
+            heavy = (base & (words[:, 7] <= 64) & (two_rounds | on_recurrence)) | small       # the heavy CLASS: the three lists together
             rows = desc.view(nf, _abi.PBP_DESC_BYTES)
-            self.heavy_desc = rows[heavy].contiguous()
+            self.small16_desc, self.small32_desc = rows[small16].contiguous(), rows[small32].contiguous()
+            self.n_small16, self.n_small32 = int(self.small16_desc.shape[0]), int(self.small32_desc.shape[0])
+            self.n_heavy_class = int(heavy.sum().item())
+            self.heavy_desc = rows[heavy & ~small].contiguous()
             self.n_heavy = int(self.heavy_desc.shape[0])
             # (output point, partner particle) terms of the heavy kernel: sum over its edges of (np + T) * nj
             hw = words[heavy].to(torch.int64)
             self.heavy_terms = int(((hw[:, 8] + hw[:, 9]) * hw[:, 7]).sum().item())
             # of those, the terms at the integral points of edges served by the grid recurrence (word 15: uniform grid;
             # at least 24 partner particles, T <= 128; the kernel's range guard is data dependent and assumed to pass)
-            on_grid = (hw[:, 15] == 1) & (hw[:, 7] >= 24) & (hw[:, 9] <= 128)
+            on_grid = (hw[:, 15] == 1) & (hw[:, 7] >= 24) & (hw[:, 9] <= 128) & ~small[heavy]
             self.heavy_grid_terms = int((hw[:, 9] * hw[:, 7])[on_grid].sum().item())
             light = ~heavy & (words[:, 14] != 0)          # word 14: set by lhvi_pbp_describe for the light kernel's edges
             self.light_desc = rows[light].contiguous()
@@ -264,6 +276,10 @@ class _ParticleSweep:
         s.fast_desc = _abi.ptr(getattr(self, 'fast_desc', None))
         s.heavy_desc, s.n_heavy = _abi.ptr(getattr(self, 'heavy_desc', None)), int(getattr(self, 'n_heavy', 0))
         s.light_desc, s.n_light = _abi.ptr(getattr(self, 'light_desc', None)), int(getattr(self, 'n_light', 0))
+        if getattr(self, 'n_small16', 0):
+            s.small16_desc, s.n_small16 = _abi.ptr(self.small16_desc), int(self.n_small16)
+        if getattr(self, 'n_small32', 0):
+            s.small32_desc, s.n_small32 = _abi.ptr(self.small32_desc), int(self.n_small32)
         if self.paired_light and getattr(self, 'pair_desc', None) is not None:
             s.pair_desc, s.n_pair = _abi.ptr(self.pair_desc), int(self.n_pair)
         s.cq_desc, s.n_cq = _abi.ptr(getattr(self, 'cq_desc', None)), int(getattr(self, 'n_cq', 0))

@@ -232,7 +232,7 @@ def test_lifted_particle_sweep_at_scale():
         draws.append(out)
         return out
     bl = _lifted_sweeps(lflat, n, sweeps, sampler=lifted_sampler)
-    assert bl.n_heavy > 0 and bl.T == 100                       # the RGM's 100 integral points: n + T = 110 output points per edge
+    assert bl.n_heavy_class > 0 and bl.T == 100                       # the RGM's 100 integral points: n + T = 110 output points per edge
     bg = _lifted_sweeps(ground, n, sweeps, sampler=lambda k, flat, q: draws[k][rvc])
     hid = small.var_hidden
     ql, qg = bl.q_dev.cpu().numpy(), bg.q_dev.cpu().numpy()

@@ -640,10 +640,10 @@ def test_conditionally_quadratic_routing_equals_the_generic_kernel(api, solver, 
         runs.append(bp)
     a, b = runs
     assert a.flags & api.PBP_CQ and not (b.flags & api.PBP_CQ)
-    assert b.n_cq == 0 and b.n_heavy == 0 and b.n_light == 0 and int(b.generic_edges.numel()) > 0
+    assert b.n_cq == 0 and b.n_heavy_class == 0 and b.n_light == 0 and int(b.generic_edges.numel()) > 0
     import torch
     types = a.cq_desc.view(torch.int32).view(a.n_cq, 64)[:, 2].cpu().numpy()
-    assert a.n_heavy > 0 and a.n_light > 0 and (types == 1).any() and (types == 2).any()
+    assert a.n_heavy_class > 0 and a.n_light > 0 and (types == 1).any() and (types == 2).any()
     # what is left on the generic list are the messages to booleans whose other arguments are all observed
     assert int(a.generic_edges.numel()) < int(b.generic_edges.numel())
     flat = a.flat
@@ -953,3 +953,54 @@ def test_sliced_proposal_matches_the_one_wave_path(api, rule, lifted, points):
     np.testing.assert_allclose(qa, qb, rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(a.eta.cpu().numpy(), b.eta.cpu().numpy(), rtol=1e-9, atol=1e-12)
     assert torch.equal(a.q_dev, c.q_dev) and torch.equal(a.eta, c.eta) and torch.equal(a.f2v, c.f2v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,points,lifted', [(10, 32, False), (16, 20, False), (24, 32, False), (32, 100, False), (12, 48, True)])
+def test_small_particle_kernel_matches_the_one_edge_per_wave_kernels(api, n, points, lifted):
+    """with at most 16 / 32 particles on both sides of an edge, four / two edges share a wavefront (pbp_f2v_small_kernel).  Same
+    messages as the heavy kernel gives for those edges (to the rounding of a differently ordered sum), whole sweeps agree, ragged
+    ends of the lists included"""
+    import torch
+    from lhvi import synth
+    from lhvi.graph import Domain
+    from lhvi.pbp import EPBP
+    flat = _with_domain(synth.hybrid_mrf_flat(V=3001, deg=4, seed=5, frac_discrete=0.15),
+                        Domain((-10.0, 10.0), continuous=True, integral_points=np.linspace(-10, 10, points)))
+    if lifted:
+        flat.edge_count = 1.0 + (np.arange(flat.E) % 3).astype(np.float64)
+        flat.lifted = True
+    runs = []
+    for small in (True, False):
+        bp = EPBP(None, n=n, proposal_approximation='simple', sampler='device', seed=4)
+        bp.small_f2v = small
+        bp._setup(None, flat=flat)
+        _init(api, bp)
+        for _ in range(3):
+            bp.sweep(last=False)
+        runs.append(bp)
+    a, b = runs
+    assert (a.n_small16 if n <= 16 else a.n_small32) > 1000 and b.n_small16 == 0 and b.n_small32 == 0
+    heavy_ok = n + points <= 128                      # (beyond two rounds of output points the general kernel serves the edge instead)
+    assert (a.n_small16 + a.n_small32 + a.n_heavy == b.n_heavy) == heavy_ok
+    hid = flat.var_hidden[flat.edge_var]
+    S = n + a.T
+    cols = np.concatenate([np.arange(n), n + np.arange(points)])
+    fa, fb = a.f2v.cpu().numpy()[hid][:, cols], b.f2v.cpu().numpy()[hid][:, cols]
+    assert np.isfinite(fa).all()
+    np.testing.assert_allclose(fa, fb, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(a.q_dev.cpu().numpy(), b.q_dev.cpu().numpy(), rtol=1e-10, atol=1e-12, equal_nan=True)
+    # one launch on the same inputs: the small lists' edges against the heavy kernel, message by message
+    l, st = api.lib(), api.stream_ptr()
+    out_a, out_b = torch.zeros_like(a.f2v), torch.zeros_like(a.f2v)
+    sa = a._struct()
+    api.check(l.lhvi_pbp_f2v(a.dg.g, a.dg.p, sa, api.ptr(a.v2f), api.ptr(out_a), st))
+    if not heavy_ok:
+        return
+    sb = a._struct()
+    both = torch.cat([a.heavy_desc, a.small16_desc, a.small32_desc]).contiguous()
+    sb.heavy_desc, sb.n_heavy = api.ptr(both), int(both.shape[0])
+    sb.small16_desc, sb.n_small16, sb.small32_desc, sb.n_small32 = None, 0, None, 0
+    api.check(l.lhvi_pbp_f2v(a.dg.g, a.dg.p, sb, api.ptr(a.v2f), api.ptr(out_b), st))
+    oa, ob = out_a.cpu().numpy()[hid][:, cols], out_b.cpu().numpy()[hid][:, cols]
+    np.testing.assert_allclose(oa, ob, rtol=1e-11, atol=1e-11)
