@@ -31,7 +31,7 @@ extern "C" {
                               * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t;  7: lhvi_pbp_t gained pair_desc;
                               * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq; the colour
                               *    refinement calls take a method and return four result words; lhvi_vi_t gained var_N; lhvi_vi_opt_t, lhvi_vi_adam_run;
-                              *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub, prop_hub / prop_partial, resample_vars, small16_desc / small32_desc; 16 ticket words; lhvi_pbp_boundary_reduce */
+                              *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub / v2f_mid16 / v2f_mid32, prop_hub / prop_partial, resample_vars, small16_desc / small32_desc; 16 ticket words; lhvi_pbp_boundary_reduce */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -271,6 +271,10 @@ typedef struct lhvi_pbp {
                                  * (template variables of relational models), a workgroup each; such variables are then NOT in
                                  * v2f_wide */
     int32_t n_v2f_hub;
+    const int32_t* v2f_mid16;   /* optional further parts of the split (with v2f_wide / v2f_narrow): variables with 5-16 and with 17-32 particles */
+    int32_t n_v2f_mid16;        /* and at most 64 incident edges, four / two per wavefront; such variables are then NOT in v2f_wide */
+    const int32_t* v2f_mid32;
+    int32_t n_v2f_mid32;
     /* optional, lhvi_pbp_proposal with prop_desc only: variables with long rows (template variables of relational models) listed in
      * prop_desc by SLICES of their var_edge row, a wavefront per slice instead of one per variable.  A slice record has word 1 =
      * -(entries in the slice), word 4 = position of its first entry in the row, word 5 = its slot in prop_partial (words 6-7

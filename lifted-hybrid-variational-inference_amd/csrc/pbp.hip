@@ -321,6 +321,63 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_narrow_kernel(lhvi_graph_t g, l
     }
 }
 
+// The same for variables with 5-16 / 17-32 particles (the particle counts of the reference's demos): a lane group of W = 16 / 32
+// lanes per variable, four / two variables per wavefront; the balance step's mean and max are the row / half-wave DPP reductions,
+// whose steps inside a group are the ones the one-variable kernel's wave reduction performs on those lanes -- same bits.
+template <int W>
+__global__ void __launch_bounds__(BLOCK) pbp_v2f_packed_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
+                                                              double* __restrict__ v2f, const int32_t* __restrict__ list, int count) {
+    constexpr int G = WAVE / W;
+    const int lane = threadIdx.x & 63;
+    const int64_t slot = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * G + lane / W;
+    const int j = lane % W;
+    const int v = slot < count ? list[slot] : -1;
+    const int n = s.n, S = s.n + s.T;
+    const bool on = v >= 0 && is_hidden(g.var_value[v]);
+    const int np = on ? s.np[v] : 0;
+    const bool valid = j < np;
+    const int lo = on ? g.var_ptr[v] : 0, deg = on ? g.var_ptr[v + 1] - lo : 0;
+    const bool lifted = g.edge_count != nullptr;
+    double total = 0.0;
+    for (int k = 0; k < deg; ++k) {
+        const int e = g.var_edge[lo + k];
+        const double m = valid ? f2v[(int64_t)e * S + j] : 0.0;
+        total += lifted ? m * g.edge_count[e] : m;
+    }
+    double logw = 0.0;
+    bool uq = false;
+    if (valid) {
+        const int d = g.var_dom[v];
+        const double sd = sqrt_pos(s.q[2 * v + 1]);
+        logw = log_importance(g, s, v, d, s.particles[(int64_t)v * n + j], s.q[2 * v], rcp_newton(sd), log_pos(2.506628274631 * sd));
+        uq = s.uniq[(int64_t)v * n + j] != 0;
+    }
+    // (a row reduction leaves every lane with the row's sum in ITS OWN order of additions; the one-variable kernel's wave reduction
+    // ends with lane 15's, so lane 15's is the one every lane of the group takes: row_newbcast:15)
+    auto group_sum = [&](double x) { return W == 16 ? dpp_move<0x15F>(dpp_row_reduce(x, SumOp())) : dpp_half_reduce(x, SumOp(), lane); };
+    auto group_max = [&](double x) { return W == 16 ? dpp_row_reduce(x, MaxOp()) : dpp_half_reduce(x, MaxOp(), lane); };
+    const uint64_t mine = (W == 16 ? 0xffffull : 0xffffffffull) << (lane / W * W);
+    const double rcnt = rcp_newton(fmax((double)__builtin_popcountll(__ballot(uq) & mine), 1.0));
+    // every lane of the wave runs the longest row of its variables (the reductions are wave-wide instructions)
+    int maxdeg = deg;
+#pragma unroll
+    for (int off = 32; off >= W; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
+    for (int k = 0; k < maxdeg; ++k) {
+        const bool live = k < deg;
+        const int e = live ? g.var_edge[lo + k] : 0;
+        const double m = (live && valid) ? f2v[(int64_t)e * S + j] : 0.0;
+        const double res = (total - m) + logw;
+        const double mean = group_sum(uq ? res : 0.0) * rcnt;
+        double shift = mean;
+        // max - mean > max_log_value  <=>  some distinct particle exceeds mean + max_log_value (as in pbp_v2f_kernel)
+        if (__ballot(uq && (res - mean > s.max_log_value))) {
+            const double mx = group_max(uq ? res : -__builtin_huge_val());
+            if (mx - mean > s.max_log_value) shift = mx - s.max_log_value;
+        }
+        if (live && valid) v2f[(int64_t)e * n + j] = res - shift;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int state_index(const lhvi_graph_t& g, int v, double x) {
     const int d = g.var_dom[v];
@@ -2201,6 +2258,13 @@ int lhvi_pbp_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, 
         if (s->n_v2f_narrow > 0)
             hipLaunchKernelGGL(pbp_v2f_narrow_kernel, dim3(grid_for(((int64_t)s->n_v2f_narrow + 15) / 16 * WAVE)), dim3(BLOCK), 0,
                                as_stream(stream), *g, *s, f2v, v2f);
+        if (s->n_v2f_mid16 < 0 || s->n_v2f_mid32 < 0 || (s->n_v2f_mid16 > 0 && !s->v2f_mid16) || (s->n_v2f_mid32 > 0 && !s->v2f_mid32)) return LHVI_E_ARG;
+        if (s->n_v2f_mid16 > 0)
+            hipLaunchKernelGGL(pbp_v2f_packed_kernel<16>, dim3(grid_for(((int64_t)s->n_v2f_mid16 + 3) / 4 * WAVE)), dim3(BLOCK), 0,
+                               as_stream(stream), *g, *s, f2v, v2f, s->v2f_mid16, s->n_v2f_mid16);
+        if (s->n_v2f_mid32 > 0)
+            hipLaunchKernelGGL(pbp_v2f_packed_kernel<32>, dim3(grid_for(((int64_t)s->n_v2f_mid32 + 1) / 2 * WAVE)), dim3(BLOCK), 0,
+                               as_stream(stream), *g, *s, f2v, v2f, s->v2f_mid32, s->n_v2f_mid32);
         return check_launch();
     }
     hipLaunchKernelGGL(pbp_v2f_kernel, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0, as_stream(stream),

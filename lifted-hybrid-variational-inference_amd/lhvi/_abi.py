@@ -60,6 +60,7 @@ class PbpStruct(C.Structure):
         ('cq_desc', C.c_void_p), ('n_cq', C.c_int32),
         ('v2f_wide', C.c_void_p), ('n_v2f_wide', C.c_int32), ('v2f_narrow', C.c_void_p), ('n_v2f_narrow', C.c_int32),
         ('v2f_hub', C.c_void_p), ('n_v2f_hub', C.c_int32),
+        ('v2f_mid16', C.c_void_p), ('n_v2f_mid16', C.c_int32), ('v2f_mid32', C.c_void_p), ('n_v2f_mid32', C.c_int32),
         ('prop_hub', C.c_void_p), ('n_prop_hub', C.c_int32), ('prop_partial', C.c_void_p),
         ('resample_vars', C.c_void_p), ('n_resample_vars', C.c_int32),
         ('small16_desc', C.c_void_p), ('n_small16', C.c_int32), ('small32_desc', C.c_void_p), ('n_small32', C.c_int32),

@@ -396,6 +396,7 @@ class ShardedRunner:
         s.prop_desc, s.n_prop_desc = None, 0                 # the sharded proposal addresses variables by range
         s.prop_hub, s.n_prop_hub, s.prop_partial = None, 0, None
         s.v2f_wide, s.n_v2f_wide, s.v2f_narrow, s.n_v2f_narrow, s.v2f_hub, s.n_v2f_hub = None, 0, None, 0, None, 0     # ... and so does the sharded v -> f half
+        s.v2f_mid16, s.n_v2f_mid16, s.v2f_mid32, s.n_v2f_mid32 = None, 0, None, 0
         if part is not None:
             s.var_lo, s.var_hi = (0, self.n_int) if part == 0 else (self.n_int, self.plan.flat.V)
         return s

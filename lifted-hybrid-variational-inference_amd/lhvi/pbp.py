@@ -146,11 +146,13 @@ class _ParticleSweep:
         narrow = self.np_host[hidden_v] <= 4
         self.v2f_lists = None
         hub = ~narrow & (np.diff(flat.var_ptr)[hidden_v] > 64) & (self.np_host[hidden_v] <= 64)
-        if self.packed_v2f and hidden_v.size and (narrow.any() or hub.any()):
+        mid16 = ~narrow & ~hub & (self.np_host[hidden_v] <= 16)
+        mid32 = ~narrow & ~hub & ~mid16 & (self.np_host[hidden_v] <= 32)
+        if self.packed_v2f and hidden_v.size and (narrow.any() or hub.any() or mid16.any() or mid32.any()):
             up = lambda a: _abi.to_dev(a.astype(np.int32) if a.size else np.zeros(1, dtype=np.int32))
-            wide = ~narrow & ~hub
+            wide = ~narrow & ~hub & ~mid16 & ~mid32
             self.v2f_lists = (up(hidden_v[wide]), int(wide.sum()), up(hidden_v[narrow]), int(narrow.sum()),
-                              up(hidden_v[hub]), int(hub.sum()))
+                              up(hidden_v[hub]), int(hub.sum()), up(hidden_v[mid16]), int(mid16.sum()), up(hidden_v[mid32]), int(mid32.sum()))
         self.fast_desc = self.heavy_desc = self.light_desc = self.pair_desc = self.small16_desc = self.small32_desc = None
         self.n_heavy = self.n_light = self.n_pair = self.n_small16 = self.n_small32 = self.n_heavy_class = 0
         self.cq_terms = 0
@@ -284,9 +286,10 @@ class _ParticleSweep:
             s.pair_desc, s.n_pair = _abi.ptr(self.pair_desc), int(self.n_pair)
         s.cq_desc, s.n_cq = _abi.ptr(getattr(self, 'cq_desc', None)), int(getattr(self, 'n_cq', 0))
         if getattr(self, 'v2f_lists', None) is not None:
-            w, nw, nr, nn, hb, nh = self.v2f_lists
+            w, nw, nr, nn, hb, nh, m16, n16, m32, n32 = self.v2f_lists
             s.v2f_wide, s.n_v2f_wide, s.v2f_narrow, s.n_v2f_narrow = _abi.ptr(w), nw, _abi.ptr(nr), nn
             s.v2f_hub, s.n_v2f_hub = _abi.ptr(hb), nh
+            s.v2f_mid16, s.n_v2f_mid16, s.v2f_mid32, s.n_v2f_mid32 = _abi.ptr(m16), n16, _abi.ptr(m32), n32
         s.f2v_ticket = _abi.ptr(self.f2v_ticket) if self.dynamic_f2v else None
         if self.listed_proposal and getattr(self, 'prop_desc', None) is not None:
             s.prop_desc, s.n_prop_desc = _abi.ptr(self.prop_desc), self.n_prop_desc

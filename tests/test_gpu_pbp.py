@@ -840,7 +840,7 @@ def test_pair_records_do_not_change_results(api, frac_discrete, evidence):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('solver', ['epbp', 'hlbp'])
+@pytest.mark.parametrize('solver', ['epbp', 'hlbp', 'epbp10', 'epbp16', 'epbp24', 'epbp32'])
 def test_packed_v2f_kernel_does_not_change_results(api, solver):
     """variables with at most four particles (binary variables, boolean atoms) served sixteen per wavefront by
     pbp_v2f_narrow_kernel against one wavefront each: whole sweeps agree bit for bit (hybrid MRF with binary and observed
@@ -850,9 +850,10 @@ def test_packed_v2f_kernel_does_not_change_results(api, solver):
     from lhvi.pbp import EPBP, HybridLBP
     runs = []
     for packed in (True, False):
-        if solver == 'epbp':
-            flat = synth.hybrid_mrf_flat(V=9000, deg=4, seed=31, frac_discrete=0.4)
-            bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=6)
+        if solver.startswith('epbp'):
+            # (10 ... 32 particles: the continuous variables go four / two to a wavefront as well, pbp_v2f_packed_kernel)
+            flat = synth.hybrid_mrf_flat(V=9001, deg=4, seed=31, frac_discrete=0.4)
+            bp = EPBP(None, n=int(solver[4:] or 64), proposal_approximation='simple', sampler='device', seed=6)
             bp.packed_v2f = packed
             bp._setup(None, flat=flat)
             _init(api, bp)
@@ -867,6 +868,10 @@ def test_packed_v2f_kernel_does_not_change_results(api, solver):
         runs.append(bp)
     a, b = runs
     assert a.v2f_lists is not None and a.v2f_lists[3] > 0 and a.v2f_lists[5] == 0 and b.v2f_lists is None
+    if solver in ('hlbp', 'epbp10', 'epbp16'):
+        assert a.v2f_lists[7] > 0 and a.v2f_lists[1] == 0
+    if solver in ('epbp24', 'epbp32'):
+        assert a.v2f_lists[9] > 0 and a.v2f_lists[1] == 0
     for name in ('v2f', 'f2v', 'q_dev', 'eta', 'particles'):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
 
