@@ -2061,7 +2061,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
             // (a half whose own variable needs no draw repeats the other's blocks: the swap below then leaves that row intact)
             const int mine = (lane >> 5) ? (cont[1] ? vv[1] : vv[0]) : (cont[0] ? vv[0] : vv[1]);
             double zc, zs;
-#ifdef LHVI_DIAG_NO_PHILOX
+#ifdef LHVI_DIAG_NO_PHILOX                                     // timing aid (scripts/diag/resample_time.py): never defined in the product build
             zc = 1e-3 * lane + mine; zs = -zc;
 #else
             philox_normal_pair(seed, gid ? (uint64_t)gid[mine] : (uint64_t)mine, (uint32_t)(lane & 31), iteration, sh_log, zc, zs);
@@ -2092,7 +2092,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
                 xlo[h] = __double2loint(x); xhi[h] = __double2hiint(x);
             }
         }
-#ifdef LHVI_DIAG_NO_UNIQ
+#ifdef LHVI_DIAG_NO_UNIQ                                           // timing aid, as above
 #pragma unroll
         for (int h = 0; h < 2; ++h) if (cont[h] && lane < n) uniq[(int64_t)vv[h] * n + lane] = (uint8_t)(lane < cnt[h]);
         continue;
