@@ -189,6 +189,73 @@ def test_boundary_exchange_gloo_world2():
     assert all(nb > 0 for _, _, nb in res)
 
 
+def _owner_gloo_worker(rank, world, port, out):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
+    import torch
+    import torch.distributed as td
+    from lhvi import synth
+    from lhvi.dist import ShardPlan, owner_exchange_layout
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    flat = synth.hybrid_mrf_flat(V=1200, deg=4, seed=7)
+    plan = ShardPlan(flat, rank, world)
+    W = 5
+    gid = plan.var_gid[plan.bvars]
+    width = np.where(gid % 3 == 0, 2, W)                       # (a function of the global id: the same on every rank)
+    lay = owner_exchange_layout(plan, width)
+    # every rank's row of a variable is a function of (rank, gid), so each rank can form the expected totals on its own
+    row = lambda r, g_: np.sin(np.arange(W) + 0.37 * g_ + 1.7 * r)
+    A = torch.zeros(max(lay['a_size'], 1), dtype=torch.float64)
+    for b in range(plan.bvars.size):
+        A[lay['pack_off'][b]:lay['pack_off'][b] + width[b]] = torch.from_numpy(row(rank, int(gid[b]))[:width[b]])
+    sa, ra = int(sum(lay['a_send'])), int(sum(lay['a_recv']))
+    recv = torch.empty(ra, dtype=torch.float64)
+    td.all_to_all_single(recv, A[:sa].clone(), output_split_sizes=lay['a_recv'], input_split_sizes=lay['a_send'])
+    A[lay['a_recv_base']:lay['a_recv_base'] + ra] = recv
+    B = torch.zeros(max(lay['b_size'], 1), dtype=torch.float64)
+    for i in range(lay['items'].size):
+        w = int(lay['width'][i])
+        tot = torch.zeros(w, dtype=torch.float64)
+        for k in range(lay['src_ptr'][i], lay['src_ptr'][i + 1]):
+            tot = tot + A[lay['src_off'][k]:lay['src_off'][k] + w]
+        for k in range(lay['dst_ptr'][i], lay['dst_ptr'][i + 1]):
+            B[lay['dst_off'][k]:lay['dst_off'][k] + w] = tot
+    sb, rb = int(sum(lay['b_send'])), int(sum(lay['b_recv']))
+    recv = torch.empty(rb, dtype=torch.float64)
+    td.all_to_all_single(recv, B[:sb].clone(), output_split_sizes=lay['b_recv'], input_split_sizes=lay['b_send'])
+    B[lay['b_recv_base']:lay['b_recv_base'] + rb] = recv
+    ok = True
+    for b in range(plan.bvars.size):
+        peers = plan.brow_peer[plan.brow_ptr[b]:plan.brow_ptr[b + 1]].tolist()
+        want = np.zeros(width[b])
+        for r in sorted(peers + [rank]):
+            want = want + row(r, int(gid[b]))[:width[b]]
+        got = B[lay['total_off'][b]:lay['total_off'][b] + width[b]].numpy()
+        ok = ok and bool((got == want).all())
+    out.put((rank, ok, int(plan.bvars.size), int((np.diff(plan.brow_ptr) >= 2).sum())))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_owner_exchange_gloo_world3():
+    """three real processes over gloo: rows to the owners, the owners' sums, totals back -- two all_to_all_single calls with
+    unequal split lists; every replica ends with the sum of the ranks' rows in ascending rank order, bit for bit"""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_owner_gloo_worker, args=(r, 3, port, out)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _, _ in res), res
+    assert all(nb > 0 for _, _, nb, _ in res) and any(three > 0 for _, _, _, three in res)      # some variable lives on all three ranks
+
+
 def _run_bench(args, env=None, timeout=600):
     import subprocess
     e = dict(os.environ)
