@@ -1018,14 +1018,32 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
         if (grid_path) {
             double gv = exp_core(fma(mine.b, d.gx0, mine.a), sh_tab);
             const double q = exp_core(mine.b * d.gh, sh_tab);
+#ifdef LHVI_DIAG_SITE_MOMENTS          // timing aid (never defined in the product build): what forming the 'simple' rule's site in this epilogue would cost
+            double mz = 0.0, ma = 0.0, mb = 0.0;
+#endif
             for (int t0 = 0; t0 < d.T; t0 += 32) {
                 const double sum = grid_sums32(gv, q, lane);
                 const int t = t0 + grid_owned_point(lane);
                 if (t < d.T && !(lane & 1)) {
                     const double xt = fma((double)t, d.gh, d.gx0);
                     out[n + t] = sum > 0.0 ? fma(kconst * xt, xt, log_table(sum, sh_log)) : -700.0;
+#ifdef LHVI_DIAG_SITE_MOMENTS
+                    const double w = sum * exp_core(kconst * xt * xt, sh_tab);      // = exp(message at x_t)
+                    mz += w; ma += w * xt; mb += w * (xt * xt);
+#endif
                 }
             }
+#ifdef LHVI_DIAG_SITE_MOMENTS
+            {
+                mz = wave_sum(mz); ma = wave_sum(ma); mb = wave_sum(mb);
+                const double rz = rcp_newton(mz);
+                const double mu = ma * rz;
+                double sig = mb * rz - mu * mu;
+                sig = fmax(sig, s.var_threshold * 4.0);
+                // (stored only under a condition no run meets: the arithmetic has to happen, the site array stays the proposal kernel's)
+                if (lane == 0 && mz < -1.0) { out[0] = mu; out[1] = sig; }
+            }
+#endif
         } else if (eligible) {
             // an exponent too close to the double range somewhere on the grid: the direct form, points fetched here
 #pragma nounroll
