@@ -201,13 +201,25 @@ def _kmeans_vec(vals, k, iteration):
     if kk <= 1:
         return None
     cen = distinct[:kk].copy()
+
+    def nearest(x):
+        if kk != 2:
+            return np.abs(cen[None, :] - x[:, None]).argmin(axis=1)
+        # two centroids (the reference's k): argmin of two columns without the 2-D temporaries -- the first wins a tie, and a NaN
+        # centroid (a piece that lost every value) wins outright, the first one first, as ndarray.argmin has it
+        if np.isnan(cen[0]):
+            return np.zeros(x.size, dtype=np.int64)
+        if np.isnan(cen[1]):
+            return np.ones(x.size, dtype=np.int64)
+        return (np.abs(cen[1] - x) < np.abs(cen[0] - x)).astype(np.int64)
+    w = distinct * cnt
     for _ in range(iteration):
-        idx = np.abs(cen[None, :] - distinct[:, None]).argmin(axis=1)
-        tot = np.bincount(idx, weights=distinct * cnt, minlength=kk)
+        idx = nearest(distinct)
+        tot = np.bincount(idx, weights=w, minlength=kk)
         num = np.bincount(idx, weights=cnt, minlength=kk)
         with np.errstate(invalid='ignore', divide='ignore'):
             cen = tot / num
-    return np.abs(cen[None, :] - vals[:, None]).argmin(axis=1)
+    return nearest(vals)
 
 
 def split_evidence_observed(ovals, oc, nc, tracked, k, iteration, epsilon):
