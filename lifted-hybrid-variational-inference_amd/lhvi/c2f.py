@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from . import _abi
 from .flat import FlatGraph, flatten
 from .lifting import CompressedGraph, initial_colors, split_evidence_colors
 
@@ -182,3 +183,304 @@ def run_c2f(g, engine, refiner, iteration, c2f, k_mean_k, k_mean_iteration, draw
             k += 1
             engine.f2v(st2)
     return st2, G2, cg, rvc, fc, history
+
+
+# ---- the same schedule on arrays (ground FlatGraph in, colours resident on the device) ------------------------------------------
+def _rep_of(colors_t, n, size):
+    """first (smallest-index) member of every colour, as a tensor on the colours' device"""
+    import torch
+    dev = colors_t.device
+    return torch.full((n,), size, dtype=torch.int64, device=dev).scatter_reduce_(0, colors_t.long(), torch.arange(size, device=dev), 'amin')
+
+
+def rv_side_graph_t(gflat, tg, rvc_t, fc_t):
+    """``rv_side_graph`` from colour TENSORS (on the device in the product): the rows of the representatives are walked with
+    tensor operations there and only lifted-size arrays reach the host.  `tg`: the ground arrays as tensors (``DeviceGraph`` or
+    ``lifting.TensorGraph``).  Same numbering as the host function: edges ordered by (cluster, first appearance of the factor
+    colour along the representative's row).  Returns (flat, pair_phi [E], rep [V] as a tensor)."""
+    import torch
+    dev = rvc_t.device
+    rl, fl = rvc_t.long(), fc_t.long()
+    nV, nF = int(rl.max().item()) + 1, int(fl.max().item()) + 1
+    rep = _rep_of(rl, nV, gflat.V)
+    var_ptr_g = tg.t['var_ptr'].long()
+    deg = var_ptr_g[rep + 1] - var_ptr_g[rep]
+    start = torch.zeros(nV + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg, 0, out=start[1:])
+    total = int(start[-1].item())
+    slots = torch.repeat_interleave(var_ptr_g[rep] - start[:-1], deg, output_size=total) + torch.arange(total, device=dev)
+    fcol = fl[tg.t['edge_fac'].long()[tg.t['var_edge'].long()[slots]]]
+    owner = torch.repeat_interleave(torch.arange(nV, device=dev), deg, output_size=total)
+    uniq, inv, cnt = torch.unique(owner * nF + fcol, return_inverse=True, return_counts=True)
+    first = torch.full((uniq.numel(),), total, dtype=torch.int64, device=dev).scatter_reduce_(0, inv, torch.arange(total, device=dev), 'amin')
+    order = torch.sort(first, stable=True).indices                   # rows are contiguous per cluster: (cluster, first seen)
+    uniq, cnt = uniq[order], cnt[order]
+    pc, pf = (uniq // nF), (uniq % nF)
+    # evidence value of a cluster: running sum of the members' values / size (SuperRV.get_value), members in ground order
+    value = tg.t['var_value']
+    val = value[rep].clone()
+    mult = torch.bincount(rl, minlength=nV).to(torch.float64)
+    obs_members = torch.nonzero(~torch.isnan(value)).flatten()
+    if obs_members.numel():
+        oc = rl[obs_members]
+        o2 = torch.sort(oc, stable=True).indices
+        sums = torch.segment_reduce(value[obs_members][o2], 'sum', lengths=torch.bincount(oc, minlength=nV), unsafe=True)
+        ob = ~torch.isnan(val)
+        val[ob] = sums[ob] / mult[ob]
+    host = lambda t: t.cpu().numpy()
+    edge_var = host(pc).astype(np.int32)
+    E = int(edge_var.size)
+    var_ptr = np.zeros(nV + 1, dtype=np.int32)
+    np.cumsum(np.bincount(edge_var, minlength=nV), out=var_ptr[1:])
+    rep_h = host(rep)
+    flat = FlatGraph(
+        V=nV, F=E, E=E, fac_ptr=np.arange(E + 1, dtype=np.int32), edge_var=edge_var,
+        edge_fac=np.arange(E, dtype=np.int32), edge_pos=np.zeros(E, dtype=np.int32), edge_canon=np.arange(E, dtype=np.int32),
+        var_ptr=var_ptr, var_edge=np.arange(E, dtype=np.int32), edge_count=host(cnt).astype(np.float64),
+        lifted=True, fac_pot=np.zeros(E, dtype=np.int32), pot_kind=gflat.pot_kind, pot_off=gflat.pot_off,
+        pot_param=gflat.pot_param, var_value=host(val), var_dom=gflat.var_dom[rep_h].astype(np.int32),
+        var_mult=host(mult), fac_mult=np.ones(E),
+        dom_cont=gflat.dom_cont, dom_lo=gflat.dom_lo, dom_hi=gflat.dom_hi, dom_ptr=gflat.dom_ptr, dom_val=gflat.dom_val,
+        domains=gflat.domains)
+    flat.rep_ground = rep_h
+    return flat, host(pf).astype(np.int64), rep
+
+
+def _lookup(keys_sorted, order, wanted, what):
+    pos = np.searchsorted(keys_sorted, wanted)
+    if wanted.size and ((pos >= keys_sorted.size).any() or (keys_sorted[np.minimum(pos, keys_sorted.size - 1)] != wanted).any()):
+        raise KeyError('coarse-to-fine inheritance: a %s pair has no parent edge' % what)
+    return order[pos]
+
+
+def edges_from_factor_side(G1, pair_phi, parent, G2):
+    """for every edge (A, phi) of the variable-side graph G1: the canonical edge of the previous factor-side graph G2 that
+    carries (factor cluster phi, rv cluster parent[A]) -- the first such edge in edge order (HLBP:268-290: a new rv cluster
+    inherits the messages of the cluster it was split from)"""
+    key2 = G2.edge_fac.astype(np.int64) * G2.V + G2.edge_var
+    order = np.argsort(key2, kind='stable')
+    ks = key2[order]
+    first = np.ones(ks.size, dtype=bool)
+    first[1:] = ks[1:] != ks[:-1]
+    e = _lookup(ks[first], order[first], pair_phi * G2.V + parent[G1.edge_var], '(factor cluster, rv cluster)')
+    return G2.edge_canon[e].astype(np.int64)
+
+
+def edges_from_variable_side(G2, parent_f, G1, pair_phi, n_phi):
+    """for every edge of the factor-side graph G2: the edge of the variable-side graph G1 that carries (its rv cluster, the
+    parent of its factor cluster) (HLBP:292-308: a new factor cluster inherits from the one it was split from)"""
+    key1 = G1.edge_var.astype(np.int64) * n_phi + pair_phi
+    order = np.argsort(key1, kind='stable')
+    return _lookup(key1[order], order, G2.edge_var.astype(np.int64) * n_phi + parent_f[G2.edge_fac], '(rv cluster, factor cluster)').astype(np.int64)
+
+
+def split_evidence_observed(ovals, oc, nc, k, iteration, epsilon, use_sqrt):
+    """``lifting.split_evidence_colors`` on the OBSERVED members only (`ovals` their values and `oc` their colours, in ground
+    order; `nc` colours in all): same pieces, same numbering (clusters in ascending colour, piece 0 keeps the colour, the others
+    are numbered from `nc` up).  Returns (new oc, new nc)."""
+    from .c2fvi import _kmeans_vec
+    oc = np.asarray(oc, dtype=np.int64)
+    n = np.bincount(oc, minlength=nc).astype(np.float64)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        mean = np.bincount(oc, weights=ovals, minlength=nc) / n
+        var = np.bincount(oc, weights=(ovals - mean[oc]) ** 2, minlength=nc) / n
+    spread = np.sqrt(np.nan_to_num(var)) if use_sqrt else np.nan_to_num(var)
+    todo = (n > 1) & (spread > epsilon)
+    if not todo.any():
+        return oc, nc
+    sel = np.flatnonzero(todo[oc])
+    order = sel[np.argsort(oc[sel], kind='stable')]
+    cols, start = np.unique(oc[order], return_index=True)
+    bounds = np.append(start, order.size)
+    out = oc.copy()
+    for gi in range(cols.size):
+        loc = order[bounds[gi]:bounds[gi + 1]]
+        assign = _kmeans_vec(ovals[loc], k, iteration)
+        if assign is None:
+            continue
+        for piece in range(1, int(assign.max()) + 1):
+            part = loc[assign == piece]
+            if part.size:
+                out[part] = nc
+                nc += 1
+    return out, nc
+
+
+class FlatRefiner:
+    """single refinement half rounds on device-resident colour tensors (``lhvi_color_refine_factors`` / ``_rvs``): the hash
+    relabelling, repeated through the radix sort when its table overflows"""
+
+    def __init__(self, flat, dg, sym):
+        torch = _abi.require_gpu()
+        self.dg = dg
+        self.sym = _abi.to_dev(np.asarray(sym, dtype=np.uint8))
+        self.ws_bytes = int(_abi.lib().lhvi_color_workspace_bytes(dg.g))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dg.device)
+        self.res = torch.zeros(4, dtype=torch.int32, device=dg.device)
+
+    def _half(self, call, what):
+        for method in (_abi.COLOR_HASH, _abi.COLOR_SORT):
+            call(method)
+            n, collision, overflow = (int(x) for x in self.res.cpu()[:3])
+            if collision:
+                raise _abi.LhviError('colour refinement fingerprint collision (%s side)' % what)
+            if not overflow:
+                return n
+        raise _abi.LhviError('colour refinement: table overflow reported by the sort path')
+
+    def factors(self, rvc, fc):
+        import torch
+        out = torch.empty_like(fc)
+        l = _abi.lib()
+        self._half(lambda m: _abi.check(l.lhvi_color_refine_factors(
+            self.dg.g, _abi.ptr(self.sym), _abi.ptr(rvc), _abi.ptr(fc), _abi.ptr(out), _abi.ptr(self.res), _abi.ptr(self.ws),
+            self.ws_bytes, m, _abi.stream_ptr())), 'factor')
+        return out
+
+    def rvs(self, fc, rvc):
+        import torch
+        out = torch.empty_like(rvc)
+        l = _abi.lib()
+        self._half(lambda m: _abi.check(l.lhvi_color_refine_rvs(
+            self.dg.g, _abi.ptr(fc), _abi.ptr(rvc), _abi.ptr(out), _abi.ptr(self.res), _abi.ptr(self.ws), self.ws_bytes, m,
+            _abi.stream_ptr())), 'variable')
+        return out
+
+
+def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_iteration, draw, rvc0, fc0, observer=None,
+                 keep_history=False, timing=None):
+    """``run_c2f`` for a ground ``FlatGraph`` (``RelationalGraph.ground_flat``, ``flatten(g)``): no Python object per ground atom.
+    The colour arrays are tensors on `tg`'s device and stay there: the half rounds of the refinement (`refiner`: ``FlatRefiner``
+    in the product), the representatives and the rows they contribute to the two lifted graphs of a sweep (``rv_side_graph_t``,
+    ``lifting.lift_flat``) run there; what reaches the host per sweep is the colours of the OBSERVED variables (the k-means
+    evidence splits) and lifted-size arrays.  `rvc0`, `fc0`: the coarse initial colours (``initial_colors_flat(gflat, False)``).
+    `timing`: optional dict that receives per-sweep lists of seconds (`lift`: both re-liftings incl. refinement,
+    `setup`: building the two solver states, `sweep`: the message kernels).
+    Returns (final state, final lifted flat (factor side), rv colours, factor colours (tensors), history)."""
+    import time
+    import torch
+    from .lifting import lift_flat
+    dev = tg.device
+    values = gflat.var_value
+    obs_idx = np.flatnonzero(~np.isnan(values))
+    ovals = values[obs_idx]
+    obs_idx_t = torch.from_numpy(obs_idx).to(dev)
+    as_t = lambda a, dt=torch.int32: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+    rvc, fc = as_t(rvc0), as_t(fc0)
+    nc = int(rvc.max().item()) + 1
+    sync = torch.cuda.synchronize if dev.type == 'cuda' else (lambda: None)
+    clock = {'lift': 0.0, 'setup': 0.0, 'sweep': 0.0}
+
+    def tick(name, t0):
+        if timing is not None:
+            sync()
+            clock[name] += time.perf_counter() - t0
+        return time.perf_counter()
+
+    def observed_colours():
+        return rvc[obs_idx_t].cpu().numpy().astype(np.int64)
+
+    def split_evidence(k, its, epsilon, use_sqrt):
+        nonlocal rvc, nc
+        if not obs_idx.size:
+            return
+        oc = observed_colours()
+        new_oc, nc2 = split_evidence_observed(ovals, oc, nc, k, its, epsilon, use_sqrt)
+        moved = np.flatnonzero(new_oc != oc)
+        if moved.size:
+            rvc = rvc.clone()
+            rvc[obs_idx_t[torch.from_numpy(moved).to(dev)]] = as_t(new_oc[moved])
+        nc = nc2
+
+    def refine_rvs():
+        nonlocal rvc, nc
+        rvc = refiner.rvs(fc, rvc)
+        nc = int(rvc.max().item()) + 1
+
+    def evidence_variance():
+        if not obs_idx.size:
+            return np.zeros(0)
+        oc = observed_colours()
+        n = np.bincount(oc, minlength=nc).astype(np.float64)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            mean = np.bincount(oc, weights=ovals, minlength=nc) / n
+            var = np.bincount(oc, weights=(ovals - mean[oc]) ** 2, minlength=nc) / n
+        return var[n > 0]
+
+    def record():
+        return (rvc.cpu().numpy().copy(), fc.cpu().numpy().copy()) if (keep_history or observer is not None) else None
+
+    t0 = time.perf_counter()
+    split_evidence(2, 50, 0.0, True)                                                # HLBP:440
+    fc = refiner.factors(rvc, fc)
+    refine_rvs()
+    history = []
+    G1, pair_phi, rep = rv_side_graph_t(gflat, tg, rvc, fc)
+    t0 = tick('lift', t0)
+    st1 = engine.make(G1)
+    engine.init(st1)
+    t0 = tick('setup', t0)
+    k = 0
+    history.append(record())
+    engine.install(st1, draw(k, G1, engine.host(engine.get(st1, 'q'))))
+    k += 1
+    var = evidence_variance()
+    epsilon = float(var.max()) if var.size else 0                                   # HLBP:460-465
+    d = (epsilon - c2f) / iteration
+    epsilon -= d
+    st2 = G2 = None
+    t0 = tick('sweep', t0)
+    per_sweep = []
+    for i in range(iteration):
+        mark = dict(clock)
+        if i > 0:
+            # ---- split_evidence + split_rvs (HLBP:475-485)
+            old_rvc = rvc
+            split_evidence(k_mean_k, k_mean_iteration, epsilon, False)
+            epsilon = max(epsilon - d, c2f)
+            refine_rvs()
+            G1, pair_phi, rep = rv_side_graph_t(gflat, tg, rvc, fc)
+            parent = old_rvc.long()[rep].cpu().numpy()
+            pe = edges_from_factor_side(G1, pair_phi, parent, G2)
+            t0 = tick('lift', t0)
+            new1 = engine.make(G1)
+            for name in ('f2v', 'eta'):
+                engine.set(new1, name, engine.gather(engine.get(st2, name), pe))
+            for name in ('q', 'particles', 'old_particles', 'uniq'):
+                engine.set(new1, name, engine.gather(engine.get(st2, name), parent))
+            st1 = new1
+            t0 = tick('setup', t0)
+        engine.v2f(st1)
+        last = i == iteration - 1
+        if not last:
+            engine.proposal(st1)
+        t0 = tick('sweep', t0)
+        # ---- split_factors (HLBP:509-513; HLBP:536 for the last sweep)
+        old_fc = fc
+        fc = refiner.factors(rvc, fc)
+        G2 = lift_flat(gflat, rvc, fc, dg=tg)
+        G2.rep_ground = G1.rep_ground
+        nF2 = G2.F
+        parent_f = old_fc.long()[_rep_of(fc, nF2, gflat.F)].cpu().numpy()
+        n_phi = int(max(pair_phi.max() if pair_phi.size else 0, parent_f.max() if parent_f.size else 0)) + 1
+        pe = edges_from_variable_side(G2, parent_f, G1, pair_phi, n_phi)
+        t0 = tick('lift', t0)
+        st2 = engine.make(G2)
+        for name in ('v2f', 'eta'):
+            engine.set(st2, name, engine.gather(engine.get(st1, name), pe))
+        for name in ('q', 'particles', 'old_particles', 'uniq'):
+            engine.set(st2, name, engine.get(st1, name))
+        t0 = tick('setup', t0)
+        if not last:
+            history.append(record())
+            if observer is not None:
+                observer(k, history[-1][0], old_fc.cpu().numpy(), G1, pair_phi, st1)
+            engine.install(st2, draw(k, G2, engine.host(engine.get(st2, 'q'))))
+            k += 1
+            engine.f2v(st2)
+            t0 = tick('sweep', t0)
+        per_sweep.append({name: clock[name] - mark[name] for name in clock})
+    if timing is not None:
+        timing['per_sweep'] = per_sweep
+        timing['total'] = dict(clock)
+    return st2, G2, rvc, fc, history

@@ -435,11 +435,23 @@ def _lift_reduce_host(flat, rv_color, f_color):
                 color_of_edge_var=lambda g_edge: rv_color[flat.edge_var[g_edge]])
 
 
+class TensorGraph:
+    """the ground arrays the lifting reductions read, as torch tensors on any device (``DeviceGraph.t`` on the GPU; CPU tensors
+    in the CPU tests of the host logic)"""
+
+    def __init__(self, flat, device='cpu'):
+        import torch
+        self.flat = flat
+        self.t = {name: torch.from_numpy(np.ascontiguousarray(getattr(flat, name))).to(device)
+                  for name in ('fac_ptr', 'edge_var', 'edge_fac', 'var_ptr', 'var_edge', 'var_value')}
+        self.device = self.t['fac_ptr'].device
+
+
 def _lift_reduce_device(flat, dg, rvc, fc):
     """the same reductions on the device, for colour arrays that are already there (``refine_flat(device_out=True)``): only
     lifted-size arrays come back to the host.  Evidence sums run over each cluster's observed members in ground order (one
     thread per cluster segment), i.e. in the order of the host path."""
-    torch = _abi.require_gpu()
+    import torch
     dev = rvc.device
     rl, fl = rvc.long(), fc.long()
     nV, nF = int(rl.max().item()) + 1, int(fl.max().item()) + 1
@@ -471,7 +483,7 @@ def _lift_reduce_device(flat, dg, rvc, fc):
     host = lambda t: t.cpu().numpy()
     return dict(nV=nV, nF=nF, rep_v=host(rep_v), rep_f=host(rep_f), mult_v=host(mult_v), mult_f=host(mult_f), val=host(val),
                 pairs=(host(uniq), host(first), host(cnt)),
-                color_of_edge_var=lambda g_edge: host(rl[edge_var_d[_abi.to_dev(np.asarray(g_edge, dtype=np.int64))].long()]))
+                color_of_edge_var=lambda g_edge: host(rl[edge_var_d[torch.from_numpy(np.asarray(g_edge, dtype=np.int64)).to(dev)].long()]))
 
 
 def lift_flat(flat, rv_color, f_color, dg=None):

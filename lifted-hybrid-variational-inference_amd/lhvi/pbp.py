@@ -120,6 +120,8 @@ class _ParticleSweep:
         rr[:, 4:6] = np.ascontiguousarray(flat.dom_hi[pdom], dtype=np.float64).view(np.int32).reshape(-1, 2)
         self.resample_vars = _abi.to_dev(rr) if pv.size else None
         self._static_rows = False
+        static = np.flatnonzero(~(flat.var_hidden & flat.var_cont))
+        self._static_idx = _abi.to_dev(static.astype(np.int64)) if static.size else None
         # rows longer than prop_slice entries go in as slices of that length, a wavefront each, ahead of the ordinary records
         self.prop_hub = self.prop_partial = None
         self.n_prop_hub = 0
@@ -332,9 +334,13 @@ class _ParticleSweep:
             gid = _abi.ptr(getattr(self, 'var_gid', None))
             if self.listed_resample and self.n <= 64 and getattr(self, 'resample_vars', None) is not None:
                 if not self._static_rows:
-                    # states of the discrete variables and the masks of the discrete / observed ones: once per buffer
-                    for buf in (self.old_particles, self.particles):
-                        _abi.check(l.lhvi_pbp_resample_uniq(self.dg.g, s, gid, int(self.seed), int(k), _abi.ptr(buf), _abi.ptr(self.uniq), st))
+                    # first device draw of this state: the full (unlisted) draw into the CURRENT buffer only -- the other one may
+                    # hold the particles the v -> f messages were evaluated at (a coarse-to-fine state, or one a host sampler
+                    # filled) and must keep them; it only receives the rows no later listed draw writes: the states of the
+                    # discrete variables and the rows of the observed ones
+                    _abi.check(l.lhvi_pbp_resample_uniq(self.dg.g, s, gid, int(self.seed), int(k), _abi.ptr(self.particles), _abi.ptr(self.uniq), st))
+                    if self._static_idx is not None:
+                        self.old_particles.index_copy_(0, self._static_idx, self.particles.index_select(0, self._static_idx))
                     self._static_rows = True
                     self._views = {}
                     return
@@ -756,28 +762,77 @@ class HybridLBP(_ParticleSweep):
         self.sampler, self.seed = sampler, seed
         self.query_cache = dict()
 
+    c2f_on_objects = False          # run(c2f >= 0) through Python objects per cluster (lhvi.c2f.run_c2f) instead of arrays
+
     @classmethod
-    def on_flat(cls, lifted_flat, n=50, proposal_approximation='EP', sampler='device', seed=0):
-        """The lifted sweep on a ready-made lifted ``FlatGraph`` (``lifting.lift_flat`` of a stable partition, e.g. of a
-        relational template grounded straight into arrays: ``ground_flat`` -> ``initial_colors_flat`` -> ``refine_flat`` ->
-        ``lift_flat``) -- no Python object per ground atom anywhere.  Run with ``run_flat``; query with the batched calls
-        (``belief_rv_all``, ``map_all``, ``belief_all``, ``probability_all``), whose rows are clusters."""
-        if not lifted_flat.lifted:
-            raise ValueError('on_flat expects a lifted FlatGraph (lifting.lift_flat)')
+    def on_flat(cls, flat, n=50, k_mean_k=2, k_mean_iteration=10, proposal_approximation='EP', sampler='device', seed=0):
+        """The lifted sweep on arrays -- no Python object per ground atom anywhere.  `flat` is either a ready-made lifted
+        ``FlatGraph`` (``lifting.lift_flat`` of a stable partition) or a GROUND one (``RelationalGraph.ground_flat``,
+        ``flatten(g)``, ``build_flat``): then ``run_flat`` does the lifting itself, to the stable partition (``c2f=-1``) or coarse
+        to fine (``c2f >= 0``).  Query with the batched calls (``belief_rv_all``, ``map_all``, ``belief_all``,
+        ``probability_all``: rows are clusters, stable partition) or per ground variable with ``belief_rv_ground``."""
         self = cls.__new__(cls)
         self.g = None
-        self.n, self.k_mean_k, self.k_mean_iteration = n, 2, 10
+        self.n, self.k_mean_k, self.k_mean_iteration = n, k_mean_k, k_mean_iteration
         self.proposal_approximation, self.sampler, self.seed = proposal_approximation, sampler, seed
         self.query_cache = dict()
-        self._flat_in = lifted_flat
+        self._flat_in = flat
         return self
 
-    def run_flat(self, iteration=10):
-        """``run(iteration, c2f=-1)`` for a solver made by ``on_flat`` (the partition is stable by construction)"""
+    def run_flat(self, iteration=10, c2f=-1, timing=None):
+        """``run(iteration, c2f)`` for a solver made by ``on_flat``.  ``timing``: dict that receives the per-sweep seconds of a
+        coarse-to-fine run (``lhvi.c2f.run_c2f_flat``)."""
         self.query_cache = dict()
-        self._setup(None, flat=self._flat_in)
-        self._run_sweeps(iteration)
-        self._stable_partition = True
+        flat = self._flat_in
+        if flat.lifted:
+            if c2f != -1:
+                raise ValueError('a coarse-to-fine run starts from the GROUND graph (on_flat(ground_flat))')
+            self._setup(None, flat=flat)
+            self._run_sweeps(iteration)
+            self._stable_partition = True
+            return
+        from .lifting import initial_colors_flat, lift_flat, refine_flat
+        dg = _abi.DeviceGraph(flat)
+        if c2f == -1:
+            rvc0, fc0, sym = initial_colors_flat(flat, True)
+            rvc, fc = refine_flat(flat, sym, rvc0, fc0, dg=dg, device_out=True)
+            self._ground = dict(flat=flat, dg=dg, rvc=rvc, fc=fc)
+            self._setup(None, flat=lift_flat(flat, rvc, fc, dg=dg))
+            self._run_sweeps(iteration)
+            self._stable_partition = True
+            return
+        self._run_c2f_arrays(flat, dg, iteration, c2f, timing, keep_history=getattr(self, 'c2f_keep_history', False))
+
+    def _c2f_draw(self):
+        def draw(k, flat, q_host):
+            if callable(self.sampler):
+                return self.sampler(k, flat, q_host)
+            if self.sampler == 'device':
+                return None                       # engine.install draws on the device
+            out = np.zeros((flat.V, self.n))      # the reference's stream: standard_normal in cluster order (HLBP:75-87)
+            for v in range(flat.V):
+                if flat.var_hidden[v] and flat.var_cont[v]:
+                    dmn = flat.var_dom[v]
+                    z = np.random.standard_normal(self.n)
+                    out[v] = np.clip(z * sqrt(q_host[v, 1]) + q_host[v, 0], flat.dom_lo[dmn], flat.dom_hi[dmn])
+            return out
+        return draw
+
+    def _run_c2f_arrays(self, gflat, dg, iteration, c2f, timing=None, keep_history=False):
+        """``run(iteration, c2f >= 0)`` on arrays (``lhvi.c2f.run_c2f_flat``): colours, refinement and both re-liftings of every
+        sweep on the device"""
+        from . import c2f as _c2f
+        from .lifting import initial_colors_flat
+        rvc0, fc0, sym = initial_colors_flat(gflat, False)                           # HLBP:432
+        observer = getattr(self, 'c2f_observer', None)
+        st, G2, rvc, fc, history = _c2f.run_c2f_flat(
+            gflat, dg, _DeviceEngine(self), _c2f.FlatRefiner(gflat, dg, sym), iteration, c2f, self.k_mean_k, self.k_mean_iteration,
+            self._c2f_draw(), rvc0, fc0, observer=observer, keep_history=keep_history, timing=timing)
+        self.c2f_history = history
+        self._stable_partition = False
+        self.__dict__.update({k: v for k, v in st.__dict__.items()})
+        self._ground = dict(flat=gflat, dg=dg, rvc=rvc, fc=fc)
+        self._views = {}
 
     def run(self, iteration=10, log_enable=False, c2f=-1):
         """``HybridLBP.run`` (HLBP:430-536).  ``c2f == -1``: colour passing to the stable partition, then the sweeps.
@@ -786,6 +841,7 @@ class HybridLBP(_ParticleSweep):
         every new cluster inherits the messages, sites, proposal and particles of the cluster it came from."""
         self.query_cache = dict()
         self._stable_partition = False
+        self._ground = None
         if c2f == -1:
             self.g.init_cluster(True)
             prev = -1
@@ -799,30 +855,76 @@ class HybridLBP(_ParticleSweep):
             self._stable_partition = True
             return
         from . import c2f as _c2f
+        ground = self.g.g
+        if not self.c2f_on_objects:
+            # the ground objects are flattened once; clusters become objects again only at the end, for the rv.cluster queries
+            from .lifting import CompressedGraph
+            gflat = flatten(ground, require_device_potentials=True)
+            self._run_c2f_arrays(gflat, _abi.DeviceGraph(gflat), iteration, c2f, keep_history=True)
+            cg = CompressedGraph(ground)
+            cg.set_colors(self._ground['rvc'].cpu().numpy(), self._ground['fc'].cpu().numpy())
+            self.g = cg
+            lf = self.flat
+            lf.rvs, lf.factors = sorted(cg.rvs), sorted(cg.factors)
+            lf.var_index = {c: i for i, c in enumerate(lf.rvs)}
+            lf.fac_index = {c: i for i, c in enumerate(lf.factors)}
+            return
         engine = _DeviceEngine(self)
-
-        def draw(k, flat, q_host):
-            if callable(self.sampler):
-                return self.sampler(k, flat, q_host)
-            if self.sampler == 'device':
-                return None                       # engine.install draws on the device
-            out = np.zeros((flat.V, self.n))      # the reference's stream: standard_normal in cluster order (HLBP:75-87)
-            for v in range(flat.V):
-                if flat.var_hidden[v] and flat.var_cont[v]:
-                    dmn = flat.var_dom[v]
-                    z = np.random.standard_normal(self.n)
-                    out[v] = np.clip(z * sqrt(q_host[v, 1]) + q_host[v, 0], flat.dom_lo[dmn], flat.dom_hi[dmn])
-            return out
-
-        refiner = _c2f.DeviceRefiner(self.g.g)
-        st, flat, cg, rvc, fc, history = _c2f.run_c2f(self.g.g, engine, refiner, iteration, c2f, self.k_mean_k,
-                                                      self.k_mean_iteration, draw,
+        refiner = _c2f.DeviceRefiner(ground)
+        st, flat, cg, rvc, fc, history = _c2f.run_c2f(ground, engine, refiner, iteration, c2f, self.k_mean_k,
+                                                      self.k_mean_iteration, self._c2f_draw(),
                                                       observer=getattr(self, 'c2f_observer', None))
         self.c2f_history = history
         self.g = cg
         # adopt the final factor-side state for the queries
         self.__dict__.update({k: v for k, v in st.__dict__.items()})
         self._views = {}
+
+    # ---- queries of GROUND variables on arrays (a solver made by on_flat) --------------------------------------------------------
+    def _ground_pairs(self):
+        """(ground variable, lifted edge, multiplicity) of every distinct pair: ``belief_rv_query`` (HLBP:313-317) walks the
+        GROUND rv's factors f and evaluates the message of (f.cluster, position of the rv)"""
+        G = self._ground
+        if 'pairs' not in G:
+            torch = _abi.require_gpu()
+            gf, lf, dg = G['flat'], self.flat, G['dg']
+            fcl = G['fc'].long()
+            dev = fcl.device
+            efac = dg.t['edge_fac'].long()
+            pos = torch.arange(gf.E, device=dev) - dg.t['fac_ptr'].long()[efac]
+            lifted_e = _abi.to_dev(lf.edge_canon.astype(np.int64))[_abi.to_dev(lf.fac_ptr.astype(np.int64))[fcl[efac]] + pos]
+            slot_edge = dg.t['var_edge'].long()
+            slot_var = dg.t['slot_var'].long()
+            key, cnt = torch.unique(slot_var * max(lf.E, 1) + lifted_e[slot_edge], return_counts=True)     # sorted: grouped per variable
+            var = key // max(lf.E, 1)
+            ptr = torch.zeros(gf.V + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(torch.bincount(var, minlength=gf.V), 0, out=ptr[1:])
+            G['pairs'] = (ptr, (key % max(lf.E, 1)).to(torch.int32), cnt.to(torch.float64))
+        return G['pairs']
+
+    def belief_rv_ground(self, vs, xs):
+        """log-beliefs ``belief_rv_query(x, rv)`` of the GROUND variables `vs` (indices into the ground FlatGraph) at `xs[i, :]`
+        (the same number of points each), one launch.  Works after any ``run_flat`` (the partition need not be stable)."""
+        torch = _abi.require_gpu()
+        ptr, edge, mult = self._ground_pairs()
+        dev = edge.device
+        vs_t = _abi.to_dev(np.asarray(vs, dtype=np.int64))
+        x = xs if torch.is_tensor(xs) else _abi.to_dev(np.ascontiguousarray(xs, dtype=np.float64))
+        x = x.reshape(vs_t.numel(), -1)
+        deg = ptr[vs_t + 1] - ptr[vs_t]
+        total = int(deg.sum().item())
+        owner = torch.repeat_interleave(torch.arange(vs_t.numel(), device=dev), deg, output_size=total)
+        start = torch.cumsum(deg, 0) - deg
+        idx = ptr[vs_t][owner] + (torch.arange(total, device=dev) - start[owner])
+        xe = x[owner].contiguous()
+        out = torch.empty_like(xe)
+        if total:
+            _abi.check(_abi.lib().lhvi_pbp_edge_points(self.dg.g, self.dg.p, self._struct(), _abi.ptr(self.v2f), total,
+                                                       _abi.ptr(edge[idx].contiguous()), int(x.shape[1]), _abi.ptr(xe), _abi.ptr(out),
+                                                       _abi.stream_ptr()))
+        res = torch.zeros_like(x)
+        res.index_add_(0, owner, out * mult[idx][:, None])
+        return res
 
     def _var_of(self, ground_rv):
         return ground_rv                      # queries walk the GROUND rv's factors, like belief_rv_query (HLBP:313-317)

@@ -354,3 +354,73 @@ if 'vi_ground' in which:
     t = ev_time(vi._grad)
     out(config='ground VI gradient + free energy, RGM C=1000 B=500, K=2 T=3', factors=int(flat.F), edges=int(flat.E), grad_ms=t,
         factors_per_s=flat.F / (t * 1e-3), quadrature_nodes_per_s=flat.F * 2 * 9 / (t * 1e-3))
+
+if 'c2f_pbp' in which:
+    # the particle coarse-to-fine run the reference's demos make (Demo/RGM/demo.py:20-21: HybridLBP(g, n=10, 'simple').run(10, c2f=0)
+    # with recession = 25 observed; Demo/RGM/RGMKLDivergence.py:54-55: n=20, run(15, c2f=0) on Demo/Data/RGM/0..4: 83 of 1 111 atoms
+    # observed ~U(-30, 30)), on arrays (lhvi.c2f.run_c2f_flat).  Per sweep: seconds in the two re-liftings (refinement half rounds on
+    # the device + building both lifted graphs), in building the two solver states (host), and in the message kernels; the C oracle
+    # driving the same schedule on the host beside it (CPU baseline, labelled; reference-size graphs only).
+    from lhvi.pbp import HybridLBP
+    from lhvi import c2f as _c2f
+
+    def demo_flat():
+        flat, _, _, _ = synth.rgm_flat(C=100, B=10, n_values=0, evidence_ratio=0.0, seed=0)
+        val = np.full(flat.V, np.nan)
+        val[0] = 25.0
+        flat.var_value = val
+        return flat
+
+    def kl_flat():
+        flat, _, _, _ = synth.rgm_flat(C=100, B=10, n_values=0, evidence_ratio=0.0, seed=0)
+        rng = np.random.default_rng(0)
+        val = np.full(flat.V, np.nan)
+        ev = rng.choice(np.arange(1, flat.V), 83, replace=False)
+        val[ev] = rng.uniform(-30, 30, 83)
+        flat.var_value = val
+        return flat
+
+    def cpu_baseline_c2f(flat, n, its):
+        """CPU baseline (labelled): the same schedule driven by the C oracle and the exact CPU refinement on this box's host cores"""
+        from oracle.engines import OracleEngine, OracleTensorRefiner
+        rvc0, fc0, sym = lifting.initial_colors_flat(flat, False)
+        rng = np.random.default_rng(0)
+
+        def draw(k, lf, q):
+            lo, hi = lf.dom_lo[lf.var_dom][:, None], lf.dom_hi[lf.var_dom][:, None]
+            return np.clip(rng.standard_normal((lf.V, n)) * np.sqrt(np.nan_to_num(q[:, 1:2], nan=1.0)) + np.nan_to_num(q[:, 0:1]), lo, hi)
+        t0 = time.perf_counter()
+        _c2f.run_c2f_flat(flat, lifting.TensorGraph(flat), OracleEngine(n, False), OracleTensorRefiner(flat, sym), its, 0, 2, 10, draw, rvc0, fc0)
+        return time.perf_counter() - t0
+
+    cases = [('RGM 100 x 10, recession = 25 observed (Demo/RGM/demo.py), n=10, run(10, c2f=0)', demo_flat, 10, 10, True),
+             ('RGM 100 x 10, 83 atoms observed ~U(-30,30) (Demo/Data/RGM/0 shape), n=20, run(15, c2f=0)', kl_flat, 20, 15, True),
+             ('RGM 2000 x 1250 (10 M ground edges, cfg 5 evidence), n=10, run(10, c2f=0)', lambda: synth.rgm_structured_flat()[0], 10, 10, False)]
+    if os.environ.get('C2F_SMALL_ONLY'):
+        cases = cases[:2]
+    for label, make, n_, its, with_cpu in cases:
+        flat = make()
+        wall, timing = None, None
+        for rep in range(2):                                    # the first pass pays code-object loads and allocator growth
+            bp = HybridLBP.on_flat(flat, n=n_, proposal_approximation='simple', sampler='device', seed=1)
+            timing = {}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            bp.run_flat(its, c2f=0, timing=timing)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+        untimed = None
+        bp2 = HybridLBP.on_flat(flat, n=n_, proposal_approximation='simple', sampler='device', seed=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bp2.run_flat(its, c2f=0)
+        torch.cuda.synchronize()
+        untimed = time.perf_counter() - t0
+        ps = timing['per_sweep']
+        med = lambda name: float(np.median([s[name] for s in ps[1:]])) * 1e3
+        out(config='particle coarse-to-fine on arrays: ' + label, ground_edges=int(flat.E), rv_clusters_final=int(bp.flat.V),
+            lifted_edges_final=int(bp.flat.E), wall_s_with_phase_syncs=wall, wall_s=untimed,
+            per_sweep_ms_median=dict(relift=med('lift'), build_states=med('setup'), message_kernels=med('sweep')),
+            totals_s=timing['total'], finite=bool(torch.isfinite(bp.v2f).all().item()),
+            cpu_oracle_same_schedule_s=(cpu_baseline_c2f(flat, n_, its) if with_cpu else None), cpu_cores_used=1)
+        del bp, bp2

@@ -1009,3 +1009,98 @@ def test_small_particle_kernel_matches_the_one_edge_per_wave_kernels(api, n, poi
     api.check(l.lhvi_pbp_f2v(a.dg.g, a.dg.p, sb, api.ptr(a.v2f), api.ptr(out_b), st))
     oa, ob = out_a.cpu().numpy()[hid][:, cols], out_b.cpu().numpy()[hid][:, cols]
     np.testing.assert_allclose(oa, ob, rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize('name', C2F_CASES)
+def test_coarse_to_fine_on_arrays_equals_the_object_path(api, golden_dir, name):
+    """``HybridLBP.run(c2f >= 0)`` goes through arrays (``lhvi.c2f.run_c2f_flat``: colours, refinement and both re-liftings of
+    every sweep on the device); ``c2f_on_objects`` keeps the path through Python objects per cluster.  Same colour arrays at
+    every draw and identical tables at the end -- and ``on_flat(ground).run_flat(c2f)`` is the same run without any object."""
+    import torch
+    from lhvi.flat import flatten
+    from lhvi.pbp import HybridLBP
+    z, meta = load_npz(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    samples = z['samples']
+    inject = lambda k, flat, q: samples[k][flat.rep_ground]
+    runs = []
+    for on_objects in (True, False):
+        bp = HybridLBP(g, n=meta['n'], proposal_approximation=meta['approx'], sampler=inject)
+        bp.c2f_on_objects = on_objects
+        bp.run(meta['iterations'], c2f=meta['c2f'])
+        runs.append(bp)
+    a, b = runs
+    for (ra, fa), (rb, fb) in zip(a.c2f_history, b.c2f_history):
+        assert (ra == rb).all() and (fa == fb).all()
+    for name_ in ('f2v', 'v2f', 'eta', 'q_dev', 'particles', 'old_particles', 'uniq'):
+        assert torch.equal(getattr(a, name_), getattr(b, name_)), name_
+    hid = [i for i, rv in enumerate(rvs) if rv.value is None]
+    # (b ran last: rv.cluster / f.cluster point at ITS cluster objects -- SURVEY quirk 6 -- so only b can be queried)
+    qb = b.belief_rv_batch([rvs[i] for i in hid], z['query_x'][hid])
+    np.testing.assert_allclose(qb, z['query_logb'][hid], rtol=1e-8, atol=1e-6)
+    # no objects at all
+    gflat = flatten(g, require_device_potentials=True)
+    c = HybridLBP.on_flat(gflat, n=meta['n'], proposal_approximation=meta['approx'], sampler=inject)
+    c.run_flat(meta['iterations'], c2f=meta['c2f'])
+    for name_ in ('f2v', 'v2f', 'eta', 'q_dev', 'particles'):
+        assert torch.equal(getattr(b, name_), getattr(c, name_)), name_
+    qc = c.belief_rv_ground(hid, z['query_x'][hid]).cpu().numpy()
+    np.testing.assert_allclose(qc, qb, rtol=1e-12, atol=1e-12)
+
+
+def test_coarse_to_fine_with_the_device_sampler_listed_draws_change_nothing(api, golden_dir):
+    """a coarse-to-fine state is rebuilt every sweep with the buffers of the previous one handed in: its first device draw may
+    not touch `old_particles` (the particles the v -> f messages were evaluated at).  The listed draw (hidden continuous
+    variables only) against the full one: bit for bit; and the f -> v tables against the C oracle on the final lifted graph"""
+    import torch
+    from lhvi.flat import flatten
+    from lhvi.pbp import HybridLBP
+    z, meta = load_npz(golden_dir, 'hlbp_c2f_rgm')
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    gflat = flatten(g, require_device_potentials=True)
+    runs = []
+    for listed in (True, False):
+        bp = HybridLBP.on_flat(gflat, n=meta['n'], proposal_approximation=meta['approx'], sampler='device', seed=3)
+        bp.listed_resample = listed
+        bp.run_flat(4, c2f=0)
+        runs.append(bp)
+    a, b = runs
+    for name_ in ('f2v', 'v2f', 'eta', 'q_dev', 'particles', 'old_particles', 'uniq'):
+        assert torch.equal(getattr(a, name_), getattr(b, name_)), name_
+    # (the full draw writes `particles` only, so equality with it shows the listed one left `old_particles` alone); the final
+    # state's messages at query points against the C oracle on the same lifted graph, particles and v -> f tables
+    from oracle import oracle
+    o = oracle.PbpOracle(a.flat, meta['n'], ep=meta['approx'] == 'EP', epbp=False, var_threshold=5)
+    o.set_particles(a.particles.cpu().numpy())
+    o.v2f = a.v2f.cpu().numpy().copy()
+    lf = a.flat
+    edges = np.flatnonzero(lf.var_hidden[lf.edge_var] & (lf.edge_canon == np.arange(lf.E)))
+    x = np.tile(np.linspace(-8, 8, 7), (edges.size, 1))
+    got = torch.empty(edges.size, 7, dtype=torch.float64, device=a.v2f.device)
+    api.check(api.lib().lhvi_pbp_edge_points(a.dg.g, a.dg.p, a._struct(), api.ptr(a.v2f), int(edges.size),
+                                             api.ptr(api.to_dev(edges.astype(np.int32))), 7, api.ptr(api.to_dev(x)), api.ptr(got),
+                                             api.stream_ptr()))
+    np.testing.assert_allclose(got.cpu().numpy(), o.edge_points(edges, x), rtol=1e-9, atol=1e-8)
+
+
+def test_first_device_draw_after_host_draws_keeps_the_old_particles(api):
+    """mixed samplers: two host draws, then the device sampler -- the listed form's first call fills the static rows of the
+    other buffer but leaves its particles (the previous sample) alone"""
+    import torch
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    flat = synth.hybrid_mrf_flat(V=600, deg=4, seed=4)
+    rng = np.random.default_rng(0)
+    host = [rng.uniform(-5, 5, (flat.V, 16)) for _ in range(2)]
+    bp = EPBP(None, n=16, proposal_approximation='simple', sampler=lambda k, f, q: host[k], seed=1)
+    bp._setup(None, flat=flat)
+    _init(api, bp)
+    bp.sweep(last=False)                 # second host draw
+    prev = bp.particles.clone()
+    bp.sampler = 'device'
+    bp._generate_sample()
+    cont = torch.from_numpy(flat.var_hidden & flat.var_cont).to(prev.device)
+    assert torch.equal(bp.old_particles[cont], prev[cont])          # (rows of observed variables are never read)
+    assert not torch.equal(bp.particles[cont], prev[cont])
+    disc = torch.from_numpy(flat.var_hidden & ~flat.var_cont).to(prev.device)
+    assert torch.equal(bp.particles[disc][:, :2], prev[disc][:, :2]) and torch.equal(bp.old_particles[disc][:, :2], prev[disc][:, :2])

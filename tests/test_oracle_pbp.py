@@ -170,24 +170,7 @@ class OracleRefiner:
         return oracle.refine_rvs(self.gflat, fc, rvc)[0]
 
 
-class OracleEngine:
-    """lhvi.c2f engine backed by the CPU oracle (PbpOracle states)"""
-
-    def __init__(self, n, ep):
-        self.n, self.ep = n, ep
-
-    def make(self, flat):
-        return oracle.PbpOracle(flat, self.n, ep=self.ep, epbp=False, var_threshold=5)
-
-    get = staticmethod(getattr)
-    set = staticmethod(lambda st, name, value: setattr(st, name, np.ascontiguousarray(value)))
-    host = staticmethod(lambda a: a)
-    gather = staticmethod(lambda a, idx: np.ascontiguousarray(a[np.asarray(idx, dtype=np.int64)]))
-    init = staticmethod(lambda st: st.init())
-    v2f = staticmethod(lambda st: st.step_v2f())
-    proposal = staticmethod(lambda st: st.step_proposal())
-    f2v = staticmethod(lambda st: st.step_f2v())
-    install = staticmethod(lambda st, p: st.set_particles(p))
+from oracle.engines import OracleEngine, OracleTensorRefiner      # noqa: E402  (shared with the scripts' CPU-baseline legs)
 
 
 def ground_edges(flat, ground_rv):
@@ -306,3 +289,65 @@ def test_pure_python_restatement_matches_reference(golden_dir, name):
     for i in hid[:4]:
         got = [bp.belief_rv(x, rvs[i]) for x in z['query_x'][i]]
         np.testing.assert_allclose(got, z['query_logb'][i], rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.parametrize('name', C2F_CASES)
+def test_hlbp_c2f_on_arrays_equals_the_object_path(golden_dir, name):
+    """``run_c2f_flat`` (ground FlatGraph in, colour tensors, both lifted graphs of every sweep built from them with tensor
+    operations, inheritance through vectorised pair maps) against ``run_c2f`` on the objects with the same engine and refiner:
+    identical partitions at every draw, identical lifted graphs, identical tables -- and through the same observer against the
+    reference's recorded tables"""
+    from lhvi import c2f
+    z, meta = load_npz(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    samples = z['samples']
+    draw = lambda k, flat, q: samples[k][flat.rep_ground]
+    graphs_a, graphs_b = [], []
+
+    class Eng(OracleEngine):
+        def __init__(self, log, *a):
+            super().__init__(*a)
+            self.log = log
+
+        def make(self, flat):
+            self.log.append(flat)
+            return super().make(flat)
+    ref = c2f.run_c2f(g, Eng(graphs_a, meta['n'], meta['approx'] == 'EP'), OracleRefiner(g), meta['iterations'], meta['c2f'], 2, 10, draw)
+    gflat = flatten(g, require_device_potentials=True)
+    rvc0, fc0, sym = lifting.initial_colors_flat(gflat, is_split_cont_evidence=False)
+    tg = lifting.TensorGraph(gflat)
+    got = c2f.run_c2f_flat(gflat, tg, Eng(graphs_b, meta['n'], meta['approx'] == 'EP'), OracleTensorRefiner(gflat, sym),
+                           meta['iterations'], meta['c2f'], 2, 10, draw, rvc0, fc0,
+                           observer=c2f_table_observer(z, rvs, factors, meta['n'], lambda a: a), keep_history=True)
+    st_a, flat_a, cg, rvc_a, fc_a, hist_a = ref
+    st_b, flat_b, rvc_b, fc_b, hist_b = got
+    assert len(hist_a) == len(hist_b) == z['draw_rv_labels'].shape[0]
+    for (ra, fa), (rb, fb) in zip(hist_a, hist_b):
+        assert (ra == rb).all() and (fa == fb).all()                  # same colours, not only the same partition
+    assert (rvc_a == rvc_b.numpy()).all() and (fc_a == fc_b.numpy()).all()
+    assert len(graphs_a) == len(graphs_b)
+    for A, B in zip(graphs_a, graphs_b):                              # every lifted graph of every sweep, both sides
+        for f in ('V', 'F', 'E'):
+            assert getattr(A, f) == getattr(B, f)
+        for f in ('fac_ptr', 'edge_var', 'edge_fac', 'edge_canon', 'var_ptr', 'var_edge', 'edge_count', 'var_mult', 'fac_mult'):
+            np.testing.assert_array_equal(getattr(A, f), getattr(B, f), err_msg=f)
+        np.testing.assert_allclose(A.var_value, B.var_value, rtol=1e-14, equal_nan=True)
+    for f in ('f2v', 'v2f', 'eta', 'q', 'particles'):
+        np.testing.assert_allclose(getattr(st_a, f), getattr(st_b, f), rtol=1e-12, atol=1e-12, err_msg=f)
+
+
+def test_split_evidence_on_observed_members_equals_the_colour_pass():
+    from lhvi import c2f
+    rng = np.random.default_rng(0)
+    V = 400
+    values = np.where(rng.random(V) < 0.6, rng.integers(0, 7, V) * 1.5 + rng.integers(0, 2, V) * 0.01, np.nan)
+    rvc = rng.integers(0, 9, V).astype(np.int32)
+    rvc[np.isnan(values)] = 9 + rng.integers(0, 3, int(np.isnan(values).sum()))
+    for eps, use_sqrt in ((0.0, True), (2.0, False), (0.5, True), (100.0, False)):
+        want = lifting.split_evidence_colors(values, rvc, 2, 10, eps, use_sqrt=use_sqrt)
+        obs = np.flatnonzero(~np.isnan(values))
+        oc, nc = c2f.split_evidence_observed(values[obs], rvc[obs], int(rvc.max()) + 1, 2, 10, eps, use_sqrt)
+        got = rvc.copy()
+        got[obs] = oc
+        np.testing.assert_array_equal(got, want)
+        assert nc == int(want.max()) + 1
