@@ -474,6 +474,12 @@ int lhvi_color_refine_factors(const lhvi_graph_t* g, const uint8_t* pot_symmetri
 int lhvi_color_refine_rvs(const lhvi_graph_t* g, const int32_t* f_color, const int32_t* rv_color,
                           int32_t* rv_color_out, int32_t* result, void* ws, size_t ws_bytes, int32_t method, void* stream);
 
+/* the representative of every cluster: first_out[c] = smallest i with color[i] == c, or n when colour c has no member
+ * (SuperRV.update_nb CompressedGraphWithObs.py:41-45 and SuperF.update_nb :148-150 read the neighbourhood of
+ * `next(iter(self.rvs))` / `next(iter(self.factors))` -- any member; this build always takes the first).  color [n] on the
+ * device, values in [0, n_colors). */
+int lhvi_color_first_members(const int32_t* color, int32_t n, int32_t n_colors, int32_t* first_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,6 +152,7 @@ SIGNATURES = {
     'lhvi_color_workspace_bytes': (_sz, [_G]),
     'lhvi_color_refine_factors': (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     'lhvi_color_refine_rvs': (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
+    'lhvi_color_first_members': (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
 }
 
 _lib = None
@@ -215,21 +216,53 @@ def to_dev(a, device=None):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device or 'cuda', non_blocking=False)
 
 
+def upload(arrays, device=None):
+    """several host arrays to the device in ONE copy: they are packed (256-byte aligned) into a staging buffer, copied once, and
+    returned as typed views of the device buffer (dict name -> tensor; a None entry stays None).  A lifted graph of a
+    coarse-to-fine sweep is some twenty small arrays -- one transfer instead of twenty."""
+    torch = require_gpu()
+    items = [(k, np.ascontiguousarray(a)) for k, a in arrays.items() if a is not None]
+    offs, total = [], 0
+    for _, a in items:
+        offs.append(total)
+        total += (a.nbytes + 255) // 256 * 256
+    if total > (1 << 28) or len(items) < 2:          # large graphs: plain per-array copies (no second host copy of 100s of MB)
+        out = {k: to_dev(a, device) for k, a in items}
+    else:
+        stage = np.zeros(max(total, 256), dtype=np.uint8)
+        for (k, a), o in zip(items, offs):
+            stage[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+        dev = torch.from_numpy(stage).to(device or 'cuda', non_blocking=False)
+        out = {}
+        for (k, a), o in zip(items, offs):
+            td = torch.from_numpy(np.zeros(0, dtype=a.dtype)).dtype
+            out[k] = dev[o:o + a.nbytes].view(td).view(a.shape)
+    for k, a in arrays.items():
+        if a is None:
+            out[k] = None
+    return out
+
+
 class DeviceGraph:
     """A ``FlatGraph`` resident in HBM plus the two C structs that point into it."""
 
     def __init__(self, flat, device=None):
         require_gpu()
         self.flat = flat
-        t = {}
-        for name in ('fac_ptr', 'edge_var', 'edge_fac', 'var_ptr', 'var_edge', 'fac_pot', 'var_value', 'var_dom',
-                     'dom_cont', 'dom_lo', 'dom_hi', 'dom_ptr', 'dom_val', 'pot_kind', 'pot_off', 'pot_param'):
-            t[name] = to_dev(getattr(flat, name), device)
+        host = {name: getattr(flat, name) for name in
+                ('fac_ptr', 'edge_var', 'edge_fac', 'var_ptr', 'var_edge', 'fac_pot', 'var_value', 'var_dom',
+                 'dom_cont', 'dom_lo', 'dom_hi', 'dom_ptr', 'dom_val', 'pot_kind', 'pot_off', 'pot_param')}
         has_alias = bool((flat.edge_canon != np.arange(flat.E, dtype=np.int32)).any())
-        t['edge_canon'] = to_dev(flat.edge_canon, device) if has_alias else None
-        t['edge_count'] = to_dev(flat.edge_count, device) if flat.lifted else None
-        t['var_mult'] = to_dev(flat.var_mult, device) if flat.lifted else None
-        t['fac_mult'] = to_dev(flat.fac_mult, device) if flat.lifted else None
+        host['edge_canon'] = flat.edge_canon if has_alias else None
+        host['edge_count'] = flat.edge_count if flat.lifted else None
+        host['var_mult'] = flat.var_mult if flat.lifted else None
+        host['fac_mult'] = flat.fac_mult if flat.lifted else None
+        # denormalised copies for the Gaussian sweep (contiguous instead of gathered)
+        host['edge_value'] = np.ascontiguousarray(flat.var_value[flat.edge_var]) if flat.E else None
+        host['slot_var'] = np.repeat(np.arange(flat.V, dtype=np.int32), np.diff(flat.var_ptr)) if flat.var_edge.size else None
+        hubs = np.flatnonzero(np.diff(flat.var_ptr) > HUB_DEGREE).astype(np.int32)
+        host['hub_vars'] = hubs if hubs.size else np.zeros(1, dtype=np.int32)   # non-NULL even when empty
+        t = upload(host, device)
         self.t = t
         self.device = t['fac_ptr'].device
         g = GraphStruct()
@@ -239,12 +272,7 @@ class DeviceGraph:
                      'dom_val'):
             setattr(g, name, ptr(t[name]))
         g.D = int(flat.dom_cont.size)
-        # denormalised copies for the Gaussian sweep (contiguous instead of gathered)
-        t['edge_value'] = to_dev(np.ascontiguousarray(flat.var_value[flat.edge_var]), device) if flat.E else None
-        t['slot_var'] = to_dev(np.repeat(np.arange(flat.V, dtype=np.int32), np.diff(flat.var_ptr)), device) if flat.var_edge.size else None
         g.edge_value, g.slot_var = ptr(t['edge_value']), ptr(t['slot_var'])
-        hubs = np.flatnonzero(np.diff(flat.var_ptr) > HUB_DEGREE).astype(np.int32)
-        t['hub_vars'] = to_dev(hubs if hubs.size else np.zeros(1, dtype=np.int32), device)   # non-NULL even when empty
         g.hub_vars, g.n_hubs = ptr(t['hub_vars']), int(hubs.size)
         self.g = g
         p = PotsStruct()

@@ -100,7 +100,7 @@ class DeviceRefiner(Refiner):
 
 
 def run_c2f(g, engine, refiner, iteration, c2f, k_mean_k, k_mean_iteration, draw, observer=None):
-    """Drive one coarse-to-fine run.  ``engine`` exposes ``make(flat) -> state``, ``init``, ``v2f``, ``proposal``,
+    """Drive one coarse-to-fine run.  ``engine`` exposes ``make(flat, sides) -> state`` (`sides`: 'v' for a state that only runs the v -> f half and the proposal update), ``init``, ``v2f``, ``proposal``,
     ``f2v``, ``install(state, host_particles)``, ``gather(array, index)``, ``get(state, name)`` / ``set(state, name, array)``
     for the arrays ``f2v v2f eta q particles old_particles uniq`` and ``host(array)``; ``draw(k, flat, q_host)`` returns the
     k-th sample as a [V, n] host array.  ``observer(k, rvc, old_fc, G1, pair_phi, st1)`` (optional) is called right before
@@ -129,7 +129,7 @@ def run_c2f(g, engine, refiner, iteration, c2f, k_mean_k, k_mean_iteration, draw
 
     # ---- sweep 0, phase 1 state
     G1, pair_phi = rv_side_graph(gflat, rvc, fc)
-    st1 = engine.make(G1)
+    st1 = engine.make(G1, sides='v')
     engine.init(st1)
     k = 0
     history.append((rvc.copy(), fc.copy()))
@@ -153,7 +153,7 @@ def run_c2f(g, engine, refiner, iteration, c2f, k_mean_k, k_mean_iteration, draw
             for e in range(G2.E):
                 pair_to_edge2.setdefault((int(G2.edge_fac[e]), int(G2.edge_var[e])), int(G2.edge_canon[e]))
             pe = np.array([pair_to_edge2[(int(phi), int(parent[A]))] for A, phi in zip(G1.edge_var, pair_phi)], dtype=np.int64)
-            new1 = engine.make(G1)
+            new1 = engine.make(G1, sides='v')
             for name in ('f2v', 'eta'):
                 engine.set(new1, name, engine.gather(engine.get(st2, name), pe))
             for name in ('q', 'particles', 'old_particles', 'uniq'):
@@ -188,9 +188,8 @@ def run_c2f(g, engine, refiner, iteration, c2f, k_mean_k, k_mean_iteration, draw
 # ---- the same schedule on arrays (ground FlatGraph in, colours resident on the device) ------------------------------------------
 def _rep_of(colors_t, n, size):
     """first (smallest-index) member of every colour, as a tensor on the colours' device"""
-    import torch
-    dev = colors_t.device
-    return torch.full((n,), size, dtype=torch.int64, device=dev).scatter_reduce_(0, colors_t.long(), torch.arange(size, device=dev), 'amin')
+    from .lifting import first_members
+    return first_members(colors_t, n, size)
 
 
 def rv_side_graph_t(gflat, tg, rvc_t, fc_t):
@@ -202,7 +201,7 @@ def rv_side_graph_t(gflat, tg, rvc_t, fc_t):
     dev = rvc_t.device
     rl, fl = rvc_t.long(), fc_t.long()
     nV, nF = int(rl.max().item()) + 1, int(fl.max().item()) + 1
-    rep = _rep_of(rl, nV, gflat.V)
+    rep = _rep_of(rvc_t, nV, gflat.V)
     var_ptr_g = tg.t['var_ptr'].long()
     deg = var_ptr_g[rep + 1] - var_ptr_g[rep]
     start = torch.zeros(nV + 1, dtype=torch.int64, device=dev)
@@ -212,7 +211,7 @@ def rv_side_graph_t(gflat, tg, rvc_t, fc_t):
     fcol = fl[tg.t['edge_fac'].long()[tg.t['var_edge'].long()[slots]]]
     owner = torch.repeat_interleave(torch.arange(nV, device=dev), deg, output_size=total)
     uniq, inv, cnt = torch.unique(owner * nF + fcol, return_inverse=True, return_counts=True)
-    first = torch.full((uniq.numel(),), total, dtype=torch.int64, device=dev).scatter_reduce_(0, inv, torch.arange(total, device=dev), 'amin')
+    first = _rep_of(inv, int(uniq.numel()), total)
     order = torch.sort(first, stable=True).indices                   # rows are contiguous per cluster: (cluster, first seen)
     uniq, cnt = uniq[order], cnt[order]
     pc, pf = (uniq // nF), (uniq % nF)
@@ -417,7 +416,7 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
     history = []
     G1, pair_phi, rep = rv_side_graph_t(gflat, tg, rvc, fc)
     t0 = tick('lift', t0)
-    st1 = engine.make(G1)
+    st1 = engine.make(G1, sides='v')
     engine.init(st1)
     t0 = tick('setup', t0)
     k = 0
@@ -443,7 +442,7 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
             parent = old_rvc.long()[rep].cpu().numpy()
             pe = edges_from_factor_side(G1, pair_phi, parent, G2)
             t0 = tick('lift', t0)
-            new1 = engine.make(G1)
+            new1 = engine.make(G1, sides='v')
             for name in ('f2v', 'eta'):
                 engine.set(new1, name, engine.gather(engine.get(st2, name), pe))
             for name in ('q', 'particles', 'old_particles', 'uniq'):

@@ -273,7 +273,8 @@ def cp_run_device(flat, sym, dg, rvc_d, fc_d, tracked, obs_mask_d):
     new_r, new_f = refine_flat(flat, sym, rvc_d, fc_d, dg=dg, device_out=True)
     nl = new_r.long()
     n_new, n_old = int(nl.max().item()) + 1, int(ol.max().item()) + 1
-    rep = torch.full((n_new,), flat.V, dtype=torch.int64, device=nl.device).scatter_reduce_(0, nl, torch.arange(flat.V, device=nl.device), 'amin')
+    from .lifting import first_members
+    rep = first_members(new_r, n_new, flat.V)
     parent = ol[rep]
     nchild = torch.bincount(parent, minlength=n_old)
     size = torch.bincount(nl, minlength=n_new)

@@ -447,6 +447,18 @@ class TensorGraph:
         self.device = self.t['fac_ptr'].device
 
 
+def first_members(colors, n_colors, size):
+    """first (smallest-index) member of every colour as an int64 tensor on the colours' device (``lhvi_color_first_members`` on
+    the GPU; CPU tensors, which only the CPU tests of the host logic use, go through torch)"""
+    import torch
+    if colors.device.type != 'cuda':
+        return torch.full((n_colors,), size, dtype=torch.int64).scatter_reduce_(0, colors.long(), torch.arange(size), 'amin')
+    c32 = colors if colors.dtype == torch.int32 and colors.is_contiguous() else colors.to(torch.int32).contiguous()
+    out = torch.empty(n_colors, dtype=torch.int32, device=colors.device)
+    _abi.check(_abi.lib().lhvi_color_first_members(_abi.ptr(c32), int(size), int(n_colors), _abi.ptr(out), _abi.stream_ptr()))
+    return out.long()
+
+
 def _lift_reduce_device(flat, dg, rvc, fc):
     """the same reductions on the device, for colour arrays that are already there (``refine_flat(device_out=True)``): only
     lifted-size arrays come back to the host.  Evidence sums run over each cluster's observed members in ground order (one
@@ -455,8 +467,7 @@ def _lift_reduce_device(flat, dg, rvc, fc):
     dev = rvc.device
     rl, fl = rvc.long(), fc.long()
     nV, nF = int(rl.max().item()) + 1, int(fl.max().item()) + 1
-    rep_v = torch.full((nV,), flat.V, dtype=torch.int64, device=dev).scatter_reduce_(0, rl, torch.arange(flat.V, device=dev), 'amin')
-    rep_f = torch.full((nF,), flat.F, dtype=torch.int64, device=dev).scatter_reduce_(0, fl, torch.arange(flat.F, device=dev), 'amin')
+    rep_v, rep_f = first_members(rvc, nV, flat.V), first_members(fc, nF, flat.F)
     mult_v = torch.bincount(rl, minlength=nV).to(torch.float64)
     mult_f = torch.bincount(fl, minlength=nF).to(torch.float64)
     value = dg.t['var_value']
@@ -478,7 +489,7 @@ def _lift_reduce_device(flat, dg, rvc, fc):
     fcol = fl[dg.t['edge_fac'].long()[dg.t['var_edge'].long()[slots]]]
     owner = torch.repeat_interleave(torch.arange(nV, device=dev), deg, output_size=total)
     uniq, inv, cnt = torch.unique(owner * nF + fcol, return_inverse=True, return_counts=True)
-    first = torch.full((uniq.numel(),), total, dtype=torch.int64, device=dev).scatter_reduce_(0, inv, torch.arange(total, device=dev), 'amin')
+    first = first_members(inv, int(uniq.numel()), total)
     edge_var_d = dg.t['edge_var']
     host = lambda t: t.cpu().numpy()
     return dict(nV=nV, nF=nF, rep_v=host(rep_v), rep_f=host(rep_f), mult_v=host(mult_v), mult_f=host(mult_f), val=host(val),

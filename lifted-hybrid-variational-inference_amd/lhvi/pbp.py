@@ -42,9 +42,12 @@ class _ParticleSweep:
     packed_v2f = True               # variables with at most four particles share a wavefront in the v -> f half (sixteen each)
 
     # ---- set-up ------------------------------------------------------------------------------
-    def _setup(self, graph_like, flat=None, edge_key=None):
+    def _setup(self, graph_like, flat=None, edge_key=None, sides='vf'):
         """`edge_key` (sharded runs): 0 / 1 per edge; every f2v work list is ordered key-0 edges first and ``part_counts``
-        gives the length of that first part per list (heavy, light, fast, generic)"""
+        gives the length of that first part per list (heavy, light, fast, generic).
+        `sides`: which half sweeps this state will run -- 'v' (v -> f, proposal, sampling: the variable-side state of a
+        coarse-to-fine sweep), 'f' (f -> v and the queries: its factor-side state) or both; the work lists of the other half
+        are not built."""
         flat = flat if flat is not None else flatten(graph_like, require_device_potentials=True)
         self.flat = flat
         self.dg = dg = _abi.DeviceGraph(flat)
@@ -60,7 +63,7 @@ class _ParticleSweep:
             # the reference fails in gaussian_product (`0 ** -1`, EPBP:30-41) on the first proposal update of such a variable
             raise ZeroDivisionError('a hidden continuous variable has no incident factor: its proposal is an empty product')
         self.np_host = np.where(flat.var_hidden, np.where(flat.var_cont, n, nst), 0).astype(np.int32)
-        self.np_dev = _abi.to_dev(self.np_host)
+        host_lists = {'np_dev': self.np_host}          # the per-variable lists below go to the device in one copy (_abi.upload)
         S = n + self.T
         self.f2v = dg.zeros(flat.E, S)
         self.v2f = dg.zeros(flat.E, n)
@@ -77,32 +80,6 @@ class _ParticleSweep:
         self._draws = 0
         self.cq_desc, self.n_cq = None, 0
         self.fast_edges = self.generic_edges = self._fast_list = self._generic_list = torch.zeros(1, dtype=torch.int32, device=dg.device)
-        # static work lists of the f -> v half sweep (which kernel serves which edge)
-        cls = torch.zeros(max(flat.E, 1), dtype=torch.uint8, device=dg.device)
-        _abi.check(_abi.lib().lhvi_pbp_classify(dg.g, dg.p, self._struct(), _abi.ptr(cls), _abi.stream_ptr()))
-        cls = cls[:flat.E]
-        self.fast_edges = torch.nonzero((cls == 1) | (cls == 2)).flatten().to(torch.int32)
-        self.generic_edges = torch.nonzero(cls == 3).flatten().to(torch.int32)
-        self.cq_edges = torch.nonzero(cls == 4).flatten().to(torch.int32)
-        key_dev = None
-        if edge_key is not None:
-            key_dev = _abi.to_dev(np.ascontiguousarray(edge_key, dtype=np.int32))
-            self.fast_edges = self.fast_edges[torch.sort(key_dev[self.fast_edges.long()], stable=True).indices].contiguous()
-            self.generic_edges = self.generic_edges[torch.sort(key_dev[self.generic_edges.long()], stable=True).indices].contiguous()
-            self.cq_edges = self.cq_edges[torch.sort(key_dev[self.cq_edges.long()], stable=True).indices].contiguous()
-
-        def first_part(edges):      # entries of an (ordered) edge list with key 0
-            return int((key_dev[edges.long()] == 0).sum().item()) if key_dev is not None and edges.numel() else 0
-        self.part_counts = {'heavy': 0, 'light': 0, 'fast': 0, 'generic': first_part(self.generic_edges),
-                            'cq': first_part(self.cq_edges)}
-        pad = torch.zeros(1, dtype=torch.int32, device=dg.device)       # keeps the pointers non-null when a list is empty
-        self._fast_list = self.fast_edges if self.fast_edges.numel() else pad
-        self._generic_list = self.generic_edges if self.generic_edges.numel() else pad
-        # lanes per generic edge: smallest power of two covering its output points (particles + integral points)
-        ge = self.generic_edges.cpu().numpy()
-        tv = flat.edge_var[ge]
-        pts = self.np_host[tv] + np.where(flat.var_cont[tv], flat.var_nstates[tv], 0) if ge.size else np.zeros(0, dtype=int)
-        self.generic_pts_log2 = int(min(6, max(0, int(np.ceil(np.log2(max(int(pts.max()), 1)))) if ge.size else 6)))
         # records of the hidden continuous variables for the proposal kernel (include/lhvi.h, lhvi_pbp_t.prop_desc)
         pv = np.flatnonzero(flat.var_hidden & flat.var_cont)
         pd = np.zeros((pv.size, 8), dtype=np.int32)
@@ -118,10 +95,10 @@ class _ParticleSweep:
         rr[:, 0], rr[:, 1] = pv, self.np_host[pv]
         rr[:, 2:4] = np.ascontiguousarray(flat.dom_lo[pdom], dtype=np.float64).view(np.int32).reshape(-1, 2)
         rr[:, 4:6] = np.ascontiguousarray(flat.dom_hi[pdom], dtype=np.float64).view(np.int32).reshape(-1, 2)
-        self.resample_vars = _abi.to_dev(rr) if pv.size else None
+        host_lists['resample_vars'] = rr if pv.size else None
         self._static_rows = False
         static = np.flatnonzero(~(flat.var_hidden & flat.var_cont))
-        self._static_idx = _abi.to_dev(static.astype(np.int64)) if static.size else None
+        host_lists['_static_idx'] = static.astype(np.int64) if static.size else None
         # rows longer than prop_slice entries go in as slices of that length, a wavefront each, ahead of the ordinary records
         self.prop_hub = self.prop_partial = None
         self.n_prop_hub = 0
@@ -139,9 +116,9 @@ class _ParticleSweep:
             ph = np.zeros((hubs.size, 4), dtype=np.int32)
             ph[:, 0], ph[:, 1], ph[:, 2] = pv[hubs], first, nsl
             pd = np.concatenate([sl, np.delete(pd, hubs, axis=0)])
-            self.prop_hub, self.n_prop_hub = _abi.to_dev(ph), int(hubs.size)
+            host_lists['prop_hub'], self.n_prop_hub = ph, int(hubs.size)
             self.prop_partial = dg.zeros(owner.size, 2)
-        self.prop_desc = _abi.to_dev(np.ascontiguousarray(pd)) if pv.size else None
+        host_lists['prop_desc'] = np.ascontiguousarray(pd) if pv.size else None
         self.n_prop_desc = int(pd.shape[0])
         # the v -> f half's split of the hidden variables (include/lhvi.h, lhvi_pbp_t.v2f_wide / v2f_narrow)
         hidden_v = np.flatnonzero(flat.var_hidden)
@@ -151,13 +128,54 @@ class _ParticleSweep:
         mid16 = ~narrow & ~hub & (self.np_host[hidden_v] <= 16)
         mid32 = ~narrow & ~hub & ~mid16 & (self.np_host[hidden_v] <= 32)
         if self.packed_v2f and hidden_v.size and (narrow.any() or hub.any() or mid16.any() or mid32.any()):
-            up = lambda a: _abi.to_dev(a.astype(np.int32) if a.size else np.zeros(1, dtype=np.int32))
             wide = ~narrow & ~hub & ~mid16 & ~mid32
-            self.v2f_lists = (up(hidden_v[wide]), int(wide.sum()), up(hidden_v[narrow]), int(narrow.sum()),
-                              up(hidden_v[hub]), int(hub.sum()), up(hidden_v[mid16]), int(mid16.sum()), up(hidden_v[mid32]), int(mid32.sum()))
+            parts = (('wide', wide), ('narrow', narrow), ('hub', hub), ('mid16', mid16), ('mid32', mid32))
+            for name, m in parts:
+                host_lists['v2f_' + name] = hidden_v[m].astype(np.int32) if m.any() else np.zeros(1, dtype=np.int32)
+        dev_lists = _abi.upload(host_lists)
+        for name in ('np_dev', 'resample_vars', '_static_idx', 'prop_desc'):
+            setattr(self, name, dev_lists[name])
+        if 'prop_hub' in dev_lists:
+            self.prop_hub = dev_lists['prop_hub']
+        if 'v2f_wide' in dev_lists:
+            self.v2f_lists = tuple(x for name, m in parts for x in (dev_lists['v2f_' + name], int(m.sum())))
+        # static work lists of the f -> v half sweep (which kernel serves which edge)
+        pad = torch.zeros(1, dtype=torch.int32, device=dg.device)       # keeps the pointers non-null when a list is empty
+        self.cq_edges = pad[:0]
+        self.part_counts = {'heavy': 0, 'light': 0, 'fast': 0, 'generic': 0, 'cq': 0, 'pair': 0}
+        self.generic_pts_log2 = 6
         self.fast_desc = self.heavy_desc = self.light_desc = self.pair_desc = self.small16_desc = self.small32_desc = None
         self.n_heavy = self.n_light = self.n_pair = self.n_small16 = self.n_small32 = self.n_heavy_class = 0
-        self.cq_terms = 0
+        self.cq_terms = self.heavy_terms = self.heavy_grid_terms = 0
+        self._has_f_side = 'f' in sides
+        if not self._has_f_side:
+            self.fast_edges = self.generic_edges = pad[:0]
+            self._fast_list = self._generic_list = pad
+            return
+        cls = torch.zeros(max(flat.E, 1), dtype=torch.uint8, device=dg.device)
+        _abi.check(_abi.lib().lhvi_pbp_classify(dg.g, dg.p, self._struct(), _abi.ptr(cls), _abi.stream_ptr()))
+        cls = cls[:flat.E]
+        self.fast_edges = torch.nonzero((cls == 1) | (cls == 2)).flatten().to(torch.int32)
+        self.generic_edges = torch.nonzero(cls == 3).flatten().to(torch.int32)
+        self.cq_edges = torch.nonzero(cls == 4).flatten().to(torch.int32)
+        key_dev = None
+        if edge_key is not None:
+            key_dev = _abi.to_dev(np.ascontiguousarray(edge_key, dtype=np.int32))
+            self.fast_edges = self.fast_edges[torch.sort(key_dev[self.fast_edges.long()], stable=True).indices].contiguous()
+            self.generic_edges = self.generic_edges[torch.sort(key_dev[self.generic_edges.long()], stable=True).indices].contiguous()
+            self.cq_edges = self.cq_edges[torch.sort(key_dev[self.cq_edges.long()], stable=True).indices].contiguous()
+
+        def first_part(edges):      # entries of an (ordered) edge list with key 0
+            return int((key_dev[edges.long()] == 0).sum().item()) if key_dev is not None and edges.numel() else 0
+        self.part_counts = {'heavy': 0, 'light': 0, 'fast': 0, 'generic': first_part(self.generic_edges),
+                            'cq': first_part(self.cq_edges), 'pair': 0}
+        self._fast_list = self.fast_edges if self.fast_edges.numel() else pad
+        self._generic_list = self.generic_edges if self.generic_edges.numel() else pad
+        # lanes per generic edge: smallest power of two covering its output points (particles + integral points)
+        ge = self.generic_edges.cpu().numpy()
+        tv = flat.edge_var[ge]
+        pts = self.np_host[tv] + np.where(flat.var_cont[tv], flat.var_nstates[tv], 0) if ge.size else np.zeros(0, dtype=int)
+        self.generic_pts_log2 = int(min(6, max(0, int(np.ceil(np.log2(max(int(pts.max()), 1)))) if ge.size else 6)))
         ncq = int(self.cq_edges.numel())
         if ncq:
             # two-partner edges of conditionally quadratic factors (include/lhvi.h, lhvi_pbp_describe_cq)
@@ -169,8 +187,6 @@ class _ParticleSweep:
             # (output point, partner particle, state) terms: type 1: (np + T) * ny * S;  type 2: S * nx * ny
             self.cq_terms = int(torch.where(cw[:, 2] == 1, (cw[:, 4] + cw[:, 5]) * cw[:, 9] * cw[:, 3],
                                             cw[:, 3] * cw[:, 12] * cw[:, 9]).sum().item())
-        self.part_counts['pair'] = 0
-        self.heavy_terms = self.heavy_grid_terms = 0
         nf = int(self.fast_edges.numel())
         if nf:
             desc = torch.empty(nf * _abi.PBP_DESC_BYTES, dtype=torch.uint8, device=dg.device)
@@ -381,6 +397,8 @@ class _ParticleSweep:
         """the f -> v half sweep (`lhvi_pbp_f2v`).  `f2v_events`: (start, end) events recorded around the heavy kernel: the
         call is then split with the SKIP flags into three, one kernel each, on the same stream."""
         l, g, p, st = _abi.lib(), self.dg.g, self.dg.p, _abi.stream_ptr()
+        if not getattr(self, '_has_f_side', True):
+            raise _abi.LhviError('this state was set up for the v -> f half only (sides="v")')
         args = (_abi.ptr(self.v2f), _abi.ptr(self.f2v))
         if f2v_events:
             base = s.flags
@@ -1011,12 +1029,12 @@ class _DeviceEngine:
         self.owner = owner
         self.draws = 0
 
-    def make(self, flat):
+    def make(self, flat, sides='vf'):
         o = self.owner
         st = HybridLBP.__new__(HybridLBP)
         st.n, st.proposal_approximation, st.sampler, st.seed = o.n, o.proposal_approximation, o.sampler, o.seed
         st.query_cache = dict()
-        st._setup(None, flat=flat)
+        st._setup(None, flat=flat, sides=sides)
         return st
 
     def get(self, st, name):

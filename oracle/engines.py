@@ -12,7 +12,7 @@ class OracleEngine:
     def __init__(self, n, ep):
         self.n, self.ep = n, ep
 
-    def make(self, flat):
+    def make(self, flat, sides='vf'):
         return oracle.PbpOracle(flat, self.n, ep=self.ep, epbp=False, var_threshold=5)
 
     get = staticmethod(getattr)

@@ -398,6 +398,8 @@ if 'c2f_pbp' in which:
              ('RGM 2000 x 1250 (10 M ground edges, cfg 5 evidence), n=10, run(10, c2f=0)', lambda: synth.rgm_structured_flat()[0], 10, 10, False)]
     if os.environ.get('C2F_SMALL_ONLY'):
         cases = cases[:2]
+    if os.environ.get('C2F_CASE'):
+        cases = [cases[int(os.environ['C2F_CASE'])]]
     for label, make, n_, its, with_cpu in cases:
         flat = make()
         wall, timing = None, None

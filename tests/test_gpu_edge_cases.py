@@ -253,3 +253,20 @@ def test_build_then_smoke_in_one_fresh_process():
     code = ("import sys; assert 'torch' not in sys.modules; import __graft_entry__ as g; g.build(); g.smoke(); print('BUILD+SMOKE OK')")
     out = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and 'BUILD+SMOKE OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_first_members_of_colours():
+    """``lhvi_color_first_members`` (wavefront-aggregated atomicMin): one giant colour, many small ones, colours without members,
+    n not a multiple of the block"""
+    import torch
+    from lhvi import lifting
+    rng = np.random.default_rng(0)
+    for n, ncol, giant in ((1, 1, 0.0), (1000, 7, 0.9), (300_001, 5000, 0.6), (2_000_003, 3, 0.0), (70_000, 70_000, 0.0)):
+        col = rng.integers(0, ncol, n)
+        col[rng.random(n) < giant] = min(2, ncol - 1)
+        if ncol > 10:
+            col[col == 5] = 6                           # colour 5 has no member
+        want = np.full(ncol, n, dtype=np.int64)
+        np.minimum.at(want, col, np.arange(n))
+        got = lifting.first_members(torch.from_numpy(col.astype(np.int32)).cuda(), ncol, n).cpu().numpy()
+        np.testing.assert_array_equal(got, want)

@@ -309,9 +309,9 @@ def test_hlbp_c2f_on_arrays_equals_the_object_path(golden_dir, name):
             super().__init__(*a)
             self.log = log
 
-        def make(self, flat):
+        def make(self, flat, sides='vf'):
             self.log.append(flat)
-            return super().make(flat)
+            return super().make(flat, sides)
     ref = c2f.run_c2f(g, Eng(graphs_a, meta['n'], meta['approx'] == 'EP'), OracleRefiner(g), meta['iterations'], meta['c2f'], 2, 10, draw)
     gflat = flatten(g, require_device_potentials=True)
     rvc0, fc0, sym = lifting.initial_colors_flat(gflat, is_split_cont_evidence=False)
