@@ -143,9 +143,14 @@ def main():
     ap.add_argument('--particles', type=int, default=64)
     ap.add_argument('--grid', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--exchange', choices=('pairs', 'owner'), default='pairs',
-                    help='multi-GPU runs: boundary rows between every pair of ranks sharing a variable (one collective), or reduced '
-                         'to an owner rank and sent back (two smaller collectives)')
+    ap.add_argument('--exchange', choices=('pairs', 'owner', 'ownercompute'), default='pairs',
+                    help='multi-GPU runs: factors partitioned, boundary rows between every pair of ranks sharing a variable (one '
+                         'collective), or reduced to an owner rank and sent back (two smaller collectives); ownercompute: VARIABLES '
+                         'partitioned, every message computed where its target lives, v->f rows of cut edges + ghost proposals in '
+                         'one collective (bit-identical to one GPU)')
+    ap.add_argument('--proposal', choices=('simple', 'EP'), default='simple',
+                    help="proposal rule of the sweep: 'simple' is what BASELINE.json's metric is quoted on; 'EP' is the reference's "
+                         "default (EPBPLogVersion.py:20)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -187,13 +192,16 @@ def main():
     E_total = flat.E
 
     if world == 1:
-        bp = EPBP(None, n=n, proposal_approximation='simple', sampler='device', seed=1)
+        bp = EPBP(None, n=n, proposal_approximation=args.proposal, sampler='device', seed=1)
         bp._setup(None, flat=flat)
         runner = dist.SingleRunner(bp)
+    elif args.exchange == 'ownercompute':
+        runner = dist.OwnerRunner(flat, n=n, seed=1, rank=rank, world=world, proposal_approximation=args.proposal,
+                                  var_owner=dist.broadcast_variable_partition(flat, rank, world))
     else:
         # the factor partition (one breadth-first sweep of the whole graph) is computed on rank 0 only and broadcast; every
         # rank then builds just its own slice of the plan
-        runner = dist.ShardedRunner(flat, n=n, seed=1, rank=rank, world=world,
+        runner = dist.ShardedRunner(flat, n=n, seed=1, rank=rank, world=world, proposal_approximation=args.proposal,
                                     fac_owner=dist.broadcast_partition(flat, rank, world),
                                     owner_reduce=args.exchange == 'owner')
     del flat
@@ -264,8 +272,11 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'cfg4x10 random hybrid pairwise MRF, EPBP particle sweep', 'edges': E_total,
-                       'variables': V, 'particles': n, 'integral_points': T, 'proposal': 'simple',
-                       'sharding': 'single GPU' if world == 1 else 'factor-partitioned edge shards, 1 all_to_all/sweep overlapped with the interior part'},
+                       'variables': V, 'particles': n, 'integral_points': T, 'proposal': args.proposal,
+                       'sharding': 'single GPU' if world == 1 else
+                                   ('variable-partitioned (owner computes), 1 all_to_all/sweep of cut-edge v->f rows + ghost proposals, overlapped with the interior part'
+                                    if args.exchange == 'ownercompute' else
+                                    'factor-partitioned edge shards, 1 all_to_all/sweep overlapped with the interior part')},
             # the dominant kernel is compute bound (~40 flop per algorithmic byte): its roof is the fp64 VECTOR peak (the
             # kernel issues VALU FMAs; the term -- rank-2 outer product + exp -- has nothing for MFMA to do, and on gfx950
             # the fp64 matrix path shares the vector fp64 pipe anyway).  The HBM view BASELINE.json asks for is in 'hbm' /

@@ -400,6 +400,18 @@ int lhvi_pbp_resample_uniq(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int
 int lhvi_pbp_belief_points(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f,
                            int32_t nq, const int32_t* qvar, int32_t npts, const double* x, double* out, void* stream);
 
+/* ---- owner-computes exchange of the edge-sharded sweep (lhvi/dist.py::OwnerRunner; csrc/halo.hip) ----------------------------
+ * The reference is one process; these two calls move its `message[(rv, f)]` tables (EPBPLogVersion.py:250-258) and proposals
+ * `q[rv]` (EPBPLogVersion.py:83-101) of the factors cut by a variable partition between ranks: pack fills the send buffer of the
+ * sweep's one all_to_all, unpack scatters the receive buffer.  Row i: `row_width[i]` doubles of v2f row `row_edge[i]` (v2f is
+ * [E][n]) at element offset `row_off[i]` of the buffer; proposal i: the two doubles of q row `q_var[i]` at `q_off[i]`. */
+int lhvi_pbp_halo_pack(const double* v2f, int32_t n, int32_t n_rows, const int32_t* row_edge, const int64_t* row_off,
+                       const int32_t* row_width, const double* q, int32_t n_q, const int32_t* q_var, const int64_t* q_off,
+                       double* out, void* stream);
+int lhvi_pbp_halo_unpack(const double* in, int32_t n, int32_t n_rows, const int32_t* row_edge, const int64_t* row_off,
+                         const int32_t* row_width, double* v2f, int32_t n_q, const int32_t* q_var, const int64_t* q_off,
+                         double* q, void* stream);
+
 /* ---- Mixture variational inference (VarInference.py / LiftedVarInference.py) --------------------- */
 
 typedef struct lhvi_vi {

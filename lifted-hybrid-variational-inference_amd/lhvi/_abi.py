@@ -139,6 +139,8 @@ SIGNATURES = {
     'lhvi_pbp_proposal_finish': (C.c_int, [_G, _S, _vp, _vp, _vp]),
     'lhvi_pbp_boundary_pack': (C.c_int, [_G, _S, _vp, _vp, _i32, _vp, _vp, _vp]),
     'lhvi_pbp_boundary_reduce': (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'lhvi_pbp_halo_pack': (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    'lhvi_pbp_halo_unpack': (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     'lhvi_pbp_init': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp, _vp]),
     'lhvi_pbp_resample': (C.c_int, [_G, _S, _vp, _u64, _u32, _vp, _vp]),
     'lhvi_pbp_edge_points': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),

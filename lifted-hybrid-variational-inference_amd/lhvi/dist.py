@@ -14,8 +14,8 @@ import numpy as np
 from . import _abi
 
 
-def joint_terms(flat, np_host):
-    """number of (output point, joint partner particle) terms one f2v launch evaluates"""
+def joint_terms(flat, np_host, edge_mask=None):
+    """number of (output point, joint partner particle) terms one f2v launch evaluates (`edge_mask`: the edges it serves)"""
     hid = flat.var_hidden
     tv = flat.edge_var
     npts = np.where(hid[tv], np_host[tv] + np.where(flat.var_cont[tv], flat.var_nstates[tv], 0), 0).astype(np.int64)
@@ -27,7 +27,7 @@ def joint_terms(flat, np_host):
     partner = np.clip(partner, 0, flat.E - 1)
     pn = np.where(hid[flat.edge_var[partner]], np_host[flat.edge_var[partner]], 1)
     terms = np.where(pair, npts * pn, npts)
-    return int(terms.sum())
+    return int(terms.sum() if edge_mask is None else terms[edge_mask].sum())
 
 
 class SingleRunner:
@@ -117,6 +117,18 @@ def broadcast_partition(flat, rank, world, partition='bfs'):
     import torch
     import torch.distributed as td
     own = partition_factors(flat, world, partition) if rank == 0 else np.empty(flat.F, dtype=np.int32)
+    t = torch.from_numpy(own)
+    if td.get_backend() == 'nccl':
+        t = t.cuda()
+    td.broadcast(t, 0)
+    return t.cpu().numpy()
+
+
+def broadcast_variable_partition(flat, rank, world, partition='bfs'):
+    """``partition_variables`` on rank 0, broadcast to the other ranks (4 bytes per variable)"""
+    import torch
+    import torch.distributed as td
+    own = partition_variables(flat, world, partition) if rank == 0 else np.empty(flat.V, dtype=np.int32)
     t = torch.from_numpy(own)
     if td.get_backend() == 'nccl':
         t = t.cuda()
@@ -382,10 +394,10 @@ class ShardedRunner:
             self.counts = list(lay['a_send'])            # (what a loopback group cuts this rank's first send by)
             self.side = None
 
-    def _struct(self, part=None):
+    def _struct(self, part=None, leave_room=True):
         """`part`: None = everything, 0 = interior variables, 1 = boundary variables (variable range only)"""
         s = self.bp._struct()
-        if self.overlap:
+        if self.overlap and leave_room:
             s.flags |= _abi.PBP_LEAVE_ROOM         # the exchange is in flight beside the persistent f2v kernels
         s.bslot, s.var_degree = _abi.ptr(self.bslot), _abi.ptr(self.var_degree)
         s.brow_ptr, s.brow_off, s.brow_peer = _abi.ptr(self.brow_ptr), _abi.ptr(self.brow_off), _abi.ptr(self.brow_peer)
@@ -565,7 +577,8 @@ class ShardedRunner:
         """the rest, once the peers' rows have arrived (after `interior`)"""
         self._install(recv)
         self._var_part(1, swapped=True)
-        self._f2v(self._edge_part(self._struct(), 1), f2v_events)
+        # (the collective has completed: this launch may fill the device; with the reduce-to-owner form nothing is in flight either)
+        self._f2v(self._edge_part(self._struct(leave_room=False), 1), f2v_events)
 
     def sweep(self, f2v_events=None):
         if not self.overlap:
@@ -626,6 +639,353 @@ class ShardedRunner:
 
     def f2v_joint_terms(self):
         return joint_terms(self.plan.flat, self.bp.np_host)
+
+    def heavy_stats(self):
+        return self.bp.n_heavy, self.bp.heavy_terms
+
+    def heavy_grid_terms(self):
+        return self.bp.heavy_grid_terms
+
+
+# =================================================================================================
+# owner-computes sharding: variables are partitioned, a rank computes every message whose target it owns
+# =================================================================================================
+def partition_variables(flat, world, partition='bfs'):
+    """owner rank of every variable: the breadth-first order of the factor graph (or the construction order) cut into `world`
+    blocks of equal total degree (a variable's share of the f -> v work is its number of incident edges)"""
+    V = flat.V
+    pos = bfs_variable_order(flat) if partition == 'bfs' and world > 1 else np.arange(V, dtype=np.int64)
+    order = np.argsort(pos, kind='stable')
+    w = np.diff(flat.var_ptr).astype(np.int64)[order] + 1
+    before = np.cumsum(w) - w
+    owner = np.empty(V, dtype=np.int32)
+    owner[order] = (before * world // max(int(w.sum()), 1)).astype(np.int32)
+    return owner
+
+
+class OwnerPlan:
+    """One rank's part of the owner-computes split of a ground ``FlatGraph`` (pure NumPy, no GPU).
+
+    * the rank OWNS the variables with ``var_owner == rank``; it holds every factor that touches a hidden variable it owns, with
+      ALL of that factor's edges (``fac_ids``, ``edge_ids``: global ids, ascending);
+    * local variables (``var_gid``): the owned ones first (``n_owned``), then the *ghosts* -- hidden variables owned elsewhere
+      that share a factor with an owned hidden one (``n_ghost``) --, then observed variables owned elsewhere; ascending global id
+      inside each block.  A local variable's adjacency row lists its local edges in the order of its row in the whole graph, so an
+      owned variable -- all of whose factors are local -- is swept in exactly the single-GPU summation order;
+    * ``edge_skip``: edges whose f -> v message is not this rank's to compute (their variable is not an owned hidden one);
+      ``edge_key``: 1 on the edges of *cut* factors (factors with a ghost), whose f -> v messages need the exchange;
+    * exchange, per peer `s` (both ends build the same order, so no index travels): ``send_rows[s]`` = local edges (owned hidden
+      variable, cut factor that touches a hidden variable owned by `s`) in ascending (global factor, position) -- their v -> f
+      rows go to `s`; ``recv_rows[s]`` = local edges whose variable is a ghost owned by `s`, same order; ``send_q[s]`` / ``recv_q[s]``
+      = the continuous variables among the former's / the ghosts owned by `s`, ascending global id -- their proposals.
+    """
+
+    def __init__(self, flat, rank, world, var_owner=None, partition='bfs'):
+        from .flat import build_flat
+        if flat.lifted or (flat.edge_canon != np.arange(flat.E)).any():
+            raise NotImplementedError('sharding expects a ground graph')
+        self.rank, self.world = rank, world
+        if var_owner is None:
+            var_owner = partition_variables(flat, world, partition)
+        var_owner = np.asarray(var_owner)
+        hidden = np.isnan(flat.var_value)
+        mine_h = (var_owner == rank) & hidden
+        arity_all = np.diff(flat.fac_ptr)
+        touch = np.maximum.reduceat(mine_h[flat.edge_var].astype(np.int8), flat.fac_ptr[:-1]) if flat.F else np.zeros(0, np.int8)
+        touch = np.where(arity_all > 0, touch, 0)
+        self.fac_ids = np.flatnonzero(touch)
+        arity = arity_all[self.fac_ids]
+        local_ptr = np.zeros(self.fac_ids.size + 1, dtype=np.int64)
+        np.cumsum(arity, out=local_ptr[1:])
+        self.edge_ids = (np.repeat(flat.fac_ptr[self.fac_ids].astype(np.int64) - local_ptr[:-1], arity) +
+                         np.arange(int(local_ptr[-1]), dtype=np.int64))
+        gvar = flat.edge_var[self.edge_ids]
+        gids = np.unique(gvar)
+        kind = np.where(var_owner[gids] == rank, 0, np.where(hidden[gids], 1, 2))
+        gids = gids[np.argsort(kind, kind='stable')]
+        self.n_owned, self.n_ghost = int((kind == 0).sum()), int((kind == 1).sum())
+        self.var_gid = gids.astype(np.int64)
+        lid = np.full(flat.V, -1, dtype=np.int64)
+        lid[gids] = np.arange(gids.size)
+        lf = build_flat(local_ptr.astype(np.int32), lid[gvar].astype(np.int32), flat.fac_pot[self.fac_ids], [], flat.var_value[gids],
+                        flat.var_dom[gids], flat.domains)
+        lf.pot_kind, lf.pot_off, lf.pot_param = flat.pot_kind, flat.pot_off, flat.pot_param
+        # adjacency rows in the order of the whole graph's rows (restricted to the local edges)
+        loc_edge = np.full(flat.E, -1, dtype=np.int64)
+        loc_edge[self.edge_ids] = np.arange(self.edge_ids.size)
+        gdeg = np.diff(flat.var_ptr)[gids].astype(np.int64)
+        start = np.zeros(gids.size + 1, dtype=np.int64)
+        np.cumsum(gdeg, out=start[1:])
+        slots = np.repeat(flat.var_ptr[gids].astype(np.int64) - start[:-1], gdeg) + np.arange(int(start[-1]), dtype=np.int64)
+        le = loc_edge[flat.var_edge[slots]]
+        keep = le >= 0
+        owner_of_slot = np.repeat(np.arange(gids.size), gdeg)[keep]
+        lf.var_edge = le[keep].astype(np.int32)
+        lf.var_ptr = np.zeros(gids.size + 1, dtype=np.int32)
+        np.cumsum(np.bincount(owner_of_slot, minlength=gids.size), out=lf.var_ptr[1:])
+        self.flat = lf
+        lv = lf.edge_var
+        is_owned_h = (np.arange(gids.size) < self.n_owned) & np.isnan(lf.var_value)
+        is_ghost = (np.arange(gids.size) >= self.n_owned) & (np.arange(gids.size) < self.n_owned + self.n_ghost)
+        self.edge_skip = ~is_owned_h[lv]
+        fac_cut = np.maximum.reduceat(is_ghost[lv].astype(np.int8), local_ptr[:-1]) if self.fac_ids.size else np.zeros(0, np.int8)
+        self.edge_key = np.repeat(fac_cut, arity).astype(np.int32)
+        # ---- exchange lists
+        efac = lf.edge_fac.astype(np.int64)
+        gfid = self.fac_ids[efac]
+        epos = lf.edge_pos.astype(np.int64)
+        order_key = gfid * (int(arity_all.max()) if flat.F else 1) + epos          # (global factor, position)
+        ghost_e = np.flatnonzero(is_ghost[lv])
+        owner_e = var_owner[gids[lv]]
+        # (owned-hidden edge, peer) pairs: all ordered pairs (i, j) of edges of a cut factor with i owned hidden, j a ghost
+        cut_fac = np.flatnonzero(fac_cut)
+        pairs_e, pairs_p = [], []
+        if cut_fac.size:
+            a_max = int(arity[cut_fac].max())
+            base = local_ptr[cut_fac]
+            ar = arity[cut_fac]
+            for i in range(a_max):
+                for j in range(a_max):
+                    if i == j:
+                        continue
+                    ok = (i < ar) & (j < ar)
+                    ei, ej = base[ok] + i, base[ok] + j
+                    sel = is_owned_h[lv[ei]] & is_ghost[lv[ej]]
+                    pairs_e.append(ei[sel])
+                    pairs_p.append(owner_e[ej[sel]].astype(np.int64))
+        pe = np.concatenate(pairs_e) if pairs_e else np.zeros(0, np.int64)
+        pp = np.concatenate(pairs_p) if pairs_p else np.zeros(0, np.int64)
+        E_l = max(int(lf.E), 1)
+        uniq_pairs = np.unique(pp * E_l + pe)
+        pp, pe = uniq_pairs // E_l, uniq_pairs % E_l
+        self.send_rows, self.recv_rows, self.send_q, self.recv_q = {}, {}, {}, {}
+        cont = lf.var_cont
+        for s in range(world):
+            if s == rank:
+                continue
+            e = pe[pp == s]
+            self.send_rows[s] = e[np.argsort(order_key[e], kind='stable')].astype(np.int64)
+            vq = np.unique(lv[e])
+            vq = vq[cont[vq]]
+            self.send_q[s] = vq[np.argsort(gids[vq], kind='stable')].astype(np.int64)
+            e = ghost_e[owner_e[ghost_e] == s]
+            self.recv_rows[s] = e[np.argsort(order_key[e], kind='stable')].astype(np.int64)
+            vq = np.flatnonzero(is_ghost & (var_owner[gids] == s) & cont)
+            self.recv_q[s] = vq[np.argsort(gids[vq], kind='stable')].astype(np.int64)
+
+    def layout(self, n, np_host):
+        """element offsets of the two buffers of the one all_to_all: per peer (ascending rank) its rows back to back -- `n` doubles
+        of a continuous variable's row, its number of states for a discrete one -- then its proposals, two doubles each"""
+        lv = self.flat.edge_var
+        out = {}
+        for side, rows, qs in (('send', self.send_rows, self.send_q), ('recv', self.recv_rows, self.recv_q)):
+            row_edge, row_off, row_w, q_var, q_off, counts = [], [], [], [], [], []
+            off = 0
+            for s in range(self.world):
+                if s == self.rank:
+                    counts.append(0)
+                    continue
+                e = rows[s]
+                w = np_host[lv[e]].astype(np.int64)
+                o = off + np.cumsum(w) - w
+                row_edge.append(e), row_off.append(o), row_w.append(w)
+                end = off + int(w.sum())
+                v = qs[s]
+                q_var.append(v), q_off.append(end + 2 * np.arange(v.size, dtype=np.int64))
+                end += 2 * int(v.size)
+                counts.append(end - off)
+                off = end
+            cat = lambda xs, dt: (np.concatenate(xs) if xs else np.zeros(0)).astype(dt)
+            out[side] = dict(row_edge=cat(row_edge, np.int32), row_off=cat(row_off, np.int64), row_width=cat(row_w, np.int32),
+                             q_var=cat(q_var, np.int32), q_off=cat(q_off, np.int64), counts=counts, size=off)
+        return out
+
+
+class OwnerRunner:
+    """One rank's part of the owner-computes particle sweep (EPBP semantics), ``bench.py --exchange ownercompute``.
+
+    Per sweep: v -> f and the proposal update of the OWNED variables (every one of them is swept once, over all its factors, in
+    the single-GPU order) -> the v -> f rows of the cut edges and the proposals of the variables that are ghosts elsewhere are
+    packed (``lhvi_pbp_halo_pack``) -> ONE all_to_all, started asynchronously -> while it is in flight: new particles of the owned
+    variables, f -> v of the factors without a ghost -> wait -> ``lhvi_pbp_halo_unpack`` puts the peers' rows into the v -> f
+    rows of the ghost edges and their proposals into q -> new particles of the ghosts (the sampler is keyed by the global id: the
+    same bits as at their owner) -> f -> v of the cut factors towards the owned variables.  No kernel reads boundary rows, no
+    per-variable work is replicated, and every array equals the single-GPU run's bit for bit."""
+
+    def __init__(self, flat, n, seed, rank, world, proposal_approximation='simple', group=None, overlap=True, var_owner=None):
+        import torch
+        from .pbp import EPBP
+        self.plan = plan = OwnerPlan(flat, rank, world, var_owner=var_owner)
+        self.rank, self.world, self.group = rank, world, group
+        bp = EPBP(None, n=n, proposal_approximation=proposal_approximation, sampler='device', seed=seed)
+        bp.small_f2v = False
+        bp._setup(None, flat=plan.flat, edge_key=plan.edge_key, edge_skip=plan.edge_skip)
+        self.bp = bp
+        bp.var_gid = _abi.to_dev(plan.var_gid)
+        self.n = n
+        self.n_owned, self.n_ghost = plan.n_owned, plan.n_ghost
+        self.overlap = bool(overlap) and world > 1
+        lay = self.lay = plan.layout(n, bp.np_host)
+        dev = bp.dg.device
+        up = {}
+        for side in ('send', 'recv'):
+            for k in ('row_edge', 'row_off', 'row_width', 'q_var', 'q_off'):
+                a = lay[side][k]
+                up[side + '_' + k] = a if a.size else np.zeros(1, dtype=a.dtype)
+        # the sampler's lists (lhvi_pbp_t.resample_vars): the owned and the ghost hidden continuous variables, two per wavefront
+        rr = bp.resample_vars.cpu().numpy() if bp.resample_vars is not None else np.zeros((0, 8), dtype=np.int32)
+        self.res_lists = None
+        if n <= 64 and rr.shape[0]:
+            own = rr[:, 0] < plan.n_owned
+            up['res_owned'] = rr[own] if own.any() else np.zeros((1, 8), dtype=np.int32)
+            up['res_ghost'] = rr[~own] if (~own).any() else np.zeros((1, 8), dtype=np.int32)
+            self.res_lists = (int(own.sum()), int((~own).sum()))
+        self.idx = _abi.upload(up)
+        self.send = torch.zeros(max(lay['send']['size'], 1), dtype=torch.float64, device=dev)
+        self.recv = torch.zeros(max(lay['recv']['size'], 1), dtype=torch.float64, device=dev)
+        self.counts = list(lay['send']['counts'])              # what a loopback group cuts this rank's send buffer by
+        self.record_phases = False
+        self._phase_events = []
+        self.f2v_extra = []
+
+    # ---- structs ------------------------------------------------------------------------------------------------------------
+    def _struct(self, lo=0, hi=0, leave_room=False):
+        s = self.bp._struct()
+        if self.overlap and leave_room:                      # only the launches that run beside the collective leave it room
+            s.flags |= _abi.PBP_LEAVE_ROOM
+        s.prop_desc, s.n_prop_desc = None, 0                 # variables are addressed by range: owned [0, n_owned), ghosts after them
+        s.prop_hub, s.n_prop_hub, s.prop_partial = None, 0, None
+        s.v2f_wide, s.n_v2f_wide, s.v2f_narrow, s.n_v2f_narrow, s.v2f_hub, s.n_v2f_hub = None, 0, None, 0, None, 0
+        s.v2f_mid16, s.n_v2f_mid16, s.v2f_mid32, s.n_v2f_mid32 = None, 0, None, 0
+        s.var_lo, s.var_hi = int(lo), int(hi)
+        return s
+
+    _edge_part = ShardedRunner._edge_part
+
+    def init(self):
+        bp = self.bp
+        _abi.check(_abi.lib().lhvi_pbp_init(bp.dg.g, self._struct(), _abi.ptr(bp.eta), _abi.ptr(bp.q_dev), _abi.ptr(bp.f2v),
+                                            _abi.ptr(bp.v2f), _abi.stream_ptr()))
+        bp._generate_sample()
+
+    # ---- the phases of a sweep ----------------------------------------------------------------------------------------------
+    def owned_half(self):
+        """v -> f and the proposal update of the owned variables; the rows and proposals the peers need, packed"""
+        bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
+        if self.n_owned:
+            s = self._struct(0, self.n_owned)
+            _abi.check(l.lhvi_pbp_v2f(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.v2f), st))
+            _abi.check(l.lhvi_pbp_proposal(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.eta), _abi.ptr(bp.q_dev), st))
+        L, ix = self.lay['send'], self.idx
+        _abi.check(l.lhvi_pbp_halo_pack(_abi.ptr(bp.v2f), self.n, int(L['row_edge'].size), _abi.ptr(ix['send_row_edge']),
+                                        _abi.ptr(ix['send_row_off']), _abi.ptr(ix['send_row_width']), _abi.ptr(bp.q_dev),
+                                        int(L['q_var'].size), _abi.ptr(ix['send_q_var']), _abi.ptr(ix['send_q_off']), _abi.ptr(self.send), st))
+        return self.send[:L['size']]
+
+    def _resample(self, lo, hi):
+        bp = self.bp
+        if hi <= lo:
+            return
+        s = self._struct(lo, hi)
+        if self.res_lists is not None:                       # the listed form: hidden continuous variables only (bit-identical draws)
+            which = 0 if lo == 0 else 1
+            if self.res_lists[which] == 0:
+                return
+            s.var_lo, s.var_hi = 0, 0
+            s.resample_vars, s.n_resample_vars = _abi.ptr(self.idx['res_owned' if which == 0 else 'res_ghost']), self.res_lists[which]
+        _abi.check(_abi.lib().lhvi_pbp_resample_uniq(bp.dg.g, s, _abi.ptr(bp.var_gid), int(bp.seed), int(bp._draws - 1),
+                                                     _abi.ptr(bp.particles), _abi.ptr(bp.uniq), _abi.stream_ptr()))
+
+    def interior(self, f2v_events=None):
+        """what needs nothing from the peers: the owned variables' new particles, f -> v of the factors without a ghost"""
+        bp = self.bp
+        bp.old_particles, bp.particles = bp.particles, bp.old_particles
+        bp._draws += 1
+        bp._views = {}
+        self._resample(0, self.n_owned)
+        bp._launch_f2v(self._edge_part(self._struct(leave_room=True), 0), f2v_events)
+
+    def boundary(self, recv, f2v_events=None):
+        """the rest, once the peers' rows have arrived (after `interior`)"""
+        bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
+        L, ix = self.lay['recv'], self.idx
+        if recv.data_ptr() != self.recv.data_ptr():
+            self.recv[:recv.shape[0]].copy_(recv)
+        _abi.check(l.lhvi_pbp_halo_unpack(_abi.ptr(self.recv), self.n, int(L['row_edge'].size), _abi.ptr(ix['recv_row_edge']),
+                                          _abi.ptr(ix['recv_row_off']), _abi.ptr(ix['recv_row_width']), _abi.ptr(bp.v2f),
+                                          int(L['q_var'].size), _abi.ptr(ix['recv_q_var']), _abi.ptr(ix['recv_q_off']), _abi.ptr(bp.q_dev), st))
+        self._resample(self.n_owned, self.n_owned + self.n_ghost)
+        bp._launch_f2v(self._edge_part(self._struct(), 1), f2v_events)
+
+    def exchange(self, send, async_op=False):
+        """the one collective of a sweep"""
+        import torch.distributed as td
+        L = self.lay
+        recv = self.recv[:L['recv']['size']]
+        work = None
+        if td.get_backend() == 'nccl':
+            work = td.all_to_all_single(recv, send, output_split_sizes=L['recv']['counts'], input_split_sizes=L['send']['counts'],
+                                        async_op=async_op)
+        else:                                               # rehearsal backend (gloo): same collective on host copies
+            h_send = send.cpu()
+            h_recv = h_send.new_empty(L['recv']['size'])
+            td.all_to_all_single(h_recv, h_send, output_split_sizes=L['recv']['counts'], input_split_sizes=L['send']['counts'])
+            recv.copy_(h_recv)
+        return (recv, work) if async_op else recv
+
+    def sweep(self, f2v_events=None):
+        import torch
+        marks = []
+
+        def mark():
+            if self.record_phases:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
+        mark()
+        send = self.owned_half()
+        mark()
+        if self.world > 1:
+            recv, work = self.exchange(send, async_op=self.overlap)
+        else:
+            recv, work = self.recv[:0], None
+        extra = None
+        if f2v_events:
+            extra = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.f2v_extra.append(extra)
+        self.interior(extra)
+        mark()
+        if work is not None:
+            work.wait()
+        mark()
+        self.boundary(recv, f2v_events)
+        mark()
+        if marks:
+            self._phase_events.append(marks)
+
+    def phase_ms(self):
+        if not self._phase_events:
+            return None
+        names = ('owned_v2f_proposal_pack', 'interior', 'exchange_wait', 'boundary')
+        acc = {k: 0.0 for k in names}
+        for m in self._phase_events:
+            for k, a, b in zip(names, m[:-1], m[1:]):
+                acc[k] += a.elapsed_time(b)
+        n = len(self._phase_events)
+        out = {k: v / n for k, v in acc.items()}
+        out.update(sweeps=n, owned_variables=int(self.n_owned), ghost_variables=int(self.n_ghost),
+                   cut_edge_rows_sent=int(self.lay['send']['row_edge'].size), exchange='owner computes: v->f rows of cut edges + ghost proposals',
+                   exchanged_MB_per_sweep=8e-6 * self.lay['send']['size'])
+        return out
+
+    def local_edges(self):
+        return int((~self.plan.edge_skip).sum())
+
+    def work_fraction(self):
+        return 1.0
+
+    def f2v_joint_terms(self):
+        return joint_terms(self.plan.flat, self.bp.np_host, ~self.plan.edge_skip)
 
     def heavy_stats(self):
         return self.bp.n_heavy, self.bp.heavy_terms

@@ -42,9 +42,11 @@ class _ParticleSweep:
     packed_v2f = True               # variables with at most four particles share a wavefront in the v -> f half (sixteen each)
 
     # ---- set-up ------------------------------------------------------------------------------
-    def _setup(self, graph_like, flat=None, edge_key=None, sides='vf'):
+    def _setup(self, graph_like, flat=None, edge_key=None, sides='vf', edge_skip=None):
         """`edge_key` (sharded runs): 0 / 1 per edge; every f2v work list is ordered key-0 edges first and ``part_counts``
         gives the length of that first part per list (heavy, light, fast, generic).
+        `edge_skip` (owner-computes shards): boolean per edge; the f -> v message of a marked edge is somebody else's to compute,
+        it enters no work list.
         `sides`: which half sweeps this state will run -- 'v' (v -> f, proposal, sampling: the variable-side state of a
         coarse-to-fine sweep), 'f' (f -> v and the queries: its factor-side state) or both; the work lists of the other half
         are not built."""
@@ -155,6 +157,8 @@ class _ParticleSweep:
         cls = torch.zeros(max(flat.E, 1), dtype=torch.uint8, device=dg.device)
         _abi.check(_abi.lib().lhvi_pbp_classify(dg.g, dg.p, self._struct(), _abi.ptr(cls), _abi.stream_ptr()))
         cls = cls[:flat.E]
+        if edge_skip is not None:
+            cls = torch.where(_abi.to_dev(np.ascontiguousarray(edge_skip, dtype=bool)), torch.zeros_like(cls), cls)
         self.fast_edges = torch.nonzero((cls == 1) | (cls == 2)).flatten().to(torch.int32)
         self.generic_edges = torch.nonzero(cls == 3).flatten().to(torch.int32)
         self.cq_edges = torch.nonzero(cls == 4).flatten().to(torch.int32)
@@ -277,6 +281,7 @@ class _ParticleSweep:
             ow[n1:, 25] = r2[:, 3].int()
         first = 0
         if key_dev is not None and n1 + n2:      # sharded runs: records of factors that touch no boundary variable first
+            # (a record's key: that of its edges -- both belong to one factor, and a factor's edges share their key)
             edge = torch.where(ow[:, 0] >= 0, ow[:, 0], ow[:, 1]).long()
             order = torch.sort(key_dev[edge], stable=True).indices
             out = out[order].contiguous()

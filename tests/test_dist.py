@@ -524,3 +524,214 @@ def test_rccl_exchange_call_path(tmp_path):
     p.join(timeout=300)
     assert p.exitcode == 0
     assert open(out).read() == 'ok'
+
+
+# ---- owner-computes split (variables partitioned; a rank computes every message whose target it owns) ---------------------------
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_owner_plan_invariants(world):
+    from lhvi import synth
+    from lhvi.dist import OwnerPlan, partition_variables
+    flat = synth.hybrid_mrf_flat(V=1500, deg=4, seed=2)
+    owner = partition_variables(flat, world)
+    assert sorted(np.unique(owner).tolist()) == list(range(world))
+    plans = [OwnerPlan(flat, r, world, var_owner=owner) for r in range(world)]
+    hid = np.isnan(flat.var_value)
+    computed = np.zeros(flat.E, dtype=int)
+    for p in plans:
+        lf = p.flat
+        np.testing.assert_array_equal(p.var_gid[lf.edge_var], flat.edge_var[p.edge_ids])
+        own = np.arange(lf.V) < p.n_owned
+        assert (owner[p.var_gid[own]] == p.rank).all() and (owner[p.var_gid[~own]] != p.rank).all()
+        # an owned hidden variable has ALL its edges here, in the order of its row in the whole graph
+        for v in np.flatnonzero(own & np.isnan(lf.var_value))[:200]:
+            g = p.var_gid[v]
+            want = flat.var_edge[flat.var_ptr[g]:flat.var_ptr[g + 1]]
+            got = p.edge_ids[lf.var_edge[lf.var_ptr[v]:lf.var_ptr[v + 1]]]
+            np.testing.assert_array_equal(got, want)
+        computed[p.edge_ids[~p.edge_skip]] += 1
+        # cut factors: exactly those with a ghost
+        ghost = (np.arange(lf.V) >= p.n_owned) & (np.arange(lf.V) < p.n_owned + p.n_ghost)
+        assert (np.isnan(lf.var_value[ghost])).all()
+        np.testing.assert_array_equal(p.edge_key.astype(bool), np.repeat(np.maximum.reduceat(ghost[lf.edge_var].astype(np.int8), lf.fac_ptr[:-1]), np.diff(lf.fac_ptr)).astype(bool))
+    # every message towards a hidden variable is computed exactly once
+    np.testing.assert_array_equal(computed, hid[flat.edge_var].astype(int))
+    # both ends of every pair list the same rows / proposals in the same order; every ghost edge receives exactly one row
+    for p in plans:
+        got_rows = np.concatenate([p.recv_rows[s] for s in range(world) if s != p.rank])
+        ghost = (np.arange(p.flat.V) >= p.n_owned) & (np.arange(p.flat.V) < p.n_owned + p.n_ghost)
+        np.testing.assert_array_equal(np.sort(got_rows), np.flatnonzero(ghost[p.flat.edge_var]))
+        for s in range(world):
+            if s == p.rank:
+                continue
+            q = plans[s]
+            np.testing.assert_array_equal(p.edge_ids[p.send_rows[s]], q.edge_ids[q.recv_rows[p.rank]])
+            np.testing.assert_array_equal(p.var_gid[p.send_q[s]], q.var_gid[q.recv_q[p.rank]])
+        lay = p.layout(16, np.where(np.isnan(p.flat.var_value), np.where(p.flat.var_cont, 16, 2), 0))
+        for side in ('send', 'recv'):
+            L = lay[side]
+            assert sum(L['counts']) == L['size'] == int(L['row_width'].sum()) + 2 * L['q_var'].size
+            offs = np.concatenate([np.repeat(L['row_off'], L['row_width']) + np.concatenate([np.arange(w) for w in L['row_width']] or [np.zeros(0, int)]),
+                                   np.repeat(L['q_off'], 2) + np.tile([0, 1], L['q_var'].size)])
+            np.testing.assert_array_equal(np.sort(offs), np.arange(L['size']))          # the buffer is covered exactly once
+
+
+def _owner_compute_gloo_worker(rank, world, port, out):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
+    import torch
+    import torch.distributed as td
+    from lhvi import synth
+    from lhvi.dist import OwnerPlan, partition_variables
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    flat = synth.hybrid_mrf_flat(V=900, deg=4, seed=5)
+    plan = OwnerPlan(flat, rank, world, var_owner=partition_variables(flat, world))
+    n = 6
+    lf = plan.flat
+    np_host = np.where(np.isnan(lf.var_value), np.where(lf.var_cont, n, 2), 0)
+    lay = plan.layout(n, np_host)
+    # a row / a proposal is a function of its global id, so every rank can check what it received on its own
+    row = lambda ge: np.sin(0.1 * ge + np.arange(n))
+    prop = lambda gv: np.array([np.cos(0.3 * gv), 1.0 + gv % 7])
+    S = lay['send']
+    send = torch.zeros(max(S['size'], 1), dtype=torch.float64)
+    for e, o, w in zip(S['row_edge'], S['row_off'], S['row_width']):
+        send[o:o + w] = torch.from_numpy(row(plan.edge_ids[e])[:w])
+    for v, o in zip(S['q_var'], S['q_off']):
+        send[o:o + 2] = torch.from_numpy(prop(plan.var_gid[v]))
+    R = lay['recv']
+    recv = torch.empty(R['size'], dtype=torch.float64)
+    td.all_to_all_single(recv, send[:S['size']], output_split_sizes=R['counts'], input_split_sizes=S['counts'])
+    ok = True
+    for e, o, w in zip(R['row_edge'], R['row_off'], R['row_width']):
+        ok = ok and bool((recv[o:o + w].numpy() == row(plan.edge_ids[e])[:w]).all())
+    for v, o in zip(R['q_var'], R['q_off']):
+        ok = ok and bool((recv[o:o + 2].numpy() == prop(plan.var_gid[v])).all())
+    out.put((rank, ok, int(R['row_edge'].size), int(R['q_var'].size)))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_owner_compute_exchange_gloo(world):
+    """real processes over gloo: the one all_to_all of the owner-computes sweep with its unequal split lists delivers every cut
+    edge's row and every ghost's proposal to the right place (both ends derive the order on their own)"""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_owner_compute_gloo_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _, _ in res), res
+    assert all(nr > 0 and nq > 0 for _, _, nr, nq in res)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_owner_compute_sweep_equals_single_gpu_bit_for_bit(world):
+    """`world` simulated ranks of the owner-computes split (loopback exchange) against the single-GPU sweep: proposals, particles
+    and both message arrays are the same BITS -- every variable is swept once, over all its factors, in the single-GPU order, and
+    ghosts are re-drawn from their owner's proposal with the sampler keyed by the global id"""
+    import torch
+    from lhvi import synth, dist, _abi
+    from lhvi.pbp import EPBP
+    _abi.require_gpu()
+    flat = synth.hybrid_mrf_flat(V=2000, deg=4, seed=6)
+    n = 64
+    bp = EPBP(None, n=n, proposal_approximation='simple', sampler='device', seed=3)
+    bp._setup(None, flat=flat)
+    single = dist.SingleRunner(bp)
+    single.init()
+    owner = dist.partition_variables(flat, world)
+    group = dist.LoopbackGroup(world)
+    runners = [dist.OwnerRunner(flat, n=n, seed=3, rank=r, world=world, group=group, var_owner=owner) for r in range(world)]
+    for r in runners:
+        r.init()
+    for it in range(3):
+        single.sweep()
+        sends = [r.owned_half() for r in runners]
+        for r, s in zip(runners, sends):
+            group.post(r.rank, s, r.counts)
+        for r in runners:
+            r.interior()
+        for r in runners:
+            r.boundary(group.collect(r.rank, None))
+        dev = bp.q_dev.device
+        for r in runners:
+            plan = r.plan
+            gid = torch.from_numpy(plan.var_gid).to(dev)
+            own = torch.from_numpy((np.arange(plan.flat.V) < plan.n_owned) & plan.flat.var_hidden).to(dev)
+            loc = torch.from_numpy((np.arange(plan.flat.V) < plan.n_owned + plan.n_ghost) & plan.flat.var_hidden).to(dev)
+            live = torch.from_numpy(np.arange(n)[None, :] < r.bp.np_host[:, None]).to(dev)
+            assert torch.equal(r.bp.q_dev[own], bp.q_dev[gid][own])
+            cont = torch.from_numpy(plan.flat.var_cont).to(dev)
+            assert torch.equal(r.bp.q_dev[loc & cont], bp.q_dev[gid][loc & cont])            # ghosts: their owner's proposal
+            assert torch.equal(torch.where(live, r.bp.particles, 0.0)[loc], torch.where(live, bp.particles[gid], 0.0)[loc])
+            eid = torch.from_numpy(plan.edge_ids).to(dev)
+            mine = torch.from_numpy(~plan.edge_skip).to(dev)
+            le = live[torch.from_numpy(plan.flat.edge_var.astype(np.int64)).to(dev)]
+            assert torch.equal(torch.where(le, r.bp.v2f, 0.0)[mine], torch.where(le, bp.v2f[eid], 0.0)[mine])
+            assert torch.equal(r.bp.f2v[mine], bp.f2v[eid][mine])
+            hid_e = torch.from_numpy(plan.flat.var_hidden[plan.flat.edge_var]).to(dev)
+            assert torch.equal(torch.where(le, r.bp.v2f, 0.0)[hid_e], torch.where(le, bp.v2f[eid], 0.0)[hid_e])   # ghost edges: received rows
+    assert torch.isfinite(bp.q_dev[torch.from_numpy(flat.var_hidden).to(dev)]).all()
+
+
+def _owner_compute_gpu_worker(rank, world, port, out_dir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
+    import torch
+    import torch.distributed as td
+    from lhvi import synth, dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    flat = synth.hybrid_mrf_flat(V=1500, deg=4, seed=6)
+    r = dist.OwnerRunner(flat, n=64, seed=3, rank=rank, world=world, var_owner=dist.broadcast_variable_partition(flat, rank, world))
+    r.init()
+    for _ in range(3):
+        r.sweep()                      # owned half -> all_to_all_single (gloo: staged through the host) -> interior, boundary
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), gid=r.plan.var_gid, q=r.bp.q_dev.cpu().numpy(), f2v=r.bp.f2v.cpu().numpy(),
+             v2f=r.bp.v2f.cpu().numpy(), edge_ids=r.plan.edge_ids, mine=~r.plan.edge_skip, n_owned=r.plan.n_owned)
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_process_owner_compute_sweep_equals_single_gpu(tmp_path):
+    """two real processes (torch.distributed, gloo rehearsal backend, both on cuda:0) run the owner-computes sweep with the real
+    collective call path; proposals and messages of the owned variables equal the unsharded run bit for bit"""
+    import torch.multiprocessing as mp
+    from lhvi import synth, dist, _abi
+    from lhvi.pbp import EPBP
+    _abi.require_gpu()
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_owner_compute_gpu_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    flat = synth.hybrid_mrf_flat(V=1500, deg=4, seed=6)
+    bp = EPBP(None, n=64, proposal_approximation='simple', sampler='device', seed=3)
+    bp._setup(None, flat=flat)
+    single = dist.SingleRunner(bp)
+    single.init()
+    for _ in range(3):
+        single.sweep()
+    q, f2v = bp.q_dev.cpu().numpy(), bp.f2v.cpu().numpy()
+    hid = flat.var_hidden
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r))
+        own = (np.arange(z['gid'].size) < int(z['n_owned'])) & hid[z['gid']]
+        assert own.any() and (z['q'][own] == q[z['gid']][own]).all()
+        m = z['mine']
+        assert m.any() and (z['f2v'][m] == f2v[z['edge_ids']][m]).all()
