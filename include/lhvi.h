@@ -27,11 +27,12 @@
 extern "C" {
 #endif
 
-#define LHVI_ABI_VERSION 8   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
+#define LHVI_ABI_VERSION 9   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
                               * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t;  7: lhvi_pbp_t gained pair_desc;
                               * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq; the colour
                               *    refinement calls take a method and return four result words; lhvi_vi_t gained var_N; lhvi_vi_opt_t, lhvi_vi_adam_run;
-                              *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub / v2f_mid16 / v2f_mid32, prop_hub / prop_partial, resample_vars, small16_desc / small32_desc; 16 ticket words; lhvi_pbp_boundary_reduce */
+                              *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub / v2f_mid16 / v2f_mid32, prop_hub / prop_partial, resample_vars, small16_desc / small32_desc; 16 ticket words; lhvi_pbp_boundary_reduce;
+                              * 9: lhvi_vi_t gained fac_list / n_cc / n_grp3 / n_grp6 / n_rest3 / n_rest6; lhvi_color_first_members, lhvi_pbp_halo_pack / _unpack */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -430,7 +431,19 @@ typedef struct lhvi_vi {
     const double* var_N;        /* [V] or NULL: rv.N = number of incident ground factors (the sum of the row's edge_count on a
                                  * lifted graph, LiftedVarInference.py:64-67).  NULL: every (variable, k) thread sums its row itself,
                                  * which serialises on the template variables of a relational model (thousands of entries) */
+    /* (ABI 9) the caller's split of the factors among the kernels of expectation() (VarInference.py:40-55), or NULL: a permutation
+     * of the factor ids in five segments --
+     *   n_cc    pairwise factors over two distinct continuous / observed variables with a Gaussian / quadratic / linear-Gaussian /
+     *           XY potential (thread per (factor, k), per-axis pdf tables in registers);
+     *   n_grp3  other factors of arity <= 3 whose axis lengths sum to <= LHVI_VI_GROUP_SLOTS with K * that <= LHVI_VI_GROUP_COMP
+     *           (8 lanes per (factor, k), per-axis tables in LDS);  n_grp6: the same for arity 4 .. LHVI_MAX_ARITY;
+     *   n_rest3 / n_rest6  whatever fits neither (thread per (factor, k), arity <= 3 / 4 .. LHVI_MAX_ARITY).
+     * NULL: every kernel classifies the factors itself (thread-per-factor kernels only). */
+    const int32_t* fac_list;
+    int32_t n_cc, n_grp3, n_grp6, n_rest3, n_rest6;
 } lhvi_vi_t;
+#define LHVI_VI_GROUP_SLOTS 24
+#define LHVI_VI_GROUP_COMP 48
 
 /* state of the optimiser for lhvi_vi_adam_run: the arrays ADAM_update (VarInference.py:249-287) reads and writes.  w, eta_c and
  * eta_d must be the arrays the lhvi_vi_t passed alongside points to (the step must see what it updates). */

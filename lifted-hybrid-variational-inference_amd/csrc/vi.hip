@@ -269,29 +269,371 @@ __device__ __forceinline__ void vi_factor_cc(const lhvi_graph_t& g, const lhvi_p
 }
 
 __global__ void __launch_bounds__(BLOCK) vi_factor_cc_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
-                                                            double* __restrict__ pe_c, double* __restrict__ pe_d) {
+                                                            double* __restrict__ pe_c, double* __restrict__ pe_d,
+                                                            const int32_t* __restrict__ list, int n_list) {
     // grid-stride over (factor, k): the exp / log tables are copied into LDS once per block; the ~9 transcendental
     // evaluations per quadrature node then cost ~12 and ~20 instructions instead of ocml's ~25 and ~95
     __shared__ double sh_tab[EXP_TAB_N];
     __shared__ LogRec sh_log[LOG_TAB_N];
     load_log_table(sh_log);
     load_exp_table(sh_tab);
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < (int64_t)g.F * p.K; i += (int64_t)gridDim.x * BLOCK)
-        vi_factor_cc(g, pots, p, ef, pe_c, pe_d, i, sh_tab, sh_log);
+    const int64_t n = (int64_t)(list ? n_list : g.F) * p.K;
+    for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (int64_t)gridDim.x * BLOCK)
+        vi_factor_cc(g, pots, p, ef, pe_c, pe_d, list ? (int64_t)list[j / p.K] * p.K + j % p.K : j, sh_tab, sh_log);
 }
 
+
+// ---- round 4: the factor terms from per-axis tables ------------------------------------------------------------------------
+// On the tensor-product grid of expectation() (VI:40-55) the mixture belief factorises along the axes:
+//   b(x[t_0], .., x[t_{a-1}]) = sum_k w_k * prod_i comp_i,k(t_i),   comp_i,k(t) = pdf of argument i under component k at ITS node t
+// so the K * a * |axis| component values are computed ONCE per (factor, k) and every grid node costs K * a multiplications
+// instead of K * a exponentials (same products in the same order as rvs_belief).
+
+// log(phi + 1e-100) for phi = exp(v): v itself while exp(v) > 1e-84 (the 1e-100 is below half an ulp of phi then)
+__device__ __forceinline__ double log_phi_eps(double v, const double* __restrict__ sh_tab, const LogRec* __restrict__ sh_log) {
+    return v > -190.0 ? v : log_table(exp_core(v, sh_tab) + 1e-100, sh_log);
+}
+
+// VarInference.norm_pdf (VI:26-30) with the two divisions by the variance replaced by its reciprocal, taken once per (variable,
+// component): exp(-(x - mu)^2 / 2 * inv) * (inv / 2.5066...)
+__device__ __forceinline__ double norm_pdf_inv(double x, double mu, double inv, double scale, const double* __restrict__ tab) {
+    const double u = x - mu;
+    return exp_core(-(u * u) * 0.5 * inv, tab) * scale;
+}
+
+// Fast path for pairwise continuous / observed factors, T quadrature points known at compile time (T <= TT): the nodes of both
+// axes, their 2 * T pdfs per mixture component and the T * T belief accumulators live in registers.
+template <int TT>
+__device__ __forceinline__ void vi_factor_cc_tab(const lhvi_graph_t& g, const lhvi_pots_t& pots, const lhvi_vi_t& p, double* __restrict__ ef,
+                                                 double* __restrict__ pe_c, double* __restrict__ pe_d, int f, int k,
+                                                 const double* __restrict__ sh_tab, const LogRec* __restrict__ sh_log) {
+    const int64_t i = (int64_t)f * p.K + k;
+    const int base = g.fac_ptr[f];
+    const int v0 = g.edge_var[base], v1 = g.edge_var[base + 1];
+    const double val0 = g.var_value[v0], val1 = g.var_value[v1];
+    const bool h0 = is_hidden(val0), h1 = is_hidden(val1);
+    const bool go0 = !h0 && is_gobs(p, v0), go1 = !h1 && is_gobs(p, v1);
+    const bool a0 = h0 || go0, a1 = h1 || go1;
+    const double* e0 = p.eta_c + ((int64_t)v0 * p.K + k) * 2;
+    const double* e1 = p.eta_c + ((int64_t)v1 * p.K + k) * 2;
+    const double mu0 = go0 ? val0 : e0[0], var0 = go0 ? p.obs_var[v0] : e0[1], mu1 = go1 ? val1 : e1[0], var1 = go1 ? p.obs_var[v1] : e1[1];
+    const double s0 = a0 ? sqrt(2 * var0) : 0.0, s1 = a1 ? sqrt(2 * var1) : 0.0;
+    const int n0 = a0 ? p.T : 1, n1 = a1 ? p.T : 1;
+    double x0[TT], x1[TT], w0[TT], w1[TT], b[TT][TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const double gx = t < p.T ? p.gh_x[t] : 0.0, gw = t < p.T ? p.gh_w[t] : 0.0;
+        x0[t] = a0 ? s0 * gx + mu0 : val0; w0[t] = a0 ? gw : 1.0;
+        x1[t] = a1 ? s1 * gx + mu1 : val1; w1[t] = a1 ? gw : 1.0;
+#pragma unroll
+        for (int u = 0; u < TT; ++u) b[t][u] = 0.0;
+    }
+    for (int kk = 0; kk < p.K; ++kk) {                                  // rvs_belief: b += ((w_kk * pdf0) * pdf1), VI:336-353
+        const double* c0 = p.eta_c + ((int64_t)v0 * p.K + kk) * 2;
+        const double* c1 = p.eta_c + ((int64_t)v1 * p.K + kk) * 2;
+        const double m0 = go0 ? mu0 : c0[0], r0 = go0 ? var0 : c0[1], m1 = go1 ? mu1 : c1[0], r1 = go1 ? var1 : c1[1];
+        const double i0 = a0 ? 1.0 / r0 : 0.0, i1 = a1 ? 1.0 / r1 : 0.0;
+        const double sc0 = i0 * (1.0 / 2.506628274631), sc1 = i1 * (1.0 / 2.506628274631);
+        double q0[TT], q1[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            q0[t] = (a0 && t < n0) ? norm_pdf_inv(x0[t], m0, i0, sc0, sh_tab) : 1.0;
+            q1[t] = (a1 && t < n1) ? norm_pdf_inv(x1[t], m1, i1, sc1, sh_tab) : 1.0;
+        }
+        const double wk = p.w[kk];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const double t0 = a0 ? wk * q0[t] : wk;
+#pragma unroll
+            for (int u = 0; u < TT; ++u) b[t][u] += a1 ? t0 * q1[u] : t0;
+        }
+    }
+    const int pot = g.fac_pot[f];
+    const int kind = pots.kind[pot];
+    const double* par = pots.param + pots.off[pot];
+    double E = 0.0, Em0 = 0.0, Ev0 = 0.0, Em1 = 0.0, Ev1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        if (t >= n0) continue;
+#pragma unroll
+        for (int u = 0; u < TT; ++u) {
+            if (u >= n1) continue;
+            const double w = 1.0 * w0[t] * w1[u];
+            const double F = log_phi_eps(pot_log_cc(kind, par, x0[t], x1[u]), sh_tab, sh_log) - log_table(b[t][u] + 1e-100, sh_log);
+            E += w * F;
+            if (h0) { Em0 += w * (F * (x0[t] - mu0)); Ev0 += w * (F * ((x0[t] - mu0) * (x0[t] - mu0) - var0)); }
+            if (h1) { Em1 += w * (F * (x1[u] - mu1)); Ev1 += w * (F * ((x1[u] - mu1) * (x1[u] - mu1) - var1)); }
+        }
+    }
+    ef[i] = (g.fac_mult ? g.fac_mult[f] : 1.0) * E;
+    const double c0 = g.edge_count ? g.edge_count[base] : 1.0, c1 = g.edge_count ? g.edge_count[base + 1] : 1.0;
+    double* o0 = pe_c + ((int64_t)base * p.K + k) * 2;
+    double* o1 = pe_c + ((int64_t)(base + 1) * p.K + k) * 2;
+    o0[0] = h0 ? c0 * Em0 / var0 : 0.0; o0[1] = h0 ? c0 * Ev0 / (2 * var0 * var0) : 0.0;
+    o1[0] = h1 ? c1 * Em1 / var1 : 0.0; o1[1] = h1 ? c1 * Ev1 / (2 * var1 * var1) : 0.0;
+    for (int d = 0; d < p.Dmax; ++d) {
+        pe_d[((int64_t)base * p.K + k) * p.Dmax + d] = 0.0;
+        pe_d[((int64_t)(base + 1) * p.K + k) * p.Dmax + d] = 0.0;
+    }
+}
+
+template <int TT>
+__global__ void __launch_bounds__(BLOCK) vi_factor_cc_tab_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
+                                                                double* __restrict__ pe_c, double* __restrict__ pe_d,
+                                                                const int32_t* __restrict__ list, int n_list) {
+    __shared__ double sh_tab[EXP_TAB_N];
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    load_log_table(sh_log);
+    load_exp_table(sh_tab);
+    const int64_t n = (int64_t)(list ? n_list : g.F) * p.K;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const int f = list ? list[i / p.K] : (int)(i / p.K), k = (int)(i % p.K);
+        if (!list && !vi_is_cc(g, pots, f)) continue;
+        vi_factor_cc_tab<TT>(g, pots, p, ef, pe_c, pe_d, f, k, sh_tab, sh_log);
+    }
+}
+
+// General factors (discrete axes, MLN formulas, arity <= 6): a GROUP of L lanes per (factor, k) instead of a thread.  The lanes
+// share the per-axis tables of this (factor, k) in LDS -- node positions, node weights, the K component values per node -- and
+// split the grid nodes (and the evaluations of the pinned expectations of gradient_category_tau, VI:133-160) among themselves;
+// partial sums are folded with xor shuffles inside the group.  A model with a few thousand factors of up to 3^5 nodes (robot
+// mapping) then runs on the whole device instead of on a hundred long threads, and a large graph spends K * a multiplications per
+// node on its belief instead of K * a exponentials.  Eligible: sum of the axis lengths <= VI_GRP_SLOTS, K * that <= VI_GRP_COMP
+// (host: lhvi/vi.py builds the lists; legacy callers without lists keep the thread-per-factor kernels).
+constexpr int VI_GRP_L = 8;
+constexpr int VI_GRP_BLOCK = 512;
+constexpr int VI_GRP_SLOTS = LHVI_VI_GROUP_SLOTS;      // 24
+constexpr int VI_GRP_COMP = LHVI_VI_GROUP_COMP;        // 48
+
+template <int L>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int m = 1; m < L; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// log(phi(x) + 1e-100)
+__device__ __forceinline__ double pot_log_eps(int kind, const double* __restrict__ par, const double* x, const int* idx,
+                                              const double* __restrict__ sh_tab, const LogRec* __restrict__ sh_log) {
+    bool is_log;
+    const double v = pot_eval(kind, par, x, idx, is_log);
+    return is_log ? log_phi_eps(v, sh_tab, sh_log) : log_table(v + 1e-100, sh_log);
+}
+
+// rvs_belief (VI:336-353) at an arbitrary point (the pinned expectations leave the grid: under the reference's quirk a continuous
+// neighbour is evaluated at the TARGET's state values)
+template <int MAXA>
+__device__ __forceinline__ double belief_direct(const lhvi_graph_t& g, const lhvi_vi_t& p, const double* x, const int* idx, const int* vars,
+                                                int arity, const double* __restrict__ sh_tab) {
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a) {
+        if (a >= arity) continue;
+        const double val = g.var_value[vars[a]];
+        if (!is_hidden(val) && !is_gobs(p, vars[a]) && x[a] != val) return 0.0;
+    }
+    double s = 0.0;
+    for (int kk = 0; kk < p.K; ++kk) {
+        double b = p.w[kk];
+#pragma unroll
+        for (int a = 0; a < MAXA; ++a) {
+            if (a >= arity) continue;
+            const int v = vars[a];
+            if (!is_hidden(g.var_value[v])) {
+                if (is_gobs(p, v)) b *= norm_pdf_var_fast(x[a], g.var_value[v], p.obs_var[v], sh_tab);
+                continue;
+            }
+            if (v_cont(g, v)) { const double* e = p.eta_c + ((int64_t)v * p.K + kk) * 2; b *= norm_pdf_var_fast(x[a], e[0], e[1], sh_tab); }
+            else b *= p.eta_d[((int64_t)v * p.K + kk) * p.Dmax + idx[a]];
+        }
+        s += b;
+    }
+    return s;
+}
+
+template <int MAXA, int L>
+__global__ void __launch_bounds__(VI_GRP_BLOCK) vi_factor_group_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
+                                                                      double* __restrict__ pe_c, double* __restrict__ pe_d,
+                                                                      const int32_t* __restrict__ list, int n_list) {
+    constexpr int GROUPS = VI_GRP_BLOCK / L;
+    __shared__ double sh_tab[EXP_TAB_N];
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    __shared__ double sh_x[GROUPS][VI_GRP_SLOTS];
+    __shared__ double sh_w[GROUPS][VI_GRP_SLOTS];
+    __shared__ double sh_c[GROUPS][VI_GRP_COMP];
+    load_log_table(sh_log);
+    load_exp_table(sh_tab);
+    const int grp = threadIdx.x / L, gl = threadIdx.x % L;
+    const int64_t item = (int64_t)blockIdx.x * GROUPS + grp;
+    if (item >= (int64_t)n_list * p.K) return;                // (whole groups leave together: the shuffles below stay inside a group)
+    const int f = list[item / p.K], k = (int)(item % p.K);
+    const int64_t i = (int64_t)f * p.K + k;
+    const int base = g.fac_ptr[f], arity = g.fac_ptr[f + 1] - base;
+    double* sx = sh_x[grp]; double* sw = sh_w[grp]; double* sc = sh_c[grp];
+    int vars[MAXA], len[MAXA], off[MAXA], fix[MAXA];
+    bool hid[MAXA], cont[MAXA], axis[MAXA];
+    double mu[MAXA], var[MAXA];
+    int S = 0, G = 1;
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a) {
+        vars[a] = a < arity ? g.edge_var[base + a] : 0;
+        const double val = g.var_value[vars[a]];
+        hid[a] = a < arity && is_hidden(val);
+        cont[a] = a < arity && v_cont(g, vars[a]);
+        axis[a] = a < arity && (hid[a] || is_gobs(p, vars[a]));                 // takes part in the belief
+        len[a] = a < arity ? axis_len(g, p, vars[a]) : 1;
+        fix[a] = (a < arity && !is_hidden(val)) ? vi_state_index(g, vars[a], val) : 0;
+        off[a] = S;
+        if (a < arity) { S += len[a]; G *= len[a]; }
+        const double* e = p.eta_c + ((int64_t)vars[a] * p.K + k) * 2;
+        mu[a] = (hid[a] && cont[a]) ? e[0] : 0.0;
+        var[a] = (hid[a] && cont[a]) ? e[1] : 1.0;
+    }
+    // ---- per-axis tables of this (factor, k): nodes (under component k) and every component's value at them
+    for (int s = gl; s < S; s += L) {
+        int a = 0;
+#pragma unroll
+        for (int b = 1; b < MAXA; ++b) if (b < arity && s >= off[b]) a = b;
+        int v = 0, o = 0;
+#pragma unroll
+        for (int b = 0; b < MAXA; ++b) if (b == a) { v = vars[b]; o = off[b]; }
+        const int t = s - o;
+        const Node nd = axis_node(g, p, v, k, t);
+        sx[s] = nd.x; sw[s] = nd.w;
+        const double val = g.var_value[v];
+        for (int kk = 0; kk < p.K; ++kk) {
+            double c = 1.0;
+            if (is_hidden(val)) {
+                if (v_cont(g, v)) { const double* e = p.eta_c + ((int64_t)v * p.K + kk) * 2; c = norm_pdf_var_fast(nd.x, e[0], e[1], sh_tab); }
+                else c = p.eta_d[((int64_t)v * p.K + kk) * p.Dmax + t];
+            } else if (is_gobs(p, v)) c = norm_pdf_var_fast(nd.x, val, p.obs_var[v], sh_tab);
+            sc[kk * S + s] = c;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int pot = g.fac_pot[f];
+    const int kind = pots.kind[pot];
+    const double* par = pots.param + pots.off[pot];
+    // ---- the expectation over the grid: E_k[F], E_k[F (x - mu)], E_k[F ((x - mu)^2 - var)]
+    double x[MAXA];
+    int idx[MAXA], it[MAXA];
+    double E = 0.0, Em[MAXA], Ev[MAXA];
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a) { Em[a] = 0.0; Ev[a] = 0.0; x[a] = 0.0; idx[a] = 0; it[a] = 0; }
+    for (int node = gl; node < G; node += L) {
+        int r = node;
+        double w = 1.0;
+#pragma unroll
+        for (int a = MAXA - 1; a >= 0; --a) if (a < arity) { it[a] = r % len[a]; r /= len[a]; }
+#pragma unroll
+        for (int a = 0; a < MAXA; ++a) {
+            if (a >= arity) continue;
+            x[a] = sx[off[a] + it[a]];
+            w *= sw[off[a] + it[a]];
+            idx[a] = hid[a] ? (cont[a] ? 0 : it[a]) : fix[a];
+        }
+        double b = 0.0;
+        for (int kk = 0; kk < p.K; ++kk) {
+            double t = p.w[kk];
+#pragma unroll
+            for (int a = 0; a < MAXA; ++a) if (axis[a]) t *= sc[kk * S + off[a] + it[a]];
+            b += t;
+        }
+        const double F = pot_log_eps(kind, par, x, idx, sh_tab, sh_log) - log_table(b + 1e-100, sh_log);
+        E += w * F;
+#pragma unroll
+        for (int a = 0; a < MAXA; ++a) {
+            if (hid[a] && cont[a]) {
+                Em[a] += w * (F * (x[a] - mu[a]));
+                Ev[a] += w * (F * ((x[a] - mu[a]) * (x[a] - mu[a]) - var[a]));
+            }
+        }
+    }
+    E = group_sum<L>(E);
+    if (gl == 0) ef[i] = (g.fac_mult ? g.fac_mult[f] : 1.0) * E;
+    // ---- per-edge partials; only the first position of a variable in the scope contributes (f.nb.index(rv), LVI:112,146)
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a) {
+        if (a >= arity) continue;
+        const int e = base + a, v = vars[a];
+        bool first = true;
+#pragma unroll
+        for (int b = 0; b < MAXA; ++b) if (b < a && vars[b] == v) first = false;
+        const double c = g.edge_count ? g.edge_count[e] : 1.0;
+        double c0 = 0.0, c1 = 0.0;
+        if (hid[a] && cont[a]) {                                           // (uniform over the group)
+            const double sm = group_sum<L>(Em[a]), sv = group_sum<L>(Ev[a]);
+            if (first) { c0 = c * sm / var[a]; c1 = c * sv / (2 * var[a] * var[a]); }
+        }
+        if (gl == 0) {
+            pe_c[((int64_t)e * p.K + k) * 2] = c0;
+            pe_c[((int64_t)e * p.K + k) * 2 + 1] = c1;
+        }
+        const bool pinned = hid[a] && first && !cont[a];
+        const int Dt = pinned ? len[a] : 0;
+        if (pinned) {
+            // gradient_category_tau (VI:133-160): the other slots integrated with slot a pinned to each of its states in turn
+            const double* tvals = v_states(g, v);
+            int nx[MAXA], nw[MAXA];
+            int64_t totx = 1, totw = 1;
+#pragma unroll
+            for (int b = 0; b < MAXA; ++b) {
+                nx[b] = 1; nw[b] = 1;
+                if (b < arity && b != a) {
+                    if (hid[b]) {
+                        if (p.quirks) { nx[b] = Dt; nw[b] = cont[b] ? 2 : len[b]; }          // VI:147-150
+                        else { nx[b] = len[b]; nw[b] = len[b]; }
+                    } else if (axis[b]) { nx[b] = p.T; nw[b] = p.T; }                        // Gaussian observation: a proper axis
+                    totx *= nx[b]; totw *= nw[b];
+                }
+            }
+            const int cnt = (int)(totx < totw ? totx : totw);     // zip(product(xs), product(ws)) truncates to the shorter
+            for (int d = 0; d < Dt; ++d) {
+                double acc = 0.0;
+                for (int j = gl; j < cnt; j += L) {
+                    int rx = j, rw = j;
+                    double w = 1.0;
+#pragma unroll
+                    for (int b = MAXA - 1; b >= 0; --b) {
+                        if (b < arity && b != a) {
+                            const int ixs = rx % nx[b]; rx /= nx[b];
+                            const int iws = rw % nw[b]; rw /= nw[b];
+                            if (!hid[b] && axis[b]) { x[b] = sx[off[b] + ixs]; idx[b] = 0; w *= p.gh_w[iws]; }
+                            else if (!hid[b]) { x[b] = g.var_value[vars[b]]; idx[b] = fix[b]; }
+                            else if (p.quirks) {
+                                x[b] = tvals[ixs]; idx[b] = vi_state_index(g, vars[b], x[b]);
+                                w *= cont[b] ? p.eta_c[((int64_t)vars[b] * p.K + k) * 2 + iws] : p.eta_d[((int64_t)vars[b] * p.K + k) * p.Dmax + iws];
+                            } else { x[b] = sx[off[b] + ixs]; idx[b] = cont[b] ? 0 : ixs; w *= sw[off[b] + ixs]; }
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < MAXA; ++b) if (b == a) { x[b] = tvals[d]; idx[b] = d; }
+                    const double bel = belief_direct<MAXA>(g, p, x, idx, vars, arity, sh_tab);
+                    acc += w * (pot_log_eps(kind, par, x, idx, sh_tab, sh_log) - log_table(bel + 1e-100, sh_log));
+                }
+                acc = group_sum<L>(acc);
+                if (gl == 0) pe_d[((int64_t)e * p.K + k) * p.Dmax + d] = c * acc;
+            }
+        }
+        if (gl == 0) for (int d = Dt; d < p.Dmax; ++d) pe_d[((int64_t)e * p.K + k) * p.Dmax + d] = 0.0;
+    }
+}
 
 // compiled for scopes of up to 3 and up to MAXA variables: every per-slot array lives in registers, and the three-slot
 // build (all of the reference's MLN templates but robot mapping) needs half of them
 template <int MAXA>
 __global__ void __launch_bounds__(BLOCK) vi_factor_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
-                                                         double* __restrict__ pe_c, double* __restrict__ pe_d) {
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= (int64_t)g.F * p.K) return;
-    const int f = (int)(i / p.K), k = (int)(i % p.K);
-    if (vi_is_cc(g, pots, f)) return;                      // served by vi_factor_cc_kernel
+                                                         double* __restrict__ pe_c, double* __restrict__ pe_d,
+                                                         const int32_t* __restrict__ list, int n_list) {
+    const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= (int64_t)(list ? n_list : g.F) * p.K) return;
+    const int f = list ? list[j / p.K] : (int)(j / p.K), k = (int)(j % p.K);
+    const int64_t i = (int64_t)f * p.K + k;
     const int base = g.fac_ptr[f], arity = g.fac_ptr[f + 1] - base;
-    if (MAXA == 3 ? arity > 3 : arity <= 3) return;        // the other build's factors
+    if (!list) {
+        if (vi_is_cc(g, pots, f)) return;                  // served by vi_factor_cc_kernel
+        if (MAXA == 3 ? arity > 3 : arity <= 3) return;    // the other build's factors
+    }
     int vars[MAXA], len[MAXA], it[MAXA], idx[MAXA];
     double x[MAXA], wt[MAXA], Em[MAXA], Ev[MAXA];
 #pragma unroll
@@ -619,13 +961,47 @@ int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t
     double* partial = (double*)base;
     if (g->V > 0)
         hipLaunchKernelGGL(vi_var_kernel, dim3(grid_for((int64_t)g->V * p->K)), dim3(BLOCK), 0, st, *g, *p, rvterm, g_c, g_d);
-    if (g->F > 0) {
+    if (g->F > 0 && p->fac_list) {
+        // the caller's split of the factors (lhvi_vi_t.fac_list): [pairwise continuous | group kernel, arity <= 3 | group kernel,
+        // arity 4..6 | thread-per-factor kernels for what fits neither]
+        const int32_t* l = p->fac_list;
+        if (p->n_cc < 0 || p->n_grp3 < 0 || p->n_grp6 < 0 || p->n_rest3 < 0 || p->n_rest6 < 0 ||
+            (int64_t)p->n_cc + p->n_grp3 + p->n_grp6 + p->n_rest3 + p->n_rest6 != g->F) return LHVI_E_ARG;
+        if (p->n_cc > 0) {
+            const int64_t want = ((int64_t)p->n_cc * p->K + BLOCK - 1) / BLOCK;
+            const dim3 grid((unsigned)(want < 2048 ? want : 2048));
+            if (p->T <= 3)
+                hipLaunchKernelGGL(vi_factor_cc_tab_kernel<3>, grid, dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d, l, p->n_cc);
+            else if (p->T <= 5)
+                hipLaunchKernelGGL(vi_factor_cc_tab_kernel<5>, grid, dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d, l, p->n_cc);
+            else
+                hipLaunchKernelGGL(vi_factor_cc_kernel, grid, dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d, l, p->n_cc);
+        }
+        l += p->n_cc;
+        constexpr int GPB = VI_GRP_BLOCK / VI_GRP_L;
+        if (p->n_grp3 > 0)
+            hipLaunchKernelGGL((vi_factor_group_kernel<3, VI_GRP_L>), dim3(grid_for((int64_t)p->n_grp3 * p->K, GPB)), dim3(VI_GRP_BLOCK), 0, st,
+                               *g, *pots, *p, ef, pe_c, pe_d, l, p->n_grp3);
+        l += p->n_grp3;
+        if (p->n_grp6 > 0)
+            hipLaunchKernelGGL((vi_factor_group_kernel<LHVI_MAX_ARITY, VI_GRP_L>), dim3(grid_for((int64_t)p->n_grp6 * p->K, GPB)), dim3(VI_GRP_BLOCK), 0, st,
+                               *g, *pots, *p, ef, pe_c, pe_d, l, p->n_grp6);
+        l += p->n_grp6;
+        if (p->n_rest3 > 0)
+            hipLaunchKernelGGL(vi_factor_kernel<3>, dim3(grid_for((int64_t)p->n_rest3 * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d, l, p->n_rest3);
+        l += p->n_rest3;
+        if (p->n_rest6 > 0)
+            hipLaunchKernelGGL(vi_factor_kernel<LHVI_MAX_ARITY>, dim3(grid_for((int64_t)p->n_rest6 * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d, l, p->n_rest6);
+    } else if (g->F > 0) {
         {
             const int64_t want = ((int64_t)g->F * p->K + BLOCK - 1) / BLOCK;
-            hipLaunchKernelGGL(vi_factor_cc_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d);
+            hipLaunchKernelGGL(vi_factor_cc_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d,
+                               (const int32_t*)nullptr, 0);
         }
-        hipLaunchKernelGGL(vi_factor_kernel<3>, dim3(grid_for((int64_t)g->F * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d);
-        hipLaunchKernelGGL(vi_factor_kernel<LHVI_MAX_ARITY>, dim3(grid_for((int64_t)g->F * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d);
+        hipLaunchKernelGGL(vi_factor_kernel<3>, dim3(grid_for((int64_t)g->F * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d,
+                           (const int32_t*)nullptr, 0);
+        hipLaunchKernelGGL(vi_factor_kernel<LHVI_MAX_ARITY>, dim3(grid_for((int64_t)g->F * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d,
+                           (const int32_t*)nullptr, 0);
     }
     if (g->V > 0)
     {

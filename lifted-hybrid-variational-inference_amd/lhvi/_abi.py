@@ -72,6 +72,8 @@ class ViStruct(C.Structure):
         ('K', C.c_int32), ('T', C.c_int32), ('Dmax', C.c_int32), ('quirks', C.c_int32),
         ('gh_x', C.c_void_p), ('gh_w', C.c_void_p), ('w', C.c_void_p), ('eta_c', C.c_void_p), ('eta_d', C.c_void_p),
         ('obs_var', C.c_void_p), ('var_N', C.c_void_p),
+        ('fac_list', C.c_void_p), ('n_cc', C.c_int32), ('n_grp3', C.c_int32), ('n_grp6', C.c_int32), ('n_rest3', C.c_int32),
+        ('n_rest6', C.c_int32),
     ]
 
 
@@ -93,10 +95,11 @@ PBP_LEAVE_ROOM = 256
 PBP_BOUNDARY_TOTALS = 2048
 PBP_CQ = 512
 PBP_SKIP_CQ = 1024
-ABI_VERSION = 8             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
+ABI_VERSION = 9             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
 PBP_DESC_BYTES = 128
 COLOR_HASH, COLOR_SORT = 0, 1     # method of lhvi_color_refine_* (LHVI_COLOR_HASH / LHVI_COLOR_SORT)
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE
+VI_GROUP_SLOTS, VI_GROUP_COMP = 24, 48     # LHVI_VI_GROUP_SLOTS / LHVI_VI_GROUP_COMP
 
 _G, _P, _S, _VI = C.POINTER(GraphStruct), C.POINTER(PotsStruct), C.POINTER(PbpStruct), C.POINTER(ViStruct)
 _GP = C.POINTER(GabpPlanStruct)

@@ -392,6 +392,7 @@ class _DeviceStage(_Variational):
         self.reference_quirks = owner.reference_quirks
         self.var_threshold = owner.var_threshold
         self.time_log, self._dev, self._cache = [], None, {}
+        self._obs_var_host = np.ascontiguousarray(obs_var, dtype=np.float64)     # (Gaussian observations are axes of T nodes: factor_lists)
         self._setup_flat(flat)
         self._dev['obs_var'] = _abi.to_dev(np.ascontiguousarray(obs_var, dtype=np.float64))
 

@@ -25,11 +25,52 @@ from . import _abi
 from .flat import flatten
 
 
+def factor_lists(flat, K, T, obs_var=None):
+    """The split of the factors among the kernels of the expectation step (``lhvi_vi_t.fac_list``, include/lhvi.h): a
+    permutation of the factor ids in five segments and their lengths (n_cc, n_grp3, n_grp6, n_rest3, n_rest6).
+    Inside the two group segments factors are ordered by (potential row, pattern of hidden arguments), so the lanes of a
+    wavefront interpret the same formula on the same kind of grid."""
+    from .potentials import POT_GAUSSIAN, POT_LINEAR_GAUSSIAN, POT_QUADRATIC, POT_XY
+    F = flat.F
+    if F == 0:
+        return np.zeros(0, dtype=np.int32), (0, 0, 0, 0, 0)
+    arity = np.diff(flat.fac_ptr).astype(np.int64)
+    ev = flat.edge_var
+    hid, cont, nst = flat.var_hidden[ev], flat.var_cont[ev], flat.var_nstates[ev]
+    gobs = np.zeros(ev.size, dtype=bool) if obs_var is None else (~hid & (np.asarray(obs_var)[ev] > 0))
+    axis_len = np.where(hid, np.where(cont, T, nst), np.where(gobs, T, 1)).astype(np.int64)
+    first = flat.fac_ptr[:-1].astype(np.int64)
+    nonempty = arity > 0
+    S = np.zeros(F, dtype=np.int64)
+    S[nonempty] = np.add.reduceat(axis_len, first[nonempty])[:int(nonempty.sum())] if ev.size else 0
+    # reduceat over consecutive non-empty segments: recompute exactly with a cumulative sum (robust to empty factors)
+    csum = np.concatenate([[0], np.cumsum(axis_len)])
+    S = csum[flat.fac_ptr[1:]] - csum[flat.fac_ptr[:-1]]
+    kind = flat.pot_kind[flat.fac_pot]
+    pair = arity == 2
+    e0 = np.minimum(first, max(ev.size - 1, 0))
+    e1 = np.minimum(first + 1, max(ev.size - 1, 0))
+    ok0 = ~hid[e0] | cont[e0]
+    ok1 = ~hid[e1] | cont[e1]
+    cc = pair & np.isin(kind, (POT_GAUSSIAN, POT_QUADRATIC, POT_LINEAR_GAUSSIAN, POT_XY)) & (ev[e0] != ev[e1]) & ok0 & ok1
+    grp = ~cc & (arity >= 1) & (S <= _abi.VI_GROUP_SLOTS) & (K * S <= _abi.VI_GROUP_COMP)
+    small = arity <= 3
+    seg = np.where(cc, 0, np.where(grp & small, 1, np.where(grp, 2, np.where(small, 3, 4))))
+    # hidden pattern of a factor: bit a set when argument a is hidden (arity <= 6)
+    pos = np.arange(ev.size, dtype=np.int64) - np.repeat(first, arity)
+    bits = np.zeros(F, dtype=np.int64)
+    np.add.at(bits, np.repeat(np.arange(F), arity), hid.astype(np.int64) << np.minimum(pos, 30))
+    order = np.lexsort((np.arange(F), bits, flat.fac_pot, seg))
+    counts = np.bincount(seg, minlength=5)
+    return order.astype(np.int32), tuple(int(c) for c in counts)
+
+
 class _Variational:
     var_threshold = 0.1
     reference_quirks = True
     verbose = False
     fused_loop = True           # ADAM_update enqueues its whole loop through lhvi_vi_adam_run (else: one call per array and step)
+    factor_lists = True         # the factors are split among the expectation kernels on the host (else: every kernel classifies them itself)
 
     def _init_common(self, num_mixtures, num_quadrature_points):
         self.K = num_mixtures
@@ -65,6 +106,10 @@ class _Variational:
             np.add.at(n_row, np.repeat(np.arange(flat.V), np.diff(flat.var_ptr)), flat.edge_count[flat.var_edge])
             d['var_N'] = _abi.to_dev(n_row)
         self._dev = d
+        self._fac_counts = None
+        if self.factor_lists:
+            order, self._fac_counts = factor_lists(flat, K, self.T, getattr(self, '_obs_var_host', None))
+            d['fac_list'] = _abi.to_dev(order if order.size else np.zeros(1, dtype=np.int32))
         ws_bytes = int(_abi.lib().lhvi_vi_workspace_bytes(dg.g, self._struct()))
         d['ws'] = torch.empty(ws_bytes, dtype=torch.uint8, device=dg.device)
         d['ws_bytes'] = ws_bytes
@@ -85,6 +130,9 @@ class _Variational:
         p.gh_x, p.gh_w, p.w = _abi.ptr(d['gh_x']), _abi.ptr(d['gh_w']), _abi.ptr(d['w'])
         p.eta_c, p.eta_d = _abi.ptr(d['eta_c']), _abi.ptr(d['eta_d'])
         p.var_N = _abi.ptr(d.get('var_N'))
+        if getattr(self, '_fac_counts', None) is not None:
+            p.fac_list = _abi.ptr(d['fac_list'])
+            p.n_cc, p.n_grp3, p.n_grp6, p.n_rest3, p.n_rest6 = self._fac_counts
         return p
 
     def _opt_struct(self):

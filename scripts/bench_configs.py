@@ -426,3 +426,121 @@ if 'c2f_pbp' in which:
             totals_s=timing['total'], finite=bool(torch.isfinite(bp.v2f).all().item()),
             cpu_oracle_same_schedule_s=(cpu_baseline_c2f(flat, n_, its) if with_cpu else None), cpu_cores_used=1)
         del bp, bp2
+
+if 'vi_models' in which:
+    # the variational step on the models the reference published timings for (VI / LVI / C2FVI seconds per ADAM
+    # update, K = 2, T = 3, 100 updates; Demo/HMLN/HMLNTimeLog.py:48-58: paper-popularity 2.93 / 1.98 / 1.68 s/it, robot-mapping
+    # 6.37 / 6.10 / 1.90 s/it on an unrecorded CPU): seconds per update end to end (set-up, lifting, loop, read-back) and device
+    # only (HIP events around the loop), with the C oracle (CPU baseline, labelled, bounded sample) on the same graph beside them.
+    import gzip
+    from lhvi import c2fvi, generators
+    from lhvi.vi import VarInference
+
+    def robot_flat():
+        rec = json.load(gzip.open(os.path.join(ROOT, 'tests', 'golden', 'grounding.json.gz'), 'rt'))['robot_mapping']
+        data = {tuple(k): v for k, v in rec['evidence']}
+        return generators.robot_mapping().ground_flat(data)[0]
+
+    def cpu_baseline_vi(flat, updates, obs_var=None):
+        """CPU baseline (labelled): the C oracle's ADAM updates on the same graph, one host core; seconds per update"""
+        from oracle import oracle
+        o = oracle.ViOracle(flat, 2, 3, obs_var=obs_var)
+        rng = np.random.default_rng(0)
+        eta_c = np.ones((flat.V, 2, 2)); eta_c[:, :, 0] = rng.random((flat.V, 2)) * 3 - 1.5
+        o.set_params(np.zeros(2), eta_c, rng.random((flat.V, 2, o.Dmax)) * 10)
+        t0 = time.perf_counter()
+        o.run(updates, lr=0.2)
+        return (time.perf_counter() - t0) / updates
+
+    def timed_loop(vi, updates):
+        np.random.seed(0)
+        vi.init_param()
+        vi.is_log, vi.log_fe = True, True
+        vi.alpha, vi.b1, vi.b2, vi.eps, vi.t = 0.2, 0.9, 0.999, 1e-8, 0
+        vi.time_log, vi.total_time = [], 0
+        vi.ADAM_update(2)                              # warm-up (code objects)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        vi.time_log = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        a.record(); vi.ADAM_update(updates); b.record()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, a.elapsed_time(b) * 1e-3, vi.time_log[-1][1]
+
+    models = [('paper-popularity HMLN 300 papers x 10 topics (Demo/Data/HMLN/0 evidence pattern)', lambda: synth.paper_popularity_flat(300, 10, seed=0, points=20)[0],
+               dict(VI=2.93, LVI=1.98, C2FVI=1.68)),
+              ('robot-mapping HMLN (Demo/Data/HMLN/robot-map evidence + closed world)', robot_flat, dict(VI=6.37, LVI=6.10, C2FVI=1.90))]
+    UPD = 100
+    for label, make, published in models:
+        flat = make()
+        base = dict(model=label, rvs=int(flat.V), factors=int(flat.F), edges=int(flat.E), hidden=int(flat.var_hidden.sum()),
+                    max_arity=int(np.diff(flat.fac_ptr).max()), K=2, T=3, updates=UPD)
+        # ---- VI on the ground graph
+        t0 = time.perf_counter()
+        vi = VarInference(None, 2, 3)
+        vi._setup_flat(flat)
+        torch.cuda.synchronize()
+        t_setup = time.perf_counter() - t0
+        wall, dev, fe = timed_loop(vi, UPD)
+        out(config='VI (ground) ' + label, **base, setup_s=t_setup, s_per_update_end_to_end=(t_setup + wall) / UPD, s_per_update_loop_wall=wall / UPD,
+            s_per_update_device=dev / UPD, fe_last=fe, reference_published_s_per_update_unknown_cpu=published['VI'],
+            cpu_oracle_s_per_update_1_core=cpu_baseline_vi(flat, 3))
+        del vi
+        # ---- LVI: colour passing to the stable partition, then the same loop on the lifted graph
+        t0 = time.perf_counter()
+        rv0, f0, sym = lifting.initial_colors_flat(flat, True)
+        dgm = _abi.DeviceGraph(flat)
+        rvc, fc = lifting.refine_flat(flat, sym, rv0, f0, dg=dgm, device_out=True)
+        lflat = lifting.lift_flat(flat, rvc, fc, dg=dgm)
+        lvi = VarInference(None, 2, 3)
+        lvi._setup_flat(lflat)
+        torch.cuda.synchronize()
+        t_setup = time.perf_counter() - t0
+        wall, dev, fe = timed_loop(lvi, UPD)
+        out(config='LVI (lifted) ' + label, **base, rv_clusters=int(lflat.V), factor_clusters=int(lflat.F), lifted_edges=int(lflat.E),
+            lifting_and_setup_s=t_setup, s_per_update_end_to_end=(t_setup + wall) / UPD, s_per_update_loop_wall=wall / UPD, s_per_update_device=dev / UPD,
+            fe_last=fe, reference_published_s_per_update_unknown_cpu=published['LVI'], cpu_oracle_s_per_update_1_core=cpu_baseline_vi(lflat, 3))
+        del lvi, dgm
+        # ---- C2FVI: coarse start, re-lift every 10 updates (C2FVarInference.py:301-352), on arrays
+        owner = c2fvi.VarInference.__new__(c2fvi.VarInference)
+        owner._init_common(2, 3)
+        opts = dict(k_mean_k=2, k_mean_its=10, update_obs_its=10, output_its=0, min_obs_var=0, gaussian_obs=True)
+        for rep in range(2):
+            np.random.seed(0)
+            seen = []
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = c2fvi.run_c2fvi_flat(flat, c2fvi._DeviceEngine(owner), 2, UPD, 0.2, opts,
+                                       observer=lambda r, st: seen.append(int(st['rvc'].max()) + 1))
+            torch.cuda.synchronize()
+            total = time.perf_counter() - t0
+        out(config='C2FVI (coarse to fine, arrays) ' + label, **base, rv_clusters_per_round=seen, total_s=total, s_per_update_end_to_end=total / UPD,
+            relift_ms_per_round=[round(1e3 * x, 2) for x in res['relift_s']], fe_last=res['fe_log'][-1],
+            reference_published_s_per_update_unknown_cpu=published['C2FVI'],
+            cpu_oracle_s_per_update_1_core_final_lifted_graph=cpu_baseline_vi(res['flat'], 3, obs_var=res['obs_var']))
+
+if 'vi_scaled' in which:
+    # ground VI on the scaled cfg 3 (286 groundings of the 300 x 10 paper-popularity HMLN: ~970 k factors, discrete axes, ternary
+    # formulas -- the general vi_factor_kernel<3>) and on the Gaussian RGM (vi_factor_cc_kernel): gradient + free energy per launch,
+    # roofline at SURVEY 8(d)'s K * T^a * (K * a * 25 + c_phi) flop per factor
+    from lhvi.vi import VarInference
+    K_, T_ = 2, 3
+    for label, flat in (('scaled cfg 3: %d x paper-popularity 300 x 10' % int(os.environ.get('CFG3_COPIES', 286)),
+                         synth.paper_popularity_copies(int(os.environ.get('CFG3_COPIES', 286)), 300, 10, seed=0, points=20)),
+                        ('RGM C=1000 B=500 ground (Gaussian pairwise)', synth.rgm_flat(C=1000, B=500, n_values=0, evidence_ratio=0.1, seed=0)[0])):
+        vi = VarInference(None, K_, T_)
+        vi._setup_flat(flat)
+        np.random.seed(0)
+        vi.init_param()
+        t = ev_time(vi._grad)
+        # algorithmic flops: per factor K * G * (K * a_h * 25 + 30), G = product of the axis lengths (T for a hidden continuous or
+        # Gaussian-observed argument, #states for a hidden discrete one, 1 for an observed one), a_h = hidden arguments
+        hid, cont, nst = flat.var_hidden, flat.var_cont, flat.var_nstates
+        axis = np.where(hid[flat.edge_var], np.where(cont[flat.edge_var], T_, nst[flat.edge_var]), 1).astype(np.float64)
+        G = np.multiply.reduceat(axis, flat.fac_ptr[:-1])
+        ah = np.add.reduceat(hid[flat.edge_var].astype(np.float64), flat.fac_ptr[:-1])
+        flop = float((K_ * G * (K_ * ah * 25 + 30)).sum())
+        out(config='ground VI gradient + free energy, ' + label + ', K=2 T=3', factors=int(flat.F), edges=int(flat.E), grad_ms=t,
+            factors_per_s=flat.F / (t * 1e-3), quadrature_nodes=float((K_ * G).sum()), algorithmic_flop=flop,
+            fp64_TFLOPs=flop / (t * 1e-3) / 1e12, fp64_frac_of_78_6=flop / (t * 1e-3) / 78.6e12)
+        del vi
