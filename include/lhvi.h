@@ -441,6 +441,10 @@ typedef struct lhvi_vi {
      * NULL: every kernel classifies the factors itself (thread-per-factor kernels only). */
     const int32_t* fac_list;
     int32_t n_cc, n_grp3, n_grp6, n_rest3, n_rest6;
+    /* (ABI 9) [E][4] or NULL: per edge {variable, axis length | hidden << 16 | continuous << 17 | Gaussian observation << 18,
+     * state index of the observed value (0 unless observed and discrete), 0} -- the shape of the factor's quadrature grid, which
+     * depends on the graph and the evidence pattern only; NULL: the group kernels derive it per (factor, k) */
+    const int32_t* edge_axis;
 } lhvi_vi_t;
 #define LHVI_VI_GROUP_SLOTS 24
 #define LHVI_VI_GROUP_COMP 48

@@ -401,7 +401,13 @@ __global__ void __launch_bounds__(BLOCK) vi_factor_cc_tab_kernel(lhvi_graph_t g,
 // node on its belief instead of K * a exponentials.  Eligible: sum of the axis lengths <= VI_GRP_SLOTS, K * that <= VI_GRP_COMP
 // (host: lhvi/vi.py builds the lists; legacy callers without lists keep the thread-per-factor kernels).
 constexpr int VI_GRP_L = 8;
-constexpr int VI_GRP_BLOCK = 512;
+#ifndef LHVI_VI_GRP_BLOCK
+#define LHVI_VI_GRP_BLOCK 256
+#endif
+#ifndef LHVI_VI_GRP_WAVES
+#define LHVI_VI_GRP_WAVES 2
+#endif
+constexpr int VI_GRP_BLOCK = LHVI_VI_GRP_BLOCK;
 constexpr int VI_GRP_SLOTS = LHVI_VI_GROUP_SLOTS;      // 24
 constexpr int VI_GRP_COMP = LHVI_VI_GROUP_COMP;        // 48
 
@@ -451,7 +457,7 @@ __device__ __forceinline__ double belief_direct(const lhvi_graph_t& g, const lhv
 }
 
 template <int MAXA, int L>
-__global__ void __launch_bounds__(VI_GRP_BLOCK) vi_factor_group_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
+__global__ void __launch_bounds__(VI_GRP_BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI_VI_GRP_WAVES, 8))) vi_factor_group_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
                                                                       double* __restrict__ pe_c, double* __restrict__ pe_d,
                                                                       const int32_t* __restrict__ list, int n_list) {
     constexpr int GROUPS = VI_GRP_BLOCK / L;
@@ -463,25 +469,36 @@ __global__ void __launch_bounds__(VI_GRP_BLOCK) vi_factor_group_kernel(lhvi_grap
     load_log_table(sh_log);
     load_exp_table(sh_tab);
     const int grp = threadIdx.x / L, gl = threadIdx.x % L;
-    const int64_t item = (int64_t)blockIdx.x * GROUPS + grp;
-    if (item >= (int64_t)n_list * p.K) return;                // (whole groups leave together: the shuffles below stay inside a group)
+    double* sx = sh_x[grp]; double* sw = sh_w[grp]; double* sc = sh_c[grp];
+    // persistent: the tables above are loaded once per workgroup; groups stride over the (factor, k) items (whole groups leave
+    // together, so the shuffles below stay inside a group)
+    for (int64_t item = (int64_t)blockIdx.x * GROUPS + grp; item < (int64_t)n_list * p.K; item += (int64_t)gridDim.x * GROUPS) {
     const int f = list[item / p.K], k = (int)(item % p.K);
     const int64_t i = (int64_t)f * p.K + k;
     const int base = g.fac_ptr[f], arity = g.fac_ptr[f + 1] - base;
-    double* sx = sh_x[grp]; double* sw = sh_w[grp]; double* sc = sh_c[grp];
     int vars[MAXA], len[MAXA], off[MAXA], fix[MAXA];
     bool hid[MAXA], cont[MAXA], axis[MAXA];
     double mu[MAXA], var[MAXA];
     int S = 0, G = 1;
+    // what the grid of this factor looks like depends on the graph and the evidence pattern only: the caller's per-edge records
+    // (lhvi_vi_t.edge_axis: variable, axis length | flags, state index of an observed value) replace four dependent loads per slot
+    const int4* __restrict__ ax = reinterpret_cast<const int4*>(p.edge_axis);
 #pragma unroll
     for (int a = 0; a < MAXA; ++a) {
-        vars[a] = a < arity ? g.edge_var[base + a] : 0;
-        const double val = g.var_value[vars[a]];
-        hid[a] = a < arity && is_hidden(val);
-        cont[a] = a < arity && v_cont(g, vars[a]);
-        axis[a] = a < arity && (hid[a] || is_gobs(p, vars[a]));                 // takes part in the belief
-        len[a] = a < arity ? axis_len(g, p, vars[a]) : 1;
-        fix[a] = (a < arity && !is_hidden(val)) ? vi_state_index(g, vars[a], val) : 0;
+        if (ax) {
+            const int4 r = a < arity ? ax[base + a] : make_int4(0, 1, 0, 0);
+            vars[a] = r.x; len[a] = r.y & 0xffff; fix[a] = r.z;
+            hid[a] = a < arity && ((r.y >> 16) & 1); cont[a] = a < arity && ((r.y >> 17) & 1);
+            axis[a] = a < arity && (hid[a] || ((r.y >> 18) & 1));
+        } else {
+            vars[a] = a < arity ? g.edge_var[base + a] : 0;
+            const double val = g.var_value[vars[a]];
+            hid[a] = a < arity && is_hidden(val);
+            cont[a] = a < arity && v_cont(g, vars[a]);
+            axis[a] = a < arity && (hid[a] || is_gobs(p, vars[a]));                 // takes part in the belief
+            len[a] = a < arity ? axis_len(g, p, vars[a]) : 1;
+            fix[a] = (a < arity && !is_hidden(val)) ? vi_state_index(g, vars[a], val) : 0;
+        }
         off[a] = S;
         if (a < arity) { S += len[a]; G *= len[a]; }
         const double* e = p.eta_c + ((int64_t)vars[a] * p.K + k) * 2;
@@ -616,6 +633,9 @@ __global__ void __launch_bounds__(VI_GRP_BLOCK) vi_factor_group_kernel(lhvi_grap
             }
         }
         if (gl == 0) for (int d = Dt; d < p.Dmax; ++d) pe_d[((int64_t)e * p.K + k) * p.Dmax + d] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // the next item overwrites this group's tables
+    __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -980,11 +1000,11 @@ int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t
         l += p->n_cc;
         constexpr int GPB = VI_GRP_BLOCK / VI_GRP_L;
         if (p->n_grp3 > 0)
-            hipLaunchKernelGGL((vi_factor_group_kernel<3, VI_GRP_L>), dim3(grid_for((int64_t)p->n_grp3 * p->K, GPB)), dim3(VI_GRP_BLOCK), 0, st,
+            hipLaunchKernelGGL((vi_factor_group_kernel<3, VI_GRP_L>), dim3(min(grid_for((int64_t)p->n_grp3 * p->K, GPB), 4096u)), dim3(VI_GRP_BLOCK), 0, st,
                                *g, *pots, *p, ef, pe_c, pe_d, l, p->n_grp3);
         l += p->n_grp3;
         if (p->n_grp6 > 0)
-            hipLaunchKernelGGL((vi_factor_group_kernel<LHVI_MAX_ARITY, VI_GRP_L>), dim3(grid_for((int64_t)p->n_grp6 * p->K, GPB)), dim3(VI_GRP_BLOCK), 0, st,
+            hipLaunchKernelGGL((vi_factor_group_kernel<LHVI_MAX_ARITY, VI_GRP_L>), dim3(min(grid_for((int64_t)p->n_grp6 * p->K, GPB), 4096u)), dim3(VI_GRP_BLOCK), 0, st,
                                *g, *pots, *p, ef, pe_c, pe_d, l, p->n_grp6);
         l += p->n_grp6;
         if (p->n_rest3 > 0)

@@ -73,7 +73,7 @@ class ViStruct(C.Structure):
         ('gh_x', C.c_void_p), ('gh_w', C.c_void_p), ('w', C.c_void_p), ('eta_c', C.c_void_p), ('eta_d', C.c_void_p),
         ('obs_var', C.c_void_p), ('var_N', C.c_void_p),
         ('fac_list', C.c_void_p), ('n_cc', C.c_int32), ('n_grp3', C.c_int32), ('n_grp6', C.c_int32), ('n_rest3', C.c_int32),
-        ('n_rest6', C.c_int32),
+        ('n_rest6', C.c_int32), ('edge_axis', C.c_void_p),
     ]
 
 

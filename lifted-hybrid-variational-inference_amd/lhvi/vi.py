@@ -33,7 +33,7 @@ def factor_lists(flat, K, T, obs_var=None):
     from .potentials import POT_GAUSSIAN, POT_LINEAR_GAUSSIAN, POT_QUADRATIC, POT_XY
     F = flat.F
     if F == 0:
-        return np.zeros(0, dtype=np.int32), (0, 0, 0, 0, 0)
+        return np.zeros(0, dtype=np.int32), (0, 0, 0, 0, 0), np.zeros((0, 4), dtype=np.int32)
     arity = np.diff(flat.fac_ptr).astype(np.int64)
     ev = flat.edge_var
     hid, cont, nst = flat.var_hidden[ev], flat.var_cont[ev], flat.var_nstates[ev]
@@ -62,7 +62,22 @@ def factor_lists(flat, K, T, obs_var=None):
     np.add.at(bits, np.repeat(np.arange(F), arity), hid.astype(np.int64) << np.minimum(pos, 30))
     order = np.lexsort((np.arange(F), bits, flat.fac_pot, seg))
     counts = np.bincount(seg, minlength=5)
-    return order.astype(np.int32), tuple(int(c) for c in counts)
+    # per-edge axis records (lhvi_vi_t.edge_axis)
+    rec = np.zeros((ev.size, 4), dtype=np.int32)
+    rec[:, 0] = ev
+    rec[:, 1] = axis_len | (hid.astype(np.int64) << 16) | (cont.astype(np.int64) << 17) | (gobs.astype(np.int64) << 18)
+    obs_d = np.flatnonzero(~hid & ~cont)
+    if obs_d.size:                                  # state index of an observed discrete value (vi_state_index of csrc/vi.hip)
+        v = ev[obs_d]
+        dom = flat.var_dom[v]
+        lo, n = flat.dom_ptr[dom].astype(np.int64), nst[obs_d].astype(np.int64)
+        val = flat.var_value[v]
+        tt = np.arange(int(n.max()))[None, :]
+        states = flat.dom_val[np.minimum(lo[:, None] + tt, flat.dom_val.size - 1)]
+        match = (tt < n[:, None]) & (states == val[:, None])
+        fix = np.where(match.any(axis=1), match.argmax(axis=1), val.astype(np.int64))      # first matching state, else (int) x
+        rec[obs_d, 2] = fix
+    return order.astype(np.int32), tuple(int(c) for c in counts), rec
 
 
 class _Variational:
@@ -108,8 +123,9 @@ class _Variational:
         self._dev = d
         self._fac_counts = None
         if self.factor_lists:
-            order, self._fac_counts = factor_lists(flat, K, self.T, getattr(self, '_obs_var_host', None))
+            order, self._fac_counts, rec = factor_lists(flat, K, self.T, getattr(self, '_obs_var_host', None))
             d['fac_list'] = _abi.to_dev(order if order.size else np.zeros(1, dtype=np.int32))
+            d['edge_axis'] = _abi.to_dev(rec if rec.size else np.zeros((1, 4), dtype=np.int32))
         ws_bytes = int(_abi.lib().lhvi_vi_workspace_bytes(dg.g, self._struct()))
         d['ws'] = torch.empty(ws_bytes, dtype=torch.uint8, device=dg.device)
         d['ws_bytes'] = ws_bytes
@@ -131,7 +147,7 @@ class _Variational:
         p.eta_c, p.eta_d = _abi.ptr(d['eta_c']), _abi.ptr(d['eta_d'])
         p.var_N = _abi.ptr(d.get('var_N'))
         if getattr(self, '_fac_counts', None) is not None:
-            p.fac_list = _abi.ptr(d['fac_list'])
+            p.fac_list, p.edge_axis = _abi.ptr(d['fac_list']), _abi.ptr(d['edge_axis'])
             p.n_cc, p.n_grp3, p.n_grp6, p.n_rest3, p.n_rest6 = self._fac_counts
         return p
 

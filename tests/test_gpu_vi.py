@@ -273,3 +273,29 @@ def test_c2fvi_on_arrays_equals_the_object_path(api, golden_dir, name):
     cont = np.array([rv.value is None and rv.domain.continuous for rv in rvs])
     np.testing.assert_allclose(res['params']['eta_c'][res['rvc']][cont], z['final_eta_c'][cont], rtol=1e-7, atol=1e-10)
     np.testing.assert_allclose(res['params']['w_tau'], z['final_w_tau'], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize('name', ['hybrid_k2', 'lifted_robot_k2', 'kalman_k3', 'lifted_rgm_small_k2'])
+def test_table_kernels_equal_the_thread_per_factor_kernels(api, golden_dir, name):
+    """round 4: the factors are split on the host (``vi.factor_lists``) between the pairwise fast path with per-axis pdf tables in
+    registers, the group-of-8-lanes kernel with per-axis tables in LDS, and the thread-per-factor kernels; without the lists
+    (``factor_lists = False``) every factor goes through the thread-per-factor kernels of rounds 1-3.  Same gradients and free
+    energy (the table kernels take log(phi + 1e-100) = log phi directly and hoist reciprocals: rounding-level differences)."""
+    from lhvi.vi import LiftedVarInference, VarInference
+    z, meta = load_vi(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    outs = []
+    for lists in (True, False):
+        vi = (LiftedVarInference if name.startswith('lifted') else VarInference)(g, meta['K'], meta['T'])
+        vi.factor_lists = lists
+        np.random.seed(3)
+        vi.init_param()
+        vi._grad()
+        d = vi._dev
+        outs.append([d[k].cpu().numpy().copy() for k in ('g_w', 'g_c', 'g_d', 'fe')] + [vi._fac_counts])
+    a, b = outs
+    assert b[4] is None and a[4] is not None and sum(a[4]) == len(vi.flat.factors)
+    if name == 'lifted_robot_k2':
+        assert a[4][2] > 0                      # arity-5 formulas on the group kernel
+    for x, y, what in zip(a[:4], b[:4], ('g_w', 'g_c', 'g_d', 'fe')):
+        np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-9, err_msg=what)

@@ -538,3 +538,25 @@ def test_robot_mapping_model_matches_the_reference_demo(golden_dir, tmp_path):
     path.write_text(text)
     # (a one-line comment opens a block that only a later "*/" line closes, exactly as the reference's parser behaves)
     assert generators.load_raw_data(str(path)) == {('PartOf', 'A1_2', 'LA1'): 1, ('SegType', 'A1_1', 'Door'): 1, ('Length', 'A1_1'): 0.0979}
+
+
+def test_vi_factor_lists_split():
+    """``vi.factor_lists``: every factor in exactly one segment; pairwise continuous factors on the fast path; the group kernel's
+    budget (axis lengths sum to <= 24, times K <= 48); per-edge axis records agree with the graph"""
+    from lhvi import synth
+    from lhvi.vi import factor_lists
+    flat, _ = synth.paper_popularity_flat(40, 5, seed=1, points=20)
+    order, counts, rec = factor_lists(flat, 2, 3)
+    assert sorted(order.tolist()) == list(range(flat.F)) and sum(counts) == flat.F
+    assert counts[0] == 0 and counts[1] == flat.F            # MLN formulas of arity <= 3, K * S <= 2 * 8
+    order5, counts5, _ = factor_lists(flat, 7, 3)            # K = 7: 7 * 8 slots > 48 for the all-hidden ternary factors
+    assert counts5[3] > 0 and counts5[1] + counts5[3] == flat.F
+    hid = flat.var_hidden[flat.edge_var]
+    assert (rec[:, 0] == flat.edge_var).all() and (((rec[:, 1] >> 16) & 1) == hid).all()
+    lens = rec[:, 1] & 0xffff
+    assert (lens[hid & flat.var_cont[flat.edge_var]] == 3).all() and (lens[~hid] == 1).all() and (lens[hid & ~flat.var_cont[flat.edge_var]] == 2).all()
+    obs_d = ~hid & ~flat.var_cont[flat.edge_var]
+    assert (rec[obs_d, 2] == flat.var_value[flat.edge_var[obs_d]].astype(int)).all()          # states (0, 1): index == value
+    rg, _, _, _ = synth.rgm_flat(C=6, B=4, evidence_ratio=0.3, seed=0)
+    o2, c2, _ = factor_lists(rg, 2, 3)
+    assert c2 == (rg.F, 0, 0, 0, 0)
