@@ -32,7 +32,7 @@ extern "C" {
                               * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq; the colour
                               *    refinement calls take a method and return four result words; lhvi_vi_t gained var_N; lhvi_vi_opt_t, lhvi_vi_adam_run;
                               *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub / v2f_mid16 / v2f_mid32, prop_hub / prop_partial, resample_vars, small16_desc / small32_desc; 16 ticket words; lhvi_pbp_boundary_reduce;
-                              * 9: lhvi_vi_t gained fac_list / n_cc / n_grp3 / n_grp6 / n_rest3 / n_rest6; lhvi_color_first_members, lhvi_pbp_halo_pack / _unpack */
+                              * 9: lhvi_vi_t gained fac_list / n_cc / n_grp3 / n_grp6 / n_rest3 / n_rest6; lhvi_color_first_members, lhvi_pbp_halo_pack / _unpack; lhvi_gabp_plan_t.rec */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -133,6 +133,9 @@ typedef struct lhvi_gabp_plan {
     const double* count;
     int32_t n_hub_rows;     /* variables with more than 512 incident edges (served by the wave-parallel hub kernel); 0 skips that
                              * launch, -1 = not counted (the kernel is launched whenever the graph lists hub_vars) */
+    const int32_t* rec;     /* (ABI 9) [nnz][4] or NULL: per slot {pslot[k], info[k], position of k in its row | row length << 10 |
+                             * variable hidden << 20 | row longer than 512 << 21, 0}: with it a slot needs no lookup through
+                             * slot_var / var_ptr / var_value (GaBP.message_rv_to_f, GaBP.py:20-35, reads rv.nb and rv.value) */
 } lhvi_gabp_plan_t;
 size_t lhvi_gabp_pull_workspace_bytes(const lhvi_graph_t* g);
 /* one sweep: v_next[k] = message_rv_to_f of slot k given the f -> v messages implied by v_prev (first != 0: given the

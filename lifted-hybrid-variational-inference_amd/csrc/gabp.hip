@@ -206,17 +206,29 @@ __global__ void __launch_bounds__(BLOCK) gabp_marginal_kernel(lhvi_graph_t g, co
     if (!is_hidden(val)) { st2(out, v, val, 0.0); return; }
     if (g.hub_vars && g.var_ptr[v + 1] - g.var_ptr[v] > GABP_HUB_DEGREE) return;      // gabp_marginal_hub_kernel
     double H = 0.0, P = 0.0;
-    for (int j = g.var_ptr[v]; j < g.var_ptr[v + 1]; ++j) {
-        const int ej = g.var_edge[j];
-        const double2 m = ld2(f2v, ej);
-        if (g.edge_count) {
+    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    if (g.edge_count) {
+        for (int j = lo; j < hi; ++j) {
+            const int ej = g.var_edge[j];
+            const double2 m = ld2(f2v, ej);
             const double c = g.edge_count[ej];
             if (m.y != m.y) H -= m.x * c;
             else { const double p = 1.0 / m.y; H += p * m.x * c; P += p * c; }
-        } else {
-            if (m.y != m.y) H -= m.x;
-            else { const double p = 1.0 / m.y; H += p * m.x; P += p; }
         }
+    } else {
+        // ground graph: four gathers (and their reciprocals) in flight per step, the additions in rv.nb order as before -- a
+        // thread of a 100-entry row used to pay one memory round trip and one division per entry, one after the other
+        int j = lo;
+        for (; j + 4 <= hi; j += 4) {
+            const double2 m0 = ld2(f2v, g.var_edge[j]), m1 = ld2(f2v, g.var_edge[j + 1]), m2 = ld2(f2v, g.var_edge[j + 2]),
+                          m3 = ld2(f2v, g.var_edge[j + 3]);
+            const double p0 = 1.0 / m0.y, p1 = 1.0 / m1.y, p2 = 1.0 / m2.y, p3 = 1.0 / m3.y;
+#define LHVI_MARG_STEP(m, p) { const bool none = (m).y != (m).y; const double h = H + (none ? -(m).x : (p) * (m).x), q = P + (p); \
+                               H = h; P = none ? P : q; }
+            LHVI_MARG_STEP(m0, p0) LHVI_MARG_STEP(m1, p1) LHVI_MARG_STEP(m2, p2) LHVI_MARG_STEP(m3, p3)
+        }
+        for (; j < hi; ++j) { const double2 m = ld2(f2v, g.var_edge[j]); const double p = 1.0 / m.y; LHVI_MARG_STEP(m, p) }
+#undef LHVI_MARG_STEP
     }
     const double var = 1.0 / P;
     st2(out, v, var * H, var);
@@ -320,6 +332,97 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_kernel(lhvi_graph_t g, lhvi_p
     st2(vnext, k, var * H, var);
 }
 
+// Round 4: the same sweep with the per-slot dependent loads folded away.  The kernel above runs at the same speed whether the partner
+// gather is random or sequential (measured: 0.295 vs 0.277 ms at 10 M slots, profiles/r04_experiments.md): it is bound by its
+// chains of dependent loads -- slot_var -> var_value / var_ptr, info -> pots.kind -> pots.off -> parameters -- not by bytes.  Here
+// one 16-byte record per slot (lhvi_gabp_plan_t.rec: partner slot, 4 * potential + position code, position in the row | row
+// length << 10 | hidden << 20 | hub row << 21) carries everything the slot needs to know about the graph, and the potential
+// parameters sit in LDS (up to GABP_LDS_POTS potentials; more: read from global memory as before).  Chain: record -> partner's
+// message -> arithmetic.  Same expressions in the same order: the same bits.
+constexpr int GABP_LDS_POTS = 40;
+constexpr int GABP_POT_WORDS = 12;            // par[0 .. 10] (the Gaussian closed form reads up to par[10]) + the kind
+
+template <bool LDS_POTS>
+__device__ __forceinline__ double2 pull_incoming_rec(const lhvi_graph_t& g, const lhvi_pots_t& pots, const int4 r,
+                                                     const double* __restrict__ vprev, const double* __restrict__ sh_par) {
+    const int code = r.y & 3, pot = r.y >> 2;
+    const double* par = LDS_POTS ? sh_par + pot * GABP_POT_WORDS : pots.param + pots.off[pot];
+    const int kind = LDS_POTS ? (int)sh_par[pot * GABP_POT_WORDS + GABP_POT_WORDS - 1] : pots.kind[pot];
+    const int arity = code == 0 ? 1 : (code == 3 ? 3 : 2), pos = code == 2 ? 1 : 0;
+    bool partner_hidden = false;
+    double u = 0.0, sv = 0.0, y = 0.0;
+    if (arity == 2) {
+        partner_hidden = r.x >= 0;
+        if (partner_hidden) { const double2 m = ld2(vprev, r.x); u = m.x; sv = m.y; }
+        else y = g.var_value[-1 - r.x];
+    }
+    return f2v_closed_form(kind, par, arity, pos, partner_hidden, u, sv, y);
+}
+
+template <bool LDS_POTS>
+__global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lhvi_pots_t pots, const int4* __restrict__ rec,
+                                                             const double* __restrict__ count, const double* __restrict__ vprev,
+                                                             double* __restrict__ vnext, int first) {
+    constexpr int CAP = BLOCK + 2 * GABP_HUB_DEGREE;
+    __shared__ double2 sh[CAP];
+    __shared__ double sh_par[LDS_POTS ? GABP_LDS_POTS * GABP_POT_WORDS : 1];
+    if (LDS_POTS) {
+        for (int i = threadIdx.x; i < pots.P * GABP_POT_WORDS; i += BLOCK) {
+            const int pot = i / GABP_POT_WORDS, j = i % GABP_POT_WORDS;
+            const int n = pots.off[pot + 1] - pots.off[pot];
+            sh_par[i] = j == GABP_POT_WORDS - 1 ? (double)pots.kind[pot] : (j < n ? pots.param[pots.off[pot] + j] : 0.0);
+        }
+        __syncthreads();
+    }
+    const int k0 = blockIdx.x * BLOCK;
+    const int kend = min(k0 + BLOCK, g.nnz);
+    const int rf = rec[k0].z, rl = rec[kend - 1].z;
+    const int lo_ext = ((rf >> 21) & 1) ? k0 : k0 - (rf & 1023);                       // (a hub row is served by gabp_pull_hub_kernel)
+    const int hi_ext = ((rl >> 21) & 1) ? kend : kend - 1 - (rl & 1023) + ((rl >> 10) & 1023);
+    for (int j = lo_ext + threadIdx.x; j < hi_ext; j += BLOCK) {
+        const int4 r = rec[j];
+        if ((r.z >> 21) & 1) continue;
+        const bool hid = (r.z >> 20) & 1;
+        const double2 m = (hid && !first) ? pull_incoming_rec<LDS_POTS>(g, pots, r, vprev, sh_par) : make_double2(0.0, 1.0);
+        const double p = 1.0 / m.y;
+        sh[j - lo_ext] = (m.y != m.y) ? m : make_double2(p * m.x, p);
+    }
+    __syncthreads();
+    const int k = k0 + threadIdx.x;
+    if (k >= g.nnz) return;
+    const int rz = rec[k].z;
+    if (!((rz >> 20) & 1)) { st2(vnext, k, NAN, NAN); return; }
+    if ((rz >> 21) & 1) return;                                 // gabp_pull_hub_kernel
+    const int lo = k - (rz & 1023), hi = lo + ((rz >> 10) & 1023);
+    double H = 0.0, P = 0.0;
+    if (count) {
+        for (int j = lo; j < hi; ++j) {
+            double c = count[j];
+            if (j == k) c -= 1.0;
+            const double2 m = sh[j - lo_ext];
+            if (m.y != m.y) H -= m.x * c;
+            else { H += m.x * c; P += m.y * c; }
+        }
+    } else {
+        // the row in rv.nb order, the slot's own entry left out (GaBP.py:23-33).  Branch-free body -- selects around the two
+        // additions, whose order is the reference's -- so that the LDS reads of four entries are in flight together: a thread
+        // of a 100-entry row used to wait out one LDS round trip per entry (22 us per launch on BASELINE cfg 2's 20 k slots)
+        const double2* __restrict__ row = sh + (lo - lo_ext);
+        const int n = hi - lo, own = k - lo;
+        int j = 0;
+        for (; j + 4 <= n; j += 4) {
+            const double2 m0 = row[j], m1 = row[j + 1], m2 = row[j + 2], m3 = row[j + 3];
+#define LHVI_ROW_STEP(m, jj) { const bool none = (m).y != (m).y; const double h = H + (none ? -(m).x : (m).x), q = P + (m).y; \
+                               const bool take = (jj) != own; H = take ? h : H; P = (take && !none) ? q : P; }
+            LHVI_ROW_STEP(m0, j) LHVI_ROW_STEP(m1, j + 1) LHVI_ROW_STEP(m2, j + 2) LHVI_ROW_STEP(m3, j + 3)
+        }
+        for (; j < n; ++j) { const double2 m = row[j]; LHVI_ROW_STEP(m, j) }
+#undef LHVI_ROW_STEP
+    }
+    const double var = 1.0 / P;
+    st2(vnext, k, var * H, var);
+}
+
 __global__ void __launch_bounds__(BLOCK) gabp_pull_hub_kernel(lhvi_graph_t g, lhvi_pots_t pots, PullPlan pl,
                                                              const double* __restrict__ vprev, double* __restrict__ vnext, int first) {
     const int lane = threadIdx.x & 63;
@@ -334,6 +437,47 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_hub_kernel(lhvi_graph_t g, lh
     for (int j = lo + lane; j < hi; j += 64) {
         const double c = pl.count ? pl.count[j] : 1.0;
         const double2 m = first ? make_double2(0.0, 1.0) : pull_incoming(g, pots, pl, vprev, j);
+        st2(vnext, j, m.x, m.y);
+        if (m.y != m.y) H -= m.x * c;
+        else { const double p = 1.0 / m.y; H += p * m.x * c; P += p * c; }
+    }
+    H = dpp_wave_reduce(H, SumOp()); P = dpp_wave_reduce(P, SumOp());
+    for (int j = lo + lane; j < hi; j += 64) {
+        const double2 m = ld2(vnext, j);
+        double h = H, p = P;
+        if (m.y != m.y) h += m.x;
+        else { const double q = 1.0 / m.y; h -= q * m.x; p -= q; }
+        const double var = 1.0 / p;
+        st2(vnext, j, var * h, var);
+    }
+}
+
+
+// the same with the slot records (and the potential parameters in LDS): a slot's incoming message costs the record, the partner's
+// message and arithmetic -- no walk through info -> pots.kind -> pots.off -> parameters per slot
+template <bool LDS_POTS>
+__global__ void __launch_bounds__(BLOCK) gabp_pull_hub_rec_kernel(lhvi_graph_t g, lhvi_pots_t pots, const int4* __restrict__ rec,
+                                                                 const double* __restrict__ count, const double* __restrict__ vprev,
+                                                                 double* __restrict__ vnext, int first) {
+    __shared__ double sh_par[LDS_POTS ? GABP_LDS_POTS * GABP_POT_WORDS : 1];
+    if (LDS_POTS) {
+        for (int i = threadIdx.x; i < pots.P * GABP_POT_WORDS; i += BLOCK) {
+            const int pot = i / GABP_POT_WORDS, j = i % GABP_POT_WORDS;
+            const int n = pots.off[pot + 1] - pots.off[pot];
+            sh_par[i] = j == GABP_POT_WORDS - 1 ? (double)pots.kind[pot] : (j < n ? pots.param[pots.off[pot] + j] : 0.0);
+        }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (i >= g.n_hubs) return;
+    const int v = g.hub_vars[i];
+    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
+    if (hi - lo <= GABP_HUB_DEGREE || !is_hidden(g.var_value[v])) return;
+    double H = 0.0, P = 0.0;
+    for (int j = lo + lane; j < hi; j += 64) {
+        const double c = count ? count[j] : 1.0;
+        const double2 m = first ? make_double2(0.0, 1.0) : pull_incoming_rec<LDS_POTS>(g, pots, rec[j], vprev, sh_par);
         st2(vnext, j, m.x, m.y);
         if (m.y != m.y) H -= m.x * c;
         else { const double p = 1.0 / m.y; H += p * m.x * c; P += p * c; }
@@ -427,10 +571,25 @@ int lhvi_gabp_pull(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_ga
     if (!v_next || (!first && !v_prev) || v_prev == v_next) return LHVI_E_ARG;
     PullPlan pl;
     pl.pslot = plan->pslot; pl.info = plan->info; pl.count = plan->count;
-    hipLaunchKernelGGL(gabp_pull_kernel, dim3(grid_for(g->nnz)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, pl, v_prev, v_next, first);
-    if (g->hub_vars && g->n_hubs > 0 && plan->n_hub_rows != 0)
-        hipLaunchKernelGGL(gabp_pull_hub_kernel, dim3(grid_for((int64_t)g->n_hubs * 64)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, pl,
-                           v_prev, v_next, first);
+    if (plan->rec && pots->P <= GABP_LDS_POTS)
+        hipLaunchKernelGGL(gabp_pull_rec_kernel<true>, dim3(grid_for(g->nnz)), dim3(BLOCK), 0, as_stream(stream), *g, *pots,
+                           reinterpret_cast<const int4*>(plan->rec), plan->count, v_prev, v_next, first);
+    else if (plan->rec)
+        hipLaunchKernelGGL(gabp_pull_rec_kernel<false>, dim3(grid_for(g->nnz)), dim3(BLOCK), 0, as_stream(stream), *g, *pots,
+                           reinterpret_cast<const int4*>(plan->rec), plan->count, v_prev, v_next, first);
+    else
+        hipLaunchKernelGGL(gabp_pull_kernel, dim3(grid_for(g->nnz)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, pl, v_prev, v_next, first);
+    if (g->hub_vars && g->n_hubs > 0 && plan->n_hub_rows != 0) {
+        const dim3 hgrid(grid_for((int64_t)g->n_hubs * 64));
+        if (plan->rec && pots->P <= GABP_LDS_POTS)
+            hipLaunchKernelGGL(gabp_pull_hub_rec_kernel<true>, hgrid, dim3(BLOCK), 0, as_stream(stream), *g, *pots,
+                               reinterpret_cast<const int4*>(plan->rec), plan->count, v_prev, v_next, first);
+        else if (plan->rec)
+            hipLaunchKernelGGL(gabp_pull_hub_rec_kernel<false>, hgrid, dim3(BLOCK), 0, as_stream(stream), *g, *pots,
+                               reinterpret_cast<const int4*>(plan->rec), plan->count, v_prev, v_next, first);
+        else
+            hipLaunchKernelGGL(gabp_pull_hub_kernel, hgrid, dim3(BLOCK), 0, as_stream(stream), *g, *pots, pl, v_prev, v_next, first);
+    }
     return check_launch();
 }
 

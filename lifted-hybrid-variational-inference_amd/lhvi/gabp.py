@@ -39,7 +39,16 @@ def pull_plan(flat):
     if (hidden_partner & (edge_slot[pce] < 0)).any():
         raise _abi.LhviError('a hidden partner argument has no variable-side slot')
     pslot = np.where(hidden_partner, edge_slot[pce], -1 - pvar)
-    return dict(pslot=pslot.astype(np.int32), info=(flat.fac_pot[f].astype(np.int64) * 4 + code).astype(np.int32),
+    info = flat.fac_pot[f].astype(np.int64) * 4 + code
+    # the 16-byte slot records of lhvi_gabp_plan_t.rec
+    deg = np.diff(flat.var_ptr).astype(np.int64)
+    svar = np.repeat(np.arange(flat.V, dtype=np.int64), deg)
+    within = np.arange(nnz, dtype=np.int64) - flat.var_ptr[svar]
+    long_row = deg[svar] > 512
+    rec = np.zeros((nnz, 4), dtype=np.int32)
+    rec[:, 0], rec[:, 1] = pslot, info
+    rec[:, 2] = np.where(long_row, 0, within | (deg[svar] << 10)) | (np.isnan(flat.var_value[svar]).astype(np.int64) << 20) | (long_row.astype(np.int64) << 21)
+    return dict(pslot=pslot.astype(np.int32), info=info.astype(np.int32), rec=rec,
                 count=np.ascontiguousarray(flat.edge_count[ve], dtype=np.float64) if flat.lifted else None)
 
 
@@ -48,6 +57,7 @@ class _GaussianSweep:
 
     verbose = False
     pull = True       # one launch per sweep, messages in slot order (lhvi_gabp_run_pull); False: the v2f / f2v kernel pair
+    slot_records = True   # the pull kernel reads one 16-byte record per slot (lhvi_gabp_plan_t.rec) instead of walking the graph arrays
 
     def _check_degrees(self, flat):
         # the reference raises ZeroDivisionError (0 ** -1) when a hidden variable has no other incoming
@@ -94,6 +104,7 @@ class _GaussianSweep:
             st['plan_dev'] = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
             plan = _abi.GabpPlanStruct()
             plan.pslot, plan.info, plan.count = (_abi.ptr(st['plan_dev'][k]) for k in ('pslot', 'info', 'count'))
+            plan.rec = _abi.ptr(st['plan_dev']['rec']) if self.slot_records else None
             plan.n_hub_rows = int((np.diff(flat.var_ptr) > 512).sum())
             st['plan'] = plan
             st['ws_bytes'] = int(l.lhvi_gabp_pull_workspace_bytes(dg.g))

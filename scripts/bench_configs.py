@@ -23,6 +23,18 @@ def out(**kw):
     print(json.dumps(kw), flush=True)
 
 
+def gabp_plan(flat, records=True):
+    """(plan struct, device arrays to keep alive) of the pull form; `records`: with the 16-byte slot records of round 4"""
+    from lhvi.gabp import pull_plan
+    host = pull_plan(flat)
+    dev = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
+    plan = _abi.GabpPlanStruct()
+    plan.pslot, plan.info, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'count'))
+    plan.rec = _abi.ptr(dev['rec']) if records and os.environ.get('GABP_NO_RECORDS') is None else None
+    plan.n_hub_rows = int((np.diff(flat.var_ptr) > 512).sum())
+    return plan, dev
+
+
 if 'gauss' in which:
     # Gaussian sweep roofline: random pairwise Gaussian MRF, E = 10M edges (+ unary priors)
     flat = synth.random_gaussian_mrf(V=2_000_000, deg=4, seed=0)
@@ -37,19 +49,15 @@ if 'gauss' in which:
         sweeps_per_s=1e3 / (t_v + t_f), algorithmic_GBs=bytes_sweep / ((t_v + t_f) * 1e-3) / 1e9,
         hbm_frac=bytes_sweep / ((t_v + t_f) * 1e-3) / 8e12)
     # pull form: one launch per sweep, messages in slot order
-    from lhvi.gabp import pull_plan
-    host = pull_plan(flat)
-    dev = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
-    plan = _abi.GabpPlanStruct()
-    plan.pslot, plan.info, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'count'))
-    plan.n_hub_rows = int((np.diff(flat.var_ptr) > 512).sum())
     nnz = int(flat.var_edge.size)
     va, vb = dg.empty(nnz, 2), dg.empty(nnz, 2)
-    _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 1, st))
-    _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(vb), _abi.ptr(va), 0, st))
-    t_p = ev_time(lambda: _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 0, st)))
-    out(config='gaussian sweep, random pairwise MRF, pull form (lhvi_gabp_pull)', edges=flat.E, sweep_ms=t_p, sweeps_per_s=1e3 / t_p,
-        algorithmic_GBs=bytes_sweep / (t_p * 1e-3) / 1e9, hbm_frac=bytes_sweep / (t_p * 1e-3) / 8e12)
+    for records in (False, True):
+        plan, dev = gabp_plan(flat, records)
+        _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 1, st))
+        _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(vb), _abi.ptr(va), 0, st))
+        t_p = ev_time(lambda: _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 0, st)))
+        out(config='gaussian sweep, random pairwise MRF, pull form (lhvi_gabp_pull)' + (', slot records' if records else ', graph arrays (round 3)'),
+            edges=flat.E, sweep_ms=t_p, sweeps_per_s=1e3 / t_p, algorithmic_GBs=bytes_sweep / (t_p * 1e-3) / 1e9, hbm_frac=bytes_sweep / (t_p * 1e-3) / 8e12)
     del dg, f2v, v2f, mv, va, vb
 
 if 'cfg2' in which:
@@ -60,12 +68,7 @@ if 'cfg2' in which:
     l, st = _abi.lib(), _abi.stream_ptr()
     t = ev_time(lambda: _abi.check(l.lhvi_gabp_run(dg.g, dg.p, _abi.ptr(f2v), _abi.ptr(v2f), 20, st)))
     out(config='cfg2 RGM C=100 B=50 ground GaBP, kernel pair', edges=flat.E, ms_20_sweeps=t, sweeps_per_s=20e3 / t)
-    from lhvi.gabp import pull_plan
-    host = pull_plan(flat)
-    dev = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
-    plan = _abi.GabpPlanStruct()
-    plan.pslot, plan.info, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'count'))
-    plan.n_hub_rows = int((np.diff(flat.var_ptr) > 512).sum())
+    plan, dev = gabp_plan(flat)
     nb = int(l.lhvi_gabp_pull_workspace_bytes(dg.g))
     ws = torch.empty(nb, dtype=torch.uint8, device=dg.device)
     t = ev_time(lambda: _abi.check(l.lhvi_gabp_run_pull(dg.g, dg.p, plan, _abi.ptr(f2v), _abi.ptr(v2f), 20, _abi.ptr(ws), nb, st)))
@@ -115,11 +118,7 @@ if 'gauss_rel' in which:
     for label, flat in graphs:
         dg = _abi.DeviceGraph(flat)
         l, st = _abi.lib(), _abi.stream_ptr()
-        host = pull_plan(flat)
-        dev = {k: (_abi.to_dev(a) if a is not None else None) for k, a in host.items()}
-        plan = _abi.GabpPlanStruct()
-        plan.pslot, plan.info, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'count'))
-        plan.n_hub_rows = int((np.diff(flat.var_ptr) > 512).sum())
+        plan, dev = gabp_plan(flat)
         nnz = int(flat.var_edge.size)
         va, vb = dg.empty(nnz, 2), dg.empty(nnz, 2)
         _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 1, st))
@@ -544,3 +543,25 @@ if 'vi_scaled' in which:
             factors_per_s=flat.F / (t * 1e-3), quadrature_nodes=float((K_ * G).sum()), algorithmic_flop=flop,
             fp64_TFLOPs=flop / (t * 1e-3) / 1e12, fp64_frac_of_78_6=flop / (t * 1e-3) / 78.6e12)
         del vi
+
+if 'gauss_probe' in which:
+    # where the pull kernel's bytes go: the same launch with the partner slots replaced by the slot itself (no random access left)
+    # and by a random permutation (every gather its own sector), next to the real plan; traffic from rocprofv3 --pmc on this command
+    from lhvi.gabp import pull_plan
+    flat = synth.random_gaussian_mrf(V=2_000_000, deg=4, seed=0)
+    dg = _abi.DeviceGraph(flat)
+    l, st = _abi.lib(), _abi.stream_ptr()
+    host = pull_plan(flat)
+    nnz = int(flat.var_edge.size)
+    va, vb = dg.empty(nnz, 2), dg.empty(nnz, 2)
+    rng = np.random.default_rng(0)
+    for label, ps in (('real plan', host['pslot']), ('identity (no gather)', np.where(host['pslot'] >= 0, np.arange(nnz), host['pslot']).astype(np.int32)),
+                      ('random permutation', np.where(host['pslot'] >= 0, rng.permutation(nnz), host['pslot']).astype(np.int32))):
+        dev = dict(pslot=_abi.to_dev(ps), info=_abi.to_dev(host['info']))
+        plan = _abi.GabpPlanStruct()
+        plan.pslot, plan.info, plan.count = _abi.ptr(dev['pslot']), _abi.ptr(dev['info']), None
+        plan.n_hub_rows = 0
+        _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 1, st))
+        va.fill_(1.0)
+        t_p = ev_time(lambda: _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 0, st)))
+        out(config='gauss probe: ' + label, slots=nnz, sweep_ms=t_p, algorithmic_frac=76.0 * flat.E / (t_p * 1e-3) / 8e12)

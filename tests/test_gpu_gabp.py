@@ -217,9 +217,19 @@ def _run_both_forms(api, flat, iterations):
     plan.n_hub_rows = int((np.diff(flat.var_ptr) > 512).sum())
     nbytes = int(l.lhvi_gabp_pull_workspace_bytes(dg.g))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dg.device)
-    for pull in (False, True):
+    for pull in (False, True, 'records', 'records, potentials from global memory'):
         f2v, v2f, mv = dg.empty(flat.E, 2), dg.empty(flat.E, 2), dg.empty(flat.V, 2)
-        if pull:
+        plan.rec = api.ptr(dev['rec']) if isinstance(pull, str) else None      # round 4: one 16-byte record per slot
+        if pull == 'records, potentials from global memory':
+            # more potentials than the kernel keeps in LDS: pad the table (the padding rows are never referenced)
+            import copy
+            wide = copy.copy(flat)
+            wide.__dict__.pop('_view_cache', None)
+            wide.pot_kind = np.concatenate([flat.pot_kind, np.full(64, flat.pot_kind[0], dtype=flat.pot_kind.dtype)])
+            wide.pot_off = np.concatenate([flat.pot_off, np.full(64, flat.pot_off[-1], dtype=flat.pot_off.dtype)])
+            dgw = api.DeviceGraph(wide)
+            api.check(l.lhvi_gabp_run_pull(dgw.g, dgw.p, plan, api.ptr(f2v), api.ptr(v2f), iterations, api.ptr(ws), nbytes, st))
+        elif pull:
             api.check(l.lhvi_gabp_run_pull(dg.g, dg.p, plan, api.ptr(f2v), api.ptr(v2f), iterations, api.ptr(ws), nbytes, st))
         else:
             api.check(l.lhvi_gabp_run(dg.g, dg.p, api.ptr(f2v), api.ptr(v2f), iterations, st))
@@ -256,9 +266,11 @@ def test_pull_form_equals_the_kernel_pair_bit_for_bit(api, case):
     else:
         flat = synth.random_gaussian_mrf(V=30000, deg=4, seed=5)
         its = {'one_sweep': 1, 'no_sweep': 0}.get(case, its)
-    (f_a, v_a, m_a), (f_b, v_b, m_b) = _run_both_forms(api, flat, its)
-    for a, b in ((f_a, f_b), (v_a, v_b), (m_a, m_b)):
-        assert a.tobytes() == b.tobytes()
+    (f_a, v_a, m_a), *others = _run_both_forms(api, flat, its)
+    assert len(others) == 3                     # pull form on the graph arrays, on slot records (potentials in LDS / in global memory)
+    for f_b, v_b, m_b in others:
+        for a, b in ((f_a, f_b), (v_a, v_b), (m_a, m_b)):
+            assert a.tobytes() == b.tobytes()
     assert np.isfinite(m_a[flat.var_hidden]).all() or case == 'no_sweep'
 
 
