@@ -40,6 +40,8 @@ class _ParticleSweep:
     sliced_proposal = True          # rows of more than prop_slice incident edges are cut into slices, a wavefront per slice
     prop_slice = 64
     packed_v2f = True               # variables with at most four particles share a wavefront in the v -> f half (sixteen each)
+    exact_queries = False           # map / probability / HybridLBP.belief answer per-variable calls from ONE batched pass over all
+                                    # variables, made at the first call after run() (True: one fminbound / log_area on the device per call)
 
     # ---- set-up ------------------------------------------------------------------------------
     def _setup(self, graph_like, flat=None, edge_key=None, sides='vf', edge_skip=None):
@@ -78,7 +80,7 @@ class _ParticleSweep:
         self.flags = (_abi.PBP_EP if self.proposal_approximation == 'EP' else 0) | \
                      (_abi.PBP_EPBP_DISCRETE if self._epbp_discrete else 0) | \
                      (_abi.PBP_CQ if self.cq_routing and bool((flat.pot_kind == 8).any()) else 0)
-        self._views = {}
+        self._views, self._batched = {}, {}
         self._draws = 0
         self.cq_desc, self.n_cq = None, 0
         self.fast_edges = self.generic_edges = self._fast_list = self._generic_list = torch.zeros(1, dtype=torch.int32, device=dg.device)
@@ -363,11 +365,11 @@ class _ParticleSweep:
                     if self._static_idx is not None:
                         self.old_particles.index_copy_(0, self._static_idx, self.particles.index_select(0, self._static_idx))
                     self._static_rows = True
-                    self._views = {}
+                    self._views, self._batched = {}, {}
                     return
                 s.resample_vars, s.n_resample_vars = _abi.ptr(self.resample_vars), int(self.resample_vars.shape[0])
             _abi.check(l.lhvi_pbp_resample_uniq(self.dg.g, s, gid, int(self.seed), int(k), _abi.ptr(self.particles), _abi.ptr(self.uniq), st))
-            self._views = {}
+            self._views, self._batched = {}, {}
             return
         elif callable(self.sampler):
             self._install(self.sampler(k, self.flat, self.q_dev.cpu().numpy()))
@@ -375,7 +377,7 @@ class _ParticleSweep:
             self._install(self._host_draw())
         _abi.check(l.lhvi_pbp_uniq(self.dg.g, self.n, _abi.ptr(self.particles), _abi.ptr(self.np_dev),
                                    _abi.ptr(self.uniq), st))
-        self._views = {}
+        self._views, self._batched = {}, {}
 
     # ---- the sweep (EPBP.run EPBP:225-289; HybridLBP.run with c2f=-1 HLBP:430-536) -------------
     def _run_sweeps(self, iteration):
@@ -385,7 +387,7 @@ class _ParticleSweep:
         self._generate_sample()
         for i in range(iteration):
             self.sweep(last=(i == iteration - 1))
-        self._views = {}
+        self._views, self._batched = {}, {}
 
     def sweep(self, last=False, f2v_events=None):
         """one flooding sweep: v2f, and unless `last`: proposal update, new sample, f2v.
@@ -637,6 +639,29 @@ class _ParticleSweep:
         num, _ = self.log_area_all(a, b, 5, shift=shift)
         return num / z
 
+    # ---- per-variable queries answered from one batched pass (the reference's callers loop `infer.map(rv)` over every rv:
+    # Demo/RGM/demo.py:32-35, Demo/HMLN/DemoPaperPopularity.py:44-47) --------------------------------------------------------
+    def _query_cache(self, name, fill):
+        c = self.__dict__.setdefault('_batched', {})
+        if name not in c:
+            c[name] = fill()
+        return c[name]
+
+    def _cached_map(self):
+        """MAP of every row of the solver's graph (``map_all``: scan + bracket refinement to 1e-6 of the domain width, finer
+        than the 1e-5 tolerance ``fminbound`` stops at), as a host array"""
+        return self._query_cache('map', lambda: self.map_all(steps=6 if self.n >= 32 else 9)[0])
+
+    def _cached_area(self):
+        """(z, shift) of ``log_area`` over the domain with 20 points for every row (``log_area_all``), host arrays"""
+        def fill():
+            flat = self.flat
+            lo = np.where(flat.var_cont, flat.dom_lo[flat.var_dom], 0.0)
+            hi = np.where(flat.var_cont, flat.dom_hi[flat.var_dom], 1.0)
+            z, shift = self.log_area_all(lo, hi, 20)
+            return z.cpu().numpy(), shift.cpu().numpy()
+        return self._query_cache('area', fill)
+
     def log_message_balance(self, message):
         """EPBP.log_message_balance (EPBP:204-215) on a host dict (used by log_area)"""
         values = list(message.values())
@@ -750,7 +775,11 @@ class EPBP(_ParticleSweep):
     def probability(self, a, b, rv):
         if rv.value is None and rv.domain.continuous:
             v = self._var_of(rv)
-            z, shift = self._log_area(v, rv.domain.values[0], rv.domain.values[1], 20)
+            if self.exact_queries:
+                z, shift = self._log_area(v, rv.domain.values[0], rv.domain.values[1], 20)
+            else:                               # the normaliser of every variable from one batched pass (same 20-point trapezoid)
+                zs, shifts = self._cached_area()
+                z, shift = float(zs[v]), float(shifts[v])
             num, _ = self._log_area(v, a, b, 5, shift)
             return num / z
         return None
@@ -759,6 +788,9 @@ class EPBP(_ParticleSweep):
         if rv.value is not None:
             return rv.value
         v = self._var_of(rv)
+        if not self.exact_queries:
+            m = self._cached_map()[v]
+            return float(m) if rv.domain.continuous else type(rv.domain.values[0])(m)
         if rv.domain.continuous:
             from scipy.optimize import fminbound
             return fminbound(lambda val: -float(self._belief_rv_points(v, [val])[0]),
@@ -855,7 +887,7 @@ class HybridLBP(_ParticleSweep):
         self._stable_partition = False
         self.__dict__.update({k: v for k, v in st.__dict__.items()})
         self._ground = dict(flat=gflat, dg=dg, rvc=rvc, fc=fc)
-        self._views = {}
+        self._views, self._batched = {}, {}
 
     def run(self, iteration=10, log_enable=False, c2f=-1):
         """``HybridLBP.run`` (HLBP:430-536).  ``c2f == -1``: colour passing to the stable partition, then the sweeps.
@@ -901,7 +933,7 @@ class HybridLBP(_ParticleSweep):
         self.g = cg
         # adopt the final factor-side state for the queries
         self.__dict__.update({k: v for k, v in st.__dict__.items()})
-        self._views = {}
+        self._views, self._batched = {}, {}
 
     # ---- queries of GROUND variables on arrays (a solver made by on_flat) --------------------------------------------------------
     def _ground_pairs(self):
@@ -988,6 +1020,114 @@ class HybridLBP(_ParticleSweep):
         flat, Q = self.flat, self._host('q_dev')
         return {rv: (float(Q[v, 0]), float(Q[v, 1])) for v, rv in enumerate(flat.rvs) if flat.var_hidden[v] and flat.var_cont[v]}
 
+    # ---- batched queries of GROUND variables (any partition): what the per-variable calls below are answered from ---------------
+    def _ground_rows(self):
+        """hidden ground variables of the run's ground graph, their domain bounds and kind (arrays path only)"""
+        G = self._ground
+        if 'rows' not in G:
+            gf = G['flat']
+            hid = np.flatnonzero(gf.var_hidden)
+            cont = gf.var_cont[hid]
+            lo = np.where(cont, gf.dom_lo[gf.var_dom[hid]], 0.0)
+            hi = np.where(cont, gf.dom_hi[gf.var_dom[hid]], 1.0)
+            G['rows'] = (hid, cont, lo, hi, {int(v): i for i, v in enumerate(hid)})
+        return G['rows']
+
+    def ground_map_all(self, scan=64, steps=6):
+        """MAP of every hidden GROUND variable in a few batched passes of ``belief_rv_ground``: a uniform scan of the domain
+        with `scan` points, then `steps` times a new 17-point grid on the bracket around the best point (the bracket shrinks 8x
+        per step: 1e-6 of the domain width after 6).  Discrete variables: the first state with the largest belief.  Returns
+        (ground variable ids, MAP values)."""
+        torch = _abi.require_gpu()
+        hid, cont, lo, hi, _ = self._ground_rows()
+        gf = self._ground['flat']
+        out = np.zeros(hid.size)
+        ci = np.flatnonzero(cont)
+        if ci.size:
+            dev = self.particles.device
+            lo_t, hi_t = _abi.to_dev(lo[ci])[:, None], _abi.to_dev(hi[ci])[:, None]
+            j = torch.arange(scan, dtype=torch.float64, device=dev)[None, :]
+            x = lo_t + (hi_t - lo_t) * (j / (scan - 1))
+            vals = self.belief_rv_ground(hid[ci], x)
+            bv, arg = vals.max(dim=1)
+            bx = x.gather(1, arg[:, None])[:, 0]
+            h = ((hi_t - lo_t) / (scan - 1))[:, 0]
+            m = 17
+            jj = torch.arange(m, dtype=torch.float64, device=dev)[None, :]
+            for _ in range(steps):
+                a = torch.maximum(bx - h, lo_t[:, 0])[:, None]
+                b = torch.minimum(bx + h, hi_t[:, 0])[:, None]
+                x = (a + (b - a) * (jj / (m - 1))).contiguous()
+                vals = self.belief_rv_ground(hid[ci], x)
+                v2, arg = vals.max(dim=1)
+                better = v2 >= bv
+                bx = torch.where(better, x.gather(1, arg[:, None])[:, 0], bx)
+                bv = torch.where(better, v2, bv)
+                h = ((b - a) / (m - 1))[:, 0]
+            out[ci] = bx.cpu().numpy()
+        di = np.flatnonzero(~cont)
+        if di.size:
+            nst = gf.var_nstates[hid[di]]
+            D = int(nst.max())
+            states = np.zeros((di.size, D))
+            for r, v in enumerate(hid[di]):
+                d = gf.var_dom[v]
+                vals = gf.dom_val[gf.dom_ptr[d]:gf.dom_ptr[d + 1]]
+                states[r, :vals.size] = vals
+                states[r, vals.size:] = vals[0]
+            lb = self.belief_rv_ground(hid[di], states).cpu().numpy()
+            lb[np.arange(D)[None, :] >= nst[:, None]] = -np.inf
+            out[di] = states[np.arange(di.size), lb.argmax(axis=1)]
+        return hid, out
+
+    def ground_log_area_all(self, npts=20):
+        """``log_area`` (HLBP:324-341) over the domain of every hidden continuous GROUND variable: (ids, area, shift)"""
+        torch = _abi.require_gpu()
+        hid, cont, lo, hi, _ = self._ground_rows()
+        ci = np.flatnonzero(cont)
+        lin = np.linspace(0.0, 1.0, npts)[None, :] * (hi[ci] - lo[ci])[:, None] + lo[ci][:, None]
+        lin[:, -1] = hi[ci]
+        y = self.belief_rv_ground(hid[ci], lin).cpu().numpy() if ci.size else np.zeros((0, npts))
+        mean, mx = y.mean(axis=1), y.max(axis=1)
+        shift = np.where(mx - mean > self.max_log_value, mx - self.max_log_value, mean)
+        w = np.exp(y - shift[:, None])
+        area = (w[:, :-1] + w[:, 1:]).sum(axis=1) * (lin[:, 1] - lin[:, 0]) * 0.5
+        return hid[ci], area, shift
+
+    def _batched_ok(self, ground_rv):
+        """can a per-variable query be answered from a batched pass?  (a stable partition: rows are clusters; an unstable one:
+        through the ground arrays of the arrays path)"""
+        if self.exact_queries:
+            return None
+        if getattr(self, '_stable_partition', False) and getattr(ground_rv, 'cluster', None) in self.flat.var_index:
+            return 'cluster'
+        G = getattr(self, '_ground', None)
+        if G is not None and ground_rv in G['flat'].var_index:
+            return 'ground'
+        return None
+
+    def _cached_ground(self, what):
+        if what == 'map':
+            def fill():
+                ids, vals = self.ground_map_all()
+                return dict(zip(ids.tolist(), vals.tolist()))
+        else:
+            def fill():
+                ids, area, shift = self.ground_log_area_all(20)
+                return {int(v): (float(a), float(s_)) for v, a, s_ in zip(ids, area, shift)}
+        return self._query_cache('ground_' + what, fill)
+
+    def _area_of(self, rv):
+        """(z, shift) of the 20-point ``log_area`` over rv's domain (HLBP:361-365), batched when possible"""
+        how = self._batched_ok(rv)
+        if how == 'cluster':
+            zs, shifts = self._cached_area()
+            c = self.flat.var_index[rv.cluster]
+            return float(zs[c]), float(shifts[c])
+        if how == 'ground':
+            return self._cached_ground('area')[self._ground['flat'].var_index[rv]]
+        return self._log_area(self._var_of(rv), rv.domain.values[0], rv.domain.values[1], 20)
+
     def belief(self, x, rv, inf_integral=False):
         """HybridLBP.belief (HLBP:343-382): 20-point trapezoid normaliser, cached per cluster"""
         if rv.value is not None:
@@ -995,7 +1135,7 @@ class HybridLBP(_ParticleSweep):
         sig, v = (rv.cluster, frozenset(self._ground_edges(rv).items())), self._var_of(rv)
         if rv.domain.continuous:
             if sig not in self.query_cache:
-                self.query_cache[sig] = self._log_area(v, rv.domain.values[0], rv.domain.values[1], 20)
+                self.query_cache[sig] = self._area_of(rv)
             z, shift = self.query_cache[sig]
             return e ** (float(self._belief_rv_points(v, [x])[0]) - shift - log(z))
         if sig not in self.query_cache:
@@ -1008,7 +1148,7 @@ class HybridLBP(_ParticleSweep):
     def probability(self, a, b, rv):
         if rv.value is None and rv.domain.continuous:
             v = self._var_of(rv)
-            z, shift = self._log_area(v, rv.domain.values[0], rv.domain.values[1], 20)
+            z, shift = self._area_of(rv)
             num, _ = self._log_area(v, a, b, 5, shift)
             return num / z
         return None
@@ -1016,6 +1156,13 @@ class HybridLBP(_ParticleSweep):
     def map(self, rv):
         if rv.value is not None:
             return rv.value
+        how = self._batched_ok(rv)
+        if how == 'cluster':
+            m = self._cached_map()[self.flat.var_index[rv.cluster]]
+            return float(m) if rv.domain.continuous else type(rv.domain.values[0])(m)
+        if how == 'ground':
+            m = self._cached_ground('map')[self._ground['flat'].var_index[rv]]
+            return float(m) if rv.domain.continuous else type(rv.domain.values[0])(m)
         v = self._var_of(rv)
         if rv.domain.continuous:
             from scipy.optimize import fminbound

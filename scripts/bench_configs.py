@@ -565,3 +565,38 @@ if 'gauss_probe' in which:
         va.fill_(1.0)
         t_p = ev_time(lambda: _abi.check(l.lhvi_gabp_pull(dg.g, dg.p, plan, _abi.ptr(va), _abi.ptr(vb), 0, st)))
         out(config='gauss probe: ' + label, slots=nnz, sweep_ms=t_p, algorithmic_frac=76.0 * flat.E / (t_p * 1e-3) / 8e12)
+
+if 'demo_loop' in which:
+    # Demo/RGM/demo.py:11-35 as a caller writes it, through the object API: ground the RGM template (100 x 10), observe
+    # recession = 25, HybridLBP(g, n=10, 'simple').run(10, c2f=0), then `infer.map(rv)` for every one of the 1 111 rvs.  The loop
+    # of per-variable calls is answered from one batched pass over the ground variables (default) or by one fminbound on the device
+    # function per call (exact_queries = True).
+    from lhvi import generators
+    from lhvi.pbp import HybridLBP
+    rel = generators.rgm(100, 10)
+    rel.ground_graph()
+    g, table = rel.add_evidence({('recession', 'all'): 25})
+    g.rvs, g.factors = sorted(g.rvs), sorted(g.factors)
+    g.init_nb()
+    for rep in range(2):
+        np.random.seed(0)
+        infer = HybridLBP(g, n=10, proposal_approximation='simple')
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        infer.run(10, c2f=0)
+        torch.cuda.synchronize()
+        t_run = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    maps = {rv: infer.map(rv) for rv in table.values()}
+    t_loop = time.perf_counter() - t0
+    some = list(table.values())[:40]
+    infer.exact_queries = True
+    t0 = time.perf_counter()
+    exact = {rv: infer.map(rv) for rv in some}
+    t_exact = (time.perf_counter() - t0) / len(some)
+    hid = [rv for rv in some if rv.value is None]
+    worse = [rv for rv in hid if infer.belief_rv_query(maps[rv], rv) < infer.belief_rv_query(exact[rv], rv) - 1e-6]
+    out(config='Demo/RGM/demo.py through the object API: HybridLBP(g, n=10, simple).run(10, c2f=0), then map(rv) for all rvs',
+        rvs=len(table), run_s=t_run, map_loop_s_batched=t_loop, per_call_ms_exact_fminbound=1e3 * t_exact,
+        map_loop_s_exact_extrapolated=t_exact * len(table), max_abs_diff_batched_vs_exact=float(max(abs(maps[rv] - exact[rv]) for rv in hid)),
+        batched_maps_with_a_lower_belief_than_exact=len(worse))

@@ -32,6 +32,19 @@ def _init(api, bp):
     bp._generate_sample()
 
 
+def _check_per_variable_map(bp, rv, want, log_belief_at):
+    """``bp.map(rv)`` both ways: answered from the one batched pass made at the first call (default; finds the mode a scan of the
+    domain sees: the reference's value to 2e-4, or a point with a belief at least as large when the belief is multi-modal) and,
+    with ``exact_queries``, by fminbound on the device function (the reference's own iterates: 1e-4)"""
+    got = bp.map(rv)
+    assert got == pytest.approx(want, abs=2e-4) or log_belief_at(got) >= log_belief_at(want) - 1e-9
+    bp.exact_queries = True
+    try:
+        assert bp.map(rv) == pytest.approx(want, abs=1e-4)
+    finally:
+        bp.exact_queries = False
+
+
 @pytest.mark.parametrize('name', EPBP_CASES)
 def test_epbp_matches_reference_golden(api, golden_dir, name):
     from lhvi.pbp import EPBP
@@ -70,7 +83,8 @@ def test_epbp_matches_reference_golden(api, golden_dir, name):
     np.testing.assert_allclose(got, z['query_logb'][hid], rtol=1e-9, atol=1e-7)
     for i in hid[:6]:
         # fminbound stops at xtol=1e-5 and follows the same iterates while the objective agrees to ~1e-9
-        assert bp.map(rvs[i]) == pytest.approx(z['map'][i], abs=1e-4)
+        _check_per_variable_map(bp, rvs[i], z['map'][i], lambda x, i=i: float(bp._belief_rv_points(i, [x])[0]))
+    assert 'map' in bp._batched                      # ... and the loop over the variables cost ONE batched pass
     for i, x0, want in z['belief']:
         # "marginals within 1e-5 of the CPU reference" (BASELINE.json north_star)
         if np.isnan(want):       # the reference's own normaliser overflowed here (e ** log-belief, EPBP:342): so does the restated one
@@ -152,7 +166,7 @@ def test_hlbp_matches_reference_golden(api, golden_dir, name):
             np.testing.assert_allclose(Q[rvs[i].cluster], z['final_q'][i], rtol=1e-9)
     overflowed = {i for i in hid if np.isnan(z['belief_mid'][i])}     # the reference's normaliser overflowed (e ** log-belief, HLBP:372)
     for i in hid[:6]:
-        assert bp.map(rvs[i]) == pytest.approx(z['map'][i], abs=1e-4)
+        _check_per_variable_map(bp, rvs[i], z['map'][i], lambda x, i=i: bp.belief_rv_query(float(x), rvs[i]))
         if i not in overflowed:
             assert bp.belief(z['query_x'][i][2], rvs[i]) == pytest.approx(z['belief_mid'][i], rel=1e-5, abs=1e-7)
     flat = bp.flat
@@ -511,8 +525,12 @@ def test_hlbp_coarse_to_fine_matches_reference(api, golden_dir, name):
     got = bp.belief_rv_batch([rvs[i] for i in hid], z['query_x'][hid])
     np.testing.assert_allclose(got, z['query_logb'][hid], rtol=1e-8, atol=1e-6)
     for i in hid[:5]:
-        assert bp.map(rvs[i]) == pytest.approx(z['map'][i], abs=1e-4)
+        _check_per_variable_map(bp, rvs[i], z['map'][i], lambda x, i=i: bp.belief_rv_query(float(x), rvs[i]))
         assert bp.belief(z['query_x'][i][2], rvs[i]) == pytest.approx(z['belief_mid'][i], rel=1e-5, abs=1e-7)
+    assert 'ground_map' in bp._batched and 'ground_area' in bp._batched      # unstable partition: batched over the GROUND variables
+    # the reference's demo loop (Demo/RGM/demo.py:32-35): every rv's MAP -- one batched pass, then dictionary look-ups
+    all_maps = [bp.map(rv) for rv in rvs]
+    assert len(all_maps) == len(rvs) and all(np.isfinite(m) for m in all_maps)
     for i, a, b, want in z['probability']:
         assert bp.probability(a, b, rvs[int(i)]) == pytest.approx(want, rel=1e-7, abs=1e-300)
 
