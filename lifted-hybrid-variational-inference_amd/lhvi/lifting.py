@@ -148,10 +148,18 @@ def initial_colors_flat(flat, is_split_cont_evidence=True):
         val = np.where(flat.var_cont, 0.0, val)
     # colours numbered in order of first appearance, like the reference's dict: hash-based factorisation (O(V), no sort), first
     # of the values, then of the (value code, domain, observed) triples
-    import pandas as pd
-    vcode = pd.factorize(val + 0.0)[0].astype(np.int64)    # (+ 0.0: -0.0 and 0.0 are one evidence value)
+    try:                                                   # pandas (optional): O(V) hash factorisation; NumPy: a sort
+        import pandas as pd
+        factorize = lambda a: pd.factorize(a)[0]
+    except ImportError:
+        def factorize(a):
+            _, first, inv = np.unique(a, return_index=True, return_inverse=True)
+            rank = np.empty(first.size, dtype=np.int64)
+            rank[np.argsort(first, kind='stable')] = np.arange(first.size)       # renumbered by first appearance
+            return rank[inv]
+    vcode = factorize(val + 0.0).astype(np.int64)          # (+ 0.0: -0.0 and 0.0 are one evidence value)
     nd = int(dom.max()) + 1 if dom.size else 1
-    rv_color = pd.factorize((vcode * nd + dom) * 2 + (~hidden))[0].astype(np.int32)
+    rv_color = factorize((vcode * nd + dom) * 2 + (~hidden)).astype(np.int32)
     pots = list(getattr(flat, 'potentials', []) or [])
     row_color = np.arange(int(flat.pot_kind.size), dtype=np.int32)
     sym_row = np.zeros(int(flat.pot_kind.size), dtype=np.uint8)

@@ -179,7 +179,7 @@ def test_device_evaluators_match_reference_values(api, golden_dir):
         assert got[i] == pytest.approx(c['kl_continuous'], rel=1e-6, abs=1e-9)
 
 
-@pytest.mark.parametrize('name', ['c2f_rgm_k2', 'c2f_hmln_k2', 'c2f_robot_k2'])
+@pytest.mark.parametrize('name', ['c2f_rgm_k2', 'c2f_hmln_k2', 'c2f_robot_k2', 'c2f_rkf_tree_k1', 'c2f_rkf_cycle_k1'])
 def test_c2f_var_inference_matches_reference(api, golden_dir, name):
     """C2FVarInference on the device (coarse-to-fine lifting with Gaussian observation clusters, csrc/vi.hip through
     lhvi_vi_t.obs_var) against the reference: every round's partition / inherited parameters / ADAM moments, the free

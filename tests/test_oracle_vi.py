@@ -69,7 +69,7 @@ def test_vi_oracle_matches_reference(golden_dir, name):
 
 
 # ---- C2FVarInference (coarse-to-fine lifted VI with Gaussian observation clusters) -----------------------------------
-C2F_CASES = ['c2f_rgm_k2', 'c2f_hmln_k2', 'c2f_robot_k2']
+C2F_CASES = ['c2f_rgm_k2', 'c2f_hmln_k2', 'c2f_robot_k2', 'c2f_rkf_tree_k1', 'c2f_rkf_cycle_k1']
 C2F_OPTS = dict(k_mean_k=2, k_mean_its=10, output_its=0, min_obs_var=0, gaussian_obs=True)
 
 
@@ -176,5 +176,6 @@ def test_c2fvi_oracle_matches_reference(golden_dir, name):
                           dict(C2F_OPTS, update_obs_its=meta['update_obs_its'], kmeans_member_order=kmeans_order_of(meta)),
                           init=(z['eta_c0'], z['tau_d0']), observer=c2fvi_round_checker(z, rvs, seen))
     assert seen == list(range(meta['iterations'] // meta['update_obs_its']))
-    assert (np.nan_to_num(z['round_variance']) > 0).any()          # the fixture does exercise Gaussian observations
+    # the fixture does exercise Gaussian observations (the RKF well data is binary: its first split already leaves exact evidence)
+    assert (np.nan_to_num(z['round_variance']) > 0).any() or 'rkf' in name
     check_c2fvi_result(z, rvs, res)
