@@ -33,6 +33,12 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 
+// The log-term of a padding record of the f -> v term loops.  The evaluated term is exp(a + b x + C) with C the output point's own
+// constant (kx x^2, plus the target's message in the joint routes), and kx > 0 occurs (MLN formulas with negative weights), so
+// the padding must stay below the underflow threshold (-745) for any C a model can produce: -6e5 leaves 1.2e5 of headroom inside
+// the table exponential's argument range (|t| < 2^31 ln2 / 2048 = 7.26e5, fastmath.hpp).
+constexpr double PAD_LOG_TERM = -6.0e5;
+
 // variable range of the per-variable kernels: [var_lo, var_hi) when set, else every variable
 __host__ __device__ __forceinline__ int var_first(const lhvi_pbp_t& s) { return s.var_hi > s.var_lo ? s.var_lo : 0; }
 __host__ __device__ __forceinline__ int var_limit(const lhvi_graph_t& g, const lhvi_pbp_t& s) { return s.var_hi > s.var_lo ? s.var_hi : g.V; }
@@ -737,7 +743,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
                 // records past the tile are padded with a term that underflows to exactly 0 (exp(-800)), so that every
                 // lane group can run the same uniform loop over ceil(jn / split) records without per-lane bounds
                 AB r;
-                r.a = -800.0; r.b = 0.0;
+                r.a = PAD_LOG_TERM; r.b = 0.0;
                 double kk = 0.0;
                 if (lane < jn) {
                     if (d.cls == EDGE_FAST_CONT) {
@@ -989,7 +995,7 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
         const bool eligible = grid_eligible(d.grid, nj, d.T);
         bool grid_path = eligible && !(s.flags & (LHVI_PBP_SKIP_TERMS | LHVI_PBP_NO_GRID));
         AB mine;
-        mine.a = -800.0; mine.b = 0.0;                     // padding: exp(-800) underflows to exactly 0
+        mine.a = PAD_LOG_TERM; mine.b = 0.0;                     // padding: underflows to exactly 0 whatever the point's own constant adds
         LHVI_WAVE_SYNC();
         {
             if (lane < nj) {
@@ -1123,7 +1129,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8
         const double pval = d.pval, kx = d.kx;
         // staging: lane = partner particle of its group's edge
         AB rec;
-        rec.a = -800.0 * LHVI_EXP_INV_STEP; rec.b = 0.0;     // padding: exp(-800) underflows to exactly 0
+        rec.a = PAD_LOG_TERM * LHVI_EXP_INV_STEP; rec.b = 0.0;     // padding: underflows to exactly 0 whatever the point's own constant adds
         if (gl < nj) {
             double y = pval, m = 0.0;
             if (is_hidden(pval)) { y = s.old_particles[(int64_t)d.pv * n + gl]; m = v2f[(int64_t)d.pce * n + gl]; }
@@ -1439,7 +1445,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
                              kx = d.coef[st][5];
                 const double ms = readlane_f64(mz, st);
                 AB mine;
-                mine.a = -800.0; mine.b = 0.0;             // padding: exp(-800) underflows to exactly 0
+                mine.a = PAD_LOG_TERM; mine.b = 0.0;             // padding: underflows to exactly 0 whatever the point's own constant adds
                 if (lane < ny) { mine.a = (ay * y + by) * y + c + my + ms; mine.b = axy * y + bx; }
                 LHVI_WAVE_SYNC();
                 {
@@ -1499,7 +1505,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8
                 const double ay = d.coef[st][0], by = d.coef[st][1], c = d.coef[st][2], axy = d.coef[st][3], bx = d.coef[st][4],
                              kx = d.coef[st][5];
                 AB mine;
-                mine.a = -800.0; mine.b = 0.0;
+                mine.a = PAD_LOG_TERM; mine.b = 0.0;
                 if (lane < ny) { mine.a = (ay * y + by) * y + c + my; mine.b = axy * y + bx; }
                 mine.a *= LHVI_EXP_INV_STEP; mine.b *= LHVI_EXP_INV_STEP;      // (records in units of the table step)
                 LHVI_WAVE_SYNC();
