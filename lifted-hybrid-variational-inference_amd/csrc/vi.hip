@@ -410,6 +410,17 @@ constexpr int VI_GRP_L = 8;
 constexpr int VI_GRP_BLOCK = LHVI_VI_GRP_BLOCK;
 constexpr int VI_GRP_SLOTS = LHVI_VI_GROUP_SLOTS;      // 24
 constexpr int VI_GRP_COMP = LHVI_VI_GROUP_COMP;        // 48
+constexpr int VI_GRP_PAR = 2 * VI_GRP_COMP;            // (1 / var, 1 / (2.5066 var)) per (argument, component): K * arity <= K * S <= 48
+
+// q = r / d, r = r % d for 0 <= r < 2^14 and 1 <= d <= 64 (grid nodes of a factor, axis lengths): a float multiply by the
+// reciprocal instead of the ~40-instruction integer division -- (r + 0.5) / d lies at least 0.5 / d = 2^-7 away from the next
+// integer while the float product is off by less than 2^-9
+__device__ __forceinline__ int small_divmod(int& r, int d, float rcp_d) {
+    const int q = (int)(((float)r + 0.5f) * rcp_d);
+    const int rem = r - q * d;
+    r = q;
+    return rem;
+}
 
 template <int L>
 __device__ __forceinline__ double group_sum(double v) {
@@ -430,25 +441,18 @@ __device__ __forceinline__ double pot_log_eps(int kind, const double* __restrict
 // neighbour is evaluated at the TARGET's state values)
 template <int MAXA>
 __device__ __forceinline__ double belief_direct(const lhvi_graph_t& g, const lhvi_vi_t& p, const double* x, const int* idx, const int* vars,
-                                                int arity, const double* __restrict__ sh_tab) {
-#pragma unroll
-    for (int a = 0; a < MAXA; ++a) {
-        if (a >= arity) continue;
-        const double val = g.var_value[vars[a]];
-        if (!is_hidden(val) && !is_gobs(p, vars[a]) && x[a] != val) return 0.0;
-    }
+                                                int arity, const bool* hid, const bool* cont, const bool* axis, const double* __restrict__ sp,
+                                                const double* __restrict__ sh_tab) {
+    // (evidence agrees by construction: the pinned expectation puts an observed argument at its value)
     double s = 0.0;
     for (int kk = 0; kk < p.K; ++kk) {
         double b = p.w[kk];
 #pragma unroll
         for (int a = 0; a < MAXA; ++a) {
-            if (a >= arity) continue;
+            if (a >= arity || !axis[a]) continue;
             const int v = vars[a];
-            if (!is_hidden(g.var_value[v])) {
-                if (is_gobs(p, v)) b *= norm_pdf_var_fast(x[a], g.var_value[v], p.obs_var[v], sh_tab);
-                continue;
-            }
-            if (v_cont(g, v)) { const double* e = p.eta_c + ((int64_t)v * p.K + kk) * 2; b *= norm_pdf_var_fast(x[a], e[0], e[1], sh_tab); }
+            if (!hid[a]) b *= norm_pdf_inv(x[a], g.var_value[v], sp[2 * (a * p.K + kk)], sp[2 * (a * p.K + kk) + 1], sh_tab);
+            else if (cont[a]) b *= norm_pdf_inv(x[a], p.eta_c[((int64_t)v * p.K + kk) * 2], sp[2 * (a * p.K + kk)], sp[2 * (a * p.K + kk) + 1], sh_tab);
             else b *= p.eta_d[((int64_t)v * p.K + kk) * p.Dmax + idx[a]];
         }
         s += b;
@@ -466,10 +470,11 @@ __global__ void __launch_bounds__(VI_GRP_BLOCK) __attribute__((amdgpu_waves_per_
     __shared__ double sh_x[GROUPS][VI_GRP_SLOTS];
     __shared__ double sh_w[GROUPS][VI_GRP_SLOTS];
     __shared__ double sh_c[GROUPS][VI_GRP_COMP];
+    __shared__ double sh_p[GROUPS][VI_GRP_PAR];
     load_log_table(sh_log);
     load_exp_table(sh_tab);
     const int grp = threadIdx.x / L, gl = threadIdx.x % L;
-    double* sx = sh_x[grp]; double* sw = sh_w[grp]; double* sc = sh_c[grp];
+    double* sx = sh_x[grp]; double* sw = sh_w[grp]; double* sc = sh_c[grp]; double* sp = sh_p[grp];
     // persistent: the tables above are loaded once per workgroup; groups stride over the (factor, k) items (whole groups leave
     // together, so the shuffles below stay inside a group)
     for (int64_t item = (int64_t)blockIdx.x * GROUPS + grp; item < (int64_t)n_list * p.K; item += (int64_t)gridDim.x * GROUPS) {
@@ -505,25 +510,39 @@ __global__ void __launch_bounds__(VI_GRP_BLOCK) __attribute__((amdgpu_waves_per_
         mu[a] = (hid[a] && cont[a]) ? e[0] : 0.0;
         var[a] = (hid[a] && cont[a]) ? e[1] : 1.0;
     }
-    // ---- per-axis tables of this (factor, k): nodes (under component k) and every component's value at them
+    // ---- per-axis tables of this (factor, k).  First 1 / var and 1 / (2.5066 var) of every (continuous argument, component):
+    // the only divisions of the belief; then the nodes (under component k) and every component's value at them
+    float rlen[MAXA];
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a) rlen[a] = __builtin_amdgcn_rcpf((float)len[a]);
+    for (int t = gl; t < arity * p.K; t += L) {
+        const int a = t / p.K, kk = t - a * p.K;
+        int v = 0; bool h = false, c = false, ax = false;
+#pragma unroll
+        for (int b = 0; b < MAXA; ++b) if (b == a) { v = vars[b]; h = hid[b]; c = cont[b]; ax = axis[b]; }
+        double inv = 0.0;
+        if (h && c) inv = 1.0 / p.eta_c[((int64_t)v * p.K + kk) * 2 + 1];
+        else if (!h && ax) inv = 1.0 / p.obs_var[v];
+        sp[2 * t] = inv; sp[2 * t + 1] = inv * (1.0 / 2.506628274631);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     for (int s = gl; s < S; s += L) {
         int a = 0;
 #pragma unroll
         for (int b = 1; b < MAXA; ++b) if (b < arity && s >= off[b]) a = b;
-        int v = 0, o = 0;
+        int v = 0, o = 0; bool h = false, c = false, ax = false;
 #pragma unroll
-        for (int b = 0; b < MAXA; ++b) if (b == a) { v = vars[b]; o = off[b]; }
+        for (int b = 0; b < MAXA; ++b) if (b == a) { v = vars[b]; o = off[b]; h = hid[b]; c = cont[b]; ax = axis[b]; }
         const int t = s - o;
         const Node nd = axis_node(g, p, v, k, t);
         sx[s] = nd.x; sw[s] = nd.w;
-        const double val = g.var_value[v];
         for (int kk = 0; kk < p.K; ++kk) {
-            double c = 1.0;
-            if (is_hidden(val)) {
-                if (v_cont(g, v)) { const double* e = p.eta_c + ((int64_t)v * p.K + kk) * 2; c = norm_pdf_var_fast(nd.x, e[0], e[1], sh_tab); }
-                else c = p.eta_d[((int64_t)v * p.K + kk) * p.Dmax + t];
-            } else if (is_gobs(p, v)) c = norm_pdf_var_fast(nd.x, val, p.obs_var[v], sh_tab);
-            sc[kk * S + s] = c;
+            double cv = 1.0;
+            if (h && c) cv = norm_pdf_inv(nd.x, p.eta_c[((int64_t)v * p.K + kk) * 2], sp[2 * (a * p.K + kk)], sp[2 * (a * p.K + kk) + 1], sh_tab);
+            else if (h) cv = p.eta_d[((int64_t)v * p.K + kk) * p.Dmax + t];
+            else if (ax) cv = norm_pdf_inv(nd.x, g.var_value[v], sp[2 * (a * p.K + kk)], sp[2 * (a * p.K + kk) + 1], sh_tab);
+            sc[kk * S + s] = cv;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -541,7 +560,7 @@ __global__ void __launch_bounds__(VI_GRP_BLOCK) __attribute__((amdgpu_waves_per_
         int r = node;
         double w = 1.0;
 #pragma unroll
-        for (int a = MAXA - 1; a >= 0; --a) if (a < arity) { it[a] = r % len[a]; r /= len[a]; }
+        for (int a = MAXA - 1; a >= 0; --a) if (a < arity) it[a] = small_divmod(r, len[a], rlen[a]);
 #pragma unroll
         for (int a = 0; a < MAXA; ++a) {
             if (a >= arity) continue;
@@ -613,8 +632,11 @@ __global__ void __launch_bounds__(VI_GRP_BLOCK) __attribute__((amdgpu_waves_per_
 #pragma unroll
                     for (int b = MAXA - 1; b >= 0; --b) {
                         if (b < arity && b != a) {
-                            const int ixs = rx % nx[b]; rx /= nx[b];
-                            const int iws = rw % nw[b]; rw /= nw[b];
+                            int ixs, iws;
+                            if (cnt <= (1 << 14)) {
+                                ixs = small_divmod(rx, nx[b], __builtin_amdgcn_rcpf((float)nx[b]));
+                                iws = small_divmod(rw, nw[b], __builtin_amdgcn_rcpf((float)nw[b]));
+                            } else { ixs = rx % nx[b]; rx /= nx[b]; iws = rw % nw[b]; rw /= nw[b]; }
                             if (!hid[b] && axis[b]) { x[b] = sx[off[b] + ixs]; idx[b] = 0; w *= p.gh_w[iws]; }
                             else if (!hid[b]) { x[b] = g.var_value[vars[b]]; idx[b] = fix[b]; }
                             else if (p.quirks) {
@@ -625,7 +647,7 @@ __global__ void __launch_bounds__(VI_GRP_BLOCK) __attribute__((amdgpu_waves_per_
                     }
 #pragma unroll
                     for (int b = 0; b < MAXA; ++b) if (b == a) { x[b] = tvals[d]; idx[b] = d; }
-                    const double bel = belief_direct<MAXA>(g, p, x, idx, vars, arity, sh_tab);
+                    const double bel = belief_direct<MAXA>(g, p, x, idx, vars, arity, hid, cont, axis, sp, sh_tab);
                     acc += w * (pot_log_eps(kind, par, x, idx, sh_tab, sh_log) - log_table(bel + 1e-100, sh_log));
                 }
                 acc = group_sum<L>(acc);
