@@ -339,8 +339,10 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_kernel(lhvi_graph_t g, lhvi_p
 // length << 10 | hidden << 20 | hub row << 21) carries everything the slot needs to know about the graph, and the potential
 // parameters sit in LDS (up to GABP_LDS_POTS potentials; more: read from global memory as before).  Chain: record -> partner's
 // message -> arithmetic.  Same expressions in the same order: the same bits.
-constexpr int GABP_LDS_POTS = 40;
+constexpr int GABP_LDS_POTS = 32;
 constexpr int GABP_POT_WORDS = 12;            // par[0 .. 10] (the Gaussian closed form reads up to par[10]) + the kind
+constexpr int GABP_ROW_DIRECT = 32;           // rows up to this length are summed entry by entry in the reference's order
+constexpr int GABP_ROW_CHUNK = 8;             // longer rows (ground graphs): sums of eight-entry chunks as intermediate results
 
 template <bool LDS_POTS>
 __device__ __forceinline__ double2 pull_incoming_rec(const lhvi_graph_t& g, const lhvi_pots_t& pots, const int4 r,
@@ -365,6 +367,7 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lh
                                                              double* __restrict__ vnext, int first) {
     constexpr int CAP = BLOCK + 2 * GABP_HUB_DEGREE;
     __shared__ double2 sh[CAP];
+    __shared__ double2 shc[CAP / GABP_ROW_CHUNK + 1];       // sums of eight-entry chunks of the long rows (ground graphs)
     __shared__ double sh_par[LDS_POTS ? GABP_LDS_POTS * GABP_POT_WORDS : 1];
     if (LDS_POTS) {
         for (int i = threadIdx.x; i < pots.P * GABP_POT_WORDS; i += BLOCK) {
@@ -379,15 +382,37 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lh
     const int rf = rec[k0].z, rl = rec[kend - 1].z;
     const int lo_ext = ((rf >> 21) & 1) ? k0 : k0 - (rf & 1023);                       // (a hub row is served by gabp_pull_hub_kernel)
     const int hi_ext = ((rl >> 21) & 1) ? kend : kend - 1 - (rl & 1023) + ((rl >> 10) & 1023);
+    int long_rows = 0;
     for (int j = lo_ext + threadIdx.x; j < hi_ext; j += BLOCK) {
         const int4 r = rec[j];
         if ((r.z >> 21) & 1) continue;
+        long_rows |= ((r.z >> 10) & 1023) > GABP_ROW_DIRECT;
         const bool hid = (r.z >> 20) & 1;
         const double2 m = (hid && !first) ? pull_incoming_rec<LDS_POTS>(g, pots, r, vprev, sh_par) : make_double2(0.0, 1.0);
         const double p = 1.0 / m.y;
-        sh[j - lo_ext] = (m.y != m.y) ? m : make_double2(p * m.x, p);
+        if (count) sh[j - lo_ext] = (m.y != m.y) ? m : make_double2(p * m.x, p);
+        // ground graph: staged as the entry's CONTRIBUTION (h, p) to the row sums -- (p mu, p), or (-mu, 0) for a `None` variance
+        // (GaBP.py:27-33: a linear term only) -- so that the sums below are additions without a case distinction
+        else sh[j - lo_ext] = (m.y != m.y) ? make_double2(-m.x, 0.0) : make_double2(p * m.x, p);
     }
-    __syncthreads();
+    long_rows = __syncthreads_or(long_rows);                    // (the staging barrier; most blocks of most graphs have no long row)
+    if (!count && long_rows) {
+        // rows of more than GABP_ROW_DIRECT entries: one thread per chunk of eight entries (the last chunk takes the remainder)
+        // adds its chunk up in rv.nb order.  Chunk starts lie at least eight apart, so (start >> 3) names a chunk uniquely.
+        for (int j = lo_ext + threadIdx.x; j < hi_ext; j += BLOCK) {
+            const int rz = rec[j].z;
+            const int len = (rz >> 10) & 1023, pos = rz & 1023;
+            if (((rz >> 21) & 1) || len <= GABP_ROW_DIRECT || (pos % GABP_ROW_CHUNK) != 0) continue;
+            const int nc = len / GABP_ROW_CHUNK, q = pos / GABP_ROW_CHUNK;
+            if (q >= nc) continue;
+            const int end = q == nc - 1 ? len - pos : GABP_ROW_CHUNK;
+            const double2* __restrict__ e = sh + (j - lo_ext);
+            double H = 0.0, P = 0.0;
+            for (int i = 0; i < end; ++i) { H += e[i].x; P += e[i].y; }
+            shc[(j - lo_ext) / GABP_ROW_CHUNK] = make_double2(H, P);
+        }
+        __syncthreads();
+    }
     const int k = k0 + threadIdx.x;
     if (k >= g.nnz) return;
     const int rz = rec[k].z;
@@ -404,19 +429,29 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lh
             else { H += m.x * c; P += m.y * c; }
         }
     } else {
-        // the row in rv.nb order, the slot's own entry left out (GaBP.py:23-33).  Branch-free body -- selects around the two
-        // additions, whose order is the reference's -- so that the LDS reads of four entries are in flight together: a thread
-        // of a 100-entry row used to wait out one LDS round trip per entry (22 us per launch on BASELINE cfg 2's 20 k slots)
         const double2* __restrict__ row = sh + (lo - lo_ext);
         const int n = hi - lo, own = k - lo;
-        int j = 0;
-        for (; j + 4 <= n; j += 4) {
-            const double2 m0 = row[j], m1 = row[j + 1], m2 = row[j + 2], m3 = row[j + 3];
-#define LHVI_ROW_STEP(m, jj) { const bool none = (m).y != (m).y; const double h = H + (none ? -(m).x : (m).x), q = P + (m).y; \
-                               const bool take = (jj) != own; H = take ? h : H; P = (take && !none) ? q : P; }
-            LHVI_ROW_STEP(m0, j) LHVI_ROW_STEP(m1, j + 1) LHVI_ROW_STEP(m2, j + 2) LHVI_ROW_STEP(m3, j + 3)
+        if (n <= GABP_ROW_DIRECT) {
+            // the row in rv.nb order, the slot's own entry left out (GaBP.py:23-33): the reference's additions in its order,
+            // four LDS reads in flight (a thread of a long row used to wait out one LDS round trip per entry)
+            int j = 0;
+            for (; j + 4 <= n; j += 4) {
+                const double2 m0 = row[j], m1 = row[j + 1], m2 = row[j + 2], m3 = row[j + 3];
+#define LHVI_ROW_STEP(m, jj) { const double h = H + (m).x, q = P + (m).y; const bool take = (jj) != own; H = take ? h : H; P = take ? q : P; }
+                LHVI_ROW_STEP(m0, j) LHVI_ROW_STEP(m1, j + 1) LHVI_ROW_STEP(m2, j + 2) LHVI_ROW_STEP(m3, j + 3)
+            }
+            for (; j < n; ++j) { const double2 m = row[j]; LHVI_ROW_STEP(m, j) }
+        } else {
+            // a long row: the chunks before the slot's own, the own chunk's other entries, the chunks after it -- ascending rv.nb
+            // order with the chunks' sums as intermediate results (O(len / 8 + 8) additions per slot instead of O(len); differs
+            // from the reference's left-to-right sum by rounding only: asserted at 1e-13 on the fixtures)
+            const int nc = n / GABP_ROW_CHUNK, q = min(own / GABP_ROW_CHUNK, nc - 1);
+            const double2* __restrict__ cs = shc + (lo - lo_ext) / GABP_ROW_CHUNK;
+            for (int c = 0; c < q; ++c) { H += cs[c].x; P += cs[c].y; }
+            const int b0 = q * GABP_ROW_CHUNK, b1 = q == nc - 1 ? n : b0 + GABP_ROW_CHUNK;
+            for (int j = b0; j < b1; ++j) { const double2 m = row[j]; LHVI_ROW_STEP(m, j) }
+            for (int c = q + 1; c < nc; ++c) { H += cs[c].x; P += cs[c].y; }
         }
-        for (; j < n; ++j) { const double2 m = row[j]; LHVI_ROW_STEP(m, j) }
 #undef LHVI_ROW_STEP
     }
     const double var = 1.0 / P;
