@@ -3,7 +3,7 @@
 # Kalman graph; colour refinement + lifted VI of cfg 5; ground variational step; lifted particle sweep): kernel stats and, in
 # separate passes, HBM read / write counters.  Run through gpurun.
 set -e
-tag=${1:-r03_secondary}
+tag=${1:-r04_secondary}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
