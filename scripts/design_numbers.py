@@ -122,6 +122,39 @@ def block(tag):
             cfg = d.pop('config')
             L.append('* (`profiles/%s%s`: %s) %s: %s' % (tag, extra, what, cfg, ', '.join(
                 '%s = %s' % (k, ('%.4g' % v) if isinstance(v, float) else v) for k, v in d.items())))
+    # round 4: further measurement files, every JSON line of each (long per-sweep lists dropped)
+    for extra, what in (('_c2f_configs.jsonl', 'particle coarse-to-fine on arrays, `scripts/bench_configs.py c2f_pbp`'),
+                        ('_vi_configs.jsonl', 'the variational step on the models the reference published timings for, `scripts/bench_configs.py vi_models vi_scaled`'),
+                        ('_particles.jsonl', 'the headline workload at the demos\' particle counts and with EP proposals, `scripts/profile_particles.sh`'),
+                        ('_demo_loop.jsonl', 'Demo/RGM/demo.py through the object API, `scripts/bench_configs.py demo_loop`')):
+        path = os.path.join(PROF, tag + extra)
+        if not os.path.exists(path):
+            continue
+        L.append('')
+        L.append('`profiles/%s%s` (%s):' % (tag, extra, what))
+        L.append('')
+        with open(path) as fh:
+            for line in fh:
+                line = line.strip()
+                if not line.startswith('{'):
+                    continue
+                d = json.loads(line)
+                if extra == '_particles.jsonl':
+                    L.append('* n = %d, %s proposals: %.1f sweeps/s, %.2f ms per sweep, heavy-class kernel %.2f ms' % (
+                        d['config']['particles'], d['config']['proposal'], d['value'], d['ms_per_step'], d['roofline']['kernel_ms']))
+                    continue
+                cfg = d.pop('config')
+                for drop in ('model', 'totals_s'):
+                    d.pop(drop, None)
+                def fmt(v):
+                    if isinstance(v, float):
+                        return '%.4g' % v
+                    if isinstance(v, dict):
+                        return '{' + ', '.join('%s: %s' % (k, fmt(x)) for k, x in v.items()) + '}'
+                    if isinstance(v, list):
+                        return '[' + ', '.join(fmt(x) for x in v) + ']'
+                    return str(v)
+                L.append('* %s: %s' % (cfg, ', '.join('%s = %s' % (k, fmt(v)) for k, v in d.items())))
     sec = os.path.join(PROF, tag + '_secondary_traffic.json')
     if os.path.exists(sec):
         t = {_short(k): v for k, v in json.load(open(sec)).items()}

@@ -15,4 +15,4 @@ pr.enable()
 bp.run_flat(10, c2f=0)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
+pstats.Stats(pr).sort_stats("tottime").print_stats(60)
