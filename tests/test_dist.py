@@ -274,6 +274,20 @@ def test_bench_rejects_a_launcher_of_another_size():
 
 
 @pytest.mark.gpu
+def test_bench_owner_compute_flag_runs_two_ranks():
+    """`python bench.py --gpus 2 --exchange ownercompute` (gloo rehearsal backend, both ranks on the box's one GPU): the
+    variable-partitioned split end to end through the benchmark's own launcher, with its phase times in the JSON line"""
+    import json
+    r = _run_bench(['--gpus', '2', '--edges', '200000', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--exchange', 'ownercompute'],
+                   env={'LHVI_DIST_BACKEND': 'gloo'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and 'owner computes' in out['config']['sharding']
+    ph = out['phases_ms']
+    assert ph['owned_variables'] > 0 and ph['ghost_variables'] > 0 and ph['cut_edge_rows_sent'] > 0 and ph['exchanged_MB_per_sweep'] > 0
+
+
+@pytest.mark.gpu
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher: the parent (no GPU call) starts two ranks under
     torch.distributed.run, rank 0 prints the one JSON line; gloo rehearsal backend, both ranks on the box's one GPU.
