@@ -136,6 +136,13 @@ typedef struct lhvi_gabp_plan {
     const int32_t* rec;     /* (ABI 9) [nnz][4] or NULL: per slot {pslot[k], info[k], position of k in its row | row length << 10 |
                              * variable hidden << 20 | row longer than 512 << 21, 0}: with it a slot needs no lookup through
                              * slot_var / var_ptr / var_value (GaBP.message_rv_to_f, GaBP.py:20-35, reads rv.nb and rv.value) */
+    const double* pot_words;/* (ABI 9) [P][12], required with rec: per potential its first eleven parameters (zero padded; the closed forms
+                             * of GaBP.message_f_to_rv, GaBP.py:37-138, read at most par[10]) and its kind as a double -- one record
+                             * instead of the walk pots.kind -> pots.off -> pots.param */
+    const int32_t* seg;     /* (ABI 9) [n_seg][2], required with rec: the slot order cut into segments [lo, hi) of whole rows -- the rows
+                             * of at most 512 entries that start inside one window of 256 slots, up to the next row of more than 512
+                             * entries (those belong to the hub kernel) -- one workgroup each */
+    int32_t n_seg;
 } lhvi_gabp_plan_t;
 size_t lhvi_gabp_pull_workspace_bytes(const lhvi_graph_t* g);
 /* one sweep: v_next[k] = message_rv_to_f of slot k given the f -> v messages implied by v_prev (first != 0: given the

@@ -341,15 +341,23 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_kernel(lhvi_graph_t g, lhvi_p
 // message -> arithmetic.  Same expressions in the same order: the same bits.
 constexpr int GABP_LDS_POTS = 32;
 constexpr int GABP_POT_WORDS = 12;            // par[0 .. 10] (the Gaussian closed form reads up to par[10]) + the kind
-constexpr int GABP_ROW_DIRECT = 32;           // rows up to this length are summed entry by entry in the reference's order
-constexpr int GABP_ROW_CHUNK = 8;             // longer rows (ground graphs): sums of eight-entry chunks as intermediate results
+#ifndef LHVI_GABP_ROW_DIRECT
+#define LHVI_GABP_ROW_DIRECT 32
+#endif
+#ifndef LHVI_GABP_ROW_CHUNK
+#define LHVI_GABP_ROW_CHUNK 8
+#endif
+constexpr int GABP_ROW_DIRECT = LHVI_GABP_ROW_DIRECT;   // rows up to this length are summed entry by entry in the reference's order
+constexpr int GABP_ROW_CHUNK = LHVI_GABP_ROW_CHUNK;     // longer rows (ground graphs): sums of eight-entry chunks as intermediate results
 
 template <bool LDS_POTS>
 __device__ __forceinline__ double2 pull_incoming_rec(const lhvi_graph_t& g, const lhvi_pots_t& pots, const int4 r,
-                                                     const double* __restrict__ vprev, const double* __restrict__ sh_par) {
+                                                     const double* __restrict__ vprev, const double* __restrict__ sh_par /* LDS, or the plan's pot_words */) {
     const int code = r.y & 3, pot = r.y >> 2;
-    const double* par = LDS_POTS ? sh_par + pot * GABP_POT_WORDS : pots.param + pots.off[pot];
-    const int kind = LDS_POTS ? (int)sh_par[pot * GABP_POT_WORDS + GABP_POT_WORDS - 1] : pots.kind[pot];
+    // the potential as twelve words -- par[0 .. 10] and the kind -- in LDS, or in the plan's table in global memory (one load
+    // behind the record instead of pots.kind -> pots.off -> parameters)
+    const double* par = sh_par + (int64_t)pot * GABP_POT_WORDS;
+    const int kind = (int)par[GABP_POT_WORDS - 1];
     const int arity = code == 0 ? 1 : (code == 3 ? 3 : 2), pos = code == 2 ? 1 : 0;
     bool partner_hidden = false;
     double u = 0.0, sv = 0.0, y = 0.0;
@@ -363,32 +371,31 @@ __device__ __forceinline__ double2 pull_incoming_rec(const lhvi_graph_t& g, cons
 
 template <bool LDS_POTS>
 __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lhvi_pots_t pots, const int4* __restrict__ rec,
+                                                             const int2* __restrict__ seg, const double* __restrict__ pot_words,
                                                              const double* __restrict__ count, const double* __restrict__ vprev,
                                                              double* __restrict__ vnext, int first) {
-    constexpr int CAP = BLOCK + 2 * GABP_HUB_DEGREE;
+    // a workgroup serves one SEGMENT of the slot order (lhvi_gabp_plan_t.seg): the rows that start inside one window of BLOCK
+    // slots, whole -- at most BLOCK - 1 + GABP_HUB_DEGREE slots, no row cut, no hub row inside -- so nothing is staged twice
+    // (workgroups of fixed 256-slot ranges staged the rows straddling their ends whole: 1.5x the gathers and closed forms on a
+    // graph with rows of 66 entries)
+    constexpr int CAP = BLOCK + GABP_HUB_DEGREE;
     __shared__ double2 sh[CAP];
     __shared__ double2 shc[CAP / GABP_ROW_CHUNK + 1];       // sums of eight-entry chunks of the long rows (ground graphs)
     __shared__ double sh_par[LDS_POTS ? GABP_LDS_POTS * GABP_POT_WORDS : 1];
     if (LDS_POTS) {
-        for (int i = threadIdx.x; i < pots.P * GABP_POT_WORDS; i += BLOCK) {
-            const int pot = i / GABP_POT_WORDS, j = i % GABP_POT_WORDS;
-            const int n = pots.off[pot + 1] - pots.off[pot];
-            sh_par[i] = j == GABP_POT_WORDS - 1 ? (double)pots.kind[pot] : (j < n ? pots.param[pots.off[pot] + j] : 0.0);
-        }
+        for (int i = threadIdx.x; i < pots.P * GABP_POT_WORDS; i += BLOCK) sh_par[i] = pot_words[i];
         __syncthreads();
     }
-    const int k0 = blockIdx.x * BLOCK;
-    const int kend = min(k0 + BLOCK, g.nnz);
-    const int rf = rec[k0].z, rl = rec[kend - 1].z;
-    const int lo_ext = ((rf >> 21) & 1) ? k0 : k0 - (rf & 1023);                       // (a hub row is served by gabp_pull_hub_kernel)
-    const int hi_ext = ((rl >> 21) & 1) ? kend : kend - 1 - (rl & 1023) + ((rl >> 10) & 1023);
+    const double* __restrict__ pw = LDS_POTS ? sh_par : pot_words;
+    const int2 sg = seg[blockIdx.x];
+    const int lo_ext = sg.x, hi_ext = sg.y;
     int long_rows = 0;
     for (int j = lo_ext + threadIdx.x; j < hi_ext; j += BLOCK) {
         const int4 r = rec[j];
         if ((r.z >> 21) & 1) continue;
         long_rows |= ((r.z >> 10) & 1023) > GABP_ROW_DIRECT;
         const bool hid = (r.z >> 20) & 1;
-        const double2 m = (hid && !first) ? pull_incoming_rec<LDS_POTS>(g, pots, r, vprev, sh_par) : make_double2(0.0, 1.0);
+        const double2 m = (hid && !first) ? pull_incoming_rec<LDS_POTS>(g, pots, r, vprev, pw) : make_double2(0.0, 1.0);
         const double p = 1.0 / m.y;
         if (count) sh[j - lo_ext] = (m.y != m.y) ? m : make_double2(p * m.x, p);
         // ground graph: staged as the entry's CONTRIBUTION (h, p) to the row sums -- (p mu, p), or (-mu, 0) for a `None` variance
@@ -413,11 +420,9 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lh
         }
         __syncthreads();
     }
-    const int k = k0 + threadIdx.x;
-    if (k >= g.nnz) return;
+    for (int k = lo_ext + threadIdx.x; k < hi_ext; k += BLOCK) {
     const int rz = rec[k].z;
-    if (!((rz >> 20) & 1)) { st2(vnext, k, NAN, NAN); return; }
-    if ((rz >> 21) & 1) return;                                 // gabp_pull_hub_kernel
+    if (!((rz >> 20) & 1)) { st2(vnext, k, NAN, NAN); continue; }
     const int lo = k - (rz & 1023), hi = lo + ((rz >> 10) & 1023);
     double H = 0.0, P = 0.0;
     if (count) {
@@ -456,6 +461,7 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lh
     }
     const double var = 1.0 / P;
     st2(vnext, k, var * H, var);
+    }
 }
 
 __global__ void __launch_bounds__(BLOCK) gabp_pull_hub_kernel(lhvi_graph_t g, lhvi_pots_t pots, PullPlan pl,
@@ -492,27 +498,28 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_hub_kernel(lhvi_graph_t g, lh
 // message and arithmetic -- no walk through info -> pots.kind -> pots.off -> parameters per slot
 template <bool LDS_POTS>
 __global__ void __launch_bounds__(BLOCK) gabp_pull_hub_rec_kernel(lhvi_graph_t g, lhvi_pots_t pots, const int4* __restrict__ rec,
-                                                                 const double* __restrict__ count, const double* __restrict__ vprev,
-                                                                 double* __restrict__ vnext, int first) {
+                                                                 const double* __restrict__ pot_words, const double* __restrict__ count,
+                                                                 const double* __restrict__ vprev, double* __restrict__ vnext, int first) {
     __shared__ double sh_par[LDS_POTS ? GABP_LDS_POTS * GABP_POT_WORDS : 1];
     if (LDS_POTS) {
-        for (int i = threadIdx.x; i < pots.P * GABP_POT_WORDS; i += BLOCK) {
-            const int pot = i / GABP_POT_WORDS, j = i % GABP_POT_WORDS;
-            const int n = pots.off[pot + 1] - pots.off[pot];
-            sh_par[i] = j == GABP_POT_WORDS - 1 ? (double)pots.kind[pot] : (j < n ? pots.param[pots.off[pot] + j] : 0.0);
-        }
+        for (int i = threadIdx.x; i < pots.P * GABP_POT_WORDS; i += BLOCK) sh_par[i] = pot_words[i];
         __syncthreads();
     }
+    const double* __restrict__ pw = LDS_POTS ? sh_par : pot_words;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (i >= g.n_hubs) return;
     const int v = g.hub_vars[i];
     const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
-    if (hi - lo <= GABP_HUB_DEGREE || !is_hidden(g.var_value[v])) return;
+    if (hi - lo <= GABP_HUB_DEGREE) return;
+    if (!is_hidden(g.var_value[v])) {                          // an observed variable sends nothing (GaBP.py:39-40): NaN rows
+        for (int j = lo + lane; j < hi; j += 64) st2(vnext, j, NAN, NAN);
+        return;
+    }
     double H = 0.0, P = 0.0;
     for (int j = lo + lane; j < hi; j += 64) {
         const double c = count ? count[j] : 1.0;
-        const double2 m = first ? make_double2(0.0, 1.0) : pull_incoming_rec<LDS_POTS>(g, pots, rec[j], vprev, sh_par);
+        const double2 m = first ? make_double2(0.0, 1.0) : pull_incoming_rec<LDS_POTS>(g, pots, rec[j], vprev, pw);
         st2(vnext, j, m.x, m.y);
         if (m.y != m.y) H -= m.x * c;
         else { const double p = 1.0 / m.y; H += p * m.x * c; P += p * c; }
@@ -606,22 +613,26 @@ int lhvi_gabp_pull(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_ga
     if (!v_next || (!first && !v_prev) || v_prev == v_next) return LHVI_E_ARG;
     PullPlan pl;
     pl.pslot = plan->pslot; pl.info = plan->info; pl.count = plan->count;
-    if (plan->rec && pots->P <= GABP_LDS_POTS)
-        hipLaunchKernelGGL(gabp_pull_rec_kernel<true>, dim3(grid_for(g->nnz)), dim3(BLOCK), 0, as_stream(stream), *g, *pots,
-                           reinterpret_cast<const int4*>(plan->rec), plan->count, v_prev, v_next, first);
-    else if (plan->rec)
-        hipLaunchKernelGGL(gabp_pull_rec_kernel<false>, dim3(grid_for(g->nnz)), dim3(BLOCK), 0, as_stream(stream), *g, *pots,
-                           reinterpret_cast<const int4*>(plan->rec), plan->count, v_prev, v_next, first);
+    const bool records = plan->rec && plan->pot_words && plan->seg && plan->n_seg >= 0;
+    if (records && plan->n_seg == 0) {}                        // (every row is a hub row)
+    else if (records && pots->P <= GABP_LDS_POTS)
+        hipLaunchKernelGGL(gabp_pull_rec_kernel<true>, dim3((unsigned)plan->n_seg), dim3(BLOCK), 0, as_stream(stream), *g, *pots,
+                           reinterpret_cast<const int4*>(plan->rec), reinterpret_cast<const int2*>(plan->seg), plan->pot_words, plan->count,
+                           v_prev, v_next, first);
+    else if (records)
+        hipLaunchKernelGGL(gabp_pull_rec_kernel<false>, dim3((unsigned)plan->n_seg), dim3(BLOCK), 0, as_stream(stream), *g, *pots,
+                           reinterpret_cast<const int4*>(plan->rec), reinterpret_cast<const int2*>(plan->seg), plan->pot_words, plan->count,
+                           v_prev, v_next, first);
     else
         hipLaunchKernelGGL(gabp_pull_kernel, dim3(grid_for(g->nnz)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, pl, v_prev, v_next, first);
     if (g->hub_vars && g->n_hubs > 0 && plan->n_hub_rows != 0) {
         const dim3 hgrid(grid_for((int64_t)g->n_hubs * 64));
-        if (plan->rec && pots->P <= GABP_LDS_POTS)
+        if (records && pots->P <= GABP_LDS_POTS)
             hipLaunchKernelGGL(gabp_pull_hub_rec_kernel<true>, hgrid, dim3(BLOCK), 0, as_stream(stream), *g, *pots,
-                               reinterpret_cast<const int4*>(plan->rec), plan->count, v_prev, v_next, first);
-        else if (plan->rec)
+                               reinterpret_cast<const int4*>(plan->rec), plan->pot_words, plan->count, v_prev, v_next, first);
+        else if (records)
             hipLaunchKernelGGL(gabp_pull_hub_rec_kernel<false>, hgrid, dim3(BLOCK), 0, as_stream(stream), *g, *pots,
-                               reinterpret_cast<const int4*>(plan->rec), plan->count, v_prev, v_next, first);
+                               reinterpret_cast<const int4*>(plan->rec), plan->pot_words, plan->count, v_prev, v_next, first);
         else
             hipLaunchKernelGGL(gabp_pull_hub_kernel, hgrid, dim3(BLOCK), 0, as_stream(stream), *g, *pots, pl, v_prev, v_next, first);
     }

@@ -36,7 +36,7 @@ class GraphStruct(C.Structure):
 
 
 class GabpPlanStruct(C.Structure):
-    _fields_ = [('pslot', C.c_void_p), ('info', C.c_void_p), ('count', C.c_void_p), ('n_hub_rows', C.c_int32), ('rec', C.c_void_p)]
+    _fields_ = [('pslot', C.c_void_p), ('info', C.c_void_p), ('count', C.c_void_p), ('n_hub_rows', C.c_int32), ('rec', C.c_void_p), ('pot_words', C.c_void_p), ('seg', C.c_void_p), ('n_seg', C.c_int32)]
 
 
 class PotsStruct(C.Structure):

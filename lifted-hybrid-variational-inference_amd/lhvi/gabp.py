@@ -7,6 +7,8 @@ issues the flooding sweeps through ``lhvi_gabp_run`` (hand-written HIP, ``csrc/g
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import _abi
@@ -48,7 +50,31 @@ def pull_plan(flat):
     rec = np.zeros((nnz, 4), dtype=np.int32)
     rec[:, 0], rec[:, 1] = pslot, info
     rec[:, 2] = np.where(long_row, 0, within | (deg[svar] << 10)) | (np.isnan(flat.var_value[svar]).astype(np.int64) << 20) | (long_row.astype(np.int64) << 21)
-    return dict(pslot=pslot.astype(np.int32), info=info.astype(np.int32), rec=rec,
+    # twelve words per potential: par[0 .. 10] (zero padded) and the kind (lhvi_gabp_plan_t.pot_words)
+    P = int(flat.pot_kind.size)
+    words = np.zeros((max(P, 1), 12))
+    npar = np.diff(flat.pot_off)
+    for j in range(11):
+        has = npar > j
+        words[:P][has, j] = flat.pot_param[flat.pot_off[:-1][has] + j]
+    words[:P, 11] = flat.pot_kind
+    # segments of the slot order (lhvi_gabp_plan_t.seg): rows of at most 512 entries grouped by the 256-slot window their first
+    # slot lies in, runs broken at every longer row
+    rows = np.flatnonzero(deg > 0)
+    start = flat.var_ptr[rows].astype(np.int64)
+    is_hub = deg[rows] > 512
+    # (a small graph is latency bound: narrower windows give it more, shorter workgroups)
+    window = int(os.environ.get('LHVI_GABP_WINDOW', 256 if nnz >= (1 << 17) else 64))
+    group = np.cumsum(is_hub) * (nnz // window + 2) + start // window
+    keep = ~is_hub
+    r_start, r_end, r_group = start[keep], start[keep] + deg[rows][keep], group[keep]
+    if r_start.size:
+        first_of = np.flatnonzero(np.concatenate([[True], r_group[1:] != r_group[:-1]]))
+        last_of = np.concatenate([first_of[1:] - 1, [r_start.size - 1]])
+        seg = np.stack([r_start[first_of], r_end[last_of]], axis=1).astype(np.int32)
+    else:
+        seg = np.zeros((0, 2), dtype=np.int32)
+    return dict(pslot=pslot.astype(np.int32), info=info.astype(np.int32), rec=rec, pot_words=words, seg=seg,
                 count=np.ascontiguousarray(flat.edge_count[ve], dtype=np.float64) if flat.lifted else None)
 
 
@@ -105,6 +131,8 @@ class _GaussianSweep:
             plan = _abi.GabpPlanStruct()
             plan.pslot, plan.info, plan.count = (_abi.ptr(st['plan_dev'][k]) for k in ('pslot', 'info', 'count'))
             plan.rec = _abi.ptr(st['plan_dev']['rec']) if self.slot_records else None
+            plan.pot_words = _abi.ptr(st['plan_dev']['pot_words'])
+            plan.seg, plan.n_seg = _abi.ptr(st['plan_dev']['seg']), int(host['seg'].shape[0])
             plan.n_hub_rows = int((np.diff(flat.var_ptr) > 512).sum())
             st['plan'] = plan
             st['ws_bytes'] = int(l.lhvi_gabp_pull_workspace_bytes(dg.g))

@@ -31,6 +31,8 @@ def gabp_plan(flat, records=True):
     plan = _abi.GabpPlanStruct()
     plan.pslot, plan.info, plan.count = (_abi.ptr(dev[k]) for k in ('pslot', 'info', 'count'))
     plan.rec = _abi.ptr(dev['rec']) if records and os.environ.get('GABP_NO_RECORDS') is None else None
+    plan.pot_words = _abi.ptr(dev['pot_words'])
+    plan.seg, plan.n_seg = _abi.ptr(dev['seg']), int(host['seg'].shape[0])
     plan.n_hub_rows = int((np.diff(flat.var_ptr) > 512).sum())
     return plan, dev
 

@@ -220,6 +220,8 @@ def _run_both_forms(api, flat, iterations):
     for pull in (False, True, 'records', 'records, potentials from global memory'):
         f2v, v2f, mv = dg.empty(flat.E, 2), dg.empty(flat.E, 2), dg.empty(flat.V, 2)
         plan.rec = api.ptr(dev['rec']) if isinstance(pull, str) else None      # round 4: one 16-byte record per slot
+        plan.pot_words = api.ptr(dev['pot_words'])
+        plan.seg, plan.n_seg = api.ptr(dev['seg']), int(host['seg'].shape[0])
         if pull == 'records, potentials from global memory':
             # more potentials than the kernel keeps in LDS: pad the table (the padding rows are never referenced)
             import copy
@@ -228,6 +230,8 @@ def _run_both_forms(api, flat, iterations):
             wide.pot_kind = np.concatenate([flat.pot_kind, np.full(64, flat.pot_kind[0], dtype=flat.pot_kind.dtype)])
             wide.pot_off = np.concatenate([flat.pot_off, np.full(64, flat.pot_off[-1], dtype=flat.pot_off.dtype)])
             dgw = api.DeviceGraph(wide)
+            wide_words = api.to_dev(pull_plan(wide)['pot_words'])
+            plan.pot_words = api.ptr(wide_words)
             api.check(l.lhvi_gabp_run_pull(dgw.g, dgw.p, plan, api.ptr(f2v), api.ptr(v2f), iterations, api.ptr(ws), nbytes, st))
         elif pull:
             api.check(l.lhvi_gabp_run_pull(dg.g, dg.p, plan, api.ptr(f2v), api.ptr(v2f), iterations, api.ptr(ws), nbytes, st))
