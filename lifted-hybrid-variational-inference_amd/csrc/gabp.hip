@@ -397,10 +397,9 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lh
         const bool hid = (r.z >> 20) & 1;
         const double2 m = (hid && !first) ? pull_incoming_rec<LDS_POTS>(g, pots, r, vprev, pw) : make_double2(0.0, 1.0);
         const double p = 1.0 / m.y;
-        if (count) sh[j - lo_ext] = (m.y != m.y) ? m : make_double2(p * m.x, p);
-        // ground graph: staged as the entry's CONTRIBUTION (h, p) to the row sums -- (p mu, p), or (-mu, 0) for a `None` variance
-        // (GaBP.py:27-33: a linear term only) -- so that the sums below are additions without a case distinction
-        else sh[j - lo_ext] = (m.y != m.y) ? make_double2(-m.x, 0.0) : make_double2(p * m.x, p);
+        // staged as the entry's CONTRIBUTION (h, p) to the row sums -- (p mu, p), or (-mu, 0) for a `None` variance (GaBP.py:27-33: a
+        // linear term only) -- so that the sums below are additions (times the count on a lifted graph) without a case distinction
+        sh[j - lo_ext] = (m.y != m.y) ? make_double2(-m.x, 0.0) : make_double2(p * m.x, p);
     }
     long_rows = __syncthreads_or(long_rows);                    // (the staging barrier; most blocks of most graphs have no long row)
     if (!count && long_rows) {
@@ -426,13 +425,19 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lh
     const int lo = k - (rz & 1023), hi = lo + ((rz >> 10) & 1023);
     double H = 0.0, P = 0.0;
     if (count) {
-        for (int j = lo; j < hi; ++j) {
-            double c = count[j];
-            if (j == k) c -= 1.0;
-            const double2 m = sh[j - lo_ext];
-            if (m.y != m.y) H -= m.x * c;
-            else { H += m.x * c; P += m.y * c; }
+        // lifted graph (GaLBP.py:24-34): every entry times rv.count[f], the slot's own factor with count - 1; four entries in flight
+        const double2* __restrict__ row = sh + (lo - lo_ext);
+        const double* __restrict__ cnt = count + lo;
+        const int n = hi - lo, own = k - lo;
+        int j = 0;
+        for (; j + 4 <= n; j += 4) {
+            const double2 m0 = row[j], m1 = row[j + 1], m2 = row[j + 2], m3 = row[j + 3];
+            const double c0 = cnt[j], c1 = cnt[j + 1], c2 = cnt[j + 2], c3 = cnt[j + 3];
+#define LHVI_CNT_STEP(m, c, jj) { const double cc = (jj) == own ? (c) - 1.0 : (c); H += (m).x * cc; P += (m).y * cc; }
+            LHVI_CNT_STEP(m0, c0, j) LHVI_CNT_STEP(m1, c1, j + 1) LHVI_CNT_STEP(m2, c2, j + 2) LHVI_CNT_STEP(m3, c3, j + 3)
         }
+        for (; j < n; ++j) { const double2 m = row[j]; const double c = cnt[j]; LHVI_CNT_STEP(m, c, j) }
+#undef LHVI_CNT_STEP
     } else {
         const double2* __restrict__ row = sh + (lo - lo_ext);
         const int n = hi - lo, own = k - lo;

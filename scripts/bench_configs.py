@@ -82,13 +82,17 @@ if 'cfg2' in which:
     lflat = lifting.lift_flat(flat, rvc, fc)
     ldg = _abi.DeviceGraph(lflat)
     lf2v, lv2f, lmv, mv = ldg.empty(lflat.E, 2), ldg.empty(lflat.E, 2), ldg.empty(lflat.V, 2), dg.empty(flat.V, 2)
-    t = ev_time(lambda: _abi.check(l.lhvi_gabp_run(ldg.g, ldg.p, _abi.ptr(lf2v), _abi.ptr(lv2f), 20, st)))
+    lplan, ldev = gabp_plan(lflat)
+    lnb = int(l.lhvi_gabp_pull_workspace_bytes(ldg.g))
+    lws = torch.empty(lnb, dtype=torch.uint8, device=ldg.device)
+    t_pair = ev_time(lambda: _abi.check(l.lhvi_gabp_run(ldg.g, ldg.p, _abi.ptr(lf2v), _abi.ptr(lv2f), 20, st)))
+    t = ev_time(lambda: _abi.check(l.lhvi_gabp_run_pull(ldg.g, ldg.p, lplan, _abi.ptr(lf2v), _abi.ptr(lv2f), 20, _abi.ptr(lws), lnb, st)))
     _abi.check(l.lhvi_gabp_marginals(ldg.g, _abi.ptr(lf2v), _abi.ptr(lmv), st))
     _abi.check(l.lhvi_gabp_marginals(dg.g, _abi.ptr(f2v), _abi.ptr(mv), st))
     hid = flat.var_hidden
     err = float(np.abs(lmv.cpu().numpy()[rvc][hid, 0] - mv.cpu().numpy()[hid, 0]).max())
     out(config='cfg2 RGM lifted GaLBP', ground_edges=flat.E, rv_clusters=int(rvc.max()) + 1, f_clusters=int(fc.max()) + 1,
-        lifted_edges=lflat.E, colour_passing_s=t_ref, ms_20_sweeps=t, max_abs_mu_diff_vs_ground=err)
+        lifted_edges=lflat.E, colour_passing_s=t_ref, ms_20_sweeps=t, ms_20_sweeps_kernel_pair=t_pair, max_abs_mu_diff_vs_ground=err)
 
 if 'cfg2' in which:
     # cfg 2 through the solver API: the first run() builds the device state and records the run, the second replays it
