@@ -305,6 +305,49 @@ def split_evidence_observed(ovals, oc, nc, k, iteration, epsilon, use_sqrt):
     return out, nc
 
 
+def split_evidence_tensors(ovals_t, vcode_t, distinct_vals, oc_t, nc, k, iteration, epsilon, use_sqrt):
+    """``split_evidence_observed`` with the grouping done by tensor operations on the colours' device: per-colour counts, means and
+    variances (three weighted ``bincount``s), then -- for the colours whose spread exceeds `epsilon` -- the distinct (colour, value)
+    pairs with multiplicities and first positions.  Only those pairs reach the host (a few per colour), where the k-means of
+    ``SuperRV.split_by_evidence`` runs on them; the pieces' colours go back as a small table.  `ovals_t` / `vcode_t`: values of the
+    observed members and their dense codes (``distinct_vals[code]``, host) in ground order; `oc_t`: their colours (int64).
+    Returns (new colours of the observed members, new number of colours); same pieces and numbering as the host function."""
+    import torch
+    from .c2fvi import _kmeans_distinct
+    from .lifting import first_members
+    dev = oc_t.device
+    n = torch.bincount(oc_t, minlength=nc).to(torch.float64)
+    mean = torch.bincount(oc_t, weights=ovals_t, minlength=nc) / n
+    var = torch.bincount(oc_t, weights=(ovals_t - mean[oc_t]) ** 2, minlength=nc) / n
+    spread = torch.sqrt(torch.nan_to_num(var)) if use_sqrt else torch.nan_to_num(var)
+    todo = (n > 1) & (spread > epsilon)
+    sel = torch.nonzero(todo[oc_t]).flatten()
+    if sel.numel() == 0:
+        return oc_t, nc
+    nvals = int(distinct_vals.size)
+    key, inv, cnt = torch.unique(oc_t[sel] * nvals + vcode_t[sel], return_inverse=True, return_counts=True)
+    first = first_members(inv, int(key.numel()), int(sel.numel()))
+    key_h, cnt_h, first_h = key.cpu().numpy(), cnt.cpu().numpy(), first.cpu().numpy()
+    col_h, code_h = key_h // nvals, key_h % nvals
+    table = col_h.copy()                                   # new colour of every (colour, value) pair
+    bounds = np.flatnonzero(np.concatenate([[True], col_h[1:] != col_h[:-1], [True]]))      # key is sorted: pairs grouped by colour
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        order = np.argsort(first_h[a:b], kind='stable')   # distinct values in first-appearance (member) order
+        res = _kmeans_distinct(distinct_vals[code_h[a:b]][order], cnt_h[a:b][order], k, iteration)
+        if res is None:
+            continue
+        assign = np.empty(b - a, dtype=np.int64)
+        assign[order] = res[0]
+        for piece in range(1, int(assign.max()) + 1):
+            hit = assign == piece
+            if hit.any():
+                table[a:b][hit] = nc
+                nc += 1
+    out = oc_t.clone()
+    out[sel] = torch.from_numpy(table).to(dev)[inv]
+    return out, nc
+
+
 class FlatRefiner:
     """single refinement half rounds on device-resident colour tensors (``lhvi_color_refine_factors`` / ``_rvs``): the hash
     relabelling, repeated through the radix sort when its table overflows"""
@@ -376,19 +419,19 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
             clock[name] += time.perf_counter() - t0
         return time.perf_counter()
 
-    def observed_colours():
-        return rvc[obs_idx_t].cpu().numpy().astype(np.int64)
+    distinct_vals, vcode = np.unique(ovals, return_inverse=True)
+    ovals_t = torch.from_numpy(np.ascontiguousarray(ovals)).to(dev)
+    vcode_t = torch.from_numpy(vcode.astype(np.int64)).to(dev)
 
     def split_evidence(k, its, epsilon, use_sqrt):
         nonlocal rvc, nc
         if not obs_idx.size:
             return
-        oc = observed_colours()
-        new_oc, nc2 = split_evidence_observed(ovals, oc, nc, k, its, epsilon, use_sqrt)
-        moved = np.flatnonzero(new_oc != oc)
-        if moved.size:
+        oc = rvc[obs_idx_t].long()
+        new_oc, nc2 = split_evidence_tensors(ovals_t, vcode_t, distinct_vals, oc, nc, k, its, epsilon, use_sqrt)
+        if nc2 != nc:
             rvc = rvc.clone()
-            rvc[obs_idx_t[torch.from_numpy(moved).to(dev)]] = as_t(new_oc[moved])
+            rvc[obs_idx_t] = new_oc.to(rvc.dtype)
         nc = nc2
 
     def refine_rvs():
@@ -399,12 +442,11 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
     def evidence_variance():
         if not obs_idx.size:
             return np.zeros(0)
-        oc = observed_colours()
-        n = np.bincount(oc, minlength=nc).astype(np.float64)
-        with np.errstate(invalid='ignore', divide='ignore'):
-            mean = np.bincount(oc, weights=ovals, minlength=nc) / n
-            var = np.bincount(oc, weights=(ovals - mean[oc]) ** 2, minlength=nc) / n
-        return var[n > 0]
+        oc = rvc[obs_idx_t].long()
+        n = torch.bincount(oc, minlength=nc).to(torch.float64)
+        mean = torch.bincount(oc, weights=ovals_t, minlength=nc) / n
+        var = torch.bincount(oc, weights=(ovals_t - mean[oc]) ** 2, minlength=nc) / n
+        return var[n > 0].cpu().numpy()
 
     def record():
         return (rvc.cpu().numpy().copy(), fc.cpu().numpy().copy()) if (keep_history or observer is not None) else None

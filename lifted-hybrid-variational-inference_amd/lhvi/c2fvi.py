@@ -188,18 +188,15 @@ def run_c2fvi(g, engine, refiner, K, iteration, lr, opts, init=None, observer=No
 
 
 # ---- the same schedule on arrays (ground FlatGraph in, no Python object per ground atom) ---------------------------------------
-def _kmeans_vec(vals, k, iteration):
-    """``lifting.kmeans_assign`` vectorised over the distinct values (same seeds -- the first k distinct values in member
-    order --, same accumulation order: ``np.bincount`` adds its weights in input order like the reference's loop over its
-    Counter), for clusters with many distinct values.  Returns the piece of every member or None."""
-    if vals.size <= 1:
-        return None
-    distinct, first, inv, cnt = np.unique(vals, return_index=True, return_inverse=True, return_counts=True)
-    order = np.argsort(first, kind='stable')            # distinct values in first-appearance (member) order
-    distinct, cnt = distinct[order], cnt[order].astype(np.float64)
+def _kmeans_distinct(distinct, cnt, k, iteration):
+    """the k-means of ``lifting.kmeans_assign`` on a cluster's DISTINCT values (in first-appearance order of its members) and their
+    multiplicities: centroids seeded with the first k of them, `iteration` Lloyd rounds (``np.bincount`` adds its weights in input
+    order like the reference's loop over its Counter).  Returns (piece of every distinct value, nearest(x) for further points), or
+    None when there is nothing to split."""
     kk = min(k, distinct.size)
     if kk <= 1:
         return None
+    cnt = cnt.astype(np.float64)
     cen = distinct[:kk].copy()
 
     def nearest(x):
@@ -219,7 +216,20 @@ def _kmeans_vec(vals, k, iteration):
         num = np.bincount(idx, weights=cnt, minlength=kk)
         with np.errstate(invalid='ignore', divide='ignore'):
             cen = tot / num
-    return nearest(vals)
+    return nearest(distinct), nearest
+
+
+def _kmeans_vec(vals, k, iteration):
+    """``lifting.kmeans_assign`` vectorised over the distinct values (same seeds -- the first k distinct values in member
+    order --, same accumulation order), for clusters with many distinct values.  Returns the piece of every member or None."""
+    if vals.size <= 1:
+        return None
+    distinct, first, inv, cnt = np.unique(vals, return_index=True, return_inverse=True, return_counts=True)
+    order = np.argsort(first, kind='stable')            # distinct values in first-appearance (member) order
+    res = _kmeans_distinct(distinct[order], cnt[order], k, iteration)
+    if res is None:
+        return None
+    return res[1](vals)
 
 
 def split_evidence_observed(ovals, oc, nc, tracked, k, iteration, epsilon):

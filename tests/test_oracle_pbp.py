@@ -351,3 +351,25 @@ def test_split_evidence_on_observed_members_equals_the_colour_pass():
         got[obs] = oc
         np.testing.assert_array_equal(got, want)
         assert nc == int(want.max()) + 1
+
+
+def test_split_evidence_by_tensor_grouping_equals_the_colour_pass():
+    """``c2f.split_evidence_tensors`` (grouping by weighted bincounts / unique on the colours' device, k-means on the distinct
+    (colour, value) pairs only) against ``lifting.split_evidence_colors`` over all variables: same pieces, same numbering"""
+    import torch
+    from lhvi import c2f
+    rng = np.random.default_rng(1)
+    V = 600
+    values = np.where(rng.random(V) < 0.6, rng.integers(0, 9, V) * 1.25 + rng.integers(0, 2, V) * 0.01, np.nan)
+    rvc = rng.integers(0, 7, V).astype(np.int32)
+    rvc[np.isnan(values)] = 7 + rng.integers(0, 3, int(np.isnan(values).sum()))
+    obs = np.flatnonzero(~np.isnan(values))
+    distinct, code = np.unique(values[obs], return_inverse=True)
+    for eps, use_sqrt in ((0.0, True), (2.0, False), (0.5, True), (100.0, False), (0.9, False)):
+        want = lifting.split_evidence_colors(values, rvc, 2, 10, eps, use_sqrt=use_sqrt)
+        oc, nc = c2f.split_evidence_tensors(torch.from_numpy(values[obs]), torch.from_numpy(code.astype(np.int64)), distinct,
+                                            torch.from_numpy(rvc[obs].astype(np.int64)), int(rvc.max()) + 1, 2, 10, eps, use_sqrt)
+        got = rvc.copy()
+        got[obs] = oc.numpy()
+        np.testing.assert_array_equal(got, want)
+        assert nc == int(want.max()) + 1
