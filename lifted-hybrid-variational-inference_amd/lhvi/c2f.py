@@ -112,8 +112,13 @@ def run_c2f(g, engine, refiner, iteration, c2f, k_mean_k, k_mean_iteration, draw
     values = gflat.var_value
     rvc, fc = initial_colors(g, is_split_cont_evidence=False)                       # HLBP:432
     rvc = split_evidence_colors(values, rvc, 2, 50, 0.0, use_sqrt=True)             # HLBP:440
-    fc = refiner.factors(rvc, fc)
-    rvc = refiner.rvs(fc, rvc)
+
+    def refined(old, new):
+        """a refinement only splits: the same number of colours means the same partition -- the old ids stay then (the
+        refinement numbers its colours afresh every time; keeping them lets the array path reuse a sweep's graphs and states)"""
+        return old if int(new.max()) == int(old.max()) else new
+    fc = refined(fc, refiner.factors(rvc, fc))
+    rvc = refined(rvc, refiner.rvs(fc, rvc))
     history = []
 
     def lift(rvc, fc):
@@ -146,7 +151,7 @@ def run_c2f(g, engine, refiner, iteration, c2f, k_mean_k, k_mean_iteration, draw
             old_rvc = rvc
             rvc = split_evidence_colors(values, rvc, k_mean_k, k_mean_iteration, epsilon, use_sqrt=False)
             epsilon = max(epsilon - d, c2f)
-            rvc = refiner.rvs(fc, rvc)
+            rvc = refined(rvc, refiner.rvs(fc, rvc))
             G1, pair_phi = rv_side_graph(gflat, rvc, fc)
             parent = old_rvc[G1.rep_ground]                                        # parent cluster of every new rv cluster
             pair_to_edge2 = {}
@@ -165,7 +170,7 @@ def run_c2f(g, engine, refiner, iteration, c2f, k_mean_k, k_mean_iteration, draw
             engine.proposal(st1)
         # ---- split_factors (HLBP:509-513; after the loop for the last sweep, HLBP:536): P_f(i) from P_rv(i), P_f(i-1)
         old_fc = fc
-        fc = refiner.factors(rvc, fc)
+        fc = refined(fc, refiner.factors(rvc, fc))
         cg, G2 = lift(rvc, fc)
         parent_f = old_fc[_first_member(fc, G2.F)]
         pair_to_edge1 = {(int(A), int(phi)): e for e, (A, phi) in enumerate(zip(G1.edge_var, pair_phi))}
@@ -409,7 +414,8 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
     obs_idx_t = torch.from_numpy(obs_idx).to(dev)
     as_t = lambda a, dt=torch.int32: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
     rvc, fc = as_t(rvc0), as_t(fc0)
-    nc = int(rvc.max().item()) + 1
+    nc, nfc = int(rvc.max().item()) + 1, int(fc.max().item()) + 1
+    ver = {'rv': 0, 'f': 0}                      # bumped whenever the rv / factor partition changes
     sync = torch.cuda.synchronize if dev.type == 'cuda' else (lambda: None)
     clock = {'lift': 0.0, 'setup': 0.0, 'sweep': 0.0}
 
@@ -432,12 +438,26 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
         if nc2 != nc:
             rvc = rvc.clone()
             rvc[obs_idx_t] = new_oc.to(rvc.dtype)
+            ver['rv'] += 1
         nc = nc2
 
     def refine_rvs():
+        """one rv half round; a refinement only splits, so an unchanged number of colours means an unchanged partition: the old ids
+        stay then (the kernels number their colours afresh every time) and the sweep's graphs and states can be reused"""
         nonlocal rvc, nc
-        rvc = refiner.rvs(fc, rvc)
-        nc = int(rvc.max().item()) + 1
+        new = refiner.rvs(fc, rvc)
+        n_new = int(new.max().item()) + 1
+        if n_new != nc:
+            rvc, nc = new, n_new
+            ver['rv'] += 1
+
+    def refine_factors():
+        nonlocal fc, nfc
+        new = refiner.factors(rvc, fc)
+        n_new = int(new.max().item()) + 1
+        if n_new != nfc:
+            fc, nfc = new, n_new
+            ver['f'] += 1
 
     def evidence_variance():
         if not obs_idx.size:
@@ -453,10 +473,13 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
 
     t0 = time.perf_counter()
     split_evidence(2, 50, 0.0, True)                                                # HLBP:440
-    fc = refiner.factors(rvc, fc)
+    refine_factors()
     refine_rvs()
     history = []
     G1, pair_phi, rep = rv_side_graph_t(gflat, tg, rvc, fc)
+    g1_ver = (ver['rv'], ver['f'])
+    g2_ver = pe1_ver = pe2_ver = None
+    pe1 = pe2 = None
     t0 = tick('lift', t0)
     st1 = engine.make(G1, sides='v')
     engine.init(st1)
@@ -480,16 +503,30 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
             split_evidence(k_mean_k, k_mean_iteration, epsilon, False)
             epsilon = max(epsilon - d, c2f)
             refine_rvs()
-            G1, pair_phi, rep = rv_side_graph_t(gflat, tg, rvc, fc)
-            parent = old_rvc.long()[rep].cpu().numpy()
-            pe = edges_from_factor_side(G1, pair_phi, parent, G2)
-            t0 = tick('lift', t0)
-            new1 = engine.make(G1, sides='v')
-            for name in ('f2v', 'eta'):
-                engine.set(new1, name, engine.gather(engine.get(st2, name), pe))
-            for name in ('q', 'particles', 'old_particles', 'uniq'):
-                engine.set(new1, name, engine.gather(engine.get(st2, name), parent))
-            st1 = new1
+            if g1_ver == (ver['rv'], ver['f']) and pe1_ver == (g1_ver, g2_ver):
+                # nothing split since this sweep's two graphs were built: same graphs, same states, same maps -- only the rows move
+                t0 = tick('lift', t0)
+                for name in ('f2v', 'eta'):
+                    engine.set(st1, name, engine.gather(engine.get(st2, name), pe1))
+                for name in ('q', 'particles', 'old_particles', 'uniq'):
+                    engine.set(st1, name, engine.get(st2, name))
+            else:
+                if g1_ver != (ver['rv'], ver['f']):
+                    G1, pair_phi, rep = rv_side_graph_t(gflat, tg, rvc, fc)
+                    g1_ver = (ver['rv'], ver['f'])
+                    parent = old_rvc.long()[rep].cpu().numpy()
+                    st1 = None
+                else:
+                    parent = np.arange(G1.V)
+                pe1 = edges_from_factor_side(G1, pair_phi, parent, G2)
+                pe1_ver = (g1_ver, g2_ver)
+                t0 = tick('lift', t0)
+                new1 = st1 if st1 is not None else engine.make(G1, sides='v')
+                for name in ('f2v', 'eta'):
+                    engine.set(new1, name, engine.gather(engine.get(st2, name), pe1))
+                for name in ('q', 'particles', 'old_particles', 'uniq'):
+                    engine.set(new1, name, engine.gather(engine.get(st2, name), parent))
+                st1 = new1
             t0 = tick('setup', t0)
         engine.v2f(st1)
         last = i == iteration - 1
@@ -498,17 +535,28 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
         t0 = tick('sweep', t0)
         # ---- split_factors (HLBP:509-513; HLBP:536 for the last sweep)
         old_fc = fc
-        fc = refiner.factors(rvc, fc)
-        G2 = lift_flat(gflat, rvc, fc, dg=tg)
-        G2.rep_ground = G1.rep_ground
-        nF2 = G2.F
-        parent_f = old_fc.long()[_rep_of(fc, nF2, gflat.F)].cpu().numpy()
-        n_phi = int(max(pair_phi.max() if pair_phi.size else 0, parent_f.max() if parent_f.size else 0)) + 1
-        pe = edges_from_variable_side(G2, parent_f, G1, pair_phi, n_phi)
-        t0 = tick('lift', t0)
-        st2 = engine.make(G2)
+        refine_factors()
+        if g2_ver == (ver['rv'], ver['f']) and pe2_ver == (g2_ver, g1_ver):
+            t0 = tick('lift', t0)
+            if last:                                   # (the last sweep computes no f -> v half: a fresh state's table is zero)
+                engine.get(st2, 'f2v')[...] = 0
+        else:
+            if g2_ver != (ver['rv'], ver['f']):
+                G2 = lift_flat(gflat, rvc, fc, dg=tg)
+                G2.rep_ground = G1.rep_ground
+                g2_ver = (ver['rv'], ver['f'])
+                parent_f = old_fc.long()[_rep_of(fc, G2.F, gflat.F)].cpu().numpy()
+                st2 = None
+            else:
+                parent_f = np.arange(G2.F)
+            n_phi = int(max(pair_phi.max() if pair_phi.size else 0, parent_f.max() if parent_f.size else 0)) + 1
+            pe2 = edges_from_variable_side(G2, parent_f, G1, pair_phi, n_phi)
+            pe2_ver = (g2_ver, g1_ver)
+            t0 = tick('lift', t0)
+            if st2 is None:
+                st2 = engine.make(G2)
         for name in ('v2f', 'eta'):
-            engine.set(st2, name, engine.gather(engine.get(st1, name), pe))
+            engine.set(st2, name, engine.gather(engine.get(st1, name), pe2))
         for name in ('q', 'particles', 'old_particles', 'uniq'):
             engine.set(st2, name, engine.get(st1, name))
         t0 = tick('setup', t0)

@@ -310,7 +310,7 @@ def test_hlbp_c2f_on_arrays_equals_the_object_path(golden_dir, name):
             self.log = log
 
         def make(self, flat, sides='vf'):
-            self.log.append(flat)
+            self.log.append((sides, flat))
             return super().make(flat, sides)
     ref = c2f.run_c2f(g, Eng(graphs_a, meta['n'], meta['approx'] == 'EP'), OracleRefiner(g), meta['iterations'], meta['c2f'], 2, 10, draw)
     gflat = flatten(g, require_device_potentials=True)
@@ -325,13 +325,23 @@ def test_hlbp_c2f_on_arrays_equals_the_object_path(golden_dir, name):
     for (ra, fa), (rb, fb) in zip(hist_a, hist_b):
         assert (ra == rb).all() and (fa == fb).all()                  # same colours, not only the same partition
     assert (rvc_a == rvc_b.numpy()).all() and (fc_a == fc_b.numpy()).all()
-    assert len(graphs_a) == len(graphs_b)
-    for A, B in zip(graphs_a, graphs_b):                              # every lifted graph of every sweep, both sides
-        for f in ('V', 'F', 'E'):
-            assert getattr(A, f) == getattr(B, f)
-        for f in ('fac_ptr', 'edge_var', 'edge_fac', 'edge_canon', 'var_ptr', 'var_edge', 'edge_count', 'var_mult', 'fac_mult'):
-            np.testing.assert_array_equal(getattr(A, f), getattr(B, f), err_msg=f)
-        np.testing.assert_allclose(A.var_value, B.var_value, rtol=1e-14, equal_nan=True)
+    # every lifted graph of every sweep, both sides.  The object path builds two graphs per sweep; the array path builds one only
+    # when a refinement split something since the last one of that side (it reuses graph, state and maps otherwise)
+    fields = ('fac_ptr', 'edge_var', 'edge_fac', 'edge_canon', 'var_ptr', 'var_edge', 'edge_count', 'var_mult', 'fac_mult')
+
+    def same(A, B):
+        return all(getattr(A, f) == getattr(B, f) for f in ('V', 'F', 'E')) and all(np.array_equal(getattr(A, f), getattr(B, f)) for f in fields)
+    assert len(graphs_b) <= len(graphs_a) and len(graphs_b) < len(graphs_a) or meta['iterations'] < 3
+    for side in ('v', 'vf'):
+        seq_a = []
+        for sd, G in graphs_a:
+            if sd == side and not (seq_a and same(seq_a[-1], G)):
+                seq_a.append(G)
+        seq_b = [G for sd, G in graphs_b if sd == side]
+        assert len(seq_a) == len(seq_b), side
+        for A, B in zip(seq_a, seq_b):
+            assert same(A, B)
+            np.testing.assert_allclose(A.var_value, B.var_value, rtol=1e-14, equal_nan=True)
     for f in ('f2v', 'v2f', 'eta', 'q', 'particles'):
         np.testing.assert_allclose(getattr(st_a, f), getattr(st_b, f), rtol=1e-12, atol=1e-12, err_msg=f)
 
