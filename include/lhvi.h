@@ -32,7 +32,7 @@ extern "C" {
                               * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq; the colour
                               *    refinement calls take a method and return four result words; lhvi_vi_t gained var_N; lhvi_vi_opt_t, lhvi_vi_adam_run;
                               *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub / v2f_mid16 / v2f_mid32, prop_hub / prop_partial, resample_vars, small16_desc / small32_desc; 16 ticket words; lhvi_pbp_boundary_reduce;
-                              * 9: lhvi_vi_t gained fac_list / n_cc / n_grp3 / n_grp6 / n_rest3 / n_rest6; lhvi_color_first_members, lhvi_pbp_halo_pack / _unpack; lhvi_gabp_plan_t.rec */
+                              * 9: lhvi_vi_t gained fac_list / n_cc / n_tiny / n_grp3 / n_grp6 / n_rest3 / n_rest6 / edge_axis; lhvi_color_first_members, lhvi_pbp_halo_pack / _unpack; lhvi_gabp_plan_t.rec */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -442,22 +442,27 @@ typedef struct lhvi_vi {
                                  * lifted graph, LiftedVarInference.py:64-67).  NULL: every (variable, k) thread sums its row itself,
                                  * which serialises on the template variables of a relational model (thousands of entries) */
     /* (ABI 9) the caller's split of the factors among the kernels of expectation() (VarInference.py:40-55), or NULL: a permutation
-     * of the factor ids in five segments --
+     * of the factor ids in six segments, in this order --
      *   n_cc    pairwise factors over two distinct continuous / observed variables with a Gaussian / quadratic / linear-Gaussian /
      *           XY potential (thread per (factor, k), per-axis pdf tables in registers);
+     *   n_tiny  other factors of arity <= 3 whose grid has at most LHVI_VI_TINY_NODES nodes, K <= 2 (thread per (factor, k), the
+     *           per-axis values held in the loop nest; needs edge_axis);
      *   n_grp3  other factors of arity <= 3 whose axis lengths sum to <= LHVI_VI_GROUP_SLOTS with K * that <= LHVI_VI_GROUP_COMP
      *           (8 lanes per (factor, k), per-axis tables in LDS);  n_grp6: the same for arity 4 .. LHVI_MAX_ARITY;
      *   n_rest3 / n_rest6  whatever fits neither (thread per (factor, k), arity <= 3 / 4 .. LHVI_MAX_ARITY).
      * NULL: every kernel classifies the factors itself (thread-per-factor kernels only). */
     const int32_t* fac_list;
     int32_t n_cc, n_grp3, n_grp6, n_rest3, n_rest6;
+    int32_t n_tiny;            /* (sits between n_cc and n_grp3 in the list; declared last: it fills the padding before edge_axis) */
     /* (ABI 9) [E][4] or NULL: per edge {variable, axis length | hidden << 16 | continuous << 17 | Gaussian observation << 18,
-     * state index of the observed value (0 unless observed and discrete), 0} -- the shape of the factor's quadrature grid, which
+     * state index of the observed value (0 unless observed and discrete), offset of the variable's states in dom_val} -- the shape
+     * of the factor's quadrature grid, which
      * depends on the graph and the evidence pattern only; NULL: the group kernels derive it per (factor, k) */
     const int32_t* edge_axis;
 } lhvi_vi_t;
 #define LHVI_VI_GROUP_SLOTS 24
 #define LHVI_VI_GROUP_COMP 48
+#define LHVI_VI_TINY_NODES 32
 
 /* state of the optimiser for lhvi_vi_adam_run: the arrays ADAM_update (VarInference.py:249-287) reads and writes.  w, eta_c and
  * eta_d must be the arrays the lhvi_vi_t passed alongside points to (the step must see what it updates). */

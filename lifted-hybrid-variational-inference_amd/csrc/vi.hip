@@ -262,10 +262,7 @@ __device__ __forceinline__ void vi_factor_cc(const lhvi_graph_t& g, const lhvi_p
     double* o1 = pe_c + ((int64_t)(base + 1) * p.K + k) * 2;
     o0[0] = h0 ? c0 * Em0 / var0 : 0.0; o0[1] = h0 ? c0 * Ev0 / (2 * var0 * var0) : 0.0;
     o1[0] = h1 ? c1 * Em1 / var1 : 0.0; o1[1] = h1 ? c1 * Ev1 / (2 * var1 * var1) : 0.0;
-    for (int d = 0; d < p.Dmax; ++d) {
-        pe_d[((int64_t)base * p.K + k) * p.Dmax + d] = 0.0;
-        pe_d[((int64_t)(base + 1) * p.K + k) * p.Dmax + d] = 0.0;
-    }
+    // (no pe_d rows: the gather reads them for hidden DISCRETE variables only, and neither argument is one)
 }
 
 __global__ void __launch_bounds__(BLOCK) vi_factor_cc_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
@@ -371,10 +368,7 @@ __device__ __forceinline__ void vi_factor_cc_tab(const lhvi_graph_t& g, const lh
     double* o1 = pe_c + ((int64_t)(base + 1) * p.K + k) * 2;
     o0[0] = h0 ? c0 * Em0 / var0 : 0.0; o0[1] = h0 ? c0 * Ev0 / (2 * var0 * var0) : 0.0;
     o1[0] = h1 ? c1 * Em1 / var1 : 0.0; o1[1] = h1 ? c1 * Ev1 / (2 * var1 * var1) : 0.0;
-    for (int d = 0; d < p.Dmax; ++d) {
-        pe_d[((int64_t)base * p.K + k) * p.Dmax + d] = 0.0;
-        pe_d[((int64_t)(base + 1) * p.K + k) * p.Dmax + d] = 0.0;
-    }
+    // (no pe_d rows: the gather reads them for hidden DISCRETE variables only, and neither argument is one)
 }
 
 template <int TT>
@@ -654,10 +648,178 @@ __global__ void __launch_bounds__(VI_GRP_BLOCK) __attribute__((amdgpu_waves_per_
                 if (gl == 0) pe_d[((int64_t)e * p.K + k) * p.Dmax + d] = c * acc;
             }
         }
-        if (gl == 0) for (int d = Dt; d < p.Dmax; ++d) pe_d[((int64_t)e * p.K + k) * p.Dmax + d] = 0.0;
+        // a repeated variable's later positions contribute zeros; rows of other kinds of variables and states beyond the
+        // variable's own are never read (vi_gather_kernel)
+        if (gl == 0 && hid[a] && !cont[a]) for (int d = Dt; d < len[a]; ++d) pe_d[((int64_t)e * p.K + k) * p.Dmax + d] = 0.0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // the next item overwrites this group's tables
     __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- tiny grids: a thread per (factor, k) -----------------------------------------------------------------------------------
+// Most formulas of a grounded hybrid MLN have one or two hidden arguments left once the evidence is in: grids of 1 .. 18 nodes
+// (paper-popularity: 21 % of the factors are fully observed, 30 % have two nodes).  Eight lanes and a set of LDS tables per such
+// item spend their time in the item's chain of dependent loads; here a thread walks its item alone.  The grid nodes and the
+// points of the pinned expectations (gradient_category_tau, VI:133-160) form ONE list of points with one evaluation site --
+// decode the point, belief as the sum over components of the product of the per-argument pdfs (1 / var hoisted per argument and
+// component), log phi - log belief, accumulate -- so the formula interpreter and the pdf code exist once in the kernel.
+// Same products in the same order as the group kernel; the points are summed in index order (the group kernel: strided over its
+// lanes, then a butterfly), so the two agree to rounding.
+// Eligible (host: lhvi/vi.py): arity <= 3, at most LHVI_VI_TINY_NODES grid nodes, K <= VI_TINY_K, axis records present.
+constexpr int VI_TINY_K = 2;
+#ifndef LHVI_VI_TINY_WAVES
+#define LHVI_VI_TINY_WAVES 2
+#endif
+
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI_VI_TINY_WAVES, 8)))
+vi_factor_tiny_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef, double* __restrict__ pe_c,
+                      double* __restrict__ pe_d, const int32_t* __restrict__ list, int n_list) {
+    __shared__ double sh_tab[EXP_TAB_N];
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    load_log_table(sh_log);
+    load_exp_table(sh_tab);
+    const int4* __restrict__ recs = reinterpret_cast<const int4*>(p.edge_axis);
+    for (int64_t item = (int64_t)blockIdx.x * BLOCK + threadIdx.x; item < (int64_t)n_list * p.K; item += (int64_t)gridDim.x * BLOCK) {
+        const int f = list[item / p.K], k = (int)(item % p.K);
+        const int base = g.fac_ptr[f], arity = g.fac_ptr[f + 1] - base;
+        int av[3], alen[3], afix[3], adom[3];
+        bool hid[3], cont[3], axis[3], gauss[3];      // gauss: integrated with Gauss-Hermite nodes (hidden continuous / Gaussian observation)
+        double mu[3], var[3], sd[3], val[3], inv[3][VI_TINY_K];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int4 r = a < arity ? recs[base + a] : make_int4(0, 1, 0, 0);
+            av[a] = r.x; alen[a] = r.y & 0xffff; afix[a] = r.z; adom[a] = r.w;
+            hid[a] = a < arity && ((r.y >> 16) & 1); cont[a] = a < arity && ((r.y >> 17) & 1);
+            const bool gobs = a < arity && ((r.y >> 18) & 1);
+            axis[a] = hid[a] || gobs;
+            gauss[a] = (hid[a] && cont[a]) || gobs;
+            val[a] = a < arity ? g.var_value[av[a]] : 0.0;
+            mu[a] = 0.0; var[a] = 1.0; sd[a] = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < VI_TINY_K; ++kk) inv[a][kk] = 0.0;
+            if (hid[a] && cont[a]) {
+                const double* e = p.eta_c + (int64_t)av[a] * p.K * 2;
+                mu[a] = e[2 * k]; var[a] = e[2 * k + 1]; sd[a] = sqrt(2 * var[a]);
+#pragma unroll
+                for (int kk = 0; kk < VI_TINY_K; ++kk) if (kk < p.K) inv[a][kk] = 1.0 / e[2 * kk + 1];
+            } else if (gobs) {
+                const double ov = p.obs_var[av[a]];
+                mu[a] = val[a]; sd[a] = sqrt(2 * ov);
+#pragma unroll
+                for (int kk = 0; kk < VI_TINY_K; ++kk) inv[a][kk] = 1.0 / ov;
+            }
+        }
+        const int pot = g.fac_pot[f];
+        const int kind = pots.kind[pot];
+        const double* par = pots.param + pots.off[pot];
+        // the pinned positions: hidden discrete arguments at their first position in the scope (f.nb.index(rv), LVI:112,146);
+        // npin[a] = points of position a's pinned expectations = states * min(prod nx, prod nw) (zip truncates to the shorter)
+        const int G = alen[0] * alen[1] * alen[2];
+        int npin[3], cntp[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            bool first = a < arity;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) if (b < a && av[b] == av[a]) first = false;
+            int totx = 1, totw = 1;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                if (b >= arity || b == a) continue;
+                if (hid[b]) { totx *= p.quirks ? alen[a] : alen[b]; totw *= p.quirks ? (cont[b] ? 2 : alen[b]) : alen[b]; }   // VI:147-150
+                else if (axis[b]) { totx *= p.T; totw *= p.T; }                                    // Gaussian observation: a proper axis
+            }
+            cntp[a] = totx < totw ? totx : totw;
+            npin[a] = (first && hid[a] && !cont[a]) ? alen[a] * cntp[a] : 0;
+            if (a < arity && hid[a] && !cont[a] && !first)                // a repeated variable's later positions contribute zeros
+                for (int d = 0; d < alen[a]; ++d) pe_d[((int64_t)(base + a) * p.K + k) * p.Dmax + d] = 0.0;
+        }
+        const int total = G + npin[0] + npin[1] + npin[2];
+        double x[3];
+        int idx[3];
+        double E = 0.0, Em[3] = {0.0, 0.0, 0.0}, Ev[3] = {0.0, 0.0, 0.0}, acc = 0.0;
+        for (int pt = 0; pt < total; ++pt) {
+            // ---- decode the point
+            int pa = -1, d = 0, j = pt, cnt = 1, Dt = 1;
+            if (pt >= G) {
+                int q = pt - G;
+                pa = 0;
+                if (q >= npin[0]) { q -= npin[0]; pa = 1; if (q >= npin[1]) { q -= npin[1]; pa = 2; } }
+                cnt = pa == 0 ? cntp[0] : pa == 1 ? cntp[1] : cntp[2];
+                Dt = pa == 0 ? alen[0] : pa == 1 ? alen[1] : alen[2];
+                d = q / cnt; j = q - d * cnt;
+            }
+            const double* tvals = g.dom_val + (pa == 1 ? adom[1] : pa == 2 ? adom[2] : adom[0]);
+            int rx = j, rw = j;
+            double wb[3];
+#pragma unroll
+            for (int b = 2; b >= 0; --b) {
+                wb[b] = 1.0; x[b] = 0.0; idx[b] = 0;
+                if (b >= arity) continue;
+                if (b == pa) { x[b] = tvals[d]; idx[b] = d; continue; }
+                int nx = alen[b], nw = alen[b];
+                const bool quirk = pa >= 0 && hid[b] && p.quirks;
+                if (quirk) { nx = Dt; nw = cont[b] ? 2 : alen[b]; }
+                const int ixs = small_divmod(rx, nx, __builtin_amdgcn_rcpf((float)nx));
+                const int iws = pa >= 0 ? small_divmod(rw, nw, __builtin_amdgcn_rcpf((float)nw)) : ixs;
+                if (quirk) {
+                    x[b] = tvals[ixs]; idx[b] = vi_state_index(g, av[b], x[b]);
+                    wb[b] = cont[b] ? p.eta_c[((int64_t)av[b] * p.K + k) * 2 + iws] : p.eta_d[((int64_t)av[b] * p.K + k) * p.Dmax + iws];
+                } else if (gauss[b]) { x[b] = sd[b] * p.gh_x[ixs] + mu[b]; wb[b] = p.gh_w[iws]; }
+                else if (hid[b]) { x[b] = g.dom_val[adom[b] + ixs]; idx[b] = ixs; wb[b] = p.eta_d[((int64_t)av[b] * p.K + k) * p.Dmax + iws]; }
+                else { x[b] = val[b]; idx[b] = afix[b]; }
+            }
+            // (the grid multiplies its weights in ascending position order, the pinned expectation in descending order)
+            const double w = pa < 0 ? ((1.0 * wb[0]) * wb[1]) * wb[2] : ((1.0 * wb[2]) * wb[1]) * wb[0];
+            // ---- rvs_belief (VI:336-353) at the point
+            double bel = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < VI_TINY_K; ++kk) {
+                if (kk >= p.K) continue;
+                double t = p.w[kk];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    if (!axis[b]) continue;
+                    if (gauss[b]) {
+                        const double m = hid[b] ? p.eta_c[((int64_t)av[b] * p.K + kk) * 2] : val[b];
+                        t *= norm_pdf_inv(x[b], m, inv[b][kk], inv[b][kk] * (1.0 / 2.506628274631), sh_tab);
+                    } else t *= p.eta_d[((int64_t)av[b] * p.K + kk) * p.Dmax + idx[b]];
+                }
+                bel += t;
+            }
+            const double F = pot_log_eps(kind, par, x, idx, sh_tab, sh_log) - log_table(bel + 1e-100, sh_log);
+            if (pa < 0) {
+                E += w * F;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    if (hid[a] && cont[a]) {
+                        Em[a] += w * (F * (x[a] - mu[a]));
+                        Ev[a] += w * (F * ((x[a] - mu[a]) * (x[a] - mu[a]) - var[a]));
+                    }
+                }
+            } else {
+                acc += w * F;
+                if (j == cnt - 1) {
+                    const int e = base + pa;
+                    pe_d[((int64_t)e * p.K + k) * p.Dmax + d] = (g.edge_count ? g.edge_count[e] : 1.0) * acc;
+                    acc = 0.0;
+                }
+            }
+        }
+        ef[(int64_t)f * p.K + k] = (g.fac_mult ? g.fac_mult[f] : 1.0) * E;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (a >= arity) continue;
+            bool first = true;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) if (b < a && av[b] == av[a]) first = false;
+            const int e = base + a;
+            const double c = g.edge_count ? g.edge_count[e] : 1.0;
+            double c0 = 0.0, c1 = 0.0;
+            if (hid[a] && cont[a] && first) { c0 = c * Em[a] / var[a]; c1 = c * Ev[a] / (2 * var[a] * var[a]); }
+            pe_c[((int64_t)e * p.K + k) * 2] = c0;
+            pe_c[((int64_t)e * p.K + k) * 2 + 1] = c1;
+        }
     }
 }
 
@@ -729,10 +891,10 @@ __global__ void __launch_bounds__(BLOCK) vi_factor_kernel(lhvi_graph_t g, lhvi_p
         }
         pe_c[((int64_t)e * p.K + k) * 2] = c0;
         pe_c[((int64_t)e * p.K + k) * 2 + 1] = c1;
-        for (int d = 0; d < p.Dmax; ++d) {
-            double val = 0.0;
-            if (hid && first && !v_cont(g, v) && d < v_nstates(g, v)) val = c * pinned_expectation<MAXA>(g, pots, p, f, base, arity, vars, a, d, k);
-            pe_d[((int64_t)e * p.K + k) * p.Dmax + d] = val;
+        if (hid && !v_cont(g, v)) {
+            const int D = v_nstates(g, v);
+            for (int d = 0; d < D; ++d)
+                pe_d[((int64_t)e * p.K + k) * p.Dmax + d] = first ? c * pinned_expectation<MAXA>(g, pots, p, f, base, arity, vars, a, d, k) : 0.0;
         }
     }
 }
@@ -1004,11 +1166,11 @@ int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t
     if (g->V > 0)
         hipLaunchKernelGGL(vi_var_kernel, dim3(grid_for((int64_t)g->V * p->K)), dim3(BLOCK), 0, st, *g, *p, rvterm, g_c, g_d);
     if (g->F > 0 && p->fac_list) {
-        // the caller's split of the factors (lhvi_vi_t.fac_list): [pairwise continuous | group kernel, arity <= 3 | group kernel,
+        // the caller's split of the factors (lhvi_vi_t.fac_list): [pairwise continuous | tiny grids | group kernel, arity <= 3 | group kernel,
         // arity 4..6 | thread-per-factor kernels for what fits neither]
         const int32_t* l = p->fac_list;
-        if (p->n_cc < 0 || p->n_grp3 < 0 || p->n_grp6 < 0 || p->n_rest3 < 0 || p->n_rest6 < 0 ||
-            (int64_t)p->n_cc + p->n_grp3 + p->n_grp6 + p->n_rest3 + p->n_rest6 != g->F) return LHVI_E_ARG;
+        if (p->n_cc < 0 || p->n_tiny < 0 || p->n_grp3 < 0 || p->n_grp6 < 0 || p->n_rest3 < 0 || p->n_rest6 < 0 ||
+            (int64_t)p->n_cc + p->n_tiny + p->n_grp3 + p->n_grp6 + p->n_rest3 + p->n_rest6 != g->F) return LHVI_E_ARG;
         if (p->n_cc > 0) {
             const int64_t want = ((int64_t)p->n_cc * p->K + BLOCK - 1) / BLOCK;
             const dim3 grid((unsigned)(want < 2048 ? want : 2048));
@@ -1020,6 +1182,12 @@ int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t
                 hipLaunchKernelGGL(vi_factor_cc_kernel, grid, dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d, l, p->n_cc);
         }
         l += p->n_cc;
+        if (p->n_tiny > 0) {
+            if (!p->edge_axis || p->K > VI_TINY_K) return LHVI_E_ARG;
+            hipLaunchKernelGGL(vi_factor_tiny_kernel, dim3(min(grid_for((int64_t)p->n_tiny * p->K), 4096u)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d,
+                               l, p->n_tiny);
+        }
+        l += p->n_tiny;
         constexpr int GPB = VI_GRP_BLOCK / VI_GRP_L;
         if (p->n_grp3 > 0)
             hipLaunchKernelGGL((vi_factor_group_kernel<3, VI_GRP_L>), dim3(min(grid_for((int64_t)p->n_grp3 * p->K, GPB), 4096u)), dim3(VI_GRP_BLOCK), 0, st,

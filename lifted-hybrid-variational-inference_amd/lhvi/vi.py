@@ -25,15 +25,20 @@ from . import _abi
 from .flat import flatten
 
 
-def factor_lists(flat, K, T, obs_var=None):
+# (factor, k) items from which the thread-per-item kernel beats the 8-lane groups (measured: 6.8 k items 0.19 vs 0.085 ms per update,
+# 1.9 M items 0.87 vs 2.43 ms; the single threads' floor is ~0.15 ms, their slope 0.45 vs 1.25 ns per item)
+TINY_MIN_ITEMS = 1 << 17
+
+
+def factor_lists(flat, K, T, obs_var=None, tiny_kernel=True):
     """The split of the factors among the kernels of the expectation step (``lhvi_vi_t.fac_list``, include/lhvi.h): a
-    permutation of the factor ids in five segments and their lengths (n_cc, n_grp3, n_grp6, n_rest3, n_rest6).
-    Inside the two group segments factors are ordered by (potential row, pattern of hidden arguments), so the lanes of a
+    permutation of the factor ids in six segments and their lengths (n_cc, n_tiny, n_grp3, n_grp6, n_rest3, n_rest6).
+    Inside the segments factors are ordered by (potential row, pattern of hidden arguments), so the lanes of a
     wavefront interpret the same formula on the same kind of grid."""
     from .potentials import POT_GAUSSIAN, POT_LINEAR_GAUSSIAN, POT_QUADRATIC, POT_XY
     F = flat.F
     if F == 0:
-        return np.zeros(0, dtype=np.int32), (0, 0, 0, 0, 0), np.zeros((0, 4), dtype=np.int32)
+        return np.zeros(0, dtype=np.int32), (0, 0, 0, 0, 0, 0), np.zeros((0, 4), dtype=np.int32)
     arity = np.diff(flat.fac_ptr).astype(np.int64)
     ev = flat.edge_var
     hid, cont, nst = flat.var_hidden[ev], flat.var_cont[ev], flat.var_nstates[ev]
@@ -53,19 +58,26 @@ def factor_lists(flat, K, T, obs_var=None):
     ok0 = ~hid[e0] | cont[e0]
     ok1 = ~hid[e1] | cont[e1]
     cc = pair & np.isin(kind, (POT_GAUSSIAN, POT_QUADRATIC, POT_LINEAR_GAUSSIAN, POT_XY)) & (ev[e0] != ev[e1]) & ok0 & ok1
-    grp = ~cc & (arity >= 1) & (S <= _abi.VI_GROUP_SLOTS) & (K * S <= _abi.VI_GROUP_COMP)
     small = arity <= 3
-    seg = np.where(cc, 0, np.where(grp & small, 1, np.where(grp, 2, np.where(small, 3, 4))))
+    # grid nodes of a factor (product of its axis lengths, capped: only "<= VI_TINY_NODES" matters)
+    lg = np.concatenate([[0.0], np.cumsum(np.log2(axis_len.astype(np.float64)))])
+    nodes = lg[flat.fac_ptr[1:]] - lg[flat.fac_ptr[:-1]]
+    tiny = ~cc & small & (arity >= 1) & (nodes <= np.log2(_abi.VI_TINY_NODES) + 1e-9) & (K <= _abi.VI_TINY_K) & bool(tiny_kernel)
+    if tiny_kernel != 'always' and int(tiny.sum()) * K < TINY_MIN_ITEMS:
+        tiny[:] = False                   # too few items to fill the device with single threads: the 8-lane groups finish sooner
+    grp = ~cc & ~tiny & (arity >= 1) & (S <= _abi.VI_GROUP_SLOTS) & (K * S <= _abi.VI_GROUP_COMP)
+    seg = np.where(cc, 0, np.where(tiny, 1, np.where(grp & small, 2, np.where(grp, 3, np.where(small, 4, 5)))))
     # hidden pattern of a factor: bit a set when argument a is hidden (arity <= 6)
     pos = np.arange(ev.size, dtype=np.int64) - np.repeat(first, arity)
     bits = np.zeros(F, dtype=np.int64)
     np.add.at(bits, np.repeat(np.arange(F), arity), hid.astype(np.int64) << np.minimum(pos, 30))
     order = np.lexsort((np.arange(F), bits, flat.fac_pot, seg))
-    counts = np.bincount(seg, minlength=5)
+    counts = np.bincount(seg, minlength=6)
     # per-edge axis records (lhvi_vi_t.edge_axis)
     rec = np.zeros((ev.size, 4), dtype=np.int32)
     rec[:, 0] = ev
     rec[:, 1] = axis_len | (hid.astype(np.int64) << 16) | (cont.astype(np.int64) << 17) | (gobs.astype(np.int64) << 18)
+    rec[:, 3] = flat.dom_ptr[flat.var_dom[ev]]
     obs_d = np.flatnonzero(~hid & ~cont)
     if obs_d.size:                                  # state index of an observed discrete value (vi_state_index of csrc/vi.hip)
         v = ev[obs_d]
@@ -85,6 +97,8 @@ class _Variational:
     reference_quirks = True
     verbose = False
     fused_loop = True           # ADAM_update enqueues its whole loop through lhvi_vi_adam_run (else: one call per array and step)
+    tiny_kernel = True          # factors with a handful of grid nodes take the thread-per-(factor, k) kernel when there are >= 2^17
+                                # such items ('always': whatever their number; False: the group kernel)
     factor_lists = True         # the factors are split among the expectation kernels on the host (else: every kernel classifies them itself)
 
     def _init_common(self, num_mixtures, num_quadrature_points):
@@ -123,7 +137,7 @@ class _Variational:
         self._dev = d
         self._fac_counts = None
         if self.factor_lists:
-            order, self._fac_counts, rec = factor_lists(flat, K, self.T, getattr(self, '_obs_var_host', None))
+            order, self._fac_counts, rec = factor_lists(flat, K, self.T, getattr(self, '_obs_var_host', None), self.tiny_kernel)
             d['fac_list'] = _abi.to_dev(order if order.size else np.zeros(1, dtype=np.int32))
             d['edge_axis'] = _abi.to_dev(rec if rec.size else np.zeros((1, 4), dtype=np.int32))
         ws_bytes = int(_abi.lib().lhvi_vi_workspace_bytes(dg.g, self._struct()))
@@ -148,7 +162,7 @@ class _Variational:
         p.var_N = _abi.ptr(d.get('var_N'))
         if getattr(self, '_fac_counts', None) is not None:
             p.fac_list, p.edge_axis = _abi.ptr(d['fac_list']), _abi.ptr(d['edge_axis'])
-            p.n_cc, p.n_grp3, p.n_grp6, p.n_rest3, p.n_rest6 = self._fac_counts
+            p.n_cc, p.n_tiny, p.n_grp3, p.n_grp6, p.n_rest3, p.n_rest6 = self._fac_counts
         return p
 
     def _opt_struct(self):

@@ -534,6 +534,7 @@ if 'vi_scaled' in which:
                          synth.paper_popularity_copies(int(os.environ.get('CFG3_COPIES', 286)), 300, 10, seed=0, points=20)),
                         ('RGM C=1000 B=500 ground (Gaussian pairwise)', synth.rgm_flat(C=1000, B=500, n_values=0, evidence_ratio=0.1, seed=0)[0])):
         vi = VarInference(None, K_, T_)
+        vi.tiny_kernel = {'1': True, '0': False, 'always': 'always'}[os.environ.get('VI_TINY', '1')]
         vi._setup_flat(flat)
         np.random.seed(0)
         vi.init_param()
@@ -546,6 +547,7 @@ if 'vi_scaled' in which:
         ah = np.add.reduceat(hid[flat.edge_var].astype(np.float64), flat.fac_ptr[:-1])
         flop = float((K_ * G * (K_ * ah * 25 + 30)).sum())
         out(config='ground VI gradient + free energy, ' + label + ', K=2 T=3', factors=int(flat.F), edges=int(flat.E), grad_ms=t,
+            kernel_split=dict(zip(('cc', 'tiny', 'grp3', 'grp6', 'rest3', 'rest6'), vi._fac_counts)),
             factors_per_s=flat.F / (t * 1e-3), quadrature_nodes=float((K_ * G).sum()), algorithmic_flop=flop,
             fp64_TFLOPs=flop / (t * 1e-3) / 1e12, fp64_frac_of_78_6=flop / (t * 1e-3) / 78.6e12)
         del vi

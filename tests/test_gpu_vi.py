@@ -296,6 +296,37 @@ def test_table_kernels_equal_the_thread_per_factor_kernels(api, golden_dir, name
     a, b = outs
     assert b[4] is None and a[4] is not None and sum(a[4]) == len(vi.flat.factors)
     if name == 'lifted_robot_k2':
-        assert a[4][2] > 0                      # arity-5 formulas on the group kernel
+        assert a[4][3] > 0 and a[4][2] > 0      # arity-5 and short formulas on the two group kernels
     for x, y, what in zip(a[:4], b[:4], ('g_w', 'g_c', 'g_d', 'fe')):
         np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-9, err_msg=what)
+
+
+@pytest.mark.parametrize('name', ['hybrid_k2', 'lifted_robot_k2', 'paper_popularity', 'paper_popularity_k1_noquirks'])
+def test_tiny_grid_kernel_equals_the_group_kernel(api, golden_dir, name):
+    """factors with at most 32 grid nodes go to the thread-per-(factor, k) kernel (``vi_factor_tiny_kernel``) when there are
+    enough of them to fill the device (forced here); with ``tiny_kernel = False`` the same factors take the 8-lane group kernel.  Same products in the same order, the grid summed in a
+    different order: agreement to rounding."""
+    from lhvi import synth
+    from lhvi.vi import LiftedVarInference, VarInference
+    outs = []
+    for tiny in ('always', False):
+        if name.startswith('paper_popularity'):
+            K = 1 if 'k1' in name else 2
+            vi = VarInference(None, K, 3)
+            vi.tiny_kernel = tiny
+            vi.reference_quirks = 'noquirks' not in name
+            vi._setup_flat(synth.paper_popularity_flat(40, 5, seed=1, points=20)[0])
+        else:
+            z, meta = load_vi(golden_dir, name)
+            g, rvs, factors = modelio.load_model(meta['model'], API)
+            vi = (LiftedVarInference if name.startswith('lifted') else VarInference)(g, meta['K'], meta['T'])
+            vi.tiny_kernel = tiny
+        np.random.seed(3)
+        vi.init_param()
+        vi._grad()
+        d = vi._dev
+        outs.append([d[k].cpu().numpy().copy() for k in ('g_w', 'g_c', 'g_d', 'fe')] + [vi._fac_counts])
+    a, b = outs
+    assert a[4][1] > 0 and b[4][1] == 0 and b[4][2] + b[4][3] >= a[4][1]
+    for x, y, what in zip(a[:4], b[:4], ('g_w', 'g_c', 'g_d', 'fe')):
+        np.testing.assert_allclose(x, y, rtol=1e-11, atol=1e-11, err_msg=what)

@@ -546,11 +546,15 @@ def test_vi_factor_lists_split():
     from lhvi import synth
     from lhvi.vi import factor_lists
     flat, _ = synth.paper_popularity_flat(40, 5, seed=1, points=20)
-    order, counts, rec = factor_lists(flat, 2, 3)
+    order, counts, rec = factor_lists(flat, 2, 3, tiny_kernel='always')
     assert sorted(order.tolist()) == list(range(flat.F)) and sum(counts) == flat.F
-    assert counts[0] == 0 and counts[1] == flat.F            # MLN formulas of arity <= 3, K * S <= 2 * 8
-    order5, counts5, _ = factor_lists(flat, 7, 3)            # K = 7: 7 * 8 slots > 48 for the all-hidden ternary factors
-    assert counts5[3] > 0 and counts5[1] + counts5[3] == flat.F
+    assert counts[0] == 0 and counts[1] == flat.F            # MLN formulas of arity <= 3 with at most 2 * 3 * 3 grid nodes: tiny
+    for policy in (True, False):                             # ... or, this few of them / without that kernel, the group kernel: K * S <= 2 * 8
+        o_g, counts_g, _ = factor_lists(flat, 2, 3, tiny_kernel=policy)
+        assert counts_g[2] == flat.F and sorted(o_g.tolist()) == list(range(flat.F))
+    order5, counts5, _ = factor_lists(flat, 7, 3, tiny_kernel='always')    # K = 7: no tiny kernel; 7 * 8 slots > 48 for the all-hidden ternary factors
+    assert counts5[1] == 0 and counts5[4] > 0 and counts5[2] + counts5[4] == flat.F
+    assert (rec[:, 3] == flat.dom_ptr[flat.var_dom[flat.edge_var]]).all()
     hid = flat.var_hidden[flat.edge_var]
     assert (rec[:, 0] == flat.edge_var).all() and (((rec[:, 1] >> 16) & 1) == hid).all()
     lens = rec[:, 1] & 0xffff
@@ -559,4 +563,4 @@ def test_vi_factor_lists_split():
     assert (rec[obs_d, 2] == flat.var_value[flat.edge_var[obs_d]].astype(int)).all()          # states (0, 1): index == value
     rg, _, _, _ = synth.rgm_flat(C=6, B=4, evidence_ratio=0.3, seed=0)
     o2, c2, _ = factor_lists(rg, 2, 3)
-    assert c2 == (rg.F, 0, 0, 0, 0)
+    assert c2 == (rg.F, 0, 0, 0, 0, 0)
