@@ -20,19 +20,33 @@ namespace lhvi {
 
 constexpr int MLN_STACK = 12;
 
-__device__ __forceinline__ double mln_formula(const double* __restrict__ code, int ncode, const double* x) {
-    double st[MLN_STACK];
+// the evaluation stack of the formula interpreter: registers (a dynamically indexed array: every access is a select chain /
+// waterfall) or a column of LDS (slot i of thread t at base[i * stride]: two instructions per access)
+struct MlnRegStack {
+    double v[MLN_STACK];
+    __device__ __forceinline__ double get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, double x) { v[i] = x; }
+};
+template <int STRIDE>
+struct MlnLdsStack {
+    double* base;
+    __device__ __forceinline__ double get(int i) const { return base[i * STRIDE]; }
+    __device__ __forceinline__ void set(int i, double x) { base[i * STRIDE] = x; }
+};
+
+template <class Stack>
+__device__ __forceinline__ double mln_formula_on(const double* __restrict__ code, int ncode, const double* x, Stack& st) {
     int sp = 0;
     for (int i = 0; i < ncode; ++i) {
         const int op = (int)code[2 * i];
         const double val = code[2 * i + 1];
-        if (op == 0) { st[sp++] = x[(int)val]; }
-        else if (op == 1) { st[sp++] = val; }
-        else if (op == 7) { st[sp - 1] = -st[sp - 1]; }
-        else if (op == 8) { st[sp - 1] = st[sp - 1] * st[sp - 1]; }
-        else if (op == 15) { st[sp - 1] = fabs(st[sp - 1]); }
+        if (op == 0) { st.set(sp++, x[(int)val]); }
+        else if (op == 1) { st.set(sp++, val); }
+        else if (op == 7) { st.set(sp - 1, -st.get(sp - 1)); }
+        else if (op == 8) { const double a = st.get(sp - 1); st.set(sp - 1, a * a); }
+        else if (op == 15) { st.set(sp - 1, fabs(st.get(sp - 1))); }
         else {
-            const double b = st[--sp], a = st[--sp];
+            const double b = st.get(--sp), a = st.get(--sp);
             double r = 0.0;
             switch (op) {
                 case 2: r = a + b; break;
@@ -47,10 +61,15 @@ __device__ __forceinline__ double mln_formula(const double* __restrict__ code, i
                 case 13: r = (a > b) ? 1.0 : 0.0; break;
                 case 14: r = (a >= b) ? 1.0 : 0.0; break;
             }
-            st[sp++] = r;
+            st.set(sp++, r);
         }
     }
-    return st[0];
+    return st.get(0);
+}
+
+__device__ __forceinline__ double mln_formula(const double* __restrict__ code, int ncode, const double* x) {
+    MlnRegStack st;
+    return mln_formula_on(code, ncode, x, st);
 }
 
 __device__ __forceinline__ double quad_form(const double* __restrict__ A, const double* __restrict__ b, double c,
@@ -66,8 +85,9 @@ __device__ __forceinline__ double quad_form(const double* __restrict__ A, const 
 }
 
 // value of the potential at the joint assignment x (idx = state indices of discrete arguments)
-__device__ __forceinline__ double pot_eval(int kind, const double* __restrict__ par, const double* x, const int* idx,
-                                           bool& is_log) {
+template <class Stack>
+__device__ __forceinline__ double pot_eval_on(int kind, const double* __restrict__ par, const double* x, const int* idx,
+                                              bool& is_log, Stack& st) {
     is_log = true;
     switch (kind) {
         case LHVI_POT_TABLE: {
@@ -108,10 +128,10 @@ __device__ __forceinline__ double pot_eval(int kind, const double* __restrict__ 
         }
         case LHVI_POT_X2: return -par[0] * (x[0] * x[0]) * 0.5 / par[1];
         case LHVI_POT_XY: return -par[0] * x[0] * x[1] * 0.5 / par[1];
-        case LHVI_POT_MLN: return mln_formula(par + 2, (int)par[1], x) * par[0];
+        case LHVI_POT_MLN: return mln_formula_on(par + 2, (int)par[1], x, st) * par[0];
         case LHVI_POT_MLN_HARD:
             is_log = false;
-            return mln_formula(par + 2, (int)par[1], x) > 0.0 ? 1.0 : 0.0;
+            return mln_formula_on(par + 2, (int)par[1], x, st) > 0.0 ? 1.0 : 0.0;
         case LHVI_POT_IMAGE_NODE: {
             is_log = false;
             const double u = (x[0] - x[1] - par[0]) / par[1];
@@ -125,6 +145,12 @@ __device__ __forceinline__ double pot_eval(int kind, const double* __restrict__ 
     }
     is_log = false;
     return NAN;
+}
+
+__device__ __forceinline__ double pot_eval(int kind, const double* __restrict__ par, const double* x, const int* idx,
+                                           bool& is_log) {
+    MlnRegStack st;
+    return pot_eval_on(kind, par, x, idx, is_log, st);
 }
 
 // phi(x) * exp(m): one exp for the exponential-family kinds

@@ -433,6 +433,14 @@ __device__ __forceinline__ double pot_log_eps(int kind, const double* __restrict
 
 // rvs_belief (VI:336-353) at an arbitrary point (the pinned expectations leave the grid: under the reference's quirk a continuous
 // neighbour is evaluated at the TARGET's state values)
+template <class Stack>
+__device__ __forceinline__ double pot_log_eps_on(int kind, const double* __restrict__ par, const double* x, const int* idx,
+                                                 const double* __restrict__ sh_tab, const LogRec* __restrict__ sh_log, Stack& st) {
+    bool is_log;
+    const double v = pot_eval_on(kind, par, x, idx, is_log, st);
+    return is_log ? log_phi_eps(v, sh_tab, sh_log) : log_table(v + 1e-100, sh_log);
+}
+
 template <int MAXA>
 __device__ __forceinline__ double belief_direct(const lhvi_graph_t& g, const lhvi_vi_t& p, const double* x, const int* idx, const int* vars,
                                                 int arity, const bool* hid, const bool* cont, const bool* axis, const double* __restrict__ sp,
@@ -677,6 +685,8 @@ vi_factor_tiny_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __r
                       double* __restrict__ pe_d, const int32_t* __restrict__ list, int n_list) {
     __shared__ double sh_tab[EXP_TAB_N];
     __shared__ LogRec sh_log[LOG_TAB_N];
+    __shared__ double sh_stack[MLN_STACK * BLOCK];      // the formula interpreter's stack: a column per thread (in registers it is
+    MlnLdsStack<BLOCK> stack{sh_stack + threadIdx.x};   // a dynamically indexed array: 0.81 ms instead of 0.70 on the scaled cfg 3)
     load_log_table(sh_log);
     load_exp_table(sh_tab);
     const int4* __restrict__ recs = reinterpret_cast<const int4*>(p.edge_axis);
@@ -787,7 +797,7 @@ vi_factor_tiny_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __r
                 }
                 bel += t;
             }
-            const double F = pot_log_eps(kind, par, x, idx, sh_tab, sh_log) - log_table(bel + 1e-100, sh_log);
+            const double F = pot_log_eps_on(kind, par, x, idx, sh_tab, sh_log, stack) - log_table(bel + 1e-100, sh_log);
             if (pa < 0) {
                 E += w * F;
 #pragma unroll
