@@ -257,17 +257,27 @@ class DeviceGraph:
         host = {name: getattr(flat, name) for name in
                 ('fac_ptr', 'edge_var', 'edge_fac', 'var_ptr', 'var_edge', 'fac_pot', 'var_value', 'var_dom',
                  'dom_cont', 'dom_lo', 'dom_hi', 'dom_ptr', 'dom_val', 'pot_kind', 'pot_off', 'pot_param')}
-        has_alias = bool((flat.edge_canon != np.arange(flat.E, dtype=np.int32)).any())
+        has_alias = flat._cached('has_alias', (flat.edge_canon,),
+                                 lambda: bool((flat.edge_canon != np.arange(flat.E, dtype=np.int32)).any()))
         host['edge_canon'] = flat.edge_canon if has_alias else None
         host['edge_count'] = flat.edge_count if flat.lifted else None
         host['var_mult'] = flat.var_mult if flat.lifted else None
         host['fac_mult'] = flat.fac_mult if flat.lifted else None
-        # denormalised copies for the Gaussian sweep (contiguous instead of gathered)
-        host['edge_value'] = np.ascontiguousarray(flat.var_value[flat.edge_var]) if flat.E else None
-        host['slot_var'] = np.repeat(np.arange(flat.V, dtype=np.int32), np.diff(flat.var_ptr)) if flat.var_edge.size else None
+        # denormalised copies for the Gaussian sweep (contiguous instead of gathered): built on the host for a small graph (one
+        # upload), on the device for a large one (two gathers there instead of 120 MB more over PCIe at 10 M edges)
+        large = flat.E >= (1 << 18)
+        if not large:
+            host['edge_value'] = np.ascontiguousarray(flat.var_value[flat.edge_var]) if flat.E else None
+            host['slot_var'] = np.repeat(np.arange(flat.V, dtype=np.int32), np.diff(flat.var_ptr)) if flat.var_edge.size else None
         hubs = np.flatnonzero(np.diff(flat.var_ptr) > HUB_DEGREE).astype(np.int32)
         host['hub_vars'] = hubs if hubs.size else np.zeros(1, dtype=np.int32)   # non-NULL even when empty
         t = upload(host, device)
+        if large:
+            torch = _torch()
+            t['edge_value'] = t['var_value'][t['edge_var'].long()]
+            vp = t['var_ptr'].long()
+            t['slot_var'] = torch.repeat_interleave(torch.arange(flat.V, dtype=torch.int32, device=vp.device), vp[1:] - vp[:-1],
+                                                    output_size=int(flat.var_edge.size))
         self.t = t
         self.device = t['fac_ptr'].device
         g = GraphStruct()

@@ -360,7 +360,7 @@ class FlatRefiner:
     def __init__(self, flat, dg, sym):
         torch = _abi.require_gpu()
         self.dg = dg
-        self.sym = _abi.to_dev(np.asarray(sym, dtype=np.uint8))
+        self.sym = sym.to(torch.uint8).contiguous() if torch.is_tensor(sym) else _abi.to_dev(np.asarray(sym, dtype=np.uint8))
         self.ws_bytes = int(_abi.lib().lhvi_color_workspace_bytes(dg.g))
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dg.device)
         self.res = torch.zeros(4, dtype=torch.int32, device=dg.device)
@@ -400,7 +400,7 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
     The colour arrays are tensors on `tg`'s device and stay there: the half rounds of the refinement (`refiner`: ``FlatRefiner``
     in the product), the representatives and the rows they contribute to the two lifted graphs of a sweep (``rv_side_graph_t``,
     ``lifting.lift_flat``) run there; what reaches the host per sweep is the colours of the OBSERVED variables (the k-means
-    evidence splits) and lifted-size arrays.  `rvc0`, `fc0`: the coarse initial colours (``initial_colors_flat(gflat, False)``).
+    evidence splits) and lifted-size arrays.  `rvc0`, `fc0`: the coarse initial colours (``initial_colors_flat(gflat, False)``; arrays or tensors).
     `timing`: optional dict that receives per-sweep lists of seconds (`lift`: both re-liftings incl. refinement,
     `setup`: building the two solver states, `sweep`: the message kernels).
     Returns (final state, final lifted flat (factor side), rv colours, factor colours (tensors), history)."""
@@ -412,7 +412,7 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
     obs_idx = np.flatnonzero(~np.isnan(values))
     ovals = values[obs_idx]
     obs_idx_t = torch.from_numpy(obs_idx).to(dev)
-    as_t = lambda a, dt=torch.int32: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+    as_t = lambda a, dt=torch.int32: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(dev).to(dt)
     rvc, fc = as_t(rvc0), as_t(fc0)
     nc, nfc = int(rvc.max().item()) + 1, int(fc.max().item()) + 1
     ver = {'rv': 0, 'f': 0}                      # bumped whenever the rv / factor partition changes

@@ -877,8 +877,8 @@ class HybridLBP(_ParticleSweep):
         """``run(iteration, c2f >= 0)`` on arrays (``lhvi.c2f.run_c2f_flat``): colours, refinement and both re-liftings of every
         sweep on the device"""
         from . import c2f as _c2f
-        from .lifting import initial_colors_flat
-        rvc0, fc0, sym = initial_colors_flat(gflat, False)                           # HLBP:432
+        from .lifting import initial_colors_device
+        rvc0, fc0, sym = initial_colors_device(gflat, dg, False)                     # HLBP:432
         observer = getattr(self, 'c2f_observer', None)
         st, G2, rvc, fc, history = _c2f.run_c2f_flat(
             gflat, dg, _DeviceEngine(self), _c2f.FlatRefiner(gflat, dg, sym), iteration, c2f, self.k_mean_k, self.k_mean_iteration,

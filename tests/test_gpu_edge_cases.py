@@ -272,6 +272,27 @@ def test_first_members_of_colours():
         np.testing.assert_array_equal(got, want)
 
 
+def test_initial_colours_on_the_device_equal_the_host_numbering():
+    """``lifting.initial_colors_device``: same colour ids (numbered by first appearance) as ``initial_colors_flat``, with and without
+    the split of continuous evidence by value; -0.0 and 0.0 are one evidence value; a graph with discrete evidence and equal
+    potentials on different table rows"""
+    from lhvi import _abi, lifting, synth
+    cases = [synth.rgm_flat(C=30, B=20, n_values=5, evidence_ratio=0.3, seed=2)[0], synth.paper_popularity_flat(30, 4, seed=1, points=8)[0]]
+    flat = synth.rgm_flat(C=12, B=6, n_values=0, evidence_ratio=0.4, seed=5)[0]
+    val = flat.var_value.copy()
+    obs = np.flatnonzero(~np.isnan(val))
+    val[obs[:4]] = [0.0, -0.0, 0.0, -0.0]
+    flat.var_value = val
+    cases.append(flat)
+    for flat in cases:
+        dg = _abi.DeviceGraph(flat)
+        for split in (True, False):
+            want = lifting.initial_colors_flat(flat, split)
+            got = lifting.initial_colors_device(flat, dg, split)
+            for w, g_, what in zip(want, got, ('rv colours', 'factor colours', 'symmetric flags')):
+                np.testing.assert_array_equal(g_.cpu().numpy(), w, err_msg='%s (split=%s)' % (what, split))
+
+
 def test_image_potentials_on_a_denoising_grid_match_the_oracle():
     """``ImageNodePotential`` / ``ImageEdgePotential`` (Potential.py:400-424; the model of Demo/old/DenoisingDemo.py:20-60: a hidden
     pixel per cell tied to its noisy observation, a truncated-exponential smoothness prior between 4-neighbours, domain
