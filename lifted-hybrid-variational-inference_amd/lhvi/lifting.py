@@ -618,7 +618,7 @@ def refine_flat(flat, symmetric, rv_color, f_color, max_rounds=1000, dg=None, st
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dg.device)
     res = torch.zeros(8, dtype=torch.int32, device=dg.device)          # [0:4] factor half, [4:8] variable half
     res_f, res_v = res[:4], res[4:]
-    sym = _abi.to_dev(np.asarray(symmetric, dtype=np.uint8))
+    sym = symmetric.to(torch.uint8).contiguous() if torch.is_tensor(symmetric) else _abi.to_dev(np.asarray(symmetric, dtype=np.uint8))
     # (device tensors are copied: the loop ping-pongs between two buffers per side and must not write into the caller's)
     rvc = rv_color.to(torch.int32).clone() if torch.is_tensor(rv_color) else _abi.to_dev(np.asarray(rv_color, dtype=np.int32))
     fc = f_color.to(torch.int32).clone() if torch.is_tensor(f_color) else _abi.to_dev(np.asarray(f_color, dtype=np.int32))

@@ -846,10 +846,10 @@ class HybridLBP(_ParticleSweep):
             self._run_sweeps(iteration)
             self._stable_partition = True
             return
-        from .lifting import initial_colors_flat, lift_flat, refine_flat
+        from .lifting import initial_colors_device, lift_flat, refine_flat
         dg = _abi.DeviceGraph(flat)
         if c2f == -1:
-            rvc0, fc0, sym = initial_colors_flat(flat, True)
+            rvc0, fc0, sym = initial_colors_device(flat, dg, True)
             rvc, fc = refine_flat(flat, sym, rvc0, fc0, dg=dg, device_out=True)
             self._ground = dict(flat=flat, dg=dg, rvc=rvc, fc=fc)
             self._setup(None, flat=lift_flat(flat, rvc, fc, dg=dg))
