@@ -445,15 +445,17 @@ typedef struct lhvi_vi {
      * of the factor ids in six segments, in this order --
      *   n_cc    pairwise factors over two distinct continuous / observed variables with a Gaussian / quadratic / linear-Gaussian /
      *           XY potential (thread per (factor, k), per-axis pdf tables in registers);
-     *   n_tiny  other factors of arity <= 3 whose grid has at most LHVI_VI_TINY_NODES nodes, K <= 2 (thread per (factor, k), the
-     *           per-axis values held in the loop nest; needs edge_axis);
+     *   n_tiny  other factors of arity <= 3 whose grid has at most LHVI_VI_TINY_NODES nodes, K <= 2 (thread per (factor, k) walking
+     *           the grid nodes and the points of the pinned expectations as one list; needs edge_axis and tiny_par_words);
      *   n_grp3  other factors of arity <= 3 whose axis lengths sum to <= LHVI_VI_GROUP_SLOTS with K * that <= LHVI_VI_GROUP_COMP
      *           (8 lanes per (factor, k), per-axis tables in LDS);  n_grp6: the same for arity 4 .. LHVI_MAX_ARITY;
      *   n_rest3 / n_rest6  whatever fits neither (thread per (factor, k), arity <= 3 / 4 .. LHVI_MAX_ARITY).
      * NULL: every kernel classifies the factors itself (thread-per-factor kernels only). */
     const int32_t* fac_list;
     int32_t n_cc, n_grp3, n_grp6, n_rest3, n_rest6;
-    int32_t n_tiny;            /* (sits between n_cc and n_grp3 in the list; declared last: it fills the padding before edge_axis) */
+    int32_t n_tiny;            /* (sits between n_cc and n_grp3 in the list) */
+    int32_t tiny_par_words;    /* pots.off[P], the length of pots.param in doubles: the tiny-grid kernel keeps the parameter rows (an MLN
+                                * formula's program) in LDS; n_tiny > 0 needs 0 < tiny_par_words <= 1024 */
     /* (ABI 9) [E][4] or NULL: per edge {variable, axis length | hidden << 16 | continuous << 17 | Gaussian observation << 18,
      * state index of the observed value (0 unless observed and discrete), offset of the variable's states in dom_val} -- the shape
      * of the factor's quadrature grid, which

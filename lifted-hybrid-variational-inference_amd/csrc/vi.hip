@@ -676,6 +676,7 @@ __global__ void __launch_bounds__(VI_GRP_BLOCK) __attribute__((amdgpu_waves_per_
 // lanes, then a butterfly), so the two agree to rounding.
 // Eligible (host: lhvi/vi.py): arity <= 3, at most LHVI_VI_TINY_NODES grid nodes, K <= VI_TINY_K, axis records present.
 constexpr int VI_TINY_K = 2;
+constexpr int VI_TINY_PAR = 1024;      // doubles of parameter rows kept in LDS
 #ifndef LHVI_VI_TINY_WAVES
 #define LHVI_VI_TINY_WAVES 2
 #endif
@@ -687,6 +688,10 @@ vi_factor_tiny_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __r
     __shared__ LogRec sh_log[LOG_TAB_N];
     __shared__ double sh_stack[MLN_STACK * BLOCK];      // the formula interpreter's stack: a column per thread (in registers it is
     MlnLdsStack<BLOCK> stack{sh_stack + threadIdx.x};   // a dynamically indexed array: 0.81 ms instead of 0.70 on the scaled cfg 3)
+    // the parameter rows of all potentials (for an MLN formula: its program) in LDS: the interpreter fetches an opcode per step, each
+    // a dependent load -- 7 to 21 global round trips per evaluation otherwise
+    __shared__ double sh_par[VI_TINY_PAR];
+    for (int t = threadIdx.x; t < p.tiny_par_words; t += BLOCK) sh_par[t] = pots.param[t];     // (the launcher checks the size)
     load_log_table(sh_log);
     load_exp_table(sh_tab);
     const int4* __restrict__ recs = reinterpret_cast<const int4*>(p.edge_axis);
@@ -722,7 +727,7 @@ vi_factor_tiny_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __r
         }
         const int pot = g.fac_pot[f];
         const int kind = pots.kind[pot];
-        const double* par = pots.param + pots.off[pot];
+        const double* par = sh_par + pots.off[pot];
         // the pinned positions: hidden discrete arguments at their first position in the scope (f.nb.index(rv), LVI:112,146);
         // npin[a] = points of position a's pinned expectations = states * min(prod nx, prod nw) (zip truncates to the shorter)
         const int G = alen[0] * alen[1] * alen[2];
@@ -745,6 +750,7 @@ vi_factor_tiny_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __r
                 for (int d = 0; d < alen[a]; ++d) pe_d[((int64_t)(base + a) * p.K + k) * p.Dmax + d] = 0.0;
         }
         const int total = G + npin[0] + npin[1] + npin[2];
+        const double wk0 = p.w[0], wk1 = p.K > 1 ? p.w[1] : 0.0;
         double x[3];
         int idx[3];
         double E = 0.0, Em[3] = {0.0, 0.0, 0.0}, Ev[3] = {0.0, 0.0, 0.0}, acc = 0.0;
@@ -773,7 +779,12 @@ vi_factor_tiny_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __r
                 const int ixs = small_divmod(rx, nx, __builtin_amdgcn_rcpf((float)nx));
                 const int iws = pa >= 0 ? small_divmod(rw, nw, __builtin_amdgcn_rcpf((float)nw)) : ixs;
                 if (quirk) {
-                    x[b] = tvals[ixs]; idx[b] = vi_state_index(g, av[b], x[b]);
+                    x[b] = tvals[ixs];
+                    idx[b] = 0;                                   // vi_state_index from the axis record: first matching state, else (int) x
+                    if (!cont[b]) {
+                        idx[b] = (int)x[b];
+                        for (int t = alen[b] - 1; t >= 0; --t) if (g.dom_val[adom[b] + t] == x[b]) idx[b] = t;
+                    }
                     wb[b] = cont[b] ? p.eta_c[((int64_t)av[b] * p.K + k) * 2 + iws] : p.eta_d[((int64_t)av[b] * p.K + k) * p.Dmax + iws];
                 } else if (gauss[b]) { x[b] = sd[b] * p.gh_x[ixs] + mu[b]; wb[b] = p.gh_w[iws]; }
                 else if (hid[b]) { x[b] = g.dom_val[adom[b] + ixs]; idx[b] = ixs; wb[b] = p.eta_d[((int64_t)av[b] * p.K + k) * p.Dmax + iws]; }
@@ -786,7 +797,7 @@ vi_factor_tiny_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __r
 #pragma unroll
             for (int kk = 0; kk < VI_TINY_K; ++kk) {
                 if (kk >= p.K) continue;
-                double t = p.w[kk];
+                double t = kk == 0 ? wk0 : wk1;
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
                     if (!axis[b]) continue;
@@ -1193,9 +1204,10 @@ int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t
         }
         l += p->n_cc;
         if (p->n_tiny > 0) {
-            if (!p->edge_axis || p->K > VI_TINY_K) return LHVI_E_ARG;
-            hipLaunchKernelGGL(vi_factor_tiny_kernel, dim3(min(grid_for((int64_t)p->n_tiny * p->K), 4096u)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d,
-                               l, p->n_tiny);
+            if (!p->edge_axis || p->K > VI_TINY_K || p->tiny_par_words <= 0 || p->tiny_par_words > VI_TINY_PAR) return LHVI_E_ARG;
+            // (4 096 workgroups, not the 512 resident ones: the hardware's dispatch balances the uneven items; 0.68 vs 0.76 ms)
+            hipLaunchKernelGGL(vi_factor_tiny_kernel, dim3(min(grid_for((int64_t)p->n_tiny * p->K), 4096u)), dim3(BLOCK), 0, st,
+                               *g, *pots, *p, ef, pe_c, pe_d, l, p->n_tiny);
         }
         l += p->n_tiny;
         constexpr int GPB = VI_GRP_BLOCK / VI_GRP_L;

@@ -73,7 +73,7 @@ class ViStruct(C.Structure):
         ('gh_x', C.c_void_p), ('gh_w', C.c_void_p), ('w', C.c_void_p), ('eta_c', C.c_void_p), ('eta_d', C.c_void_p),
         ('obs_var', C.c_void_p), ('var_N', C.c_void_p),
         ('fac_list', C.c_void_p), ('n_cc', C.c_int32), ('n_grp3', C.c_int32), ('n_grp6', C.c_int32), ('n_rest3', C.c_int32),
-        ('n_rest6', C.c_int32), ('n_tiny', C.c_int32), ('edge_axis', C.c_void_p),
+        ('n_rest6', C.c_int32), ('n_tiny', C.c_int32), ('tiny_par_words', C.c_int32), ('edge_axis', C.c_void_p),
     ]
 
 
@@ -99,7 +99,7 @@ ABI_VERSION = 9             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts
 PBP_DESC_BYTES = 128
 COLOR_HASH, COLOR_SORT = 0, 1     # method of lhvi_color_refine_* (LHVI_COLOR_HASH / LHVI_COLOR_SORT)
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE
-VI_GROUP_SLOTS, VI_GROUP_COMP, VI_TINY_NODES, VI_TINY_K = 24, 48, 32, 2     # LHVI_VI_GROUP_SLOTS / LHVI_VI_GROUP_COMP
+VI_GROUP_SLOTS, VI_GROUP_COMP, VI_TINY_NODES, VI_TINY_K, VI_TINY_PAR = 24, 48, 32, 2, 1024     # LHVI_VI_GROUP_SLOTS / LHVI_VI_GROUP_COMP
 
 _G, _P, _S, _VI = C.POINTER(GraphStruct), C.POINTER(PotsStruct), C.POINTER(PbpStruct), C.POINTER(ViStruct)
 _GP = C.POINTER(GabpPlanStruct)
