@@ -446,13 +446,13 @@ if 'vi_models' in which:
         data = {tuple(k): v for k, v in rec['evidence']}
         return generators.robot_mapping().ground_flat(data)[0]
 
-    def cpu_baseline_vi(flat, updates, obs_var=None):
+    def cpu_baseline_vi(flat, updates, obs_var=None, K=2):
         """CPU baseline (labelled): the C oracle's ADAM updates on the same graph, one host core; seconds per update"""
         from oracle import oracle
-        o = oracle.ViOracle(flat, 2, 3, obs_var=obs_var)
+        o = oracle.ViOracle(flat, K, 3, obs_var=obs_var)
         rng = np.random.default_rng(0)
-        eta_c = np.ones((flat.V, 2, 2)); eta_c[:, :, 0] = rng.random((flat.V, 2)) * 3 - 1.5
-        o.set_params(np.zeros(2), eta_c, rng.random((flat.V, 2, o.Dmax)) * 10)
+        eta_c = np.ones((flat.V, K, 2)); eta_c[:, :, 0] = rng.random((flat.V, K)) * 3 - 1.5
+        o.set_params(np.zeros(K), eta_c, rng.random((flat.V, K, o.Dmax)) * 10)
         t0 = time.perf_counter()
         o.run(updates, lr=0.2)
         return (time.perf_counter() - t0) / updates
@@ -472,24 +472,31 @@ if 'vi_models' in which:
         torch.cuda.synchronize()
         return time.perf_counter() - t0, a.elapsed_time(b) * 1e-3, vi.time_log[-1][1]
 
+    # (the RGM instances of Demo/RGM/RGMTimeLog.py:14-38: 100 categories x 5 banks = 606 atoms, 121 / 30 of them observed, K = 1,
+    # T = 3, 200 updates; Demo/Data/RGM/time_log_20_result, time_log_5_result)
     models = [('paper-popularity HMLN 300 papers x 10 topics (Demo/Data/HMLN/0 evidence pattern)', lambda: synth.paper_popularity_flat(300, 10, seed=0, points=20)[0],
-               dict(VI=2.93, LVI=1.98, C2FVI=1.68)),
-              ('robot-mapping HMLN (Demo/Data/HMLN/robot-map evidence + closed world)', robot_flat, dict(VI=6.37, LVI=6.10, C2FVI=1.90))]
-    UPD = 100
-    for label, make, published in models:
+               dict(VI=2.93, LVI=1.98, C2FVI=1.68), 2, 100),
+              ('robot-mapping HMLN (Demo/Data/HMLN/robot-map evidence + closed world)', robot_flat, dict(VI=6.37, LVI=6.10, C2FVI=1.90), 2, 100),
+              ('RGM 100 x 5, 20 % of the atoms observed (Demo/RGM/RGMTimeLog.py)', lambda: synth.rgm_flat(C=100, B=5, n_values=0, evidence_ratio=0.2, seed=0)[0],
+               dict(VI=1.65, LVI=1.08, C2FVI=0.99), 1, 200),
+              ('RGM 100 x 5, 5 % of the atoms observed (Demo/RGM/RGMTimeLog.py)', lambda: synth.rgm_flat(C=100, B=5, n_values=0, evidence_ratio=0.05, seed=0)[0],
+               dict(VI=2.17, LVI=0.50, C2FVI=0.46), 1, 200)]
+    if os.environ.get('VI_MODEL'):
+        models = [models[int(os.environ['VI_MODEL'])]]
+    for label, make, published, K_, UPD in models:
         flat = make()
         base = dict(model=label, rvs=int(flat.V), factors=int(flat.F), edges=int(flat.E), hidden=int(flat.var_hidden.sum()),
-                    max_arity=int(np.diff(flat.fac_ptr).max()), K=2, T=3, updates=UPD)
+                    max_arity=int(np.diff(flat.fac_ptr).max()), K=K_, T=3, updates=UPD)
         # ---- VI on the ground graph
         t0 = time.perf_counter()
-        vi = VarInference(None, 2, 3)
+        vi = VarInference(None, K_, 3)
         vi._setup_flat(flat)
         torch.cuda.synchronize()
         t_setup = time.perf_counter() - t0
         wall, dev, fe = timed_loop(vi, UPD)
         out(config='VI (ground) ' + label, **base, setup_s=t_setup, s_per_update_end_to_end=(t_setup + wall) / UPD, s_per_update_loop_wall=wall / UPD,
             s_per_update_device=dev / UPD, fe_last=fe, reference_published_s_per_update_unknown_cpu=published['VI'],
-            cpu_oracle_s_per_update_1_core=cpu_baseline_vi(flat, 3))
+            cpu_oracle_s_per_update_1_core=cpu_baseline_vi(flat, 3, K=K_))
         del vi
         # ---- LVI: colour passing to the stable partition, then the same loop on the lifted graph
         t0 = time.perf_counter()
@@ -497,32 +504,32 @@ if 'vi_models' in which:
         dgm = _abi.DeviceGraph(flat)
         rvc, fc = lifting.refine_flat(flat, sym, rv0, f0, dg=dgm, device_out=True)
         lflat = lifting.lift_flat(flat, rvc, fc, dg=dgm)
-        lvi = VarInference(None, 2, 3)
+        lvi = VarInference(None, K_, 3)
         lvi._setup_flat(lflat)
         torch.cuda.synchronize()
         t_setup = time.perf_counter() - t0
         wall, dev, fe = timed_loop(lvi, UPD)
         out(config='LVI (lifted) ' + label, **base, rv_clusters=int(lflat.V), factor_clusters=int(lflat.F), lifted_edges=int(lflat.E),
             lifting_and_setup_s=t_setup, s_per_update_end_to_end=(t_setup + wall) / UPD, s_per_update_loop_wall=wall / UPD, s_per_update_device=dev / UPD,
-            fe_last=fe, reference_published_s_per_update_unknown_cpu=published['LVI'], cpu_oracle_s_per_update_1_core=cpu_baseline_vi(lflat, 3))
+            fe_last=fe, reference_published_s_per_update_unknown_cpu=published['LVI'], cpu_oracle_s_per_update_1_core=cpu_baseline_vi(lflat, 3, K=K_))
         del lvi, dgm
         # ---- C2FVI: coarse start, re-lift every 10 updates (C2FVarInference.py:301-352), on arrays
         owner = c2fvi.VarInference.__new__(c2fvi.VarInference)
-        owner._init_common(2, 3)
+        owner._init_common(K_, 3)
         opts = dict(k_mean_k=2, k_mean_its=10, update_obs_its=10, output_its=0, min_obs_var=0, gaussian_obs=True)
         for rep in range(2):
             np.random.seed(0)
             seen = []
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            res = c2fvi.run_c2fvi_flat(flat, c2fvi._DeviceEngine(owner), 2, UPD, 0.2, opts,
+            res = c2fvi.run_c2fvi_flat(flat, c2fvi._DeviceEngine(owner), K_, UPD, 0.2, opts,
                                        observer=lambda r, st: seen.append(int(st['rvc'].max()) + 1))
             torch.cuda.synchronize()
             total = time.perf_counter() - t0
         out(config='C2FVI (coarse to fine, arrays) ' + label, **base, rv_clusters_per_round=seen, total_s=total, s_per_update_end_to_end=total / UPD,
             relift_ms_per_round=[round(1e3 * x, 2) for x in res['relift_s']], fe_last=res['fe_log'][-1],
             reference_published_s_per_update_unknown_cpu=published['C2FVI'],
-            cpu_oracle_s_per_update_1_core_final_lifted_graph=cpu_baseline_vi(res['flat'], 3, obs_var=res['obs_var']))
+            cpu_oracle_s_per_update_1_core_final_lifted_graph=cpu_baseline_vi(res['flat'], 3, obs_var=res['obs_var'], K=K_))
 
 if 'vi_scaled' in which:
     # ground VI on the scaled cfg 3 (286 groundings of the 300 x 10 paper-popularity HMLN: ~970 k factors, discrete axes, ternary
