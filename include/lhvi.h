@@ -455,7 +455,7 @@ typedef struct lhvi_vi {
     int32_t n_cc, n_grp3, n_grp6, n_rest3, n_rest6;
     int32_t n_tiny;            /* (sits between n_cc and n_grp3 in the list) */
     int32_t tiny_par_words;    /* pots.off[P], the length of pots.param in doubles: the tiny-grid kernel keeps the parameter rows (an MLN
-                                * formula's program) in LDS; n_tiny > 0 needs 0 < tiny_par_words <= 1024 */
+                                * formula's program) in LDS; n_tiny > 0 needs 0 < tiny_par_words <= 3072 */
     /* (ABI 9) [E][4] or NULL: per edge {variable, axis length | hidden << 16 | continuous << 17 | Gaussian observation << 18,
      * state index of the observed value (0 unless observed and discrete), offset of the variable's states in dom_val} -- the shape
      * of the factor's quadrature grid, which

@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(VI_GRP_BLOCK) __attribute__((amdgpu_waves_per_
 // lanes, then a butterfly), so the two agree to rounding.
 // Eligible (host: lhvi/vi.py): arity <= 3, at most LHVI_VI_TINY_NODES grid nodes, K <= VI_TINY_K, axis records present.
 constexpr int VI_TINY_K = 2;
-constexpr int VI_TINY_PAR = 1024;      // doubles of parameter rows kept in LDS
+constexpr int VI_TINY_PAR = 3072;      // doubles of parameter rows kept in LDS (24 KB: two workgroups per CU still fit)
 #ifndef LHVI_VI_TINY_WAVES
 #define LHVI_VI_TINY_WAVES 2
 #endif

@@ -99,7 +99,7 @@ ABI_VERSION = 9             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts
 PBP_DESC_BYTES = 128
 COLOR_HASH, COLOR_SORT = 0, 1     # method of lhvi_color_refine_* (LHVI_COLOR_HASH / LHVI_COLOR_SORT)
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE
-VI_GROUP_SLOTS, VI_GROUP_COMP, VI_TINY_NODES, VI_TINY_K, VI_TINY_PAR = 24, 48, 32, 2, 1024     # LHVI_VI_GROUP_SLOTS / LHVI_VI_GROUP_COMP
+VI_GROUP_SLOTS, VI_GROUP_COMP, VI_TINY_NODES, VI_TINY_K, VI_TINY_PAR = 24, 48, 32, 2, 3072     # LHVI_VI_GROUP_SLOTS / LHVI_VI_GROUP_COMP
 
 _G, _P, _S, _VI = C.POINTER(GraphStruct), C.POINTER(PotsStruct), C.POINTER(PbpStruct), C.POINTER(ViStruct)
 _GP = C.POINTER(GabpPlanStruct)

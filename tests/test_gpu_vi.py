@@ -330,3 +330,98 @@ def test_tiny_grid_kernel_equals_the_group_kernel(api, golden_dir, name):
     assert a[4][1] > 0 and b[4][1] == 0 and b[4][2] + b[4][3] >= a[4][1]
     for x, y, what in zip(a[:4], b[:4], ('g_w', 'g_c', 'g_d', 'fe')):
         np.testing.assert_allclose(x, y, rtol=1e-11, atol=1e-11, err_msg=what)
+
+
+def _random_hybrid_graph(rng, n_rv=40, n_f=90, one_discrete_domain=False):
+    """a random hybrid factor graph through the object API: binary / ternary / four-state / continuous variables (30 % observed),
+    factors of arity 1-3 -- dict-keyed tables over discrete scopes, MLN formulas over mixed
+    scopes, Gaussian / linear-Gaussian / XY pairs over continuous ones"""
+    from lhvi import mln as M, potentials as P
+    from lhvi.graph import Domain, F, Graph, RV
+    d2, d3, d4 = Domain((0, 1)), Domain((0, 1, 2)), Domain((1, 2, 3, 5))
+    dc = Domain((-10, 10), continuous=True, integral_points=np.linspace(-10, 10, 9))
+    rvs = []
+    for i in range(n_rv):
+        # (under the reference's quirk 10 a discrete neighbour is evaluated at the TARGET's state values: only graphs whose discrete
+        # variables share a domain are valid inputs then -- anything else indexes eta out of range, in the reference as here)
+        dom = (d4, d4, d4, dc, dc)[rng.integers(5)] if one_discrete_domain else (d2, d3, d4, dc, dc)[rng.integers(5)]
+        val = None
+        if rng.random() < 0.3:
+            val = float(np.round(rng.uniform(-3, 3), 2)) if dom.continuous else dom.values[rng.integers(len(dom.values))]
+        rvs.append(RV(dom, val))
+    formulas = {1: [lambda x: M.eq_op(x[0], 1), lambda x: x[0] * 0.5 - 1],
+                2: [lambda x: M.eq_op(x[0], x[1]), lambda x: M.or_op(M.neg_op(x[0] > 0), x[1] > 1), lambda x: -abs(x[0] - 2 * x[1])],
+                3: [lambda x: x[0] * M.eq_op(x[1], x[2]), lambda x: M.imp_op(x[0] >= 1, M.eq_op(x[1], x[2]) + 1) / 2,
+                    lambda x: (x[0] + x[1] - x[2]) ** 2 * -0.1]}
+    pots = {(a, i): M.MLNPotential(f, w=float(np.round(rng.uniform(-1, 2), 2))) for a in formulas for i, f in enumerate(formulas[a])}
+    pair_pots = [P.GaussianPotential([0.0, 0.0], [[2.0, 0.6], [0.6, 1.5]]), P.LinearGaussianPotential(0.8, 1.3), P.XYPotential(0.7, 2.0)]
+    tables = {}
+    factors = []
+    for i in range(n_f):
+        a = int(rng.integers(1, 4))
+        scope = [rvs[j] for j in rng.choice(n_rv, a, replace=False)]
+        # (a table over one domain only: under the reference's quirk 10 a neighbour is evaluated at the TARGET's state values)
+        if all(not r.domain.continuous and r.domain is scope[0].domain for r in scope) and rng.random() < 0.7:
+            key = tuple(id(r.domain) for r in scope)
+            if key not in tables:
+                import itertools
+                tables[key] = P.TablePotential({vals: float(rng.uniform(0.2, 2.0)) for vals in itertools.product(*[r.domain.values for r in scope])})
+            pot = tables[key]
+        elif a == 2 and all(r.domain.continuous for r in scope) and rng.random() < 0.7:
+            pot = pair_pots[rng.integers(len(pair_pots))]
+        else:
+            pot = pots[(a, int(rng.integers(len(formulas[a]))))]
+        factors.append(F(pot, nb=scope))
+    g = Graph()
+    g.rvs, g.factors = [r for r in rvs if any(r in f.nb for f in factors)], factors
+    g.init_nb()
+    return g
+
+
+@pytest.mark.parametrize('seed,K,T,quirks', [(0, 2, 3, True), (1, 1, 3, True), (2, 2, 2, False), (3, 2, 3, False), (4, 2, 5, True)])
+def test_random_hybrid_graphs_through_every_factor_kernel(api, seed, K, T, quirks):
+    """random hybrid graphs (observed discrete states, three- and four-state variables, formulas
+    with comparisons / abs / divisions / squares, dict-keyed tables, Gaussian observations on some observed continuous variables):
+    gradient and free energy through (a) the tiny-grid kernel, (b) the group kernel, (c) the thread-per-factor kernels of rounds
+    1-3, against the C oracle and against each other"""
+    from lhvi import c2fvi
+    from lhvi.flat import flatten
+    from oracle import oracle
+    rng = np.random.default_rng(100 + seed)
+    g = _random_hybrid_graph(rng, one_discrete_domain=quirks)
+    flat = flatten(g, require_device_potentials=True)
+    obs_c = np.flatnonzero(~flat.var_hidden & flat.var_cont)
+    obs_var = np.zeros(flat.V)
+    obs_var[obs_c[::2]] = rng.uniform(0.3, 1.5, obs_c[::2].size)       # every other observed continuous variable: a Gaussian observation
+    owner = c2fvi.VarInference.__new__(c2fvi.VarInference)
+    owner._init_common(K, T)
+    owner.reference_quirks = quirks
+    w_tau = rng.normal(size=K)
+    eta_c = np.ones((flat.V, K, 2))
+    eta_c[:, :, 0] = rng.uniform(-1.5, 1.5, (flat.V, K))
+    eta_c[:, :, 1] = rng.uniform(0.5, 3.0, (flat.V, K))
+    o = oracle.ViOracle(flat, K, T, quirks=1 if quirks else 0, obs_var=obs_var)
+    tau_d = rng.uniform(0, 2, (flat.V, K, o.Dmax))
+    o.set_params(w_tau, eta_c, tau_d)
+    want = o.grad()
+    outs = {}
+    for label, lists, tiny in (('tiny', True, 'always'), ('group', True, False), ('thread per factor', False, False)):
+        Stage = type('Stage', (c2fvi._DeviceStage,), dict(factor_lists=lists, tiny_kernel=tiny))
+        st = Stage(owner, flat, obs_var)
+        st._upload_params(w_tau, eta_c, tau_d)
+        st._grad()
+        d = st._dev
+        outs[label] = [d[k].cpu().numpy().copy() for k in ('g_w', 'g_c', 'g_d', 'fe')]
+        if label == 'tiny':
+            assert st._fac_counts[1] > 20 and st._fac_counts[0] > 0, st._fac_counts
+        if label == 'group':
+            assert st._fac_counts[1] == 0 and st._fac_counts[2] > 20, st._fac_counts
+    cont, disc = flat.var_hidden & flat.var_cont, flat.var_hidden & ~flat.var_cont
+    for label, (g_w, g_c, g_d, fe) in outs.items():
+        np.testing.assert_allclose(fe[0], want[3], rtol=1e-9, err_msg=label)
+        np.testing.assert_allclose(g_w, want[0], rtol=1e-8, atol=1e-8, err_msg=label)
+        np.testing.assert_allclose(g_c[cont], want[1][cont], rtol=1e-8, atol=1e-8, err_msg=label)
+        np.testing.assert_allclose(g_d[disc], want[2][disc], rtol=1e-8, atol=1e-8, err_msg=label)
+    for a, b in (('tiny', 'group'), ('group', 'thread per factor')):
+        for x, y, what in zip(outs[a], outs[b], ('g_w', 'g_c', 'g_d', 'fe')):
+            np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-9, err_msg='%s vs %s: %s' % (a, b, what))
