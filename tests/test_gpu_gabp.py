@@ -242,6 +242,66 @@ def _run_both_forms(api, flat, iterations):
     return out
 
 
+def _ragged_gaussian_flat(seed=0, n_small=6000):
+    """every row class of the pull kernel in one graph: thousands of rows of 2-6 entries, rows of 33-480 entries (chunk sums), two
+    rows of more than 512 (wave-parallel hub kernel), evidence in each class -- a star forest (each big variable tied to its own
+    leaves by linear-Gaussian / XY / Gaussian factors, leaves tied among themselves at random, a unary prior everywhere)"""
+    from lhvi import potentials as P
+    from lhvi.flat import build_flat
+    from lhvi.graph import Domain
+    rng = np.random.default_rng(seed)
+    big = [700, 1500] + rng.integers(33, 480, 40).tolist() + [32, 33, 64, 65, 511, 512, 513]
+    pairs, pot = [], []
+    nv = len(big)
+    for c, d in enumerate(big):
+        leaves = np.arange(nv, nv + d - 1)
+        nv += d - 1
+        for lf in leaves:
+            pairs.append((c, lf) if rng.random() < 0.5 else (lf, c))
+            pot.append(int(rng.integers(0, 3)))
+    first_small = nv
+    nv += n_small
+    for _ in range(2 * n_small):
+        a, b = rng.integers(len(big), nv, 2)
+        if a != b:
+            pairs.append((int(a), int(b)))
+            pot.append(int(rng.integers(0, 3)))
+    F2 = len(pairs)
+    edge_var = np.concatenate([np.array(pairs, dtype=np.int32).ravel(), np.arange(nv, dtype=np.int32)])
+    fac_ptr = np.concatenate([np.arange(0, 2 * F2 + 1, 2), 2 * F2 + np.arange(1, nv + 1)]).astype(np.int32)
+    fac_pot = np.concatenate([np.array(pot), np.full(nv, 3)]).astype(np.int32)
+    value = np.full(nv, np.nan)
+    obs = rng.random(nv) < 0.1
+    obs[[0, 5, 44]] = True                                   # a hub row, two chunked rows
+    value[obs] = np.round(rng.uniform(-2, 2, int(obs.sum())), 3)
+    dom = Domain((-10, 10), continuous=True, integral_points=np.linspace(-10, 10, 8))
+    pots = [(P.POT_LINEAR_GAUSSIAN, [0.7, 2.0]), (P.POT_XY, [0.3, 3.0]), (P.POT_GAUSSIAN, P.GaussianPotential([0.0, 0.0], [[2.0, 0.5], [0.5, 1.5]]).device_spec([dom, dom])[1]),
+            (P.POT_X2, [1.0, 4.0])]
+    return build_flat(fac_ptr, edge_var, fac_pot, pots, value, np.zeros(nv, dtype=np.int32), [dom])
+
+
+def test_pull_form_on_a_graph_with_every_row_class(api):
+    """rows of 2-6, of 33-512 and of more than 512 entries in ONE graph with evidence in each class: after two sweeps (the first
+    one sums equal initial messages: exact either way) the slots of rows of at most 32 and of more than 512 entries carry the bits
+    of the kernel pair and the chunk-summed rows agree to 1e-13; after seven sweeps everything agrees to 1e-11 (the rounding of the
+    chunked rows has travelled)"""
+    flat = _ragged_gaussian_flat()
+    deg = np.diff(flat.var_ptr)
+    assert (deg > 512).sum() >= 2 and ((deg > 32) & (deg <= 512)).sum() >= 40 and (deg <= 32).sum() > 5000
+    chunked = (deg > 32) & (deg <= 512)
+    (f_a, v_a, m_a), _, (f_b, v_b, m_b), (f_c, v_c, m_c) = _run_both_forms(api, flat, 2)
+    for v_x in (v_b, v_c):
+        same = ~chunked[flat.edge_var]
+        assert v_a[same].tobytes() == v_x[same].tobytes()
+        np.testing.assert_allclose(v_a, v_x, rtol=1e-13, atol=1e-13, equal_nan=True)
+        assert v_a[~same].tobytes() != v_x[~same].tobytes()          # (the chunked sums did run)
+    (f_a, v_a, m_a), *others = _run_both_forms(api, flat, 7)
+    for f_x, v_x, m_x in others[1:]:
+        for a, b in ((f_a, f_x), (v_a, v_x), (m_a, m_x)):
+            np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-11, equal_nan=True)
+    assert np.isfinite(m_a[flat.var_hidden]).all()
+
+
 @pytest.mark.parametrize('case', ['random', 'lifted_rgm', 'hub', 'one_sweep', 'no_sweep', 'long_rows'])
 def test_pull_form_equals_the_kernel_pair_bit_for_bit(api, case):
     """lhvi_gabp_run_pull (messages in slot order, f -> v recomputed from the partner's v -> f, one launch per sweep) against
