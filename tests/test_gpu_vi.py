@@ -380,6 +380,10 @@ def _random_hybrid_graph(rng, n_rv=40, n_f=90, one_discrete_domain=False):
 
 @pytest.mark.parametrize('seed,K,T,quirks', [(0, 2, 3, True), (1, 1, 3, True), (2, 2, 2, False), (3, 2, 3, False), (4, 2, 5, True)])
 def test_random_hybrid_graphs_through_every_factor_kernel(api, seed, K, T, quirks):
+    assert _random_hybrid_check(seed, K, T, quirks, require_every_kernel=True) is None
+
+
+def _random_hybrid_check(seed, K, T, quirks, require_every_kernel):
     """random hybrid graphs (observed discrete states, three- and four-state variables, formulas
     with comparisons / abs / divisions / squares, dict-keyed tables, Gaussian observations on some observed continuous variables):
     gradient and free energy through (a) the tiny-grid kernel, (b) the group kernel, (c) the thread-per-factor kernels of rounds
@@ -404,6 +408,10 @@ def test_random_hybrid_graphs_through_every_factor_kernel(api, seed, K, T, quirk
     tau_d = rng.uniform(0, 2, (flat.V, K, o.Dmax))
     o.set_params(w_tau, eta_c, tau_d)
     want = o.grad()
+    if not np.isfinite(want[3]):
+        # exp(w * formula) overflowed somewhere on a grid: the reference raises OverflowError there (MLNPotential.py:37, e ** x), the
+        # oracle returns inf, the device kernels take log(exp(v) + 1e-100) = v without forming exp(v) -- not a valid input
+        return 'overflow'
     outs = {}
     for label, lists, tiny in (('tiny', True, 'always'), ('group', True, False), ('thread per factor', False, False)):
         Stage = type('Stage', (c2fvi._DeviceStage,), dict(factor_lists=lists, tiny_kernel=tiny))
@@ -412,9 +420,9 @@ def test_random_hybrid_graphs_through_every_factor_kernel(api, seed, K, T, quirk
         st._grad()
         d = st._dev
         outs[label] = [d[k].cpu().numpy().copy() for k in ('g_w', 'g_c', 'g_d', 'fe')]
-        if label == 'tiny':
+        if label == 'tiny' and require_every_kernel:
             assert st._fac_counts[1] > 20 and st._fac_counts[0] > 0, st._fac_counts
-        if label == 'group':
+        if label == 'group' and require_every_kernel:
             assert st._fac_counts[1] == 0 and st._fac_counts[2] > 20, st._fac_counts
     cont, disc = flat.var_hidden & flat.var_cont, flat.var_hidden & ~flat.var_cont
     for label, (g_w, g_c, g_d, fe) in outs.items():
