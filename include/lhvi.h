@@ -32,7 +32,7 @@ extern "C" {
                               * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq; the colour
                               *    refinement calls take a method and return four result words; lhvi_vi_t gained var_N; lhvi_vi_opt_t, lhvi_vi_adam_run;
                               *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub / v2f_mid16 / v2f_mid32, prop_hub / prop_partial, resample_vars, small16_desc / small32_desc; 16 ticket words; lhvi_pbp_boundary_reduce;
-                              * 9: lhvi_vi_t gained fac_list / n_cc / n_tiny / n_grp3 / n_grp6 / n_rest3 / n_rest6 / edge_axis; lhvi_color_first_members, lhvi_pbp_halo_pack / _unpack; lhvi_gabp_plan_t.rec */
+                              * 9: lhvi_vi_t gained fac_list / n_cc / n_tiny / n_grp3 / n_grp6 / n_rest3 / n_rest6 / edge_axis; lhvi_color_first_members, lhvi_color_segment_sums, lhvi_pbp_halo_pack / _unpack; lhvi_gabp_plan_t.rec */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -525,6 +525,10 @@ int lhvi_color_refine_rvs(const lhvi_graph_t* g, const int32_t* f_color, const i
  * `next(iter(self.rvs))` / `next(iter(self.factors))` -- any member; this build always takes the first).  color [n] on the
  * device, values in [0, n_colors). */
 int lhvi_color_first_members(const int32_t* color, int32_t n, int32_t n_colors, int32_t* first_out, void* stream);
+
+/* sums_out[s] = values[offsets[s]] + values[offsets[s] + 1] + ... in index order (one running sum per segment, like
+ * SuperRV.get_value CompressedGraphWithObs.py:24-28 over a cluster's observed members); offsets [n_segments + 1], ascending. */
+int lhvi_color_segment_sums(const double* values, const int64_t* offsets, int32_t n_segments, double* sums_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -453,6 +453,18 @@ static int rank_and_scatter(Workspace& w, int n, int32_t* color_out, int32_t* re
     return check_launch();
 }
 
+// sums of consecutive runs of `values` in index order, one thread per run: the evidence value of a cluster is the RUNNING sum of
+// its members' values over its size (SuperRV.get_value, CompressedGraphWithObs.py:24-28; members in ground order here), and a
+// library segmented reduction adds in a tree -- the last bit of a cluster's value then depends on who summed it
+__global__ void __launch_bounds__(BLOCK) segment_sum_kernel(int n_segments, const double* __restrict__ values,
+                                                           const int64_t* __restrict__ offsets, double* __restrict__ out) {
+    const int s = blockIdx.x * BLOCK + threadIdx.x;
+    if (s >= n_segments) return;
+    double acc = 0.0;
+    for (int64_t i = offsets[s]; i < offsets[s + 1]; ++i) acc += values[i];
+    out[s] = acc;
+}
+
 }  // namespace lhvi
 
 using namespace lhvi;
@@ -523,6 +535,13 @@ int lhvi_color_refine_rvs(const lhvi_graph_t* g, const int32_t* f_color, const i
     }
     if (int rc = check_launch()) return rc;
     return rank_and_scatter(w, g->V, rv_color_out, n_colors_out, st);
+}
+
+int lhvi_color_segment_sums(const double* values, const int64_t* offsets, int32_t n_segments, double* sums_out, void* stream) {
+    if (n_segments < 0 || (n_segments > 0 && (!offsets || !sums_out))) return LHVI_E_ARG;
+    if (n_segments == 0) return LHVI_OK;
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(grid_for(n_segments)), dim3(BLOCK), 0, as_stream(stream), n_segments, values, offsets, sums_out);
+    return check_launch();
 }
 
 int lhvi_color_first_members(const int32_t* color, int32_t n, int32_t n_colors, int32_t* first_out, void* stream) {

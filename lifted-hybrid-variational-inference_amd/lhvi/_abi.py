@@ -158,6 +158,7 @@ SIGNATURES = {
     'lhvi_color_refine_factors': (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     'lhvi_color_refine_rvs': (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     'lhvi_color_first_members': (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    'lhvi_color_segment_sums': (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
 }
 
 _lib = None

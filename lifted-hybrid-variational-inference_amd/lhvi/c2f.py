@@ -203,6 +203,7 @@ def rv_side_graph_t(gflat, tg, rvc_t, fc_t):
     ``lifting.TensorGraph``).  Same numbering as the host function: edges ordered by (cluster, first appearance of the factor
     colour along the representative's row).  Returns (flat, pair_phi [E], rep [V] as a tensor)."""
     import torch
+    from .lifting import segment_sums
     dev = rvc_t.device
     rl, fl = rvc_t.long(), fc_t.long()
     nV, nF = int(rl.max().item()) + 1, int(fl.max().item()) + 1
@@ -228,7 +229,7 @@ def rv_side_graph_t(gflat, tg, rvc_t, fc_t):
     if obs_members.numel():
         oc = rl[obs_members]
         o2 = torch.sort(oc, stable=True).indices
-        sums = torch.segment_reduce(value[obs_members][o2], 'sum', lengths=torch.bincount(oc, minlength=nV), unsafe=True)
+        sums = segment_sums(value[obs_members][o2], torch.bincount(oc, minlength=nV))
         ob = ~torch.isnan(val)
         val[ob] = sums[ob] / mult[ob]
     host = lambda t: t.cpu().numpy()
@@ -495,8 +496,12 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
     st2 = G2 = None
     t0 = tick('sweep', t0)
     per_sweep = []
+    import os
+    no_reuse = os.environ.get('LHVI_C2F_NO_REUSE') == '1'          # diagnostic: rebuild both graphs and states every sweep
     for i in range(iteration):
         mark = dict(clock)
+        if no_reuse:
+            g1_ver = g2_ver = pe1_ver = pe2_ver = None
         if i > 0:
             # ---- split_evidence + split_rvs (HLBP:475-485)
             old_rvc = rvc
@@ -555,6 +560,8 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
             t0 = tick('lift', t0)
             if st2 is None:
                 st2 = engine.make(G2)
+            elif last:                                 # (a kept state on the last sweep: same as above)
+                engine.get(st2, 'f2v')[...] = 0
         for name in ('v2f', 'eta'):
             engine.set(st2, name, engine.gather(engine.get(st1, name), pe2))
         for name in ('q', 'particles', 'old_particles', 'uniq'):

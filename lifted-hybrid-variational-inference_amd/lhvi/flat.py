@@ -87,6 +87,13 @@ class FlatGraph:
         raise KeyError((f, rv))
 
 
+def ground_order(items):
+    """the order in which a graph's rvs / factors are numbered: a list as it stands; a Python ``set`` (what the reference's
+    ``Graph`` / ``RelationalGraph.ground_graph`` hold) sorted by node id, i.e. in creation order -- iterating the set itself would
+    number the ground graph by object hashes, differently in every process"""
+    return sorted(items) if isinstance(items, (set, frozenset)) else list(items)
+
+
 def _value_or_nan(v):
     return np.nan if v is None else float(v)
 
@@ -101,8 +108,8 @@ def flatten(g, require_device_potentials=False):
     """
     if isinstance(g, FlatGraph):
         return g
-    rvs = list(g.rvs)
-    factors = list(g.factors)
+    rvs = ground_order(g.rvs)
+    factors = ground_order(g.factors)
     var_index = {rv: i for i, rv in enumerate(rvs)}
     fac_index = {f: i for i, f in enumerate(factors)}
     V, F = len(rvs), len(factors)

@@ -19,17 +19,18 @@ from collections import Counter
 import numpy as np
 
 from . import _abi
-from .flat import flatten
+from .flat import flatten, ground_order
 
 
 class SuperRV:
     """Cluster of ground rvs (``CompressedGraphWithObs.py:8-45``; ids as in ``CompressedGraphSorted.py:13-32``)."""
 
-    def __init__(self, rvs, domain=None, value=None, cid=-1):
+    def __init__(self, rvs, domain=None, value=None, cid=-1, order=None):
         self.rvs = rvs
+        self._order = order                      # the members in ground order (None: sorted by node id)
         first = next(iter(rvs))
         self.domain = first.domain if domain is None else domain
-        self.value = self.get_value(rvs) if value is None and first.value is not None else value
+        self.value = self.get_value(rvs if order is None else order) if value is None and first.value is not None else value
         self.variance = None if self.value is None else self.get_variance()
         self.nb = None
         self.N = 0
@@ -43,13 +44,17 @@ class SuperRV:
 
     @staticmethod
     def get_value(rvs):
+        """running sum of the members' values over the size (CGWO:24-28).  The reference walks a Python ``set`` of RV objects, i.e.
+        in an order that changes from process to process, and the last bit of the mean with it; here the members are walked in
+        ground order (node ids), which is also the order of the array path (``lifting.segment_sums``) -- the two paths then give
+        a cluster the same value bit for bit."""
         total = 0
-        for rv in rvs:
+        for rv in (sorted(rvs) if isinstance(rvs, (set, frozenset)) else rvs):
             total += rv.value
         return total / len(rvs)
 
     def get_variance(self):
-        return np.var(tuple(rv.value for rv in self.rvs))
+        return np.var(tuple(rv.value for rv in (sorted(self.rvs) if self._order is None else self._order)))
 
     @property
     def sharing_count(self):
@@ -68,7 +73,7 @@ class SuperRV:
         return next(iter(self.rvs)).values
 
     def update_nb(self, representative=None):
-        rv = representative if representative is not None else min(self.rvs)
+        rv = representative if representative is not None else (min(self.rvs) if self._order is None else self._order[0])
         self.count = Counter(f.cluster for f in rv.nb)
         self.nb = tuple(self.count)
         self.N = rv.N
@@ -80,8 +85,9 @@ class SuperRV:
 class SuperF:
     """Cluster of ground factors (``CompressedGraphWithObs.py:133-150``)."""
 
-    def __init__(self, factors, cid=-1):
+    def __init__(self, factors, cid=-1, order=None):
         self.factors = factors
+        self._order = order
         first = next(iter(factors))
         self.potential = first.potential
         self.log_potential_fun = getattr(first, 'log_potential_fun', None)
@@ -106,7 +112,7 @@ class SuperF:
         return next(iter(self.factors)).nb_domain_types
 
     def update_nb(self, representative=None):
-        f = representative if representative is not None else min(self.factors)
+        f = representative if representative is not None else (min(self.factors) if self._order is None else self._order[0])
         self.nb = tuple(rv.cluster for rv in f.nb)
 
     def __repr__(self):
@@ -120,7 +126,7 @@ def initial_colors(g, is_split_cont_evidence=True):
     (Domain object, 'evidence') for continuous domains when ``is_split_cont_evidence`` is False.
     factors: one colour per potential under the potential's own ``__hash__`` / ``__eq__``.
     """
-    rvs, factors = list(g.rvs), list(g.factors)
+    rvs, factors = ground_order(g.rvs), ground_order(g.factors)
     table, rv_color = {}, np.zeros(len(rvs), dtype=np.int32)
     for i, rv in enumerate(rvs):
         if rv.value is None:
@@ -327,14 +333,14 @@ class CompressedGraph:
     def split_evidence(self, k=2, iteration=10, epsilon=0, use_sqrt=True):
         """k-means split of evidence clusters by value (CGWO:236-247; ``use_sqrt=False`` gives HLBP:250-266)"""
         rv_color, f_color = self.colors()
-        values = np.array([np.nan if rv.value is None else float(rv.value) for rv in self.g.rvs], dtype=np.float64)
+        values = np.array([np.nan if rv.value is None else float(rv.value) for rv in ground_order(self.g.rvs)], dtype=np.float64)
         new = split_evidence_colors(values, rv_color, k, iteration, epsilon, use_sqrt)
         self.set_colors(new, f_color)
 
     def evidence_variances(self):
         """np.var of the member values of every evidence cluster (``SuperRV.get_variance``)"""
         rv_color, _ = self.colors()
-        values = np.array([np.nan if rv.value is None else float(rv.value) for rv in self.g.rvs], dtype=np.float64)
+        values = np.array([np.nan if rv.value is None else float(rv.value) for rv in ground_order(self.g.rvs)], dtype=np.float64)
         out = []
         for c in np.unique(rv_color[~np.isnan(values)]):
             out.append(float(np.var(values[(rv_color == c) & ~np.isnan(values)])))
@@ -429,15 +435,15 @@ class CompressedGraph:
 
 def build_lifted_objects(g, rv_color, f_color):
     """``SuperRV`` / ``SuperF`` sets for a partition; cluster representative = member with the smallest id."""
-    rvs, factors = list(g.rvs), list(g.factors)
+    rvs, factors = ground_order(g.rvs), ground_order(g.factors)
     groups = {}
     for rv, c in zip(rvs, rv_color.tolist()):
         groups.setdefault(c, []).append(rv)
     fgroups = {}
     for f, c in zip(factors, f_color.tolist()):
         fgroups.setdefault(c, []).append(f)
-    super_rvs = [SuperRV(set(members), cid=c) for c, members in sorted(groups.items())]
-    super_fs = [SuperF(set(members), cid=c) for c, members in sorted(fgroups.items())]
+    super_rvs = [SuperRV(set(members), cid=c, order=members) for c, members in sorted(groups.items())]
+    super_fs = [SuperF(set(members), cid=c, order=members) for c, members in sorted(fgroups.items())]
     for s in super_rvs:
         s.update_nb()
     for s in super_fs:
@@ -509,6 +515,22 @@ def first_members(colors, n_colors, size):
     return out.long()
 
 
+def segment_sums(values, lengths):
+    """sums of consecutive runs of `values` (run s has lengths[s] entries), each a running sum in index order
+    (``lhvi_color_segment_sums`` on the GPU: torch's segmented reduction adds in a tree there, so the last bit of a cluster's
+    evidence value would depend on the device; CPU tensors: ``torch.segment_reduce``, which is sequential)"""
+    import torch
+    if values.device.type != 'cuda':
+        return torch.segment_reduce(values, 'sum', lengths=lengths, unsafe=True)
+    n = int(lengths.numel())
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=values.device)
+    torch.cumsum(lengths, 0, out=offsets[1:])
+    out = torch.empty(n, dtype=torch.float64, device=values.device)
+    vals = values.contiguous()
+    _abi.check(_abi.lib().lhvi_color_segment_sums(_abi.ptr(vals), _abi.ptr(offsets), n, _abi.ptr(out), _abi.stream_ptr()))
+    return out
+
+
 def _lift_reduce_device(flat, dg, rvc, fc):
     """the same reductions on the device, for colour arrays that are already there (``refine_flat(device_out=True)``): only
     lifted-size arrays come back to the host.  Evidence sums run over each cluster's observed members in ground order (one
@@ -527,7 +549,7 @@ def _lift_reduce_device(flat, dg, rvc, fc):
         oc = rl[obs_members]
         order = torch.sort(oc, stable=True).indices                   # members grouped by cluster, ground order inside
         lengths = torch.bincount(oc, minlength=nV)
-        sums = torch.segment_reduce(value[obs_members][order], 'sum', lengths=lengths, unsafe=True)
+        sums = segment_sums(value[obs_members][order], lengths)
         ob = ~torch.isnan(val)
         val[ob] = sums[ob] / mult_v[ob]
     var_ptr = dg.t['var_ptr'].long()

@@ -272,6 +272,23 @@ def test_first_members_of_colours():
         np.testing.assert_array_equal(got, want)
 
 
+def test_segment_sums_are_running_sums_in_index_order():
+    """``lhvi_color_segment_sums``: every segment summed left to right, bit for bit what NumPy's sequential ``add.at`` gives (torch's
+    segmented reduction on the GPU adds in a tree: a cluster's evidence value must not depend on where it was summed); empty
+    segments, one huge segment, a million small ones"""
+    import torch
+    from lhvi import lifting
+    rng = np.random.default_rng(0)
+    for n, nseg in ((0, 3), (1000, 37), (250_000, 5), (1_000_000, 400_000)):
+        vals = rng.uniform(-30, 30, n)
+        seg = np.sort(rng.integers(0, nseg, n)) if n else np.zeros(0, dtype=np.int64)
+        lengths = np.bincount(seg, minlength=nseg)
+        want = np.zeros(nseg)
+        np.add.at(want, seg, vals)
+        got = lifting.segment_sums(torch.from_numpy(vals).cuda(), torch.from_numpy(lengths).cuda()).cpu().numpy()
+        assert got.tobytes() == want.tobytes()
+
+
 def test_initial_colours_on_the_device_equal_the_host_numbering():
     """``lifting.initial_colors_device``: same colour ids (numbered by first appearance) as ``initial_colors_flat``, with and without
     the split of continuous evidence by value; -0.0 and 0.0 are one evidence value; a graph with discrete evidence and equal

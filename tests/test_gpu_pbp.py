@@ -1066,6 +1066,17 @@ def test_coarse_to_fine_on_arrays_equals_the_object_path(api, golden_dir, name):
     np.testing.assert_allclose(qc, qb, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize('seed', [5, 6, 13])
+def test_coarse_to_fine_on_random_instances_arrays_objects_and_flat_agree_bit_for_bit(api, seed):
+    """random RGM instances (template sizes, evidence with tied and distinct values, thresholds, k-means settings; the seeds are
+    three of those a soak of 40 found: evidence clusters of three and more members, whose value is a running sum, and runs whose last
+    sweep keeps the factor-side state) through arrays, through objects and without objects (``scripts/soak_c2f_random.py``)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'soak_c2f_random.py'), str(seed), '1'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and '1 of 1 seeds pass' in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
 def test_coarse_to_fine_with_the_device_sampler_listed_draws_change_nothing(api, golden_dir):
     """a coarse-to-fine state is rebuilt every sweep with the buffers of the previous one handed in: its first device draw may
     not touch `old_particles` (the particles the v -> f messages were evaluated at).  The listed draw (hidden continuous
