@@ -44,7 +44,19 @@ for seed in range(first, first + count):
     gflat = flatten(g, require_device_potentials=True)
     samples = np.clip(rng.normal(0, 8, (its + 1, gflat.V, n)), -50, 50)
     inject = lambda k, flat, q: samples[k][flat.rep_ground]
+    if seed % 4 == 3:
+        c2f = -1.0                 # every fourth instance: colour passing to the stable partition, then the sweeps
     try:
+        if c2f == -1.0:
+            a = HybridLBP(g, n=n, k_mean_k=kk, k_mean_iteration=kit, proposal_approximation='simple', sampler='device', seed=7)
+            a.run(its, c2f=-1)
+            c = HybridLBP.on_flat(gflat, n=n, k_mean_k=kk, k_mean_iteration=kit, proposal_approximation='simple', sampler='device', seed=7)
+            c.run_flat(its, c2f=-1)
+            for name in ('f2v', 'v2f', 'eta', 'q_dev', 'particles', 'old_particles', 'uniq'):
+                same(getattr(a, name), getattr(c, name), 'stable partition, objects vs on_flat: ' + name)
+            assert torch.isfinite(a.v2f).all()
+            ok += 1
+            continue
         runs = []
         for on_objects in (True, False):
             bp = HybridLBP(g, n=n, k_mean_k=kk, k_mean_iteration=kit, proposal_approximation='simple', sampler=inject)
