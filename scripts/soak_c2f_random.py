@@ -1,7 +1,8 @@
 """soak of the particle coarse-to-fine run on random instances: HybridLBP.run(it, c2f) through arrays (lhvi.c2f.run_c2f_flat), through
 Python objects per cluster (c2f_on_objects) and without any object (on_flat(...).run_flat) -- same partitions at every draw, same
 state arrays bit for bit.  Random RGM instances (template sizes, evidence patterns with tied and distinct values, c2f thresholds,
-k-means settings).  usage: python scripts/soak_c2f_random.py [first seed] [count]"""
+k-means settings), and -- third argument `hmln` / `mixed` -- instances of the paper-popularity hybrid MLN.
+usage: python scripts/soak_c2f_random.py [first seed] [count] [rgm | hmln | mixed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
@@ -23,26 +24,38 @@ def same(x, y, what):
 
 
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
+MODEL = sys.argv[3] if len(sys.argv) > 3 else 'rgm'          # rgm | hmln | mixed
 ok, t0 = 0, time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    C, B = int(rng.integers(4, 16)), int(rng.integers(2, 6))
-    rel = generators.rgm(C, B)
-    rel.ground_graph()
-    keys = [('market', 'c%d' % c) for c in range(C)] + [('loss', 'c%d' % c, 'b%d' % b) for c in range(C) for b in range(B)] + \
-           [('revenue', 'b%d' % b) for b in range(B)] + [('recession', 'all')]
-    pool = np.round(rng.uniform(-30, 30, int(rng.integers(1, 6))), 2)          # a few tied values ...
-    data = {}
-    for k in keys:
-        if rng.random() < rng.choice([0.05, 0.15, 0.4]):
-            data[k] = float(rng.choice(pool)) if rng.random() < 0.6 else float(np.round(rng.uniform(-30, 30), 3))     # ... and distinct ones
+    hmln = MODEL == 'hmln' or (MODEL == 'mixed' and seed % 3 == 2)
+    if hmln:
+        # the paper-popularity hybrid MLN (binary SameSession / PaperIn atoms, continuous popularities, ternary formulas)
+        C, B = int(rng.integers(3, 9)), int(rng.integers(2, 4))
+        rel = generators.paper_popularity(C, B, points=int(rng.choice([8, 12])))
+        rel.ground_graph()
+        data = {}
+        for k in rel.rvs_dict:
+            if rng.random() < rng.choice([0.1, 0.3, 0.6]):
+                data[k] = int(rng.integers(0, 2)) if k[0] in ('SameSession', 'PaperIn') else float(np.round(rng.choice([rng.uniform(0, 10), 2.5, 7.0]), 2))
+    else:
+        C, B = int(rng.integers(4, 16)), int(rng.integers(2, 6))
+        rel = generators.rgm(C, B)
+        rel.ground_graph()
+        keys = [('market', 'c%d' % c) for c in range(C)] + [('loss', 'c%d' % c, 'b%d' % b) for c in range(C) for b in range(B)] + \
+               [('revenue', 'b%d' % b) for b in range(B)] + [('recession', 'all')]
+        pool = np.round(rng.uniform(-30, 30, int(rng.integers(1, 6))), 2)          # a few tied values ...
+        data = {}
+        for k in keys:
+            if rng.random() < rng.choice([0.05, 0.15, 0.4]):
+                data[k] = float(rng.choice(pool)) if rng.random() < 0.6 else float(np.round(rng.uniform(-30, 30), 3))     # ... and distinct ones
     g, table = rel.add_evidence(data)
     rvs = list(g.rvs)
     n, its = int(rng.choice([5, 10, 16])), int(rng.integers(3, 7))
     c2f = float(rng.choice([0.0, 0.5, 5.0]))
     kk, kit = int(rng.choice([2, 3])), int(rng.choice([3, 10]))
     gflat = flatten(g, require_device_potentials=True)
-    samples = np.clip(rng.normal(0, 8, (its + 1, gflat.V, n)), -50, 50)
+    samples = np.clip(rng.normal(5, 4, (its + 1, gflat.V, n)), -15, 15) if hmln else np.clip(rng.normal(0, 8, (its + 1, gflat.V, n)), -50, 50)
     inject = lambda k, flat, q: samples[k][flat.rep_ground]
     if seed % 4 == 3:
         c2f = -1.0                 # every fourth instance: colour passing to the stable partition, then the sweeps
