@@ -672,7 +672,15 @@ __device__ __forceinline__ double fast_accumulate_floor(const AB* __restrict__ s
             acc2 = exp_accumulate_floor(acc2, fma(r2.b, X1, r2.a), sft.magic, tab);
             acc3 = exp_accumulate_floor(acc3, fma(r3.b, X1, r3.a), sft.magic, tab);
         }
+        // the remainder: term j + k stays with accumulator k and the accumulators are folded at the very end, as if the list were
+        // padded with zero terms to a multiple of four -- so a list that IS padded (the few-particle kernel runs every edge of a
+        // wavefront to the longest list among them) gives every edge the bits it would get alone, whatever shares its wavefront
+        if (j < jn) { const AB r0 = sh[j]; acc0 = exp_accumulate_floor(acc0, fma(r0.b, X1, r0.a), sft.magic, tab); }
+        if (j + 1 < jn) { const AB r1 = sh[j + 1]; acc1 = exp_accumulate_floor(acc1, fma(r1.b, X1, r1.a), sft.magic, tab); }
+        if (j + 2 < jn) { const AB r2 = sh[j + 2]; acc2 = exp_accumulate_floor(acc2, fma(r2.b, X1, r2.a), sft.magic, tab); }
         acc0 += acc2; acc1 += acc3;
+        round_down_off();
+        return (acc0 + acc1) * sft.scale;
     }
     for (; j + 2 <= jn; j += 2) {
         const AB r0 = sh[j], r1 = sh[j + 1];

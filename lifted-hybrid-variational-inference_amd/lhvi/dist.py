@@ -422,6 +422,10 @@ class ShardedRunner:
         D = _abi.PBP_DESC_BYTES
         off, cnt = cut(bp.n_heavy, pc['heavy'])
         s.heavy_desc, s.n_heavy = (bp.heavy_desc.data_ptr() + off * D if cnt else None), cnt
+        for name in ('small16', 'small32'):              # (heavy-class edges with few particles: four / two per wavefront)
+            off, cnt = cut(int(getattr(bp, 'n_' + name, 0)), pc.get(name, 0))
+            setattr(s, name + '_desc', (getattr(bp, name + '_desc').data_ptr() + off * D) if cnt else None)
+            setattr(s, 'n_' + name, cnt)
         off, cnt = cut(bp.n_light, pc['light'])
         s.light_desc, s.n_light = (bp.light_desc.data_ptr() + off * D if cnt else None), cnt
         off, cnt = cut(int(getattr(bp, 'n_pair', 0)), pc.get('pair', 0))
@@ -818,7 +822,6 @@ class OwnerRunner:
         self.plan = plan = OwnerPlan(flat, rank, world, var_owner=var_owner)
         self.rank, self.world, self.group = rank, world, group
         bp = EPBP(None, n=n, proposal_approximation=proposal_approximation, sampler='device', seed=seed)
-        bp.small_f2v = False
         bp._setup(None, flat=plan.flat, edge_key=plan.edge_key, edge_skip=plan.edge_skip)
         self.bp = bp
         bp.var_gid = _abi.to_dev(plan.var_gid)

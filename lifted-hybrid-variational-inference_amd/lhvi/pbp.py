@@ -146,7 +146,7 @@ class _ParticleSweep:
         # static work lists of the f -> v half sweep (which kernel serves which edge)
         pad = torch.zeros(1, dtype=torch.int32, device=dg.device)       # keeps the pointers non-null when a list is empty
         self.cq_edges = pad[:0]
-        self.part_counts = {'heavy': 0, 'light': 0, 'fast': 0, 'generic': 0, 'cq': 0, 'pair': 0}
+        self.part_counts = {'heavy': 0, 'light': 0, 'fast': 0, 'generic': 0, 'cq': 0, 'pair': 0, 'small16': 0, 'small32': 0}
         self.generic_pts_log2 = 6
         self.fast_desc = self.heavy_desc = self.light_desc = self.pair_desc = self.small16_desc = self.small32_desc = None
         self.n_heavy = self.n_light = self.n_pair = self.n_small16 = self.n_small32 = self.n_heavy_class = 0
@@ -174,7 +174,7 @@ class _ParticleSweep:
         def first_part(edges):      # entries of an (ordered) edge list with key 0
             return int((key_dev[edges.long()] == 0).sum().item()) if key_dev is not None and edges.numel() else 0
         self.part_counts = {'heavy': 0, 'light': 0, 'fast': 0, 'generic': first_part(self.generic_edges),
-                            'cq': first_part(self.cq_edges), 'pair': 0}
+                            'cq': first_part(self.cq_edges), 'pair': 0, 'small16': 0, 'small32': 0}
         self._fast_list = self.fast_edges if self.fast_edges.numel() else pad
         self._generic_list = self.generic_edges if self.generic_edges.numel() else pad
         # lanes per generic edge: smallest power of two covering its output points (particles + integral points)
@@ -205,7 +205,7 @@ class _ParticleSweep:
             # edges with few particles on both sides go four / two to a wavefront, whatever their number of integral points
             # (include/lhvi.h, small16_desc)
             small16 = small32 = torch.zeros_like(base)
-            if self.small_f2v and edge_key is None:
+            if self.small_f2v:
                 small16 = base & (words[:, 7] <= 16) & (words[:, 8] <= 16)
                 small32 = base & ~small16 & (words[:, 7] <= 32) & (words[:, 8] <= 32)
             small = small16 | small32
@@ -235,8 +235,10 @@ class _ParticleSweep:
             all_fast = self.fast_edges
             self.fast_edges = all_fast[rest].contiguous()
             self._fast_list = self.fast_edges if self.fast_edges.numel() else pad
-            self.part_counts.update(heavy=first_part(all_fast[heavy]), light=first_part(all_fast[light]),
-                                    fast=first_part(self.fast_edges))
+            # (sharded runs: every list is ordered interior part first -- all_fast is -- and split at these counts)
+            self.part_counts.update(heavy=first_part(all_fast[heavy & ~small]), light=first_part(all_fast[light]),
+                                    fast=first_part(self.fast_edges), small16=first_part(all_fast[small16]),
+                                    small32=first_part(all_fast[small32]))
             self._build_pairs(key_dev)
 
     def _build_pairs(self, key_dev):
