@@ -18,6 +18,8 @@ for seed in range(first, first + count):
     hmln = seed % 2 == 1
     if hmln:
         P, Tn = int(rng.integers(3, 10)), int(rng.integers(2, 4))
+        if os.environ.get('SOAK_HUBS'):
+            P, Tn = int(rng.integers(70, 200)), int(rng.integers(1, 3))          # a topic's popularity touches every paper
         rel = generators.paper_popularity(P, Tn, points=int(rng.choice([8, 20, 32])))
         rel.ground_graph()
         data = {}
@@ -26,6 +28,8 @@ for seed in range(first, first + count):
                 data[k] = int(rng.integers(0, 2)) if k[0] in ('SameSession', 'PaperIn') else float(np.round(rng.choice([rng.uniform(0, 10), 2.5, 7.0]), 2))
     else:
         C, B = int(rng.integers(4, 16)), int(rng.integers(2, 6))
+        if os.environ.get('SOAK_HUBS'):          # template variables with 70 ... 700 incident factors: the hub rows of the v -> f and proposal kernels
+            C, B = int(rng.integers(70, 700)), int(rng.integers(1, 3))
         rel = generators.rgm(C, B)
         rel.ground_graph()
         pool = np.round(rng.uniform(-30, 30, int(rng.integers(1, 4))), 2)
