@@ -40,6 +40,8 @@ for seed in range(first, first + count):
                 data[k] = int(rng.integers(0, 2)) if k[0] in ('SameSession', 'PaperIn') else float(np.round(rng.choice([rng.uniform(0, 10), 2.5, 7.0]), 2))
     else:
         C, B = int(rng.integers(4, 16)), int(rng.integers(2, 6))
+        if os.environ.get('SOAK_HUBS'):          # the shared atoms touch 70 ... 400 factors: hub rows in the lifted graphs of the early sweeps
+            C, B = int(rng.integers(70, 400)), int(rng.integers(1, 3))
         rel = generators.rgm(C, B)
         rel.ground_graph()
         keys = [('market', 'c%d' % c) for c in range(C)] + [('loss', 'c%d' % c, 'b%d' % b) for c in range(C) for b in range(B)] + \

@@ -15,6 +15,8 @@ ok, t0 = 0, time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     C, B = int(rng.integers(3, 40)), int(rng.integers(2, 12))
+    if os.environ.get('SOAK_HUBS'):              # rows of 33-512 entries (chunk sums) and of more than 512 (hub kernel) in the same graph
+        C, B = int(rng.integers(40, 1500)), int(rng.integers(1, 3))
     rel = generators.rgm(C, B)
     rel.ground_graph()
     keys = [('market', 'c%d' % c) for c in range(C)] + [('loss', 'c%d' % c, 'b%d' % b) for c in range(C) for b in range(B)] + \
