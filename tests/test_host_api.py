@@ -564,3 +564,34 @@ def test_vi_factor_lists_split():
     rg, _, _, _ = synth.rgm_flat(C=6, B=4, evidence_ratio=0.3, seed=0)
     o2, c2, _ = factor_lists(rg, 2, 3)
     assert c2 == (rg.F, 0, 0, 0, 0, 0)
+
+
+def test_ground_order_of_set_based_graphs_is_node_id_order():
+    """a reference-style Graph holds its rvs / factors in Python sets: the ground numbering (``flat.ground_order``) is creation order,
+    not set-iteration order (which follows object hashes and changes from process to process); lists keep their order.  A cluster's
+    evidence mean is the running sum of its members in that order -- the array path's order (``lifting.segment_sums``)."""
+    from lhvi import lifting
+    from lhvi.flat import flatten, ground_order
+    from lhvi.graph import Domain, F, Graph, RV
+    from lhvi.potentials import GaussianPotential
+    dom = Domain((-10, 10), continuous=True, integral_points=np.linspace(-10, 10, 5))
+    vals = [0.1, 0.7, 1e16, -1e16, 0.3, 0.2, None, None]
+    rvs = [RV(dom, v) for v in vals]
+    pot = GaussianPotential([0.0, 0.0], [[2.0, 0.5], [0.5, 2.0]])
+    fs = [F(pot, nb=[rvs[i], rvs[6 + i % 2]]) for i in range(6)]
+    g = Graph()
+    g.rvs, g.factors = set(rvs[::-1]), set(fs[::-1])
+    g.init_nb()
+    assert ground_order(g.rvs) == rvs and ground_order(g.factors) == fs and ground_order(rvs[::-1]) == rvs[::-1]
+    flat = flatten(g)
+    assert [flat.var_index[r] for r in rvs] == list(range(8))
+    # all observed variables in one cluster: the mean is the running sum in ground order, 1e16 and -1e16 included
+    rv_color = np.array([0, 0, 0, 0, 0, 0, 1, 2], dtype=np.int32)
+    f_color = np.arange(6, dtype=np.int32)
+    super_rvs, _ = lifting.build_lifted_objects(g, rv_color, f_color)
+    total = 0
+    for v in vals[:6]:
+        total += v
+    assert super_rvs[0].value == total / 6 and super_rvs[0].value != sum(sorted(vals[:6])) / 6
+    R = lifting._lift_reduce_host(flat, rv_color, f_color)
+    assert R['val'][0] == total / 6
