@@ -5,7 +5,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
 import numpy as np
-from lhvi import generators
+from lhvi import generators, lifting
 from lhvi.flat import flatten
 from lhvi.gabp import GaBP, GaLBP
 from oracle import oracle
@@ -40,6 +40,15 @@ for seed in range(first, first + count):
         b.run(its)
         mb = np.array([b.map(flat.rvs[v]) for v in hid])
         np.testing.assert_allclose(mb, mv[hid, 0], rtol=1e-9, atol=1e-9, err_msg='GaLBP vs ground')
+        # the array path of the same lifting: colours, refinement and the lifted graph without objects, GaBP on the lifted FlatGraph
+        rv0, f0, sym = lifting.initial_colors_flat(flat, True)
+        rvc, fc = lifting.refine_flat(flat, sym, rv0, f0)
+        orv, of = b.g.colors()
+        assert (oracle.canonical_labels(rvc) == oracle.canonical_labels(orv)) and (oracle.canonical_labels(fc) == oracle.canonical_labels(of)), 'partitions of the two liftings'
+        c = GaBP(lifting.lift_flat(flat, rvc, fc))
+        c.run(its)
+        mc = c._mu_var[rvc[hid], 0]
+        np.testing.assert_allclose(mc, mv[hid, 0], rtol=1e-9, atol=1e-9, err_msg='lifted on arrays vs ground')
         ok += 1
     except Exception as e:
         print('FAIL seed %d (C %d B %d evidence %d its %d): %s' % (seed, C, B, len(data), its, str(e)[:300].replace('\n', ' ')), flush=True)
