@@ -282,6 +282,59 @@ if 'cfg5' in which:
         colour_ms_per_round=1e3 * t_ref / max(st5.get('rounds', 1), 1), colour_GBs_at_120B_per_edge_round=120.0 * flat.E * st5.get('rounds', 0) / t_ref / 1e9,
         colour_refinement_by_radix_sort_s=t_ref_sort, lift_flat_device_assisted_s=t_lift_dev, lift_flat_host_s=t_lift, adam_iterations_per_s=20 / dt, fe_start=fe0, fe_after_20=vi.free_energy())
 
+if 'full_size' in which:
+    # size-independent parity properties at BASELINE's full size (cfg 5: the RGM template at 10.0 M ground edges, structured evidence),
+    # where no oracle finishes: (1) lifting is exact for Gaussian BP -- the counted sweep on the lifted graph (39 k edges) gives every
+    # ground variable the marginal the ground sweep over 10 M edges gives it; (2) the lifted free energy and gradient of the
+    # variational step equal the ground ones at parameters tied per cluster (multiplicities len(rv.rvs), len(f.factors), rv.count[f]:
+    # LVI:59-199 against VI:57-195); (3) hash-table and radix-sort refinement give the same colour arrays; (4) the device
+    # reductions of lift_flat equal the host ones
+    from lhvi.gabp import GaBP
+    from lhvi.vi import VarInference
+    flat, sym, rv0, f0 = synth.rgm_structured_flat()
+    dgf = _abi.DeviceGraph(flat)
+    rvc_d, fc_d = lifting.refine_flat(flat, sym, rv0, f0, dg=dgf, device_out=True)
+    rvc_s, fc_s = lifting.refine_flat(flat, sym, rv0, f0, dg=dgf, method=_abi.COLOR_SORT, device_out=True)
+    same_colours = bool((rvc_s == rvc_d).all()) and bool((fc_s == fc_d).all())
+    lflat = lifting.lift_flat(flat, rvc_d, fc_d, dg=dgf)
+    rvc, fc = rvc_d.cpu().numpy(), fc_d.cpu().numpy()
+    lflat_h = lifting.lift_flat(flat, rvc, fc)
+    same_lift = all(np.array_equal(getattr(lflat, k), getattr(lflat_h, k), equal_nan=True) for k in
+                    ('fac_ptr', 'edge_var', 'var_ptr', 'var_edge', 'edge_count', 'var_value', 'var_mult', 'fac_mult', 'fac_pot'))
+    del dgf
+    its = 10
+    ground, lifted = GaBP(flat), GaBP(lflat)
+    ground.run(its)
+    lifted.run(its)
+    hid = flat.var_hidden
+    mg, ml = ground._mu_var[hid], lifted._mu_var[rvc[hid]]
+    d_mu = float(np.abs(mg[:, 0] - ml[:, 0]).max())
+    d_var = float(np.abs(mg[:, 1] / ml[:, 1] - 1).max())
+    del ground, lifted
+    K_, T_ = 2, 3
+    lv = VarInference(None, K_, T_)
+    lv._setup_flat(lflat)
+    np.random.seed(0)
+    lv.init_param()
+    lv._grad()
+    gv = VarInference(None, K_, T_)
+    gv._setup_flat(flat)
+    d = lv._dev
+    gv._upload_params(d['w_tau'].cpu().numpy(), d['eta_c'].cpu().numpy()[rvc], d['tau_d'].cpu().numpy()[rvc])
+    gv._grad()
+    fe_l, fe_g = float(lv._dev['fe'].cpu().numpy()[0]), float(gv._dev['fe'].cpu().numpy()[0])
+    gw_l, gw_g = lv._dev['g_w'].cpu().numpy(), gv._dev['g_w'].cpu().numpy()
+    # the gradient of a cluster's parameters is the ground gradient of any one of its members (LVI:94-134 walks the factor clusters
+    # of ONE variable with rv.count[f]; the cluster size enters the free energy, not this gradient): every member against its cluster
+    gc_g, gc_l = gv._dev['g_c'].cpu().numpy(), lv._dev['g_c'].cpu().numpy()
+    contg = flat.var_hidden & flat.var_cont
+    d_gc = float(np.abs(gc_g[contg] - gc_l[rvc][contg]).max() / max(np.abs(gc_l).max(), 1e-300))
+    out(config='full-size properties, cfg 5 RGM (10.0 M ground edges -> %d lifted)' % lflat.E, ground_edges=int(flat.E), lifted_edges=int(lflat.E),
+        hash_and_sort_refinement_same_colours=same_colours, device_and_host_lift_same_graph=same_lift,
+        gabp_sweeps=its, max_abs_mu_lifted_vs_ground=d_mu, max_rel_var_lifted_vs_ground=d_var,
+        free_energy_lifted=fe_l, free_energy_ground=fe_g, rel_diff_free_energy=abs(fe_l - fe_g) / abs(fe_g),
+        max_rel_diff_g_w=float(np.abs(gw_l - gw_g).max() / np.abs(gw_g).max()), max_rel_diff_member_gradient_vs_cluster_gradient=d_gc)
+
 if 'c2fvi' in which:
     # C2FVarInference on the 10 M-edge RGM of cfg 5, on arrays: coarse start, evidence split by k-means under a shrinking threshold,
     # re-lift every 10 ADAM updates (C2FVarInference.py:301-352).  Reported: what a round spends re-lifting (evidence split, colour

@@ -366,3 +366,19 @@ def test_image_potentials_on_a_denoising_grid_match_the_oracle():
     clean = np.where((np.arange(rows)[:, None] // 8 + np.arange(cols)[None, :] // 8) % 2 == 0, 20.0, 90.0)
     assert np.isfinite(mp).all() and mp.min() >= -30 and mp.max() <= 130
     assert np.abs(mp - clean).mean() < np.abs(img - clean).mean()
+
+
+def test_full_size_properties_of_cfg5():
+    """BASELINE cfg 5 at its full size (10.0 M ground edges, where no oracle finishes), through size-independent properties
+    (`scripts/bench_configs.py full_size`): hash-table and radix-sort refinement give the same colours; device and host lifting the
+    same graph; the counted Gaussian sweep on the 39 k lifted edges gives every ground variable the ground sweep's marginal; the
+    lifted free energy, mixture-weight gradient and per-cluster gradients equal the ground ones at tied parameters"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'bench_configs.py'), 'full_size'], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['ground_edges'] >= 10_000_000 and d['lifted_edges'] < 50_000
+    assert d['hash_and_sort_refinement_same_colours'] and d['device_and_host_lift_same_graph']
+    assert d['max_abs_mu_lifted_vs_ground'] < 1e-12 and d['max_rel_var_lifted_vs_ground'] < 1e-12
+    assert d['rel_diff_free_energy'] < 1e-12 and d['max_rel_diff_g_w'] < 1e-11 and d['max_rel_diff_member_gradient_vs_cluster_gradient'] < 1e-12
