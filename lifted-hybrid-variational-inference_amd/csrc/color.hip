@@ -453,16 +453,60 @@ static int rank_and_scatter(Workspace& w, int n, int32_t* color_out, int32_t* re
     return check_launch();
 }
 
-// sums of consecutive runs of `values` in index order, one thread per run: the evidence value of a cluster is the RUNNING sum of
-// its members' values over its size (SuperRV.get_value, CompressedGraphWithObs.py:24-28; members in ground order here), and a
-// library segmented reduction adds in a tree -- the last bit of a cluster's value then depends on who summed it
+// sums of consecutive runs of `values` in index order: the evidence value of a cluster is the RUNNING sum of its members' values
+// over its size (SuperRV.get_value, CompressedGraphWithObs.py:24-28; members in ground order here), and a library segmented
+// reduction adds in a tree -- the last bit of a cluster's value then depends on who summed it.  A thread per run; a run of 256 or
+// more entries (the coarse stage of a coarse-to-fine schedule holds all 250 k observed atoms of a 10 M-edge model in a handful of
+// clusters) is streamed through LDS by the whole wavefront, 256 coalesced values at a time, and added up by one lane in order --
+// the same additions, ~10 cycles each instead of a dependent global load each.
+constexpr int SEG_LONG = 256;
 __global__ void __launch_bounds__(BLOCK) segment_sum_kernel(int n_segments, const double* __restrict__ values,
                                                            const int64_t* __restrict__ offsets, double* __restrict__ out) {
+    __shared__ double stage[BLOCK / WAVE][SEG_LONG];
     const int s = blockIdx.x * BLOCK + threadIdx.x;
-    if (s >= n_segments) return;
+    const int lane = threadIdx.x & 63;
+    double* buf = stage[threadIdx.x >> 6];
+    const int64_t lo = s < n_segments ? offsets[s] : 0, hi = s < n_segments ? offsets[s + 1] : 0;
+    const bool is_long = hi - lo >= SEG_LONG;
     double acc = 0.0;
-    for (int64_t i = offsets[s]; i < offsets[s + 1]; ++i) acc += values[i];
-    out[s] = acc;
+    if (!is_long) for (int64_t i = lo; i < hi; ++i) acc += values[i];
+    uint64_t todo = __ballot(is_long);
+    while (todo) {
+        const int l = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const int64_t a = __shfl(lo, l), b = __shfl(hi, l);
+        double run = 0.0;
+        // the next batch's loads are in flight while lane 0 adds the current one (a batch is ~2 500 cycles of dependent additions,
+        // a load round trip about as long)
+        double nxt[SEG_LONG / WAVE];
+#pragma unroll
+        for (int k = 0; k < SEG_LONG / WAVE; ++k) { const int64_t i = a + k * WAVE + lane; nxt[k] = i < b ? values[i] : 0.0; }
+        for (int64_t base = a; base < b; base += SEG_LONG) {
+            const int cnt = (int)(b - base < SEG_LONG ? b - base : SEG_LONG);
+#pragma unroll
+            for (int k = 0; k < SEG_LONG / WAVE; ++k) buf[k * WAVE + lane] = nxt[k];
+#pragma unroll
+            for (int k = 0; k < SEG_LONG / WAVE; ++k) { const int64_t i = base + SEG_LONG + k * WAVE + lane; nxt[k] = i < b ? values[i] : 0.0; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                int j = 0;
+                for (; j + 16 <= cnt; j += 16) {                    // sixteen LDS reads in flight, then their additions in order
+                    double t[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) t[k] = buf[j + k];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) run += t[k];
+                }
+                for (; j < cnt; ++j) run += buf[j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        run = __shfl(run, 0);
+        if (lane == l) acc = run;
+    }
+    if (s < n_segments) out[s] = acc;
 }
 
 }  // namespace lhvi
