@@ -6,8 +6,9 @@ import numpy as np
 
 def log_likelihood(g, assignment):
     """negative log of the unnormalised joint at `assignment` (``utils.py:6-15``)"""
+    from .flat import ground_order
     res = 0
-    for f in g.factors:
+    for f in ground_order(g.factors):        # (a set in the reference: creation order here, so the sum does not change from process to process)
         value = f.potential.get([assignment[rv] for rv in f.nb])
         if value == 0:
             return -np.inf
