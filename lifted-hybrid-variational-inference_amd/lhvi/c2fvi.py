@@ -303,7 +303,7 @@ def run_c2fvi_flat(flat, engine, K, iteration, lr, opts, init=None, observer=Non
     children inherit: C2FVI:39-60).  ``init``: optional (eta_c [V, K, 2], tau_d [V, K, D]) per ground variable.  Returns
     dict(rvc, fc (host arrays), flat (lifted), stage, params (per cluster), fe_log, obs_var, t, relift_s (seconds per round))."""
     import time as _time
-    from .lifting import initial_colors_flat, lift_flat
+    from .lifting import initial_colors_device, lift_flat
     torch = _abi.require_gpu()
     dg = dg or _abi.DeviceGraph(flat)
     values = flat.var_value
@@ -313,7 +313,8 @@ def run_c2fvi_flat(flat, engine, K, iteration, lr, opts, init=None, observer=Non
     obs_idx_d, obs_mask_d = _abi.to_dev(obs_idx), _abi.to_dev(obs)
     hid_d = flat.var_hidden & ~flat.var_cont
     D = int(flat.var_nstates[hid_d].max()) if hid_d.any() else 1
-    rvc0, fc0, sym = initial_colors_flat(flat, is_split_cont_evidence=False)       # C2FVI:302
+    rvc0_d, fc0_d, sym = initial_colors_device(flat, dg, is_split_cont_evidence=False)     # C2FVI:302 (on the device: lifting.py)
+    rvc0 = rvc0_d.cpu().numpy()
     nc = int(rvc0.max()) + 1
     tracked = np.zeros(nc, dtype=bool)
     tracked[np.unique(rvc0[obs & flat.var_cont])] = True                           # CGWO:204-210
@@ -345,7 +346,7 @@ def run_c2fvi_flat(flat, engine, K, iteration, lr, opts, init=None, observer=Non
             mean = np.bincount(oc, weights=ovals, minlength=n_colours) / n
             return np.bincount(oc, weights=(ovals - mean[oc]) ** 2, minlength=n_colours) / n
     t = 0
-    rvc_d, fc_d = _abi.to_dev(rvc0), _abi.to_dev(fc0)
+    rvc_d, fc_d = rvc0_d, fc0_d
     rvc_d, fc_d, tracked, parent = cp_run_device(flat, sym, dg, rvc_d, fc_d, tracked, obs_mask_d)     # C2FVI:324
     inherit(parent)
     oc = rvc_d[obs_idx_d].cpu().numpy().astype(np.int64)
