@@ -2,9 +2,9 @@
 Python objects per cluster (c2f_on_objects) and without any object (on_flat(...).run_flat) -- same partitions at every draw, same
 state arrays bit for bit.  Random RGM instances (template sizes, evidence patterns with tied and distinct values, c2f thresholds,
 k-means settings), and -- third argument `hmln` / `mixed` -- instances of the paper-popularity hybrid MLN.
-usage: python scripts/soak_c2f_random.py [first seed] [count] [rgm | hmln | mixed]"""
+usage: python tests/soak/soak_c2f_random.py [first seed] [count] [rgm | hmln | mixed]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
 import numpy as np, torch
 from lhvi import generators

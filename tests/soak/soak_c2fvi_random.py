@@ -1,9 +1,9 @@
 """soak of the coarse-to-fine variational run on random instances: run_c2fvi_flat (ground arrays in: refinement and re-lifting on the
 device, parameters per cluster) against run_c2fvi (Python objects per cluster), same start -- every round's partition and Gaussian
 observations identical, free energies and final parameters to rounding.  Random RGM instances and evidence patterns.
-usage: python scripts/soak_c2fvi_random.py [first seed] [count]"""
+usage: python tests/soak/soak_c2fvi_random.py [first seed] [count]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
 import numpy as np, torch
 from lhvi import c2fvi, generators

@@ -1,9 +1,9 @@
 """soak of the two multi-GPU splits against the single-GPU sweep on random graphs: `world` simulated ranks on one GPU (loopback
 exchange), random hybrid MRFs (size, degree, share of discrete variables, evidence, grid size), particle counts, proposal rules.
 Owner-computes: proposals, particles and both message arrays bit for bit; factor-partitioned pairs exchange: to rounding (remote
-partial sums are added as a block).  usage: python scripts/soak_dist_random.py [first seed] [count]"""
+partial sums are added as a block).  usage: python tests/soak/soak_dist_random.py [first seed] [count]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
 import numpy as np, torch
 from lhvi import _abi, dist, synth

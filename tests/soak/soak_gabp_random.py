@@ -1,8 +1,8 @@
 """soak of the Gaussian sweep on random relational instances: GaBP(g).run through the device (pull form, recorded launches) against
 the C oracle's kernel-pair loops (1e-12), and GaLBP(g).run (colour passing + counted sweep) against GaBP on the ground graph
-(MAP of every hidden variable, 1e-9).  usage: python scripts/soak_gabp_random.py [first seed] [count]"""
+(MAP of every hidden variable, 1e-9).  usage: python tests/soak/soak_gabp_random.py [first seed] [count]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
 import numpy as np
 from lhvi import generators, lifting

@@ -2,9 +2,9 @@
 objects, flatten) against the array path (initial_colors_flat -> refine_flat -> lift_flat -> VarInference on the lifted FlatGraph)
 and against the C oracle on the same lifted graph: gradient and free energy after the reference's init_param draw, then after five
 ADAM updates.  Instances: the RGM (Gaussian pairs) and the paper-popularity hybrid MLN (binary atoms, ternary formulas) with random
-evidence.  usage: python scripts/soak_lvi_random.py [first seed] [count]"""
+evidence.  usage: python tests/soak/soak_lvi_random.py [first seed] [count]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
 import numpy as np, torch
 from lhvi import _abi, generators, lifting

@@ -1,9 +1,9 @@
 """soak of the particle sweep on random relational instances: EPBP(g).run on the ground graph and HybridLBP(g).run lifted (c2f = -1),
 'simple' and 'EP' proposals, 5 ... 64 particles, against the C oracle replaying the same samples on the same (lifted) graph:
 proposals, sites, v -> f and f -> v tables after the run.  Instances: the RGM (Gaussian pairs, 100 integral points) and the
-paper-popularity hybrid MLN (binary atoms, ternary formulas).  usage: python scripts/soak_pbp_random.py [first seed] [count]"""
+paper-popularity hybrid MLN (binary atoms, ternary formulas).  usage: python tests/soak/soak_pbp_random.py [first seed] [count]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
 import numpy as np, torch
 from lhvi import generators

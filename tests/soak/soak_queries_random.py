@@ -2,9 +2,9 @@
 against the reference's per-call forms (exact_queries = True: fminbound, the 20-point log_area) on random relational instances after
 HybridLBP / EPBP runs with stable and with coarse-to-fine partitions.  map: the batched maximum is at least as high as fminbound's
 (to 1e-9 in log-belief) and within 1e-4 of the domain width of it when the belief is unimodal on the scan; probability / belief: same
-formula, 1e-9.  usage: python scripts/soak_queries_random.py [first seed] [count]"""
+formula, 1e-9.  usage: python tests/soak/soak_queries_random.py [first seed] [count]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
 import numpy as np, torch
 from lhvi import generators

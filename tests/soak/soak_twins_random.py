@@ -1,9 +1,9 @@
 """soak of twin code paths that must not change a result, on random graphs: (a) the listed device draw (hidden continuous variables only)
 against the full one, (b) the heavy kernel's ticketed work distribution against static striding, (c) the recorded (hipGraph) Gaussian
 run against direct launches, (d) the fused ADAM loop against one call per step -- all bit for bit.
-usage: python scripts/soak_twins_random.py [first seed] [count]"""
+usage: python tests/soak/soak_twins_random.py [first seed] [count]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
 import numpy as np, torch
 from lhvi import _abi, dist, synth

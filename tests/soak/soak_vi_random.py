@@ -1,8 +1,8 @@
 """soak of tests/test_gpu_vi.py::test_random_hybrid_graphs_through_every_factor_kernel: many more seeds than the suite runs (random hybrid
 graphs through the tiny-grid, the group and the thread-per-factor kernels against the C oracle and against each other).
-usage: python scripts/soak_vi_random.py [first seed] [count]"""
+usage: python tests/soak/soak_vi_random.py [first seed] [count]"""
 import importlib.util, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd'), os.path.join(ROOT, 'tests')]
 spec = importlib.util.spec_from_file_location('t', os.path.join(ROOT, 'tests', 'test_gpu_vi.py'))
 t = importlib.util.module_from_spec(spec)

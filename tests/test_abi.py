@@ -82,6 +82,12 @@ def test_product_never_imports_oracle():
     assert hits.strip() == '', hits
     hits = subprocess.run(['grep', '-rIl', 'liboracle', PKG], capture_output=True, text=True).stdout
     assert hits.strip() == '', hits
+    # outside tests/ the oracle is named by __graft_entry__.py (build, smoke), bench.py (cpu_baseline) and the labelled CPU
+    # baselines of scripts/bench_configs.py only; the random-instance soaks, which check against it, live under tests/soak/
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hits = subprocess.run(['grep', '-rIl', '-E', r'^\s*(from|import)\s+oracle|from oracle import', os.path.join(root, 'scripts')],
+                          capture_output=True, text=True).stdout.split()
+    assert [os.path.relpath(h, root) for h in hits] == ['scripts/bench_configs.py'], hits
 
 
 def test_graft_entry_build_runs():

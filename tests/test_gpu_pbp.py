@@ -1070,10 +1070,10 @@ def test_coarse_to_fine_on_arrays_equals_the_object_path(api, golden_dir, name):
 def test_coarse_to_fine_on_random_instances_arrays_objects_and_flat_agree_bit_for_bit(api, seed):
     """random RGM instances (template sizes, evidence with tied and distinct values, thresholds, k-means settings; the seeds are
     three of those a soak of 40 found: evidence clusters of three and more members, whose value is a running sum, and runs whose last
-    sweep keeps the factor-side state) through arrays, through objects and without objects (``scripts/soak_c2f_random.py``)"""
+    sweep keeps the factor-side state) through arrays, through objects and without objects (``tests/soak/soak_c2f_random.py``)"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'soak_c2f_random.py'), str(seed), '1'], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'soak', 'soak_c2f_random.py'), str(seed), '1'], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and '1 of 1 seeds pass' in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
 
 
