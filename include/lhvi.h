@@ -141,7 +141,9 @@ typedef struct lhvi_gabp_plan {
                              * instead of the walk pots.kind -> pots.off -> pots.param */
     const int32_t* seg;     /* (ABI 9) [n_seg][2], required with rec: the slot order cut into segments [lo, hi) of whole rows -- the rows
                              * of at most 512 entries that start inside one window of 256 slots, up to the next row of more than 512
-                             * entries (those belong to the hub kernel) -- one workgroup each */
+                             * entries (those belong to the hub kernel) -- one workgroup each.  BOUND: hi - lo <= 768 (the kernel
+                             * stages a segment whole in LDS: window - 1 + 512 slots at most, window <= 256); a longer segment is
+                             * left unswept */
     int32_t n_seg;
 } lhvi_gabp_plan_t;
 size_t lhvi_gabp_pull_workspace_bytes(const lhvi_graph_t* g);
@@ -410,6 +412,27 @@ int lhvi_pbp_resample_uniq(const lhvi_graph_t* g, const lhvi_pbp_t* s, const int
  * qvar [nq] variable ids, x [nq][npts], out [nq][npts]; uses s->particles as the partners' sample. */
 int lhvi_pbp_belief_points(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f,
                            int32_t nq, const int32_t* qvar, int32_t npts, const double* x, double* out, void* stream);
+/* map(rv) of nq query rows in ONE launch: EPBP.map EPBP.py:377-394, HybridLBP.map HLBP.py:405-424.  Every continuous row runs
+ * scipy.optimize.fminbound (Brent's bounded minimiser, the reference's call with its defaults xtol = 1e-5, maxfun = 500) on
+ * f(x) = -belief_rv(x) over the row's domain [dom_lo, dom_hi], decision for decision, in IEEE double without contraction; a
+ * discrete row returns its first state with the largest belief.  row_var [nq]: the variable of g whose domain the row searches.
+ * qptr == NULL: the row's belief is belief_rv of row_var[i] (its incident edges, count-weighted on a lifted graph).
+ * qptr [nq + 1] / qedge / qmult: the row's belief is sum_k qmult[k] * message_f_to_rv(x, edge qedge[k]) for k in
+ * [qptr[i], qptr[i+1]) -- a GROUND variable's factors on the lifted graph (belief_rv_query HLBP.py:313-317).
+ * xout [nq] the minimiser, fout [nq] (optional) the log-belief there, nfev [nq] (optional) function evaluations used. */
+/* The normaliser of EPBP.belief for nq query rows in ONE launch: EPBP.py:325-328 calls scipy.integrate.quad on e ** belief_rv over
+ * [lo, hi] (= the domain widened by 20 on both sides).  A thread per row runs QUADPACK's 21-point Gauss-Kronrod rule (dqk21 and
+ * its error estimate) inside dqage's globally adaptive bisection (at most 50 intervals) until the summed error estimate meets
+ * max(epsabs, epsrel |z|); scipy's quad (dqagse) adds an extrapolation step to the same rule and bisection, so both lie within
+ * the tolerance of the integral (scipy's default request: 1.49e-8 for both).  Rows as for lhvi_pbp_map_brent.  z [nq] the integral
+ * (NaN where e ** belief_rv overflowed: the reference raises OverflowError there), abserr [nq] (optional) the error estimate,
+ * status [nq] (optional) 0 converged / 1 interval limit / 3 overflow. */
+int lhvi_pbp_quad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f, int64_t nq,
+                  const int32_t* row_var, const int64_t* qptr, const int32_t* qedge, const double* qmult, const double* lo,
+                  const double* hi, double epsabs, double epsrel, double* z, double* abserr, int32_t* status, void* stream);
+int lhvi_pbp_map_brent(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f, int64_t nq,
+                       const int32_t* row_var, const int64_t* qptr, const int32_t* qedge, const double* qmult, double xtol,
+                       int32_t maxfun, double* xout, double* fout, int32_t* nfev, void* stream);
 
 /* ---- owner-computes exchange of the edge-sharded sweep (lhvi/dist.py::OwnerRunner; csrc/halo.hip) ----------------------------
  * The reference is one process; these two calls move its `message[(rv, f)]` tables (EPBPLogVersion.py:250-258) and proposals

@@ -389,6 +389,9 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lh
     const double* __restrict__ pw = LDS_POTS ? sh_par : pot_words;
     const int2 sg = seg[blockIdx.x];
     const int lo_ext = sg.x, hi_ext = sg.y;
+    // a segment longer than the LDS stage (a plan not built by the rule of lhvi_gabp_plan_t.seg) is left unswept rather than
+    // written past the stage; the whole workgroup takes this exit, ahead of every barrier
+    if (hi_ext - lo_ext > CAP || hi_ext < lo_ext || lo_ext < 0 || hi_ext > g.nnz) return;
     int long_rows = 0;
     for (int j = lo_ext + threadIdx.x; j < hi_ext; j += BLOCK) {
         const int4 r = rec[j];

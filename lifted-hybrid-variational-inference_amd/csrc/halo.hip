@@ -17,7 +17,8 @@ template <bool PACK>
 __global__ void __launch_bounds__(BLOCK) halo_rows_kernel(int n, int n_rows, const int32_t* __restrict__ row_edge,
                                                           const int64_t* __restrict__ row_off, const int32_t* __restrict__ row_width,
                                                           double* __restrict__ v2f, double* __restrict__ buf) {
-    const int row = (blockIdx.x * BLOCK + threadIdx.x) / WAVE, lane = threadIdx.x & (WAVE - 1);
+    const int64_t row = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) / WAVE;      // (64-bit: n_rows * 64 passes 2^31 from 33 M rows on)
+    const int lane = threadIdx.x & (WAVE - 1);
     if (row >= n_rows) return;
     const int64_t e = row_edge[row], off = row_off[row];
     const int w = row_width[row];

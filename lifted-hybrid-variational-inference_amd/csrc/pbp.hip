@@ -1645,6 +1645,236 @@ __global__ void __launch_bounds__(BLOCK) pbp_edge_points_kernel(lhvi_graph_t g, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// map(rv) for every query row at once (EPBP.map EPBP:377-394; HLBP.map HLBP:405-424).  A row is either a variable of the
+// solver's graph (qvar: its incident edges, count-weighted on a lifted graph) or an explicit list of (edge, multiplicity)
+// pairs (qptr / qedge / qmult: a GROUND variable's factors on the lifted graph, belief_rv_query HLBP:313-317).
+struct QueryRows {
+    const int32_t* qvar; const int64_t* qptr; const int32_t* qedge; const double* qmult;
+};
+
+__device__ double query_log_belief(const lhvi_graph_t& g, const lhvi_pots_t& pots, const lhvi_pbp_t& s, const double* __restrict__ v2f,
+                                   const QueryRows& rows, int64_t i, int v, double x) {
+    double res = 0.0;
+    if (rows.qptr) {
+        for (int64_t k = rows.qptr[i]; k < rows.qptr[i + 1]; ++k) {
+            const int e = rows.qedge[k];
+            res += f2v_point_generic(g, pots, s, v2f, s.particles, e, x, state_index(g, g.edge_var[e], x)) * rows.qmult[k];
+        }
+    } else {
+        const int xi = state_index(g, v, x);
+        for (int k = g.var_ptr[v]; k < g.var_ptr[v + 1]; ++k) {
+            const int e = g.var_edge[k];
+            const double m = f2v_point_generic(g, pots, s, v2f, s.particles, e, x, xi);
+            res += g.edge_count ? m * g.edge_count[e] : m;
+        }
+    }
+    return res;
+}
+
+// One thread per row runs the whole of scipy.optimize.fminbound (SciPy's `_minimize_scalar_bounded`: Brent's golden-section /
+// parabolic-interpolation minimiser on [lo, hi], what the reference's map() calls with its defaults xtol = 1e-5, maxfun = 500)
+// on f(x) = -belief_rv(x): the same decisions in the same order, in IEEE double without contraction, so that every row steps
+// through the reference's iterates.  A discrete row returns the first state with the largest belief (`max` over a dict in
+// insertion order).  nfev [nq] (optional) receives the number of function evaluations.
+__global__ void __launch_bounds__(BLOCK) pbp_map_brent_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
+                                                             const double* __restrict__ v2f, int64_t nq, QueryRows rows,
+                                                             const int32_t* __restrict__ row_var,
+                                                             double xatol_third, int maxfun, double* __restrict__ xout,
+                                                             double* __restrict__ fout, int32_t* __restrict__ nfev) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nq) return;
+    const int v = row_var[i];                      // a variable of g whose domain the row searches
+    const int d = g.var_dom[v];
+    if (!g.dom_cont[d]) {
+        double best = 0.0, bestv = -__builtin_huge_val();
+        int evals = 0;
+        for (int k = g.dom_ptr[d]; k < g.dom_ptr[d + 1]; ++k, ++evals) {
+            const double val = query_log_belief(g, pots, s, v2f, rows, i, v, g.dom_val[k]);
+            if (k == g.dom_ptr[d] || val > bestv) { bestv = val; best = g.dom_val[k]; }
+        }
+        xout[i] = best;
+        if (fout) fout[i] = bestv;
+        if (nfev) nfev[i] = evals;
+        return;
+    }
+    const double sqrt_eps = 0x1.fda324be34921p-27;         // sqrt(2.2e-16)
+    const double golden_mean = 0x1.8722191a02d60p-2;       // 0.5 * (3 - sqrt(5))
+    double a = g.dom_lo[d], b = g.dom_hi[d];
+    double fulc = a + golden_mean * (b - a);
+    double nfc = fulc, xf = fulc;
+    double rat = 0.0, e = 0.0;
+    double x = xf;
+    double fx = -query_log_belief(g, pots, s, v2f, rows, i, v, x);
+    int num = 1;
+    double fu = __builtin_huge_val();
+    double ffulc = fx, fnfc = fx;
+    double xm = 0.5 * (a + b);
+    double tol1 = sqrt_eps * fabs(xf) + xatol_third;
+    double tol2 = 2.0 * tol1;
+    while (fabs(xf - xm) > (tol2 - 0.5 * (b - a))) {
+        bool golden = true;
+        if (fabs(e) > tol1) {                               // parabolic fit
+            golden = false;
+            double r = (xf - nfc) * (fx - ffulc);
+            double q = (xf - fulc) * (fx - fnfc);
+            double p = (xf - fulc) * q - (xf - nfc) * r;
+            q = 2.0 * (q - r);
+            if (q > 0.0) p = -p;
+            q = fabs(q);
+            r = e;
+            e = rat;
+            if ((fabs(p) < fabs(0.5 * q * r)) && (p > q * (a - xf)) && (p < q * (b - xf))) {
+                rat = (p + 0.0) / q;
+                x = xf + rat;
+                if (((x - a) < tol2) || ((b - x) < tol2)) {
+                    const double dm = xm - xf;
+                    const double si = (dm > 0.0 ? 1.0 : (dm < 0.0 ? -1.0 : 0.0)) + (dm == 0.0 ? 1.0 : 0.0);
+                    rat = tol1 * si;
+                }
+            } else {
+                golden = true;
+            }
+        }
+        if (golden) {
+            e = xf >= xm ? a - xf : b - xf;
+            rat = golden_mean * e;
+        }
+        const double si = (rat > 0.0 ? 1.0 : (rat < 0.0 ? -1.0 : 0.0)) + (rat == 0.0 ? 1.0 : 0.0);
+        x = xf + si * fmax(fabs(rat), tol1);
+        fu = -query_log_belief(g, pots, s, v2f, rows, i, v, x);
+        ++num;
+        if (fu <= fx) {
+            if (x >= xf) a = xf; else b = xf;
+            fulc = nfc; ffulc = fnfc;
+            nfc = xf; fnfc = fx;
+            xf = x; fx = fu;
+        } else {
+            if (x < xf) a = x; else b = x;
+            if ((fu <= fnfc) || (nfc == xf)) {
+                fulc = nfc; ffulc = fnfc;
+                nfc = x; fnfc = fu;
+            } else if ((fu <= ffulc) || (fulc == xf) || (fulc == nfc)) {
+                fulc = x; ffulc = fu;
+            }
+        }
+        xm = 0.5 * (a + b);
+        tol1 = sqrt_eps * fabs(xf) + xatol_third;
+        tol2 = 2.0 * tol1;
+        if (num >= maxfun) break;
+    }
+    xout[i] = xf;
+    if (fout) fout[i] = -fx;
+    if (nfev) nfev[i] = num;
+}
+
+// The normaliser of EPBP.belief (EPBP:325-328: scipy.integrate.quad of e ** belief_rv over [lo - 20, hi + 20]) for every query
+// row at once, a thread each: QUADPACK's 21-point Gauss-Kronrod rule (dqk21, with its error estimate) inside the globally adaptive
+// bisection of dqage -- the interval with the largest error estimate is halved until the summed estimate meets
+// max(epsabs, epsrel |result|), at most `limit` intervals.  scipy's quad (dqagse) runs the same rule and the same bisection and
+// adds the epsilon-algorithm extrapolation, so both answers lie within the requested tolerance (1.49e-8) of the integral:
+// they agree to ~1e-7 relative (tests/test_gpu_pbp.py pins 1e-6).  status: 0 converged, 1 interval limit reached,
+// 3 the integrand overflowed (e ** belief_rv = inf: the reference raises OverflowError there).
+constexpr int QUAD_LIMIT = 50;
+
+struct Gk21 { double result, abserr, resabs, resasc; bool overflow; };
+
+template <typename F>
+__device__ Gk21 gk21(F&& f, double a, double b) {
+    const double xgk[11] = {0.995657163025808080735527280689003, 0.973906528517171720077964012084452,
+                            0.930157491355708226001207180059508, 0.865063366688984510732096688423493,
+                            0.780817726586416897063717578345042, 0.679409568299024406234327365114874,
+                            0.562757134668604683339000099272694, 0.433395394129247190799265943165784,
+                            0.294392862701460198131126603103866, 0.148874338981631210884826001129720, 0.0};
+    const double wgk[11] = {0.011694638867371874278064396062192, 0.032558162307964727478818972459390,
+                            0.054755896574351996031381300244580, 0.075039674810919952767043140916190,
+                            0.093125454583697605535065465083366, 0.109387158802297641899210590325805,
+                            0.123491976262065851077958109585166, 0.134709217311473325928054001771707,
+                            0.142775938577060080797094273138717, 0.147739104901338491374841515972068,
+                            0.149445554002916905664936468389821};
+    const double wg[5] = {0.066671344308688137593568809893332, 0.149451349150580593145776339657697,
+                          0.219086362515982043995534934228163, 0.269266719309996355091226921569469,
+                          0.295524224714752870173815619188769};
+    const double epmach = 2.220446049250313e-16, uflow = 2.2250738585072014e-308;
+    const double centr = 0.5 * (a + b), hlgth = 0.5 * (b - a), dhlgth = fabs(hlgth);
+    double fv1[10], fv2[10];
+    const double fc = f(centr);
+    double resg = 0.0, resk = wgk[10] * fc, resabs = fabs(resk);
+    for (int j = 0; j < 5; ++j) {
+        const int jtw = 2 * j + 1;
+        const double absc = hlgth * xgk[jtw];
+        const double f1 = f(centr - absc), f2 = f(centr + absc);
+        fv1[jtw] = f1; fv2[jtw] = f2;
+        resg += wg[j] * (f1 + f2);
+        resk += wgk[jtw] * (f1 + f2);
+        resabs += wgk[jtw] * (fabs(f1) + fabs(f2));
+    }
+    for (int j = 0; j < 5; ++j) {
+        const int jtwm1 = 2 * j;
+        const double absc = hlgth * xgk[jtwm1];
+        const double f1 = f(centr - absc), f2 = f(centr + absc);
+        fv1[jtwm1] = f1; fv2[jtwm1] = f2;
+        resk += wgk[jtwm1] * (f1 + f2);
+        resabs += wgk[jtwm1] * (fabs(f1) + fabs(f2));
+    }
+    const double reskh = resk * 0.5;
+    double resasc = wgk[10] * fabs(fc - reskh);
+    for (int j = 0; j < 10; ++j) resasc += wgk[j] * (fabs(fv1[j] - reskh) + fabs(fv2[j] - reskh));
+    Gk21 r;
+    r.result = resk * hlgth;
+    r.resabs = resabs * dhlgth;
+    r.resasc = resasc * dhlgth;
+    r.abserr = fabs((resk - resg) * hlgth);
+    if (r.resasc != 0.0 && r.abserr != 0.0) r.abserr = r.resasc * fmin(1.0, pow(200.0 * r.abserr / r.resasc, 1.5));
+    if (r.resabs > uflow / (50.0 * epmach)) r.abserr = fmax((epmach * 50.0) * r.resabs, r.abserr);
+    r.overflow = !(fabs(resk) < __builtin_huge_val());
+    return r;
+}
+
+__global__ void __launch_bounds__(BLOCK) pbp_quad_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
+                                                        const double* __restrict__ v2f, int64_t nq, QueryRows rows,
+                                                        const int32_t* __restrict__ row_var, const double* __restrict__ lo,
+                                                        const double* __restrict__ hi, double epsabs, double epsrel,
+                                                        double* __restrict__ zout, double* __restrict__ errout,
+                                                        int32_t* __restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nq) return;
+    const int v = row_var[i];
+    auto f = [&](double x) { return exp(query_log_belief(g, pots, s, v2f, rows, i, v, x)); };
+    double alist[QUAD_LIMIT], blist[QUAD_LIMIT], rlist[QUAD_LIMIT], elist[QUAD_LIMIT];
+    Gk21 r = gk21(f, lo[i], hi[i]);
+    int n = 1, st = 0;
+    alist[0] = lo[i]; blist[0] = hi[i]; rlist[0] = r.result; elist[0] = r.abserr;
+    double area = r.result, errsum = r.abserr;
+    bool overflow = r.overflow;
+    double errbnd = fmax(epsabs, epsrel * fabs(area));
+    const bool done0 = (r.abserr <= errbnd && r.abserr != r.resabs) || r.abserr == 0.0;
+    if (!done0 && !overflow) {
+        st = 1;
+        while (n < QUAD_LIMIT) {
+            int m = 0;
+            for (int k = 1; k < n; ++k) if (elist[k] > elist[m]) m = k;
+            const double a1 = alist[m], b2 = blist[m], mid = 0.5 * (a1 + b2);
+            const Gk21 r1 = gk21(f, a1, mid), r2 = gk21(f, mid, b2);
+            overflow = overflow || r1.overflow || r2.overflow;
+            if (overflow) break;
+            errsum += (r1.abserr + r2.abserr) - elist[m];
+            area += (r1.result + r2.result) - rlist[m];
+            blist[m] = mid; rlist[m] = r1.result; elist[m] = r1.abserr;
+            alist[n] = mid; blist[n] = b2; rlist[n] = r2.result; elist[n] = r2.abserr;
+            ++n;
+            errbnd = fmax(epsabs, epsrel * fabs(area));
+            if (errsum <= errbnd) { st = 0; break; }
+        }
+    }
+    double total = 0.0;
+    for (int k = 0; k < n; ++k) total += rlist[k];
+    zout[i] = overflow ? __builtin_nan("") : total;
+    if (errout) errout[i] = errsum;
+    if (status) status[i] = overflow ? 3 : st;
+}
+
+// ---------------------------------------------------------------------------------------------
 // gaussian_division (EPBP:43-47)
 __device__ __forceinline__ void gdiv(double a0, double a1, double b0, double b1, double& mu, double& sig) {
     sig = a1 * b1 / (b1 - a1);
@@ -2532,6 +2762,34 @@ int lhvi_pbp_belief_points(const lhvi_graph_t* g, const lhvi_pots_t* pots, const
     if (!qvar || !x || !out) return LHVI_E_ARG;
     hipLaunchKernelGGL(pbp_belief_kernel, dim3(grid_for((int64_t)nq * npts)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, *s,
                        v2f, nq, qvar, npts, x, out);
+    return check_launch();
+}
+
+int lhvi_pbp_map_brent(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f, int64_t nq,
+                       const int32_t* row_var, const int64_t* qptr, const int32_t* qedge, const double* qmult, double xtol,
+                       int32_t maxfun, double* xout, double* fout, int32_t* nfev, void* stream) {
+    if (int rc = validate_pbp(g, s)) return rc;
+    if (!pots || !v2f || nq < 0 || maxfun < 1 || !(xtol > 0.0)) return LHVI_E_ARG;
+    if (nq == 0) return LHVI_OK;
+    if (!row_var || !xout || !g->dom_lo || !g->dom_hi || !g->dom_val) return LHVI_E_ARG;
+    if (qptr && (!qedge || !qmult)) return LHVI_E_ARG;
+    QueryRows rows{row_var, qptr, qedge, qmult};
+    hipLaunchKernelGGL(pbp_map_brent_kernel, dim3(grid_for(nq)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, *s, v2f, nq, rows,
+                       row_var, xtol / 3.0, maxfun, xout, fout, nfev);
+    return check_launch();
+}
+
+int lhvi_pbp_quad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f, int64_t nq,
+                  const int32_t* row_var, const int64_t* qptr, const int32_t* qedge, const double* qmult, const double* lo,
+                  const double* hi, double epsabs, double epsrel, double* z, double* abserr, int32_t* status, void* stream) {
+    if (int rc = validate_pbp(g, s)) return rc;
+    if (!pots || !v2f || nq < 0 || !(epsabs >= 0.0) || !(epsrel >= 0.0)) return LHVI_E_ARG;
+    if (nq == 0) return LHVI_OK;
+    if (!row_var || !lo || !hi || !z) return LHVI_E_ARG;
+    if (qptr && (!qedge || !qmult)) return LHVI_E_ARG;
+    QueryRows rows{row_var, qptr, qedge, qmult};
+    hipLaunchKernelGGL(pbp_quad_kernel, dim3(grid_for(nq)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, *s, v2f, nq, rows, row_var,
+                       lo, hi, epsabs, epsrel, z, abserr, status);
     return check_launch();
 }
 

@@ -149,6 +149,8 @@ SIGNATURES = {
     'lhvi_pbp_edge_points': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     'lhvi_pbp_resample_uniq': (C.c_int, [_G, _S, _vp, _u64, _u32, _vp, _vp, _vp]),
     'lhvi_pbp_belief_points': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
+    'lhvi_pbp_map_brent': (C.c_int, [_G, _P, _S, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32, _vp, _vp, _vp, _vp]),
+    'lhvi_pbp_quad': (C.c_int, [_G, _P, _S, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp]),
     'lhvi_vi_workspace_bytes': (_sz, [_G, _VI]),
     'lhvi_vi_grad': (C.c_int, [_G, _P, _VI, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'lhvi_vi_adam_run': (C.c_int, [_G, _P, _VI, C.POINTER(ViOptStruct), _i32, _vp, _vp, _sz, _vp]),

@@ -311,9 +311,23 @@ def split_evidence_observed(ovals, oc, nc, k, iteration, epsilon, use_sqrt):
     return out, nc
 
 
+def colour_mean_var(oc_t, vals_t, nc):
+    """(count, mean, variance) per colour of the observed members' values, every sum a running sum over the colour's members in
+    ground order -- ``numpy.bincount``'s order in the objects path -- whatever the device (a weighted ``torch.bincount`` adds with
+    atomics on the GPU: its last bit, and with it a ``spread > epsilon`` decision at a tie, would change from run to run)"""
+    import torch
+    from .lifting import segment_sums
+    cnt = torch.bincount(oc_t, minlength=nc)
+    order = torch.sort(oc_t, stable=True).indices
+    n = cnt.to(torch.float64)
+    mean = segment_sums(vals_t[order], cnt) / n
+    var = segment_sums(((vals_t - mean[oc_t]) ** 2)[order], cnt) / n
+    return n, mean, var
+
+
 def split_evidence_tensors(ovals_t, vcode_t, distinct_vals, oc_t, nc, k, iteration, epsilon, use_sqrt):
     """``split_evidence_observed`` with the grouping done by tensor operations on the colours' device: per-colour counts, means and
-    variances (three weighted ``bincount``s), then -- for the colours whose spread exceeds `epsilon` -- the distinct (colour, value)
+    variances (``colour_mean_var``: sequential sums in ground order), then -- for the colours whose spread exceeds `epsilon` -- the distinct (colour, value)
     pairs with multiplicities and first positions.  Only those pairs reach the host (a few per colour), where the k-means of
     ``SuperRV.split_by_evidence`` runs on them; the pieces' colours go back as a small table.  `ovals_t` / `vcode_t`: values of the
     observed members and their dense codes (``distinct_vals[code]``, host) in ground order; `oc_t`: their colours (int64).
@@ -322,9 +336,7 @@ def split_evidence_tensors(ovals_t, vcode_t, distinct_vals, oc_t, nc, k, iterati
     from .c2fvi import _kmeans_distinct
     from .lifting import first_members
     dev = oc_t.device
-    n = torch.bincount(oc_t, minlength=nc).to(torch.float64)
-    mean = torch.bincount(oc_t, weights=ovals_t, minlength=nc) / n
-    var = torch.bincount(oc_t, weights=(ovals_t - mean[oc_t]) ** 2, minlength=nc) / n
+    n, mean, var = colour_mean_var(oc_t, ovals_t, nc)
     spread = torch.sqrt(torch.nan_to_num(var)) if use_sqrt else torch.nan_to_num(var)
     todo = (n > 1) & (spread > epsilon)
     sel = torch.nonzero(todo[oc_t]).flatten()
@@ -464,9 +476,7 @@ def run_c2f_flat(gflat, tg, engine, refiner, iteration, c2f, k_mean_k, k_mean_it
         if not obs_idx.size:
             return np.zeros(0)
         oc = rvc[obs_idx_t].long()
-        n = torch.bincount(oc, minlength=nc).to(torch.float64)
-        mean = torch.bincount(oc, weights=ovals_t, minlength=nc) / n
-        var = torch.bincount(oc, weights=(ovals_t - mean[oc]) ** 2, minlength=nc) / n
+        n, mean, var = colour_mean_var(oc, ovals_t, nc)
         return var[n > 0].cpu().numpy()
 
     def record():

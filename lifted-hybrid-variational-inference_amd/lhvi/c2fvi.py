@@ -175,6 +175,20 @@ def run_c2fvi(g, engine, refiner, K, iteration, lr, opts, init=None, observer=No
         if observer is not None:
             observer(rnd, dict(rvc=rvc, fc=fc, tracked=set(tracked), flat=flat, obs_var=obs_var, params=P, t=t))
         stage = engine.stage(flat, obs_var)
+        if opts.get('log_map_likelihood'):
+            # the reference's other log (C2FVI:393-404): -log phi of the GROUND graph at the current MAP after every update; the
+            # MAP of a ground variable is its cluster's (same parameters), an observed one keeps its own value
+            def loglik(cmap, rvc=rvc):
+                from .utils import log_likelihood
+                assignment = {}
+                for i, rv in enumerate(gflat.rvs):
+                    if rv.value is not None:
+                        assignment[rv] = rv.value
+                    else:
+                        m = cmap[rvc[i]]
+                        assignment[rv] = float(m) if rv.domain.continuous else type(rv.domain.values[0])(m)
+                return log_likelihood(g, assignment)
+            stage.loglik = loglik
         local = {name: (a if name.endswith('w_tau') else np.ascontiguousarray(a[rep])) for name, a in P.items()}
         stage.load(local)
         fe_log += stage.adam(opts['update_obs_its'], t, lr)
@@ -382,6 +396,12 @@ def run_c2fvi_flat(flat, engine, K, iteration, lr, opts, init=None, observer=Non
             observer(rnd, dict(rvc=rvc_d.cpu().numpy(), fc=fc_d.cpu().numpy(), tracked=set(np.flatnonzero(tracked).tolist()), flat=lflat,
                                obs_var=obs_var, params=P, t=t))
         stage = engine.stage(lflat, obs_var)
+        if opts.get('log_map_likelihood'):
+            def loglik(cmap, rvc_d=rvc_d):
+                from .utils import log_likelihood_flat
+                x = _abi.to_dev(cmap)[rvc_d.long()]
+                return log_likelihood_flat(dg, torch.where(obs_mask_d, dg.t['var_value'], x))
+            stage.loglik = loglik
         stage.load(P)
         fe_log += stage.adam(opts['update_obs_its'], t, lr)
         t += opts['update_obs_its']
@@ -424,13 +444,21 @@ class _DeviceStage(_Variational):
                 dst[..., :w] = src[..., :w]
                 d[pre + name].copy_(_abi.to_dev(dst))
 
+    loglik = None          # set by the schedule for run(log_fe=False): cluster MAPs [V] -> -log phi of the ground graph there
+
     def adam(self, n, t, lr):
-        # (a round always logs the free energy after each update -- what the schedule's caller gets back -- whatever ``run`` was
-        # asked to log: the reference's other log, -log phi at the current MAP (C2FVI:393-404), needs the ground graph's MAP
-        # queries between updates and is not produced by the coarse-to-fine run)
-        self.is_log, self.log_fe = True, True
+        """n ADAM updates; returns what the reference logs after each of them: the free energy (``log_fe=True``), or with
+        ``loglik`` set -- ``run(log_fe=False)``, C2FVI:393-404 -- ``log_likelihood`` of the ground graph at the current MAP"""
         self.time_log, self.total_time = [], 0
         self.alpha, self.b1, self.b2, self.eps, self.t = lr, 0.9, 0.999, 1e-8, t
+        if self.loglik is not None:
+            self.is_log, self.log_fe = False, True
+            out = []
+            for _ in range(n):
+                self.ADAM_update(1)
+                out.append(self.loglik(self.map_rows()))
+            return out
+        self.is_log, self.log_fe = True, True
         self.ADAM_update(n)
         return [fe for _, fe in self.time_log]
 
@@ -473,8 +501,10 @@ class VarInference(_Variational):
         self.kmeans_member_order = None   # members -> permutation: the order k-means walks a cluster in (default: ground order)
 
     def _options(self):
-        return {k: getattr(self, k) for k in ('k_mean_k', 'k_mean_its', 'update_obs_its', 'output_its', 'min_obs_var', 'gaussian_obs',
+        opts = {k: getattr(self, k) for k in ('k_mean_k', 'k_mean_its', 'update_obs_its', 'output_its', 'min_obs_var', 'gaussian_obs',
                                               'kmeans_member_order')}
+        opts['log_map_likelihood'] = bool(self.is_log and not self.log_fe)      # C2FVI:393-404
+        return opts
 
     def run(self, iteration=100, lr=0.1, is_log=True, log_fe=True):
         self.is_log, self.log_fe = is_log, log_fe

@@ -111,29 +111,28 @@ def partition_factors(flat, world, partition='bfs'):
     return ((np.arange(F, dtype=np.int64) * world) // max(F, 1)).astype(dtype)
 
 
-def broadcast_partition(flat, rank, world, partition='bfs'):
-    """``partition_factors`` on rank 0, broadcast to the other ranks of the initialised process group (4 bytes per factor);
-    the other ranks never run the global breadth-first sweep"""
+def _broadcast_from_first(own, group=None):
+    """broadcast a host array from the first rank of `group` (None: the default group) to the others"""
     import torch
     import torch.distributed as td
+    t = torch.from_numpy(own)
+    if td.get_backend(group) == 'nccl':
+        t = t.cuda()
+    td.broadcast(t, td.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return t.cpu().numpy()
+
+
+def broadcast_partition(flat, rank, world, partition='bfs', group=None):
+    """``partition_factors`` on rank 0 (of `group`), broadcast to the other ranks of the initialised process group (4 bytes per
+    factor); the other ranks never run the global breadth-first sweep"""
     own = partition_factors(flat, world, partition) if rank == 0 else np.empty(flat.F, dtype=np.int32)
-    t = torch.from_numpy(own)
-    if td.get_backend() == 'nccl':
-        t = t.cuda()
-    td.broadcast(t, 0)
-    return t.cpu().numpy()
+    return _broadcast_from_first(own, group)
 
 
-def broadcast_variable_partition(flat, rank, world, partition='bfs'):
-    """``partition_variables`` on rank 0, broadcast to the other ranks (4 bytes per variable)"""
-    import torch
-    import torch.distributed as td
+def broadcast_variable_partition(flat, rank, world, partition='bfs', group=None):
+    """``partition_variables`` on rank 0 (of `group`), broadcast to the other ranks (4 bytes per variable)"""
     own = partition_variables(flat, world, partition) if rank == 0 else np.empty(flat.V, dtype=np.int32)
-    t = torch.from_numpy(own)
-    if td.get_backend() == 'nccl':
-        t = t.cuda()
-    td.broadcast(t, 0)
-    return t.cpu().numpy()
+    return _broadcast_from_first(own, group)
 
 
 class ShardPlan:
@@ -492,14 +491,14 @@ class ShardedRunner:
         recv = self.recv[:self.n_elems]         # symmetric: the rows shared with rank s are sent to and received from s
         splits = list(self.counts)
         work = None
-        if td.get_backend() == 'nccl':
+        if td.get_backend(self.group) == 'nccl':
             work = td.all_to_all_single(recv.view(-1), send.reshape(-1), output_split_sizes=splits, input_split_sizes=splits,
-                                        async_op=async_op)
+                                        async_op=async_op, group=self.group)
         else:
             # rehearsal backend (gloo): same collective on host copies
             h_send = send.reshape(-1).cpu()
             h_recv = h_send.new_empty(h_send.shape)
-            td.all_to_all_single(h_recv, h_send, output_split_sizes=splits, input_split_sizes=splits)
+            td.all_to_all_single(h_recv, h_send, output_split_sizes=splits, input_split_sizes=splits, group=self.group)
             recv.view(-1).copy_(h_recv)
         return (recv, work) if async_op else recv
 
@@ -514,28 +513,28 @@ class ShardedRunner:
         recvA = self.bufA[lay['a_recv_base']:lay['a_recv_base'] + self.a_recv_elems]
         sendB = self.bufB[:self.b_send_elems]
         recvB = self.bufB[lay['b_recv_base']:lay['b_recv_base'] + self.b_recv_elems]
-        if td.get_backend() != 'nccl':
+        if td.get_backend(self.group) != 'nccl':
             # rehearsal backend (gloo): same collectives on host copies
             h = torch.empty(self.a_recv_elems, dtype=torch.float64)
-            td.all_to_all_single(h, sendA.cpu(), output_split_sizes=lay['a_recv'], input_split_sizes=lay['a_send'])
+            td.all_to_all_single(h, sendA.cpu(), output_split_sizes=lay['a_recv'], input_split_sizes=lay['a_send'], group=self.group)
             recvA.copy_(h)
             self.owner_sums()
             h = torch.empty(self.b_recv_elems, dtype=torch.float64)
-            td.all_to_all_single(h, sendB.cpu(), output_split_sizes=lay['b_recv'], input_split_sizes=lay['b_send'])
+            td.all_to_all_single(h, sendB.cpu(), output_split_sizes=lay['b_recv'], input_split_sizes=lay['b_send'], group=self.group)
             recvB.copy_(h)
             return (recvB, None) if async_op else recvB
         if not async_op:
-            td.all_to_all_single(recvA, sendA, output_split_sizes=lay['a_recv'], input_split_sizes=lay['a_send'])
+            td.all_to_all_single(recvA, sendA, output_split_sizes=lay['a_recv'], input_split_sizes=lay['a_send'], group=self.group)
             self.owner_sums()
-            td.all_to_all_single(recvB, sendB, output_split_sizes=lay['b_recv'], input_split_sizes=lay['b_send'])
+            td.all_to_all_single(recvB, sendB, output_split_sizes=lay['b_recv'], input_split_sizes=lay['b_send'], group=self.group)
             return recvB
         if self.side is None:
             self.side = torch.cuda.Stream()
         self.side.wait_stream(torch.cuda.current_stream())            # the packed rows (own rows included) are ready
         with torch.cuda.stream(self.side):
-            td.all_to_all_single(recvA, sendA, output_split_sizes=lay['a_recv'], input_split_sizes=lay['a_send'])
+            td.all_to_all_single(recvA, sendA, output_split_sizes=lay['a_recv'], input_split_sizes=lay['a_send'], group=self.group)
             self.owner_sums(stream=self.side.cuda_stream)
-            work = td.all_to_all_single(recvB, sendB, output_split_sizes=lay['b_recv'], input_split_sizes=lay['b_send'], async_op=True)
+            work = td.all_to_all_single(recvB, sendB, output_split_sizes=lay['b_recv'], input_split_sizes=lay['b_send'], async_op=True, group=self.group)
         return recvB, work
 
     # -- phase 2: the rest of the sweep, reading the peers' rows straight from the receive buffer ---------------------
@@ -926,13 +925,13 @@ class OwnerRunner:
         L = self.lay
         recv = self.recv[:L['recv']['size']]
         work = None
-        if td.get_backend() == 'nccl':
+        if td.get_backend(self.group) == 'nccl':
             work = td.all_to_all_single(recv, send, output_split_sizes=L['recv']['counts'], input_split_sizes=L['send']['counts'],
-                                        async_op=async_op)
+                                        async_op=async_op, group=self.group)
         else:                                               # rehearsal backend (gloo): same collective on host copies
             h_send = send.cpu()
             h_recv = h_send.new_empty(L['recv']['size'])
-            td.all_to_all_single(h_recv, h_send, output_split_sizes=L['recv']['counts'], input_split_sizes=L['send']['counts'])
+            td.all_to_all_single(h_recv, h_send, output_split_sizes=L['recv']['counts'], input_split_sizes=L['send']['counts'], group=self.group)
             recv.copy_(h_recv)
         return (recv, work) if async_op else recv
 

@@ -64,7 +64,8 @@ def pull_plan(flat):
     start = flat.var_ptr[rows].astype(np.int64)
     is_hub = deg[rows] > 512
     # (a small graph is latency bound: narrower windows give it more, shorter workgroups)
-    window = int(os.environ.get('LHVI_GABP_WINDOW', 256 if nnz >= (1 << 17) else 64))
+    # (at most 256: the kernel stages a whole segment -- window - 1 + 512 slots at most -- in 768 LDS slots)
+    window = min(max(int(os.environ.get('LHVI_GABP_WINDOW', 256 if nnz >= (1 << 17) else 64)), 1), 256)
     group = np.cumsum(is_hub) * (nnz // window + 2) + start // window
     keep = ~is_hub
     r_start, r_end, r_group = start[keep], start[keep] + deg[rows][keep], group[keep]

@@ -40,8 +40,10 @@ class _ParticleSweep:
     sliced_proposal = True          # rows of more than prop_slice incident edges are cut into slices, a wavefront per slice
     prop_slice = 64
     packed_v2f = True               # variables with at most four particles share a wavefront in the v -> f half (sixteen each)
-    exact_queries = False           # map / probability / HybridLBP.belief answer per-variable calls from ONE batched pass over all
-                                    # variables, made at the first call after run() (True: one fminbound / log_area on the device per call)
+    exact_queries = False           # map / probability / belief answer per-variable calls from ONE batched pass over all
+                                    # variables, made at the first call after run() (True: one fminbound / log_area / quad per call)
+    map_mode = 'fminbound'          # what the batched map() runs per variable: the reference's fminbound iteration (lhvi_pbp_map_brent)
+                                    # or 'global': scan + bracket refinement (map_all)
 
     # ---- set-up ------------------------------------------------------------------------------
     def _setup(self, graph_like, flat=None, edge_key=None, sides='vf', edge_skip=None):
@@ -564,6 +566,66 @@ class _ParticleSweep:
             _abi.check(l.lhvi_pbp_refine_grid(self.dg.g, s, _abi.ptr(logb), _abi.ptr(x), _abi.ptr(best), _abi.ptr(val), st))
         return best.cpu().numpy(), val.cpu().numpy()
 
+    def _brent(self, row_var, pairs=None, xtol=1e-5, maxfun=500):
+        """``lhvi_pbp_map_brent`` on the rows `row_var` (variables of the solver's graph; with `pairs` = (ptr, edge, mult) the rows'
+        beliefs are sums over explicit (edge, multiplicity) lists).  Returns device tensors (x, log-belief, evaluations)."""
+        torch = _abi.require_gpu()
+        rv_t = row_var if torch.is_tensor(row_var) else _abi.to_dev(np.ascontiguousarray(row_var, dtype=np.int32))
+        rv_t = rv_t.to(torch.int32).contiguous()
+        nq = int(rv_t.numel())
+        x = torch.empty(nq, dtype=torch.float64, device=rv_t.device)
+        fx = torch.empty_like(x)
+        nfev = torch.empty(nq, dtype=torch.int32, device=rv_t.device)
+        qptr = qedge = qmult = None
+        if pairs is not None:
+            qptr, qedge, qmult = (t.contiguous() for t in pairs)
+            assert qptr.dtype == torch.int64 and qedge.dtype == torch.int32 and qmult.dtype == torch.float64 and qptr.numel() == nq + 1
+        _abi.check(_abi.lib().lhvi_pbp_map_brent(self.dg.g, self.dg.p, self._struct(), _abi.ptr(self.v2f), nq, _abi.ptr(rv_t),
+                                                 _abi.ptr(qptr), _abi.ptr(qedge), _abi.ptr(qmult), float(xtol), int(maxfun),
+                                                 _abi.ptr(x), _abi.ptr(fx), _abi.ptr(nfev), _abi.stream_ptr()))
+        return x, fx, nfev
+
+    def map_fminbound_all(self, xtol=1e-5, maxfun=500):
+        """MAP of every variable of the solver's graph the way the reference finds it (EPBP:377-394, HLBP:405-424): every
+        continuous hidden variable runs ``scipy.optimize.fminbound``'s iteration on ``-belief_rv`` over its domain -- all of
+        them in ONE launch, a thread each (``lhvi_pbp_map_brent``) -- and every discrete one takes its first state with the
+        largest belief.  Returns (map [V], log-belief [V], evaluations [V]) as host arrays; observed rows hold their value."""
+        flat = self.flat
+        if flat.lifted and not getattr(self, '_stable_partition', False):
+            raise NotImplementedError('batched queries on a lifted graph need a stable partition (run(c2f=-1))')
+        hid = np.flatnonzero(flat.var_hidden).astype(np.int32)
+        out = np.nan_to_num(np.array(flat.var_value, dtype=np.float64), nan=0.0)
+        val, nfev = np.zeros(flat.V), np.zeros(flat.V, dtype=np.int32)
+        if hid.size:
+            x, fx, k = self._brent(hid, xtol=xtol, maxfun=maxfun)
+            out[hid], val[hid], nfev[hid] = x.cpu().numpy(), fx.cpu().numpy(), k.cpu().numpy()
+        return out, val, nfev
+
+    def quad_all(self, margin=20.0, epsabs=1.49e-8, epsrel=1.49e-8):
+        """The normaliser of ``EPBP.belief`` (EPBP:325-328: ``quad`` of ``e ** belief_rv`` over the domain widened by 20 on both
+        sides) of every continuous hidden variable in ONE launch (``lhvi_pbp_quad``: QUADPACK's 21-point Gauss-Kronrod rule in its
+        adaptive bisection, to scipy's default tolerances; agrees with ``scipy.integrate.quad`` to ~1e-7 relative).  Returns host
+        arrays (z [V], status [V]); z is NaN where the integrand overflowed (the reference raises OverflowError there) and for
+        rows that are not continuous hidden variables."""
+        torch = _abi.require_gpu()
+        flat = self.flat
+        if flat.lifted and not getattr(self, '_stable_partition', False):
+            raise NotImplementedError('batched queries on a lifted graph need a stable partition (run(c2f=-1))')
+        rows = np.flatnonzero(flat.var_hidden & flat.var_cont).astype(np.int32)
+        z, st = np.full(flat.V, np.nan), np.zeros(flat.V, dtype=np.int32)
+        if rows.size:
+            dom = flat.var_dom[rows]
+            rv_t = _abi.to_dev(rows)
+            lo, hi = _abi.to_dev(flat.dom_lo[dom] - margin), _abi.to_dev(flat.dom_hi[dom] + margin)
+            zt = torch.empty(rows.size, dtype=torch.float64, device=rv_t.device)
+            et = torch.empty_like(zt)
+            stt = torch.empty(rows.size, dtype=torch.int32, device=rv_t.device)
+            _abi.check(_abi.lib().lhvi_pbp_quad(self.dg.g, self.dg.p, self._struct(), _abi.ptr(self.v2f), int(rows.size), _abi.ptr(rv_t),
+                                                None, None, None, _abi.ptr(lo), _abi.ptr(hi), float(epsabs), float(epsrel),
+                                                _abi.ptr(zt), _abi.ptr(et), _abi.ptr(stt), _abi.stream_ptr()))
+            z[rows], st[rows] = zt.cpu().numpy(), stt.cpu().numpy()
+        return z, st
+
     def _per_var(self, a):
         torch = _abi.require_gpu()
         t = torch.as_tensor(np.broadcast_to(np.asarray(a, dtype=np.float64), (self.flat.V,)).copy()) if not torch.is_tensor(a) else a
@@ -650,9 +712,12 @@ class _ParticleSweep:
         return c[name]
 
     def _cached_map(self):
-        """MAP of every row of the solver's graph (``map_all``: scan + bracket refinement to 1e-6 of the domain width, finer
-        than the 1e-5 tolerance ``fminbound`` stops at), as a host array"""
-        return self._query_cache('map', lambda: self.map_all(steps=6 if self.n >= 32 else 9)[0])
+        """MAP of every row of the solver's graph as a host array: the reference's ``fminbound`` iterates for all rows in one
+        launch (``map_fminbound_all``); with ``map_mode = 'global'`` the scan + bracket refinement of ``map_all`` (the highest
+        mode a 64-point scan sees, which need not be the one Brent's golden section runs into)"""
+        if self.map_mode == 'global':
+            return self._query_cache('map_global', lambda: self.map_all(steps=6 if self.n >= 32 else 9)[0])
+        return self._query_cache('map', lambda: self.map_fminbound_all()[0])
 
     def _cached_area(self):
         """(z, shift) of ``log_area`` over the domain with 20 points for every row (``log_area_all``), host arrays"""
@@ -760,6 +825,13 @@ class EPBP(_ParticleSweep):
         if rv.domain.continuous:
             if rv in self.cache:
                 z, shift = self.cache[rv]
+            elif not self.exact_queries and not inf_integral:
+                # the normalisers of all variables from one launch (quad_all), made at the first call after run()
+                zs, status = self._query_cache('quad', self.quad_all)
+                if status[v] == 3:
+                    raise OverflowError('(34, \'Numerical result out of range\')')      # e ** belief_rv overflowed, as in the reference (EPBP:326)
+                z, shift = float(zs[v]), 0
+                self.cache[rv] = (z, shift)
             else:
                 from scipy.integrate import quad
                 lb, ub = (-np.inf, np.inf) if inf_integral else (rv.domain.values[0] - 20, rv.domain.values[1] + 20)
@@ -1087,8 +1159,7 @@ class HybridLBP(_ParticleSweep):
         torch = _abi.require_gpu()
         hid, cont, lo, hi, _ = self._ground_rows()
         ci = np.flatnonzero(cont)
-        lin = np.linspace(0.0, 1.0, npts)[None, :] * (hi[ci] - lo[ci])[:, None] + lo[ci][:, None]
-        lin[:, -1] = hi[ci]
+        lin = np.linspace(lo[ci], hi[ci], npts, axis=1)          # the per-call form's abscissae, bit for bit (numpy.linspace per row)
         y = self.belief_rv_ground(hid[ci], lin).cpu().numpy() if ci.size else np.zeros((0, npts))
         mean, mx = y.mean(axis=1), y.max(axis=1)
         shift = np.where(mx - mean > self.max_log_value, mx - self.max_log_value, mean)
@@ -1108,10 +1179,31 @@ class HybridLBP(_ParticleSweep):
             return 'ground'
         return None
 
+    def ground_map_fminbound_all(self, xtol=1e-5, maxfun=500):
+        """MAP of every hidden GROUND variable the way ``HybridLBP.map`` finds it (HLBP:405-424: ``fminbound`` on
+        ``-belief_rv_query``; discrete: first state with the largest belief), all in one launch; works on any partition.
+        Returns (ground variable ids, MAP values)."""
+        hid, cont, lo, hi, _ = self._ground_rows()
+        ptr, edge, mult = self._ground_pairs()
+        torch = _abi.require_gpu()
+        hid_t = _abi.to_dev(hid.astype(np.int64))
+        deg = ptr[hid_t + 1] - ptr[hid_t]
+        qptr = torch.zeros(hid.size + 1, dtype=torch.int64, device=deg.device)
+        torch.cumsum(deg, 0, out=qptr[1:])
+        total = int(qptr[-1].item()) if hid.size else 0
+        owner = torch.repeat_interleave(torch.arange(hid.size, device=deg.device), deg, output_size=total)
+        idx = ptr[hid_t][owner] + (torch.arange(total, device=deg.device) - qptr[:-1][owner])
+        rows = self._ground['rvc'].to(torch.int32)[hid_t]
+        x, _, _ = self._brent(rows, pairs=(qptr, edge[idx], mult[idx]), xtol=xtol, maxfun=maxfun)
+        return hid, x.cpu().numpy()
+
     def _cached_ground(self, what):
         if what == 'map':
+            glob = self.map_mode == 'global'
+            what = 'map_global' if glob else 'map'
+
             def fill():
-                ids, vals = self.ground_map_all()
+                ids, vals = self.ground_map_all() if glob else self.ground_map_fminbound_all()
                 return dict(zip(ids.tolist(), vals.tolist()))
         else:
             def fill():

@@ -406,6 +406,37 @@ class _Variational:
         p = {x: self.belief(x, rv) for x in rv.domain.values}
         return max(p.keys(), key=lambda k: p[k])
 
+    def _row_belief(self, v, x):
+        """``belief(x, rv)`` of row `v` of the solver's graph (VI:333-353 for a single hidden variable)"""
+        b = np.copy(self._w_host())
+        if self.flat.var_cont[v]:
+            eta = self._host('eta_c')[v]
+            xi = x if np.ndim(x) == 0 else float(np.ravel(x)[0])
+            for k in range(self.K):
+                b[k] *= self.norm_pdf(xi, eta[k])
+        else:
+            b *= self._host('eta_d')[v, :, int(x)]
+        return np.sum(b)
+
+    def map_rows(self):
+        """``map`` (VI:355-376, C2FVI:439-461) of every hidden ROW of the solver's graph -- one ``scipy.optimize.minimize`` per
+        row instead of one per ground variable (the members of a cluster share its parameters, hence its answer).  Returns an
+        array [V]: the maximiser for a continuous row, the state VALUE for a discrete one, NaN for an observed one."""
+        from scipy.optimize import minimize
+        flat = self.flat
+        out = np.full(flat.V, np.nan)
+        for v in np.flatnonzero(flat.var_hidden):
+            if flat.var_cont[v]:
+                p = {x: self._row_belief(v, x) for x in self._host('eta_c')[v][:, 0]}
+                x0 = max(p.keys(), key=lambda k: p[k])
+                out[v] = minimize(lambda val: -self._row_belief(v, val), x0=np.array([x0]), options={'disp': False})['x'][0]
+            else:
+                d = flat.var_dom[v]
+                vals = flat.dom_val[flat.dom_ptr[d]:flat.dom_ptr[d + 1]]
+                p = [self._row_belief(v, i) for i in range(vals.size)]
+                out[v] = vals[int(np.argmax(p))]
+        return out
+
     def rvs_map(self, rvs):
         """VI:378-456: coordinate ascent on the joint mixture belief"""
         from scipy.optimize import minimize

@@ -9,7 +9,7 @@ The reference is pure Python; it imports under Python 3.10 / NumPy 2 once three 
 modified or copied: models are built with the reference's own classes, its solvers are run, and only
 *data* (serialised models, messages, marginals, partitions) is written out.
 
-usage: python oracle/capture_golden.py [gauss] [color] [pbp] [vi] [c2fvi] [robot | robot:grounding,lvi,c2fvi,epbp,hlbp]
+usage: python oracle/capture_golden.py [gauss] [color] [pbp] [vi] [c2fvi] [c2fvi_loglik] [robot | robot:grounding,lvi,c2fvi,epbp,hlbp]
 """
 import collections
 import collections.abc
@@ -251,6 +251,9 @@ if __name__ == '__main__':
     if 'c2fvi' in what:
         from capture_vi import capture_c2f
         capture_c2f(sys.modules[__name__])
+    if 'c2fvi_loglik' in what:
+        from capture_vi import capture_c2f_loglik
+        capture_c2f_loglik(sys.modules[__name__])
     for w in what:
         if w.split(':')[0] == 'robot':
             from capture_robot import capture_robot

@@ -188,7 +188,7 @@ def _c2f_state(cg, vi, g):
     return st
 
 
-def capture_c2fvi(cg, name, g, K, T, seed, iterations, lr, update_obs_its=10):
+def capture_c2fvi(cg, name, g, K, T, seed, iterations, lr, update_obs_its=10, log_fe=True):
     import C2FVarInference as RC
     vi = RC.VarInference(g, K, T)
     vi.update_obs_its = update_obs_its
@@ -218,7 +218,7 @@ def capture_c2fvi(cg, name, g, K, T, seed, iterations, lr, update_obs_its=10):
     np.random.seed(seed)
     try:
         with cg.quiet():
-            vi.run(iterations, lr=lr)
+            vi.run(iterations, lr=lr, log_fe=log_fe)
     finally:
         CGWO.SuperRV.split_by_evidence = orig_split
     vi.ADAM_update = orig_adam
@@ -239,7 +239,7 @@ def capture_c2fvi(cg, name, g, K, T, seed, iterations, lr, update_obs_its=10):
                                   if rv.value is None else np.nan for rv in rvs])
     rec['map'] = np.array([float(vi.map(rv)) for rv in rvs])
     rec['meta'] = json.dumps({'model': cg.modelio.dump_model(g), 'K': K, 'T': T, 'seed': seed, 'iterations': iterations,
-                              'lr': lr, 'update_obs_its': update_obs_its, 'solver': 'C2FVarInference',
+                              'lr': lr, 'update_obs_its': update_obs_its, 'solver': 'C2FVarInference', 'log_fe': log_fe,
                               'kmeans_orders': orders})
     path = os.path.join(cg.OUT, 'vi_%s.npz' % name)
     np.savez_compressed(path, **rec)
@@ -268,3 +268,10 @@ def _c2f_state_init(cg, vi, g):
 def capture_c2f(cg):
     capture_c2fvi(cg, 'c2f_rgm_k2', model_rgm_c2fvi(cg), 2, 3, 41, 30, 0.1)
     capture_c2fvi(cg, 'c2f_hmln_k2', model_hmln_c2fvi(cg), 2, 3, 42, 30, 0.2)
+
+
+def capture_c2f_loglik(cg):
+    """the run's OTHER log (C2FVarInference.py:393-404, run(log_fe=False)): -log phi of the ground graph at the current MAP after
+    every update -- the quantity of the reference's published HMLN logs (Demo/HMLN/HMLNTimeLog.py:57)"""
+    capture_c2fvi(cg, 'c2f_rgm_k2_loglik', model_rgm_c2fvi(cg), 2, 3, 44, 20, 0.1, log_fe=False)
+    capture_c2fvi(cg, 'c2f_hmln_k2_loglik', model_hmln_c2fvi(cg), 2, 3, 45, 20, 0.2, log_fe=False)

@@ -33,16 +33,26 @@ def _init(api, bp):
 
 
 def _check_per_variable_map(bp, rv, want, log_belief_at):
-    """``bp.map(rv)`` both ways: answered from the one batched pass made at the first call (default; finds the mode a scan of the
-    domain sees: the reference's value to 2e-4, or a point with a belief at least as large when the belief is multi-modal) and,
-    with ``exact_queries``, by fminbound on the device function (the reference's own iterates: 1e-4)"""
+    """``bp.map(rv)`` three ways: answered from the one batched pass made at the first call (default: every variable runs the
+    reference's fminbound iteration in one launch, ``lhvi_pbp_map_brent`` -- the reference's value to 1e-4, the tolerance of a run
+    whose objective agrees to ~1e-9 and stops at xtol = 1e-5); with ``exact_queries`` by scipy's fminbound on the device function,
+    one call per evaluation; and with ``map_mode = 'global'`` from the scan + bracket refinement (the reference's value, or a point
+    with a belief at least as large when the belief is multi-modal)"""
     got = bp.map(rv)
-    assert got == pytest.approx(want, abs=2e-4) or log_belief_at(got) >= log_belief_at(want) - 1e-9
+    assert got == pytest.approx(want, abs=1e-4)
     bp.exact_queries = True
     try:
-        assert bp.map(rv) == pytest.approx(want, abs=1e-4)
+        exact = bp.map(rv)
+        assert exact == pytest.approx(want, abs=1e-4)
+        assert got == pytest.approx(exact, abs=2e-6)          # the same iterates (the two sums differ in rounding at most)
     finally:
         bp.exact_queries = False
+    bp.map_mode = 'global'
+    try:
+        glob = bp.map(rv)
+        assert glob == pytest.approx(want, abs=2e-4) or log_belief_at(glob) >= log_belief_at(want) - 1e-9
+    finally:
+        bp.map_mode = 'fminbound'
 
 
 @pytest.mark.parametrize('name', EPBP_CASES)
@@ -92,6 +102,22 @@ def test_epbp_matches_reference_golden(api, golden_dir, name):
                 bp.belief(x0, rvs[int(i)])
             continue
         assert bp.belief(x0, rvs[int(i)]) == pytest.approx(want, rel=1e-5, abs=1e-7)
+    assert 'quad' in bp._batched                     # the normalisers of ALL variables came from one launch (lhvi_pbp_quad) ...
+    from scipy.integrate import quad
+    zs, status = bp.quad_all()
+    for i in [i for i in hid if flat.var_cont[i]][:8]:     # ... and are scipy.integrate.quad's of the same device function to 1e-6
+        if status[i] == 3:
+            continue
+        lo_, hi_ = rvs[i].domain.values[0] - 20, rvs[i].domain.values[1] + 20
+        want_z = quad(lambda val: np.e ** float(bp._belief_rv_points(i, [val])[0]), lo_, hi_)[0]
+        assert status[i] == 0 and zs[i] == pytest.approx(want_z, rel=1e-6)
+    bp.exact_queries, bp.cache = True, dict()        # one scipy quad per variable on the device function, as before
+    try:
+        for i, x0, want in z['belief'][:4]:
+            if not np.isnan(want):
+                assert bp.belief(x0, rvs[int(i)]) == pytest.approx(want, rel=1e-5, abs=1e-7)
+    finally:
+        bp.exact_queries, bp.cache = False, dict()
     # batched queries: every variable in one f2v launch -- the recorded log-beliefs again, and the reference's MAPs
     k = z['query_x'].shape[1]
     xq = bp.particles.cpu().numpy().copy()                 # discrete rows keep their states
@@ -108,6 +134,11 @@ def test_epbp_matches_reference_golden(api, golden_dir, name):
             # same mode as fminbound unless the belief is multi-modal: accept a better optimum, never a worse one
             ref_val = float(bp._belief_rv_points(i, [want])[0])
             assert mp[i] == pytest.approx(want, abs=2e-4) or mval[i] >= ref_val - 1e-9
+    # ... and the reference's own answer for EVERY variable from one launch of the batched fminbound
+    fm, fval, nfev = bp.map_fminbound_all()
+    for i in hid:
+        assert fm[i] == pytest.approx(z['map'][i], abs=1e-4)
+    assert 0 < nfev[hid].max() < 100
         else:
             assert mp[i] == want
     # interval probabilities (5-point over 20-point trapezoid, EPBP:356-375) against the reference's recorded values:
@@ -187,6 +218,10 @@ def test_hlbp_matches_reference_golden(api, golden_dir, name):
             assert mp[c] == pytest.approx(z['map'][i], abs=2e-4) or mval[c] >= ref_val - 1e-9
         else:
             assert mp[c] == z['map'][i]
+    fm, _, _ = bp.map_fminbound_all()                  # the reference's fminbound iterates, every cluster in one launch
+    for i in hid:
+        c = flat.var_index[rvs[i].cluster]
+        assert fm[c] == (pytest.approx(z['map'][i], abs=1e-4) if rvs[i].domain.continuous else z['map'][i])
     # batched normalised beliefs / interval probabilities: the per-variable queries for every cluster at once
     first = {}
     for i in hid:

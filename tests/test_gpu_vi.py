@@ -216,6 +216,29 @@ def test_c2f_var_inference_matches_reference(api, golden_dir, name):
             assert vi.map(rv) == rv.value
 
 
+@pytest.mark.parametrize('name', ['c2f_rgm_k2_loglik', 'c2f_hmln_k2_loglik'])
+def test_c2f_var_inference_logs_the_map_likelihood(api, golden_dir, name):
+    """``C2FVarInference.run(log_fe=False)`` (C2FVI:393-404; the quantity of the reference's published HMLN logs): after every
+    update ``log_likelihood`` of the ground graph at the MAP of every ground variable, through the objects and on arrays"""
+    from lhvi import c2fvi
+    from lhvi.flat import flatten
+    from test_oracle_vi import kmeans_order_of
+    z, meta = load_vi(golden_dir, name)
+    g, rvs, factors = modelio.load_model(meta['model'], API)
+    vi = c2fvi.VarInference(g, meta['K'], meta['T'])
+    vi.update_obs_its = meta['update_obs_its']
+    vi.kmeans_member_order = kmeans_order_of(meta)
+    vi.init = (z['eta_c0'], z['tau_d0'])
+    vi.run(meta['iterations'], lr=meta['lr'], log_fe=False)
+    got = [fe for _, fe in vi.time_log]
+    assert len(got) == meta['iterations']
+    np.testing.assert_allclose(got, z['fe_log'], rtol=1e-6, atol=1e-6)
+    vi.is_log, vi.log_fe = True, False
+    res = c2fvi.run_c2fvi_flat(flatten(g, require_device_potentials=True), c2fvi._DeviceEngine(vi), meta['K'], meta['iterations'],
+                               meta['lr'], vi._options(), init=(z['eta_c0'], z['tau_d0']))
+    np.testing.assert_allclose(res['fe_log'], z['fe_log'], rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize('name', ['hybrid_k2', 'lifted_hybrid_k2', 'lifted_rgm_small_k2', 'kalman_k3', 'lifted_robot_k2'])
 def test_fused_adam_loop_equals_the_per_array_calls(api, golden_dir, name):
     """lhvi_vi_adam_run (one gradient pass + one update launch per iteration, enqueued by a single call) against the loop of

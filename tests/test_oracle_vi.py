@@ -97,12 +97,56 @@ class OracleViEngine:
                         a[..., :min(a.shape[-1], src.shape[-1])] = src[..., :a.shape[-1]]
                         self.mom[pre + name] = a
 
+            loglik = None      # set by the schedule for run(log_fe=False)
+
             def adam(self, n, t, lr):
-                return self.o.run(n, lr, moments=self.mom, t0=t)
+                if self.loglik is None:
+                    return self.o.run(n, lr, moments=self.mom, t0=t)
+                out = []
+                for i in range(n):                        # C2FVI:393-404: -log phi of the ground graph at the MAP after every update
+                    self.o.run(1, lr, moments=self.mom, t0=t + i)
+                    out.append(self.loglik(_OracleRows(self.o, flat).map_rows()))
+                return out
 
             def dump(self):
                 return dict(w_tau=self.o.w_tau, eta_c=self.o.eta_c, tau_d=self.o.tau_d, **self.mom)
         return Stage()
+
+
+class _OracleRows:
+    """the product's host-side ``map_rows`` (lhvi/vi.py: scipy.optimize.minimize per hidden row, as VI:355-376) on the CPU
+    oracle's parameters"""
+    from lhvi.vi import _Variational as _V
+    norm_pdf, map_rows, _row_belief = staticmethod(_V.norm_pdf), _V.map_rows, _V._row_belief
+
+    def __init__(self, o, flat):
+        self.o, self.flat, self.K = o, flat, o.K
+
+    def _w_host(self):
+        return self.o.w
+
+    def _host(self, name):
+        return getattr(self.o, name)
+
+
+def test_c2fvi_logs_the_map_likelihood_like_the_reference(golden_dir):
+    """``run(log_fe=False)`` (C2FVI:393-404): after every update the reference logs ``log_likelihood`` of the GROUND graph at the
+    current MAP of every ground variable; the schedule computes one MAP per cluster and spreads it (CPU oracle as the engine)"""
+    from lhvi import c2fvi
+    from test_oracle_pbp import OracleRefiner
+    for name in ('c2f_rgm_k2_loglik', 'c2f_hmln_k2_loglik'):
+        z, meta = load_vi(golden_dir, name)
+        assert meta['log_fe'] is False
+        g, rvs, factors = modelio.load_model(meta['model'], API)
+        seen = []
+        res = c2fvi.run_c2fvi(g, OracleViEngine(meta['K'], meta['T']), OracleRefiner(g), meta['K'], meta['iterations'], meta['lr'],
+                              dict(C2F_OPTS, update_obs_its=meta['update_obs_its'], kmeans_member_order=kmeans_order_of(meta),
+                                   log_map_likelihood=True),
+                              init=(z['eta_c0'], z['tau_d0']), observer=c2fvi_round_checker(z, rvs, seen))
+        assert len(res['fe_log']) == meta['iterations'] == len(z['fe_log'])
+        # (a MAP is a BFGS answer to ~1e-6; -log phi is quadratic around it)
+        np.testing.assert_allclose(res['fe_log'], z['fe_log'], rtol=1e-6, atol=1e-6)
+        assert not np.allclose(res['fe_log'], [0.0] * len(z['fe_log']))
 
 
 def c2fvi_round_checker(z, rvs, seen):
