@@ -78,6 +78,32 @@ def progress(msg):
 
 
 _T0 = time.perf_counter()
+_PHASE = {'name': 'start', 'since': time.perf_counter(), 'limit': None}
+
+
+def phase(name, limit_s=None):
+    """name the phase this rank is in (one flushed line, rank tagged) and arm the watchdog for it: a phase that lasts longer than
+    `limit_s` (default: LHVI_BENCH_PHASE_TIMEOUT, 600 s) makes the process say which one and exit 124 -- a stuck collective ends
+    the run with a non-zero code and its name instead of hanging the node"""
+    _PHASE.update(name=name, since=time.perf_counter(), limit=limit_s)
+    progress('rank %s: %s' % (os.environ.get('RANK', '0'), name))
+
+
+def start_watchdog():
+    import threading
+    default = float(os.environ.get('LHVI_BENCH_PHASE_TIMEOUT', '600'))
+
+    def watch():
+        while True:
+            time.sleep(1.0)
+            limit = _PHASE['limit'] or default
+            waited = time.perf_counter() - _PHASE['since']
+            if waited > limit:
+                sys.stderr.write('[bench] rank %s STUCK in phase "%s" for %.0f s (limit %.0f s): exiting 124\n'
+                                 % (os.environ.get('RANK', '0'), _PHASE['name'], waited, limit))
+                sys.stderr.flush()
+                os._exit(124)
+    threading.Thread(target=watch, daemon=True).start()
 
 
 def cpu_baseline(n, T, seconds_target=15.0):
@@ -143,11 +169,16 @@ def main():
     ap.add_argument('--particles', type=int, default=64)
     ap.add_argument('--grid', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--exchange', choices=('pairs', 'owner', 'ownercompute'), default='pairs',
-                    help='multi-GPU runs: factors partitioned, boundary rows between every pair of ranks sharing a variable (one '
-                         'collective), or reduced to an owner rank and sent back (two smaller collectives); ownercompute: VARIABLES '
-                         'partitioned, every message computed where its target lives, v->f rows of cut edges + ghost proposals in '
-                         'one collective (bit-identical to one GPU)')
+    ap.add_argument('--exchange', choices=('pairs', 'owner', 'ownercompute'), default=None,
+                    help='multi-GPU runs, the split that `value` is quoted on (default: LHVI_BENCH_EXCHANGE or ownercompute): '
+                         'ownercompute: VARIABLES partitioned, every message computed where its target lives, v->f rows of cut '
+                         'edges + ghost proposals in one collective (bit-identical to one GPU); pairs: factors partitioned, boundary '
+                         'rows between every pair of ranks sharing a variable (one collective); owner: those rows reduced at an owner '
+                         'rank and sent back (two smaller collectives)')
+    ap.add_argument('--also', default=None,
+                    help='multi-GPU runs: comma-separated other splits to build, time and free after the first one in the same '
+                         'launch (default: the other of ownercompute / pairs; "none" to skip); all of them are printed under '
+                         '"exchanges" with their phases_ms')
     ap.add_argument('--proposal', choices=('simple', 'EP'), default='simple',
                     help="proposal rule of the sweep: 'simple' is what BASELINE.json's metric is quoted on; 'EP' is the reference's "
                          "default (EPBPLogVersion.py:20)")
@@ -162,7 +193,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
         raise SystemExit('--gpus %d does not match WORLD_SIZE=%d of the launcher' % (args.gpus, world))
+    primary = args.exchange or os.environ.get('LHVI_BENCH_EXCHANGE', 'ownercompute')
+    if args.also is None:
+        also = [x for x in ('ownercompute', 'pairs') if x != primary][:1]
+    else:
+        also = [x for x in args.also.split(',') if x and x != 'none' and x != primary]
+    for x in [primary] + also:
+        if x not in ('pairs', 'owner', 'ownercompute'):
+            raise SystemExit('unknown exchange %r' % x)
+    start_watchdog()
 
+    import datetime
     import torch
     from lhvi import _abi, synth, dist
     from lhvi.pbp import EPBP
@@ -179,34 +220,21 @@ def main():
     if world > 1:
         import torch.distributed as td
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # a collective that does not complete within this time is aborted by the process group's watchdog (RCCL) or raises
+        # (gloo): the run then ends non-zero instead of hanging; the phase watchdog above names where it stood
+        limit = datetime.timedelta(seconds=float(os.environ.get('LHVI_BENCH_COLLECTIVE_TIMEOUT', '300')))
+        phase('init_process_group (%s)' % backend)
         if backend == 'nccl':
-            td.init_process_group('nccl', device_id=torch.device('cuda', device_index))
+            td.init_process_group('nccl', device_id=torch.device('cuda', device_index), timeout=limit)
         else:
-            td.init_process_group(backend)
+            td.init_process_group(backend, timeout=limit)
 
-    progress('rank %d of %d on device %d' % (rank, world, device_index))
+    phase('rank %d of %d on device %d: building the graph' % (rank, world, device_index))
     n, T = args.particles, args.grid
     deg = 4
     V = args.edges // deg
     flat = synth.hybrid_mrf_flat(V=V, deg=deg, seed=0, T=T)     # identical on every rank (seeded)
     E_total = flat.E
-
-    if world == 1:
-        bp = EPBP(None, n=n, proposal_approximation=args.proposal, sampler='device', seed=1)
-        bp._setup(None, flat=flat)
-        runner = dist.SingleRunner(bp)
-    elif args.exchange == 'ownercompute':
-        runner = dist.OwnerRunner(flat, n=n, seed=1, rank=rank, world=world, proposal_approximation=args.proposal,
-                                  var_owner=dist.broadcast_variable_partition(flat, rank, world))
-    else:
-        # the factor partition (one breadth-first sweep of the whole graph) is computed on rank 0 only and broadcast; every
-        # rank then builds just its own slice of the plan
-        runner = dist.ShardedRunner(flat, n=n, seed=1, rank=rank, world=world, proposal_approximation=args.proposal,
-                                    fac_owner=dist.broadcast_partition(flat, rank, world),
-                                    owner_reduce=args.exchange == 'owner')
-    del flat
-    progress('graph on the device, work lists built')
-    runner.init()
 
     def barrier():
         torch.cuda.synchronize()
@@ -215,27 +243,68 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        runner.sweep()
-    barrier()
-    progress('%d warm-up sweeps done' % args.warmup)
-    if hasattr(runner, 'record_phases'):
-        runner.record_phases = True
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        runner.sweep(f2v_events=ev[i])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    progress('%d timed sweeps done in %.3f s' % (args.steps, elapsed))
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if os.environ.get('LHVI_DIST_BACKEND', 'nccl') == 'nccl' else 'cpu')
+    def build(exchange):
+        if world == 1:
+            bp = EPBP(None, n=n, proposal_approximation=args.proposal, sampler='device', seed=1)
+            bp._setup(None, flat=flat)
+            return dist.SingleRunner(bp)
+        if exchange == 'ownercompute':
+            phase('%s: variable partition on rank 0 + broadcast' % exchange)
+            owner = dist.broadcast_variable_partition(flat, rank, world)
+            phase('%s: this rank\'s plan and work lists' % exchange)
+            return dist.OwnerRunner(flat, n=n, seed=1, rank=rank, world=world, proposal_approximation=args.proposal, var_owner=owner)
+        # the factor partition (one breadth-first sweep of the whole graph) is computed on rank 0 only and broadcast; every
+        # rank then builds just its own slice of the plan
+        phase('%s: factor partition on rank 0 + broadcast' % exchange)
+        fac_owner = dist.broadcast_partition(flat, rank, world)
+        phase('%s: this rank\'s plan and work lists' % exchange)
+        return dist.ShardedRunner(flat, n=n, seed=1, rank=rank, world=world, proposal_approximation=args.proposal,
+                                  fac_owner=fac_owner, owner_reduce=exchange == 'owner')
+
+    def time_runner(runner, label):
+        """W untimed sweeps, then exactly K sweeps bracketed by barrier + synchronize on both sides; MAX over ranks"""
+        phase('%s: init' % label)
+        runner.init()
+        phase('%s: %d warm-up sweeps' % (label, args.warmup))
+        for _ in range(args.warmup):
+            runner.sweep()
+        barrier()
+        if hasattr(runner, 'record_phases'):
+            runner.record_phases = True
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        phase('%s: %d timed sweeps' % (label, args.steps))
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            runner.sweep(f2v_events=ev[i])
+        barrier()
+        elapsed = time.perf_counter() - t0
+        phase('%s: %d timed sweeps done in %.3f s on this rank; max over ranks' % (label, args.steps, elapsed))
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+        if world > 1:
+            import torch.distributed as td
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+        f2v_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))     # HIP events on the launch stream
+        # sharded runs may launch the dominant kernel twice per sweep (interior edges while the exchange is in flight, then the rest)
+        f2v_ms += float(sum(a.elapsed_time(b) for a, b in getattr(runner, 'f2v_extra', []))) / args.steps
+        return elapsed, f2v_ms
+
+    runner = build(primary if world > 1 else None)
+    elapsed, f2v_ms = time_runner(runner, primary if world > 1 else 'single GPU')
+    exchanges = None
     if world > 1:
-        import torch.distributed as td
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-    elapsed = float(t.item())
-    f2v_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))     # HIP events on the launch stream
-    # sharded runs launch the dominant kernel twice per sweep (interior edges while the exchange is in flight, then the rest)
-    f2v_ms += float(sum(a.elapsed_time(b) for a, b in getattr(runner, 'f2v_extra', []))) / args.steps
+        def line(r, el):
+            return {'value': args.steps / el, 'unit': 'sweeps/s', 'ms_per_step': 1e3 * el / args.steps,
+                    'phases_ms': r.phase_ms() if getattr(r, 'phase_ms', None) else None}
+        exchanges = {primary: line(runner, elapsed)}
+        for other in also:
+            # build, time, free: the other split of the same graph in the same launch, so that one node run compares them
+            r2 = build(other)
+            el2, _ = time_runner(r2, other)
+            exchanges[other] = line(r2, el2)
+            del r2
+            torch.cuda.empty_cache()
+    del flat
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         sweeps_per_s = args.steps / elapsed
@@ -275,8 +344,9 @@ def main():
                        'variables': V, 'particles': n, 'integral_points': T, 'proposal': args.proposal,
                        'sharding': 'single GPU' if world == 1 else
                                    ('variable-partitioned (owner computes), 1 all_to_all/sweep of cut-edge v->f rows + ghost proposals, overlapped with the interior part'
-                                    if args.exchange == 'ownercompute' else
-                                    'factor-partitioned edge shards, 1 all_to_all/sweep overlapped with the interior part')},
+                                    if primary == 'ownercompute' else
+                                    'factor-partitioned edge shards, 1 all_to_all/sweep overlapped with the interior part'),
+                       'exchange': None if world == 1 else primary},
             # the dominant kernel is compute bound (~40 flop per algorithmic byte): its roof is the fp64 VECTOR peak (the
             # kernel issues VALU FMAs; the term -- rank-2 outer product + exp -- has nothing for MFMA to do, and on gfx950
             # the fp64 matrix path shares the vector fp64 pipe anyway).  The HBM view BASELINE.json asks for is in 'hbm' /
@@ -309,10 +379,12 @@ def main():
         }
         if getattr(runner, 'phase_ms', None):
             out['phases_ms'] = runner.phase_ms()      # sharded runs: HIP-event times of pack / interior / exchange wait / boundary
+        if exchanges is not None:
+            out['exchanges'] = exchanges              # every split timed in this launch (`value` is the first one's)
         if not args.no_cpu_baseline and world == 1:
-            progress('CPU baseline: C oracle on a bounded sample')
+            phase('CPU baseline: C oracle on a bounded sample')
             Es, sw, dt, edge_rate, cores = cpu_baseline(n, T)
-            progress('CPU baseline: pure-Python restatement at 1e3 / 1e4 / 1e5 edges')
+            phase('CPU baseline: pure-Python restatement at 1e3 / 1e4 / 1e5 edges')
             py = python_baseline(n, T)
             out['cpu_baseline'] = {'value': edge_rate / (2.0 * E_total), 'unit': 'sweeps/s', 'cores': cores, 'kind': 'port',
                                    'edge_messages_per_sec': edge_rate,
@@ -329,10 +401,12 @@ def main():
                                                         % (n, T, py[0]['edges'], py[1]['edges'], py[2]['edges'], py[0]['f2v_edges_done'],
                                                            py[1]['f2v_edges_done'], py[2]['f2v_edges_done'], E_total),
                                               'runs': py}}
-        progress('done')
         print(json.dumps(out))
+        sys.stdout.flush()
+    phase('done')
     if world > 1:
         import torch.distributed as td
+        phase('destroy_process_group', 60)
         td.destroy_process_group()
 
 

@@ -503,7 +503,7 @@ class VarInference(_Variational):
     def _options(self):
         opts = {k: getattr(self, k) for k in ('k_mean_k', 'k_mean_its', 'update_obs_its', 'output_its', 'min_obs_var', 'gaussian_obs',
                                               'kmeans_member_order')}
-        opts['log_map_likelihood'] = bool(self.is_log and not self.log_fe)      # C2FVI:393-404
+        opts['log_map_likelihood'] = bool(getattr(self, 'is_log', True) and not getattr(self, 'log_fe', True))      # C2FVI:393-404
         return opts
 
     def run(self, iteration=100, lr=0.1, is_log=True, log_fe=True):

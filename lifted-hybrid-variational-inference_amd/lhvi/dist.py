@@ -303,6 +303,18 @@ def owner_exchange_layout(plan, bwidth):
                 a_send=a_send.tolist(), a_recv=a_recv.tolist(), b_send=b_send.tolist(), b_recv=b_recv.tolist())
 
 
+class _EventWork:
+    """what ``exchange(async_op=True)`` hands back when the exchange ran on a side stream: ``wait()`` makes the CURRENT stream wait
+    for the event recorded behind it (the call ``torch.distributed``'s work handle offers, on an event of ours)"""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        import torch
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class LoopbackGroup:
     """In-process stand-in for the all-to-all of `world` simulated ranks (single-GPU parity tests of the sharded path)."""
 
@@ -530,12 +542,19 @@ class ShardedRunner:
             return recvB
         if self.side is None:
             self.side = torch.cuda.Stream()
-        self.side.wait_stream(torch.cuda.current_stream())            # the packed rows (own rows included) are ready
+            self.packed, self.exchanged = torch.cuda.Event(), torch.cuda.Event()
+        # explicit ordering of the two buffers across the streams (not the collectives' work handles alone): the side stream
+        # starts when the compute stream has packed buffer A (`packed`); the compute stream may read buffer B -- and, one sweep
+        # later, overwrite buffer A -- only after `exchanged`, recorded on the side stream behind the first collective (reads A's
+        # send block, writes its receive block), the owners' sums (read A, write B) and the second collective (reads / writes B)
+        self.packed.record(torch.cuda.current_stream())
+        self.side.wait_event(self.packed)
         with torch.cuda.stream(self.side):
             td.all_to_all_single(recvA, sendA, output_split_sizes=lay['a_recv'], input_split_sizes=lay['a_send'], group=self.group)
             self.owner_sums(stream=self.side.cuda_stream)
-            work = td.all_to_all_single(recvB, sendB, output_split_sizes=lay['b_recv'], input_split_sizes=lay['b_send'], async_op=True, group=self.group)
-        return recvB, work
+            td.all_to_all_single(recvB, sendB, output_split_sizes=lay['b_recv'], input_split_sizes=lay['b_send'], group=self.group)
+            self.exchanged.record(self.side)
+        return recvB, _EventWork(self.exchanged)
 
     # -- phase 2: the rest of the sweep, reading the peers' rows straight from the receive buffer ---------------------
     def _f2v(self, s, f2v_events=None):

@@ -274,24 +274,11 @@ def test_bench_rejects_a_launcher_of_another_size():
 
 
 @pytest.mark.gpu
-def test_bench_owner_compute_flag_runs_two_ranks():
-    """`python bench.py --gpus 2 --exchange ownercompute` (gloo rehearsal backend, both ranks on the box's one GPU): the
-    variable-partitioned split end to end through the benchmark's own launcher, with its phase times in the JSON line"""
-    import json
-    r = _run_bench(['--gpus', '2', '--edges', '200000', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--exchange', 'ownercompute'],
-                   env={'LHVI_DIST_BACKEND': 'gloo'})
-    assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
-    assert out['n_gpus'] == 2 and out['value'] > 0 and 'owner computes' in out['config']['sharding']
-    ph = out['phases_ms']
-    assert ph['owned_variables'] > 0 and ph['ghost_variables'] > 0 and ph['cut_edge_rows_sent'] > 0 and ph['exchanged_MB_per_sweep'] > 0
-
-
-@pytest.mark.gpu
-def test_bench_starts_its_own_ranks():
-    """`python bench.py --gpus 2` without a launcher: the parent (no GPU call) starts two ranks under
-    torch.distributed.run, rank 0 prints the one JSON line; gloo rehearsal backend, both ranks on the box's one GPU.
-    The sharded result of the same command must equal the single-GPU line's workload."""
+def test_bench_times_both_splits_in_one_launch():
+    """`python bench.py --gpus 2` without a launcher (gloo rehearsal backend, both ranks on the box's one GPU): the parent (no GPU
+    call) starts two ranks under torch.distributed.run; rank 0 prints ONE JSON line whose `value` is the default split's
+    (owner computes) and whose `exchanges` holds every split timed in this launch -- the other one (factor-partitioned rows
+    between pairs) built, timed and freed after it -- each with its phase times, so that one node run compares them"""
     import json
     r = _run_bench(['--gpus', '2', '--edges', '200000', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'],
                    env={'LHVI_DIST_BACKEND': 'gloo'})
@@ -301,6 +288,29 @@ def test_bench_starts_its_own_ranks():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['value'] > 0 and out['config']['edges'] == 200000
     assert out['scaling'] == 'strong' and out['roofline']['bound'] == 'fp64_valu'
+    assert out['config']['exchange'] == 'ownercompute' and 'owner computes' in out['config']['sharding']
+    ex = out['exchanges']
+    assert list(ex) == ['ownercompute', 'pairs'] and ex['ownercompute']['value'] == out['value']
+    ph = ex['ownercompute']['phases_ms']
+    assert ph['owned_variables'] > 0 and ph['ghost_variables'] > 0 and ph['cut_edge_rows_sent'] > 0 and ph['exchanged_MB_per_sweep'] > 0
+    assert ex['pairs']['value'] > 0 and ex['pairs']['phases_ms']['boundary_variables'] > 0
+    # every rank named its phases on stderr (what a stuck run would end with)
+    assert 'rank 1: ownercompute: 3 timed sweeps' in r.stderr and 'rank 0: pairs: 3 timed sweeps' in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_flag_picks_the_split_and_a_stuck_phase_exits_non_zero():
+    """`--exchange pairs --also none`: one split only, the factor-partitioned one; and the phase watchdog: with a phase limit no
+    run can meet, every rank says where it stood and exits 124 instead of hanging"""
+    import json
+    r = _run_bench(['--gpus', '2', '--edges', '200000', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--exchange', 'pairs',
+                    '--also', 'none'], env={'LHVI_DIST_BACKEND': 'gloo'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert list(out['exchanges']) == ['pairs'] and 'factor-partitioned' in out['config']['sharding']
+    r = _run_bench(['--gpus', '2', '--edges', '200000', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'],
+                   env={'LHVI_DIST_BACKEND': 'gloo', 'LHVI_BENCH_PHASE_TIMEOUT': '0.001'})
+    assert r.returncode != 0 and 'STUCK in phase' in r.stderr
 
 
 @pytest.mark.gpu
@@ -623,6 +633,63 @@ def _owner_compute_gloo_worker(rank, world, port, out):
     out.put((rank, ok, int(R['row_edge'].size), int(R['q_var'].size)))
     td.barrier()
     td.destroy_process_group()
+
+
+def _subgroup_worker(rank, world, port, out):
+    """ranks 1 and 2 of three form a sub-group and run the owner-computes exchange inside it; rank 0 stays outside"""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'lifted-hybrid-variational-inference_amd')]
+    import torch
+    import torch.distributed as td
+    from lhvi import synth
+    from lhvi.dist import OwnerPlan, broadcast_partition, broadcast_variable_partition, partition_factors, partition_variables
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    members = [1, 2]
+    grp = td.new_group(members)                    # (every rank of the default group calls new_group)
+    ok, nrows = True, 0
+    if rank in members:
+        r, w = members.index(rank), len(members)
+        flat = synth.hybrid_mrf_flat(V=700, deg=4, seed=9)
+        # the partitions come from the GROUP's first rank (global rank 1), not from global rank 0
+        owner = broadcast_variable_partition(flat, r, w, group=grp)
+        fac_owner = broadcast_partition(flat, r, w, group=grp)
+        ok = ok and bool((owner == partition_variables(flat, w)).all()) and bool((fac_owner == partition_factors(flat, w)).all())
+        plan = OwnerPlan(flat, r, w, var_owner=owner)
+        n = 4
+        lf = plan.flat
+        lay = plan.layout(n, np.where(np.isnan(lf.var_value), np.where(lf.var_cont, n, 2), 0))
+        row = lambda ge: np.sin(0.1 * ge + np.arange(n))
+        S, R = lay['send'], lay['recv']
+        send = torch.zeros(max(S['size'], 1), dtype=torch.float64)
+        for e, o, wd in zip(S['row_edge'], S['row_off'], S['row_width']):
+            send[o:o + wd] = torch.from_numpy(row(plan.edge_ids[e])[:wd])
+        recv = torch.empty(R['size'], dtype=torch.float64)
+        td.all_to_all_single(recv, send[:S['size']], output_split_sizes=R['counts'], input_split_sizes=S['counts'], group=grp)
+        for e, o, wd in zip(R['row_edge'], R['row_off'], R['row_width']):
+            ok = ok and bool((recv[o:o + wd].numpy() == row(plan.edge_ids[e])[:wd]).all())
+        nrows = int(R['row_edge'].size)
+    out.put((rank, ok, nrows))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_partition_broadcast_and_exchange_on_a_sub_group():
+    """the runners take a process group: partitions are broadcast from the GROUP's first rank and the exchange runs inside the group
+    (three gloo processes, the group is ranks 1 and 2; ADVICE round 4: the collectives used to ignore the group they were given)"""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, 3, port, out)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == 0 and res[1][2] > 0 and res[2][2] > 0
 
 
 @pytest.mark.parametrize('world', [2, 3])
