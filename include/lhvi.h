@@ -27,12 +27,13 @@
 extern "C" {
 #endif
 
-#define LHVI_ABI_VERSION 9   /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
+#define LHVI_ABI_VERSION 10  /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
                               * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t;  7: lhvi_pbp_t gained pair_desc;
                               * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq; the colour
                               *    refinement calls take a method and return four result words; lhvi_vi_t gained var_N; lhvi_vi_opt_t, lhvi_vi_adam_run;
                               *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub / v2f_mid16 / v2f_mid32, prop_hub / prop_partial, resample_vars, small16_desc / small32_desc; 16 ticket words; lhvi_pbp_boundary_reduce;
-                              * 9: lhvi_vi_t gained fac_list / n_cc / n_tiny / n_grp3 / n_grp6 / n_rest3 / n_rest6 / edge_axis; lhvi_color_first_members, lhvi_color_segment_sums, lhvi_pbp_halo_pack / _unpack; lhvi_gabp_plan_t.rec */
+                              * 9: lhvi_vi_t gained fac_list / n_cc / n_tiny / n_grp3 / n_grp6 / n_rest3 / n_rest6 / edge_axis; lhvi_color_first_members, lhvi_color_segment_sums, lhvi_pbp_halo_pack / _unpack; lhvi_gabp_plan_t.rec;
+                              * 10: lhvi_pbp_t gained halo_off / halo_buf, LHVI_PBP_NO_UNIQ, edge_canon may name rows beyond E; lhvi_pbp_map_brent, lhvi_pbp_quad */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -64,7 +65,11 @@ typedef struct lhvi_graph {
     const int32_t* fac_ptr;     /* [F+1] */
     const int32_t* edge_var;    /* [E] variable of edge e */
     const int32_t* edge_fac;    /* [E] factor of edge e */
-    const int32_t* edge_canon;  /* [E] canonical edge of the (factor, variable) pair, or NULL if all e */
+    const int32_t* edge_canon;  /* [E] canonical edge of the (factor, variable) pair, or NULL if all e: the ROW of the message arrays that
+                                 * holds the pair's messages.  An edge with edge_canon[e] != e is served by no kernel (its messages are
+                                 * another row's).  (ABI 10) edge_canon[e] >= E is allowed for the particle sweep: a row of the caller's
+                                 * v -> f array BEHIND the graph's own E rows, where a message computed elsewhere arrives in place
+                                 * (the ghost edges of the owner-computes split, lhvi/dist.py::OwnerPlan.ghost_rows) */
     const int32_t* var_ptr;     /* [V+1] */
     const int32_t* var_edge;    /* [nnz] canonical edge ids in rv.nb order */
     const double* edge_count;   /* [E] lifted multiplicity rv.count[f], or NULL (ground: all 1) */
@@ -199,6 +204,8 @@ int lhvi_log_likelihood(const lhvi_graph_t* g, const lhvi_pots_t* pots, const do
 #define LHVI_PBP_SKIP_CQ 1024u   /* lhvi_pbp_f2v: do not launch the kernel of the cq_desc list (profiling aid) */
 #define LHVI_PBP_BOUNDARY_TOTALS 2048u /* sharded runs: a boundary variable's one listed row of s->recv holds the finished total over all ranks
                                         * (lhvi_pbp_boundary_reduce); without it the rows are the peers' sums and the kernels add them */
+#define LHVI_PBP_NO_UNIQ 4096u   /* lhvi_pbp_resample_uniq with a resample_vars list: draw the particles only, leave uniq_out untouched (ghost variables of
+                                  * the owner-computes split: their first-occurrence masks are read by nobody on this rank) */
 #define LHVI_PBP_NO_GRID 128u    /* lhvi_pbp_f2v: integral points always by the direct form (one exponential per term), never by the
                                    * uniform-grid recurrence (testing / profiling aid) */
 
@@ -313,6 +320,11 @@ typedef struct lhvi_pbp {
     int32_t n_small16;
     const void* small32_desc;
     int32_t n_small32;
+    /* (ABI 10) optional, lhvi_pbp_v2f only -- the owner-computes split of a sharded sweep (lhvi/dist.py::OwnerRunner): halo_off [E],
+     * per edge the element offset in halo_buf that its v -> f row is ALSO written to as it is formed (the send buffer of the
+     * sweep's all_to_all: no pack pass re-reads the rows), or -1.  NULL: no copies. */
+    const int64_t* halo_off;
+    double* halo_buf;
 } lhvi_pbp_t;
 
 #define LHVI_PBP_DESC_BYTES 128

@@ -177,6 +177,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
         auto emit = [&](int e, double m) {
             // ground: sum over nb != f; lifted: own factor keeps count-1 copies (HLBP:182-191) -> total - m either way
             const double res = (total - m) + logw;
+            // owner-computes shards: the row of a cut edge goes to its place in the send buffer as it is formed (s.halo_off)
+            const int64_t halo = s.halo_off ? s.halo_off[e] : -1;
             if (nchunk == 1) {
                 // log_message_balance over the distinct keys (EPBP:204-215)
                 const double tot = wave_sum(uq ? res : 0.0);
@@ -186,7 +188,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
                 // decides, and the max reduction runs only in that (rare) case
                 if (__ballot(uq && (res - mean > s.max_log_value)))
                     shift = wave_max(uq ? res : -__builtin_huge_val()) - s.max_log_value;
-                if (valid) v2f[(int64_t)e * n + j] = res - shift;
+                if (valid) {
+                    v2f[(int64_t)e * n + j] = res - shift;
+                    if (halo >= 0) s.halo_buf[halo + j] = res - shift;
+                }
             } else if (valid) {
                 v2f[(int64_t)e * n + j] = res;       // balanced below once every chunk is written
             }
@@ -214,9 +219,14 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
             const double mean = wave_sum(lsum) / (double)wave_sum_i(lcnt);
             const double mx = wave_max(lmax);
             const double shift = (mx - mean > s.max_log_value) ? mx - s.max_log_value : mean;
+            const int64_t halo = s.halo_off ? s.halo_off[e] : -1;
             for (int c = 0; c < nchunk; ++c) {
                 const int j = c * 64 + lane;
-                if (j < np) v2f[(int64_t)e * n + j] -= shift;
+                if (j < np) {
+                    const double val = v2f[(int64_t)e * n + j] - shift;
+                    v2f[(int64_t)e * n + j] = val;
+                    if (halo >= 0) s.halo_buf[halo + j] = val;
+                }
             }
         }
     }
@@ -826,17 +836,23 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
 template <int WORK_CHUNK, int WAVES_PER_BLOCK = BLOCK / WAVE>
 struct WorkCursor {
     uint32_t* ticket;       // nullptr: static striding
-    int item, limit, left, stride, pending, lo;
+    int item, limit, left, stride, pending, lo, body, mid;
+    // A claim always advances the counter by WORK_CHUNK.  The first `body` positions of a part are real entries, claimed
+    // WORK_CHUNK at a time; behind them every claim stands for ONE entry of the part's tail zone [mid, limit): a wave that
+    // comes late then owes one entry, not a whole chunk -- a launch ends with the tail of a single entry per wave (what
+    // matters when a shard's list gives a wave only a few chunks), for one atomic per entry on ~2 entries per wave only.
     __device__ __forceinline__ int claim(int lane) const {
         int v = 0;
-        if (lane == 0) v = lo + (int)atomicAdd(ticket, (uint32_t)WORK_CHUNK);
-        return v;                                           // valid in lane 0
+        if (lane == 0) v = (int)atomicAdd(ticket, (uint32_t)WORK_CHUNK);
+        return v;                                           // a position, valid in lane 0
     }
+    __device__ __forceinline__ int entry_of(int pos) const { return pos < body ? lo + pos : mid + (pos - body) / WORK_CHUNK; }
+    __device__ __forceinline__ int chunk_of(int pos) const { return pos < body ? WORK_CHUNK - 1 : 0; }       // entries left after the first
     // with tickets the list is cut into one contiguous range per XCD (workgroup i runs on XCD i mod 8, and each XCD has
     // its own L2: its waves then walk one region of the descriptors, particles and messages), each with its own counter
     __device__ __forceinline__ bool start(uint32_t* base, int nitems, int lane) {
         stride = gridDim.x * WAVES_PER_BLOCK;
-        left = 0; pending = 0; lo = 0; limit = nitems;
+        left = 0; pending = 0; lo = 0; limit = nitems; body = 0; mid = 0;
         ticket = base;
         if (ticket) {
             const int parts = min((int)gridDim.x, LHVI_PBP_TICKET_COUNTERS);
@@ -844,10 +860,15 @@ struct WorkCursor {
             const int per = ((nitems + parts - 1) / parts + WORK_CHUNK - 1) / WORK_CHUNK * WORK_CHUNK;
             lo = min(part * per, nitems);
             limit = min(lo + per, nitems);
+            const int waves = (gridDim.x + parts - 1) / parts * WAVES_PER_BLOCK;          // waves that draw from this counter
+            const int tail = min(limit - lo, 2 * waves);
+            body = (limit - lo - tail) / WORK_CHUNK * WORK_CHUNK;
+            mid = lo + body;
             ticket = base + part;
-            item = __builtin_amdgcn_readfirstlane(claim(lane));
+            const int first = __builtin_amdgcn_readfirstlane(claim(lane));
+            item = entry_of(first);
+            left = chunk_of(first);
             pending = claim(lane);
-            left = WORK_CHUNK - 1;
         } else {
             item = blockIdx.x * WAVES_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         }
@@ -855,12 +876,12 @@ struct WorkCursor {
     }
     __device__ __forceinline__ int next() const {           // the entry after `item` (>= limit: none)
         if (!ticket) return item + stride;
-        return left > 0 ? item + 1 : __builtin_amdgcn_readfirstlane(pending);
+        return left > 0 ? item + 1 : entry_of(__builtin_amdgcn_readfirstlane(pending));
     }
     __device__ __forceinline__ void advance(int nxt, int lane) {     // move to `nxt` = next()
         if (ticket) {
             if (left > 0) --left;
-            else { left = WORK_CHUNK - 1; pending = claim(lane); }
+            else { left = chunk_of(__builtin_amdgcn_readfirstlane(pending)); pending = claim(lane); }
         }
         item = nxt;
     }
@@ -2359,6 +2380,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
         for (int h = 0; h < 2; ++h) if (cont[h] && lane < n) uniq[(int64_t)vv[h] * n + lane] = (uint8_t)(lane < cnt[h]);
         continue;
 #endif
+        if (LISTED && (s.flags & LHVI_PBP_NO_UNIQ)) continue;      // particles only (ghost variables: nobody reads their masks here)
         if (!(cont[0] || cont[1])) continue;
         // first-occurrence masks of the (up to two) drawn rows, in step so that the LDS round trips are paid once.  Pass 1 only
         // asks "can two live particles be equal at all?": every lane sets the bit its low word hashes to in a wave-private LDS
@@ -2509,6 +2531,7 @@ int lhvi_debug_exp_acc(const double* x, const double* c, double* y, int64_t n, v
 int lhvi_pbp_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* v2f, void* stream) {
     if (int rc = validate_pbp(g, s)) return rc;
     if (!f2v || !v2f || !s->uniq || !s->q) return LHVI_E_ARG;
+    if (s->halo_off && (!s->halo_buf || s->v2f_wide || s->v2f_narrow)) return LHVI_E_ARG;      // (copies are made by the range form only)
     if (g->V == 0) return LHVI_OK;
     if (s->v2f_wide || s->v2f_narrow) {
         // the caller's split of the hidden variables: one wavefront per variable / sixteen variables per wavefront

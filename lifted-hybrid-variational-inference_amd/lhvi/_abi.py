@@ -64,6 +64,7 @@ class PbpStruct(C.Structure):
         ('prop_hub', C.c_void_p), ('n_prop_hub', C.c_int32), ('prop_partial', C.c_void_p),
         ('resample_vars', C.c_void_p), ('n_resample_vars', C.c_int32),
         ('small16_desc', C.c_void_p), ('n_small16', C.c_int32), ('small32_desc', C.c_void_p), ('n_small32', C.c_int32),
+        ('halo_off', C.c_void_p), ('halo_buf', C.c_void_p),
     ]
 
 
@@ -94,8 +95,9 @@ PBP_NO_GRID = 128
 PBP_LEAVE_ROOM = 256
 PBP_BOUNDARY_TOTALS = 2048
 PBP_CQ = 512
+PBP_NO_UNIQ = 4096
 PBP_SKIP_CQ = 1024
-ABI_VERSION = 9             # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
+ABI_VERSION = 10            # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
 PBP_DESC_BYTES = 128
 COLOR_HASH, COLOR_SORT = 0, 1     # method of lhvi_color_refine_* (LHVI_COLOR_HASH / LHVI_COLOR_SORT)
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE

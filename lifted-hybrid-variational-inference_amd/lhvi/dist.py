@@ -795,32 +795,61 @@ class OwnerPlan:
             vq = np.flatnonzero(is_ghost & (var_owner[gids] == s) & cont)
             self.recv_q[s] = vq[np.argsort(gids[vq], kind='stable')].astype(np.int64)
 
-    def layout(self, n, np_host):
-        """element offsets of the two buffers of the one all_to_all: per peer (ascending rank) its rows back to back -- `n` doubles
-        of a continuous variable's row, its number of states for a discrete one -- then its proposals, two doubles each"""
-        lv = self.flat.edge_var
+    def layout(self, n, np_host=None):
+        """element offsets of the two buffers of the one all_to_all.  Per peer (ascending rank): the rows of the CONTINUOUS
+        variables' edges first -- `n` doubles each --, then the rows of the discrete ones (their number of states each), then the
+        proposals (two doubles each), then padding up to a multiple of `n` doubles -- so that every peer's block, and with it
+        every continuous row, starts a whole number of rows from the buffer's base: the receive buffer is laid behind the E
+        message rows of the rank's v -> f array and a continuous ghost edge's row is READ WHERE IT ARRIVED (``ghost_rows``: its
+        ``edge_canon``), no unpack pass; only the short discrete rows and the proposals are scattered after the exchange.
+        Inside a block rows keep the ascending (global factor, position) order on both ends."""
+        lf = self.flat
+        lv = lf.edge_var
+        cont = lf.var_cont
+        width = np.where(cont, n, lf.var_nstates).astype(np.int64)         # doubles in a variable's v -> f row
         out = {}
         for side, rows, qs in (('send', self.send_rows, self.send_q), ('recv', self.recv_rows, self.recv_q)):
             row_edge, row_off, row_w, q_var, q_off, counts = [], [], [], [], [], []
+            c_edge, c_off = [], []
             off = 0
             for s in range(self.world):
                 if s == self.rank:
                     counts.append(0)
                     continue
                 e = rows[s]
-                w = np_host[lv[e]].astype(np.int64)
-                o = off + np.cumsum(w) - w
-                row_edge.append(e), row_off.append(o), row_w.append(w)
-                end = off + int(w.sum())
+                ec, ed = e[cont[lv[e]]], e[~cont[lv[e]]]                    # (a boolean cut of a sorted list keeps its order)
+                c_edge.append(ec), c_off.append(off + n * np.arange(ec.size, dtype=np.int64))
+                end = off + n * int(ec.size)
+                w = width[lv[ed]]
+                row_edge.append(ed), row_off.append(end + np.cumsum(w) - w), row_w.append(w)
+                end += int(w.sum())
                 v = qs[s]
                 q_var.append(v), q_off.append(end + 2 * np.arange(v.size, dtype=np.int64))
                 end += 2 * int(v.size)
+                end = off + -(-(end - off) // n) * n                        # pad the block to whole rows
                 counts.append(end - off)
                 off = end
             cat = lambda xs, dt: (np.concatenate(xs) if xs else np.zeros(0)).astype(dt)
-            out[side] = dict(row_edge=cat(row_edge, np.int32), row_off=cat(row_off, np.int64), row_width=cat(row_w, np.int32),
+            out[side] = dict(cont_edge=cat(c_edge, np.int32), cont_off=cat(c_off, np.int64),
+                             row_edge=cat(row_edge, np.int32), row_off=cat(row_off, np.int64), row_width=cat(row_w, np.int32),
                              q_var=cat(q_var, np.int32), q_off=cat(q_off, np.int64), counts=counts, size=off)
         return out
+
+    @staticmethod
+    def rows_of(side_layout, n):
+        """(edge, offset, width) of EVERY row of one side of ``layout``: the continuous rows, then the discrete ones"""
+        L = side_layout
+        return (np.concatenate([L['cont_edge'], L['row_edge']]).astype(np.int64), np.concatenate([L['cont_off'], L['row_off']]),
+                np.concatenate([np.full(L['cont_edge'].size, n, dtype=np.int64), L['row_width'].astype(np.int64)]))
+
+    def ghost_rows(self, n):
+        """``edge_canon`` of the local graph with every continuous ghost edge pointing at the row of the v -> f array its message
+        arrives in: row E + (offset in the receive buffer) / n (``layout``).  (A ghost edge's own row is never written: its
+        v -> f message is its owner's to compute.)  Returns (edge_canon, rows of the receive buffer)."""
+        lay = self.layout(n)['recv']
+        canon = np.arange(self.flat.E, dtype=np.int32)
+        canon[lay['cont_edge']] = (self.flat.E + lay['cont_off'] // n).astype(np.int32)
+        return canon, -(-lay['size'] // n)
 
 
 class OwnerRunner:
@@ -839,6 +868,11 @@ class OwnerRunner:
         from .pbp import EPBP
         self.plan = plan = OwnerPlan(flat, rank, world, var_owner=var_owner)
         self.rank, self.world, self.group = rank, world, group
+        # the peers' continuous rows are read where they arrive: the receive buffer lies behind the E rows of the v -> f array and
+        # the ghost edges' canonical rows point into it (OwnerPlan.ghost_rows) -- set before the work lists are described
+        lay = self.lay = plan.layout(n)
+        canon, halo_rows = plan.ghost_rows(n)
+        plan.flat.edge_canon = canon
         bp = EPBP(None, n=n, proposal_approximation=proposal_approximation, sampler='device', seed=seed)
         bp._setup(None, flat=plan.flat, edge_key=plan.edge_key, edge_skip=plan.edge_skip)
         self.bp = bp
@@ -846,13 +880,31 @@ class OwnerRunner:
         self.n = n
         self.n_owned, self.n_ghost = plan.n_owned, plan.n_ghost
         self.overlap = bool(overlap) and world > 1
-        lay = self.lay = plan.layout(n, bp.np_host)
         dev = bp.dg.device
+        E = int(plan.flat.E)
+        bp.v2f = torch.zeros(E + max(halo_rows, 1), n, dtype=torch.float64, device=dev)
+        self.recv = bp.v2f.view(-1)[E * n:E * n + max(lay['recv']['size'], 1)]
+        self.send = torch.zeros(max(lay['send']['size'], 1), dtype=torch.float64, device=dev)
         up = {}
         for side in ('send', 'recv'):
             for k in ('row_edge', 'row_off', 'row_width', 'q_var', 'q_off'):
                 a = lay[side][k]
                 up[side + '_' + k] = a if a.size else np.zeros(1, dtype=a.dtype)
+        # where the v -> f half writes a copy of a cut edge's row as it forms it (lhvi_pbp_t.halo_off): its place in the send buffer.
+        # An edge listed for more than one peer (a cut factor of three or more variables with ghosts of several owners) keeps its
+        # first place there; the others are filled by the pack pass (`send_more_*`), like the proposals
+        S = lay['send']
+        all_edge = np.concatenate([S['cont_edge'], S['row_edge']]).astype(np.int64)
+        all_off = np.concatenate([S['cont_off'], S['row_off']])
+        all_w = np.concatenate([np.full(S['cont_edge'].size, n, dtype=np.int32), S['row_width']])
+        halo = np.full(max(E, 1), -1, dtype=np.int64)
+        first = np.unique(all_edge, return_index=True)[1]
+        halo[all_edge[first]] = all_off[first]
+        more = np.setdiff1d(np.arange(all_edge.size), first)
+        up['halo_off'] = halo
+        for k, a in (('send_more_edge', all_edge[more].astype(np.int32)), ('send_more_off', all_off[more]), ('send_more_width', all_w[more])):
+            up[k] = a if a.size else np.zeros(1, dtype=a.dtype)
+        self.n_send_more = int(more.size)
         # the sampler's lists (lhvi_pbp_t.resample_vars): the owned and the ghost hidden continuous variables, two per wavefront
         rr = bp.resample_vars.cpu().numpy() if bp.resample_vars is not None else np.zeros((0, 8), dtype=np.int32)
         self.res_lists = None
@@ -862,12 +914,18 @@ class OwnerRunner:
             up['res_ghost'] = rr[~own] if (~own).any() else np.zeros((1, 8), dtype=np.int32)
             self.res_lists = (int(own.sum()), int((~own).sum()))
         self.idx = _abi.upload(up)
-        self.send = torch.zeros(max(lay['send']['size'], 1), dtype=torch.float64, device=dev)
-        self.recv = torch.zeros(max(lay['recv']['size'], 1), dtype=torch.float64, device=dev)
         self.counts = list(lay['send']['counts'])              # what a loopback group cuts this rank's send buffer by
         self.record_phases = False
         self._phase_events = []
         self.f2v_extra = []
+
+    def message_rows(self):
+        """the v -> f array with every edge's row at its own index ([E, n]): the continuous ghost edges' rows gathered from where
+        they arrived (tests compare this with the single-GPU array)"""
+        import torch
+        E = int(self.plan.flat.E)
+        canon = _abi.to_dev(self.plan.flat.edge_canon.astype(np.int64))
+        return self.bp.v2f.index_select(0, canon)[:E]
 
     # ---- structs ------------------------------------------------------------------------------------------------------------
     def _struct(self, lo=0, hi=0, leave_room=False):
@@ -891,15 +949,18 @@ class OwnerRunner:
 
     # ---- the phases of a sweep ----------------------------------------------------------------------------------------------
     def owned_half(self):
-        """v -> f and the proposal update of the owned variables; the rows and proposals the peers need, packed"""
+        """v -> f and the proposal update of the owned variables.  The rows the peers need go into the send buffer as the v -> f
+        half forms them (``halo_off``); a small pass adds the proposals of the owned variables that are ghosts elsewhere"""
         bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
         if self.n_owned:
             s = self._struct(0, self.n_owned)
+            s.halo_off, s.halo_buf = _abi.ptr(self.idx['halo_off']), _abi.ptr(self.send)
             _abi.check(l.lhvi_pbp_v2f(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.v2f), st))
+            s.halo_off = s.halo_buf = None
             _abi.check(l.lhvi_pbp_proposal(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.eta), _abi.ptr(bp.q_dev), st))
         L, ix = self.lay['send'], self.idx
-        _abi.check(l.lhvi_pbp_halo_pack(_abi.ptr(bp.v2f), self.n, int(L['row_edge'].size), _abi.ptr(ix['send_row_edge']),
-                                        _abi.ptr(ix['send_row_off']), _abi.ptr(ix['send_row_width']), _abi.ptr(bp.q_dev),
+        _abi.check(l.lhvi_pbp_halo_pack(_abi.ptr(bp.v2f), self.n, self.n_send_more, _abi.ptr(ix['send_more_edge']),
+                                        _abi.ptr(ix['send_more_off']), _abi.ptr(ix['send_more_width']), _abi.ptr(bp.q_dev),
                                         int(L['q_var'].size), _abi.ptr(ix['send_q_var']), _abi.ptr(ix['send_q_off']), _abi.ptr(self.send), st))
         return self.send[:L['size']]
 
@@ -914,6 +975,8 @@ class OwnerRunner:
                 return
             s.var_lo, s.var_hi = 0, 0
             s.resample_vars, s.n_resample_vars = _abi.ptr(self.idx['res_owned' if which == 0 else 'res_ghost']), self.res_lists[which]
+            if which == 1:
+                s.flags |= _abi.PBP_NO_UNIQ                    # a ghost's first-occurrence mask is read by nobody here (no v -> f of its own)
         _abi.check(_abi.lib().lhvi_pbp_resample_uniq(bp.dg.g, s, _abi.ptr(bp.var_gid), int(bp.seed), int(bp._draws - 1),
                                                      _abi.ptr(bp.particles), _abi.ptr(bp.uniq), _abi.stream_ptr()))
 
@@ -930,8 +993,9 @@ class OwnerRunner:
         """the rest, once the peers' rows have arrived (after `interior`)"""
         bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
         L, ix = self.lay['recv'], self.idx
-        if recv.data_ptr() != self.recv.data_ptr():
+        if recv.data_ptr() != self.recv.data_ptr():            # (a loopback group's copy; a real collective wrote the rows in place)
             self.recv[:recv.shape[0]].copy_(recv)
+        # the continuous rows are read where they are; the short rows of discrete ghosts and the ghosts' proposals are scattered
         _abi.check(l.lhvi_pbp_halo_unpack(_abi.ptr(self.recv), self.n, int(L['row_edge'].size), _abi.ptr(ix['recv_row_edge']),
                                           _abi.ptr(ix['recv_row_off']), _abi.ptr(ix['recv_row_width']), _abi.ptr(bp.v2f),
                                           int(L['q_var'].size), _abi.ptr(ix['recv_q_var']), _abi.ptr(ix['recv_q_off']), _abi.ptr(bp.q_dev), st))
@@ -995,7 +1059,7 @@ class OwnerRunner:
         n = len(self._phase_events)
         out = {k: v / n for k, v in acc.items()}
         out.update(sweeps=n, owned_variables=int(self.n_owned), ghost_variables=int(self.n_ghost),
-                   cut_edge_rows_sent=int(self.lay['send']['row_edge'].size), exchange='owner computes: v->f rows of cut edges + ghost proposals',
+                   cut_edge_rows_sent=int(self.lay['send']['row_edge'].size + self.lay['send']['cont_edge'].size), exchange='owner computes: v->f rows of cut edges + ghost proposals',
                    exchanged_MB_per_sweep=8e-6 * self.lay['send']['size'])
         return out
 

@@ -4,7 +4,8 @@ The reference's MLN potentials hold arbitrary Python callables (``MLNPotential.p
 formulas it actually ships (``Demo/Data/HMLN/Generator*.py``) are arithmetic over ``x[i]`` with
 ``+ - * ** ==`` and constants.  We run the callable once on tracer objects that overload those
 operators and record a postfix program; ``csrc/potential.hpp::mln_eval`` executes it per joint
-assignment.  Formulas that branch on values (``1 if ... else 0``) cannot be traced and raise
+assignment.  A formula that branches on the values of its DISCRETE arguments (``1 if ... else 0``) is traced once per joint
+discrete state (``trace_by_state``); one that branches on a continuous value cannot be traced and raises
 ``FormulaNotTraceable`` -- the caller then fails loudly instead of silently evaluating on the CPU.
 """
 from __future__ import annotations
@@ -127,6 +128,71 @@ def trace(formula, arity):
         raise FormulaNotTraceable('formula needs an evaluation stack deeper than %d' % MAX_STACK)
     flat = []
     for op, val in out.prog:
+        flat += [float(op), float(val)]
+    return flat
+
+
+class _MixedArgs(_Args):
+    """arguments of a formula with its DISCRETE ones fixed to plain values (one joint state) and tracers for the rest"""
+
+    def __init__(self, n, fixed):
+        _Args.__init__(self, n)
+        self.fixed = fixed
+
+    def __getitem__(self, i):
+        if not isinstance(i, slice):
+            j = i + self.n if i < 0 else i
+            if j in self.fixed:
+                return self.fixed[j]
+        return _Args.__getitem__(self, i)
+
+
+MAX_PROGRAM_OPS = 1024      # longest program trace_by_state may emit (the device interpreter walks it per joint assignment)
+
+
+def trace_by_state(formula, roles):
+    """Program of a formula that BRANCHES on the values of its discrete arguments (``1 if x[0] + x[1] + x[2] > 0 else 0``: the
+    reference keeps such variants beside the arithmetic ones, Demo/Data/HMLN/GeneratorRobotMapping.py:37,42; MLNPotential accepts
+    any callable, MLNPotential.py:36-37).  ``roles[a]`` = the state values of a discrete argument, ``None`` for a continuous one.
+    The formula is run once per joint discrete state with those arguments as the plain values they take -- every branch on them
+    resolves -- and tracers for the continuous ones; the program is sum_state [x_disc == state] * program_state (states whose
+    program is the constant 0 are left out).  A branch on a CONTINUOUS value still raises ``FormulaNotTraceable``."""
+    import itertools
+    n = len(roles)
+    disc = [a for a, r in enumerate(roles) if r is not None]
+    if not disc:
+        raise FormulaNotTraceable('formula branches on a continuous value; cannot be compiled for the device')
+    prog = []
+    for states in itertools.product(*[roles[a] for a in disc]):
+        fixed = dict(zip(disc, states))
+        try:
+            out = Sym.lift(formula(_MixedArgs(n, fixed)))
+        except FormulaNotTraceable:
+            raise
+        except Exception as exc:
+            raise FormulaNotTraceable('formula is not traceable: %s: %s' % (type(exc).__name__, exc))
+        sub = out.prog
+        if all(op != OP_ARG for op, _ in sub):             # a constant for this state: fold it
+            flat = []
+            for op, val in sub:
+                flat += [float(op), float(val)]
+            c = run(flat, [])
+            if c == 0.0:
+                continue
+            sub = [(OP_CONST, float(c))]
+        term = []
+        for k, (a, v) in enumerate(fixed.items()):
+            term += [(OP_ARG, float(a)), (OP_CONST, float(v)), (OP_EQ, 0.0)] + ([(OP_MUL, 0.0)] if k else [])
+        term += sub + [(OP_MUL, 0.0)]
+        prog += term + ([(OP_ADD, 0.0)] if prog else [])
+    if not prog:
+        prog = [(OP_CONST, 0.0)]
+    if stack_depth(prog) > MAX_STACK:
+        raise FormulaNotTraceable('formula needs an evaluation stack deeper than %d' % MAX_STACK)
+    if len(prog) > MAX_PROGRAM_OPS:
+        raise FormulaNotTraceable('formula resolved per discrete state needs %d operations (limit %d)' % (len(prog), MAX_PROGRAM_OPS))
+    flat = []
+    for op, val in prog:
         flat += [float(op), float(val)]
     return flat
 

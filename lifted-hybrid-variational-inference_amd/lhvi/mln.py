@@ -67,8 +67,20 @@ class _FormulaPotential(Potential):
 
     cq_max_states = 4096        # joint discrete states a conditional-quadratic view may tabulate
 
+    def _program_for(self, domains):
+        """the formula's program over these domains: traced once per arity; a formula that branches on its discrete arguments,
+        once per joint discrete state of THESE domains (``expr.trace_by_state``)"""
+        try:
+            return self._program(len(domains))
+        except expr.FormulaNotTraceable:
+            roles = tuple(None if d.continuous else tuple(d.values) for d in domains)
+            key = ('by state', roles)
+            if key not in self._programs:
+                self._programs[key] = expr.trace_by_state(self.formula, roles)
+            return self._programs[key]
+
     def device_spec(self, domains):
-        program = self._program(len(domains))
+        program = self._program_for(domains)
         return self.kind, [float(self.w), float(len(program) // 2)] + program + self._cq_tail(program, domains)
 
     def _cq_tail(self, program, domains):

@@ -46,9 +46,9 @@ for it in range(sweeps):
         eid = torch.from_numpy(plan.edge_ids).to(dev)
         mine = torch.from_numpy(~plan.edge_skip).to(dev)
         le = live[torch.from_numpy(plan.flat.edge_var.astype(np.int64)).to(dev)]
-        assert torch.equal(torch.where(le, r.bp.v2f, 0.0)[mine], torch.where(le, bp.v2f[eid], 0.0)[mine]), 'v2f'
+        assert torch.equal(torch.where(le, r.message_rows(), 0.0)[mine], torch.where(le, bp.v2f[eid], 0.0)[mine]), 'v2f'
         assert torch.equal(r.bp.f2v[mine], bp.f2v[eid][mine]), 'f2v'
         checked += int(mine.sum().item())
     print('sweep %d: every rank equals the single-GPU run bit for bit' % it, flush=True)
 print(json.dumps(dict(config='owner-computes split at the headline size against one GPU', edges=int(flat.E), world=world, sweeps=sweeps, particles=n,
-                      f2v_rows_compared=checked, bit_identical=True, cut_rows_sent=[int(r.lay['send']['row_edge'].size) for r in runners])))
+                      f2v_rows_compared=checked, bit_identical=True, cut_rows_sent=[int(r.lay['send']['row_edge'].size + r.lay['send']['cont_edge'].size) for r in runners])))

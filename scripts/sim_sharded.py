@@ -35,7 +35,7 @@ if mode == 'ownercompute':
     torch.cuda.synchronize()
     sent = np.array([[8e-6 * c for c in r.lay['send']['counts']] for r in runners])
     print(json.dumps(dict(world=world, edges=int(flat.E), owned=[r.n_owned for r in runners], ghosts=[r.n_ghost for r in runners],
-                          local_target_edges=[r.local_edges() for r in runners], cut_rows_sent=[int(r.lay['send']['row_edge'].size) for r in runners],
+                          local_target_edges=[r.local_edges() for r in runners], cut_rows_sent=[int(r.lay['send']['row_edge'].size + r.lay['send']['cont_edge'].size) for r in runners],
                           send_MB_per_rank=[round(float(x), 1) for x in sent.sum(axis=1)], busiest_pair_MB=round(float(sent.max()), 1),
                           total_payload_GB=round(float(sent.sum()) / 1e3, 3))), flush=True)
     for it in range(3):

@@ -43,7 +43,7 @@ def owner_compute(flat, n, world, approx, sweeps):
             eid = torch.from_numpy(plan.edge_ids).to(dev)
             mine = torch.from_numpy(~plan.edge_skip).to(dev)
             le = live[torch.from_numpy(plan.flat.edge_var.astype(np.int64)).to(dev)]
-            assert torch.equal(torch.where(le, r.bp.v2f, 0.0)[mine], torch.where(le, bp.v2f[eid], 0.0)[mine]), 'v2f'
+            assert torch.equal(torch.where(le, r.message_rows(), 0.0)[mine], torch.where(le, bp.v2f[eid], 0.0)[mine]), 'v2f'
             assert torch.equal(r.bp.f2v[mine], bp.f2v[eid][mine]), 'f2v'
     assert torch.isfinite(bp.q_dev[torch.from_numpy(flat.var_hidden).to(dev)]).all()
 

@@ -590,13 +590,27 @@ def test_owner_plan_invariants(world):
             q = plans[s]
             np.testing.assert_array_equal(p.edge_ids[p.send_rows[s]], q.edge_ids[q.recv_rows[p.rank]])
             np.testing.assert_array_equal(p.var_gid[p.send_q[s]], q.var_gid[q.recv_q[p.rank]])
-        lay = p.layout(16, np.where(np.isnan(p.flat.var_value), np.where(p.flat.var_cont, 16, 2), 0))
+        n = 16
+        lay = p.layout(n)
         for side in ('send', 'recv'):
             L = lay[side]
-            assert sum(L['counts']) == L['size'] == int(L['row_width'].sum()) + 2 * L['q_var'].size
-            offs = np.concatenate([np.repeat(L['row_off'], L['row_width']) + np.concatenate([np.arange(w) for w in L['row_width']] or [np.zeros(0, int)]),
+            e, o, w = p.rows_of(L, n)
+            used = int(w.sum()) + 2 * L['q_var'].size
+            # per peer: continuous rows, discrete rows, proposals, then padding to whole rows of n doubles (fewer than n per peer)
+            assert sum(L['counts']) == L['size'] and all(c % n == 0 for c in L['counts']) and 0 <= L['size'] - used < n * world
+            offs = np.concatenate([np.repeat(o, w) + np.concatenate([np.arange(k) for k in w] or [np.zeros(0, int)]),
                                    np.repeat(L['q_off'], 2) + np.tile([0, 1], L['q_var'].size)])
-            np.testing.assert_array_equal(np.sort(offs), np.arange(L['size']))          # the buffer is covered exactly once
+            assert np.unique(offs).size == offs.size == used and offs.min(initial=0) >= 0 and offs.max(initial=-1) < L['size']    # nothing overlaps
+            assert (L['cont_off'] % n == 0).all() and (p.flat.var_cont[p.flat.edge_var[L['cont_edge']]]).all()
+        canon, extra = p.ghost_rows(n)
+        R = lay['recv']
+        assert (canon[R['cont_edge']] == p.flat.E + R['cont_off'] // n).all() and extra * n >= R['size']
+        rest = np.setdiff1d(np.arange(p.flat.E), R['cont_edge'])
+        assert (canon[rest] == rest).all()
+        # the two ends of a pair cut a block at the same places
+        for s in range(world):
+            if s != p.rank:
+                assert lay['send']['counts'][s] == plans[s].layout(n)['recv']['counts'][p.rank]
 
 
 def _owner_compute_gloo_worker(rank, world, port, out):
@@ -618,7 +632,7 @@ def _owner_compute_gloo_worker(rank, world, port, out):
     prop = lambda gv: np.array([np.cos(0.3 * gv), 1.0 + gv % 7])
     S = lay['send']
     send = torch.zeros(max(S['size'], 1), dtype=torch.float64)
-    for e, o, w in zip(S['row_edge'], S['row_off'], S['row_width']):
+    for e, o, w in zip(*plan.rows_of(S, n)):
         send[o:o + w] = torch.from_numpy(row(plan.edge_ids[e])[:w])
     for v, o in zip(S['q_var'], S['q_off']):
         send[o:o + 2] = torch.from_numpy(prop(plan.var_gid[v]))
@@ -626,11 +640,15 @@ def _owner_compute_gloo_worker(rank, world, port, out):
     recv = torch.empty(R['size'], dtype=torch.float64)
     td.all_to_all_single(recv, send[:S['size']], output_split_sizes=R['counts'], input_split_sizes=S['counts'])
     ok = True
-    for e, o, w in zip(R['row_edge'], R['row_off'], R['row_width']):
+    for e, o, w in zip(*plan.rows_of(R, n)):
         ok = ok and bool((recv[o:o + w].numpy() == row(plan.edge_ids[e])[:w]).all())
+    # every continuous row starts a whole number of rows from the buffer's base (it is read in place behind the E message rows)
+    canon, extra = plan.ghost_rows(n)
+    ok = ok and bool((R['cont_off'] % n == 0).all()) and bool((canon[R['cont_edge']] == lf.E + R['cont_off'] // n).all()) \
+        and extra * n >= R['size'] and all(c % n == 0 for c in R['counts'] + S['counts'])
     for v, o in zip(R['q_var'], R['q_off']):
         ok = ok and bool((recv[o:o + 2].numpy() == prop(plan.var_gid[v])).all())
-    out.put((rank, ok, int(R['row_edge'].size), int(R['q_var'].size)))
+    out.put((rank, ok, int(R['row_edge'].size + R['cont_edge'].size), int(R['q_var'].size)))
     td.barrier()
     td.destroy_process_group()
 
@@ -661,13 +679,13 @@ def _subgroup_worker(rank, world, port, out):
         row = lambda ge: np.sin(0.1 * ge + np.arange(n))
         S, R = lay['send'], lay['recv']
         send = torch.zeros(max(S['size'], 1), dtype=torch.float64)
-        for e, o, wd in zip(S['row_edge'], S['row_off'], S['row_width']):
+        for e, o, wd in zip(*plan.rows_of(S, n)):
             send[o:o + wd] = torch.from_numpy(row(plan.edge_ids[e])[:wd])
         recv = torch.empty(R['size'], dtype=torch.float64)
         td.all_to_all_single(recv, send[:S['size']], output_split_sizes=R['counts'], input_split_sizes=S['counts'], group=grp)
-        for e, o, wd in zip(R['row_edge'], R['row_off'], R['row_width']):
+        for e, o, wd in zip(*plan.rows_of(R, n)):
             ok = ok and bool((recv[o:o + wd].numpy() == row(plan.edge_ids[e])[:wd]).all())
-        nrows = int(R['row_edge'].size)
+        nrows = int(R['row_edge'].size + R['cont_edge'].size)
     out.put((rank, ok, nrows))
     td.barrier()
     td.destroy_process_group()
@@ -756,10 +774,11 @@ def test_owner_compute_sweep_equals_single_gpu_bit_for_bit(world):
             eid = torch.from_numpy(plan.edge_ids).to(dev)
             mine = torch.from_numpy(~plan.edge_skip).to(dev)
             le = live[torch.from_numpy(plan.flat.edge_var.astype(np.int64)).to(dev)]
-            assert torch.equal(torch.where(le, r.bp.v2f, 0.0)[mine], torch.where(le, bp.v2f[eid], 0.0)[mine])
+            rows = r.message_rows()                     # (continuous ghost edges: gathered from where their rows arrived)
+            assert torch.equal(torch.where(le, rows, 0.0)[mine], torch.where(le, bp.v2f[eid], 0.0)[mine])
             assert torch.equal(r.bp.f2v[mine], bp.f2v[eid][mine])
             hid_e = torch.from_numpy(plan.flat.var_hidden[plan.flat.edge_var]).to(dev)
-            assert torch.equal(torch.where(le, r.bp.v2f, 0.0)[hid_e], torch.where(le, bp.v2f[eid], 0.0)[hid_e])   # ghost edges: received rows
+            assert torch.equal(torch.where(le, rows, 0.0)[hid_e], torch.where(le, bp.v2f[eid], 0.0)[hid_e])   # ghost edges: received rows
     assert torch.isfinite(bp.q_dev[torch.from_numpy(flat.var_hidden).to(dev)]).all()
 
 
@@ -778,7 +797,7 @@ def _owner_compute_gpu_worker(rank, world, port, out_dir):
         r.sweep()                      # owned half -> all_to_all_single (gloo: staged through the host) -> interior, boundary
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), gid=r.plan.var_gid, q=r.bp.q_dev.cpu().numpy(), f2v=r.bp.f2v.cpu().numpy(),
-             v2f=r.bp.v2f.cpu().numpy(), edge_ids=r.plan.edge_ids, mine=~r.plan.edge_skip, n_owned=r.plan.n_owned)
+             v2f=r.message_rows().cpu().numpy(), edge_ids=r.plan.edge_ids, mine=~r.plan.edge_skip, n_owned=r.plan.n_owned)
     td.barrier()
     td.destroy_process_group()
 

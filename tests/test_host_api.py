@@ -69,6 +69,50 @@ def test_mln_ops_and_tracing():
     assert hard.get((1,)) == 1 and hard.get((0,)) == 0
 
 
+def test_formulas_that_branch_on_discrete_arguments_are_traced_per_state():
+    """``MLNPotential`` accepts any callable (MLNPotential.py:36-37); the reference keeps ``1 if ... else 0`` variants of two
+    robot-mapping formulas beside the arithmetic ones it runs (Demo/Data/HMLN/GeneratorRobotMapping.py:37,42).  A branch on the
+    values of DISCRETE arguments is resolved by tracing the formula once per joint discrete state; the traced program, its
+    conditional-quadratic view and the device parameter row equal those of the arithmetic variant's values on every state"""
+    import itertools
+    from lhvi.graph import Domain
+    neg = M.neg_op
+    boolean = Domain((0, 1), continuous=False)
+    cont = Domain((-5, 5), continuous=True, integral_points=np.linspace(-5, 5, 8))
+    cases = [
+        # GeneratorRobotMapping.py:37 / :38 -- "some type holds"
+        (lambda x: 1 if x[0] + x[1] + x[2] > 0 else 0, lambda x: 1 - (x[0] == 0) * (x[1] == 0) * (x[2] == 0), [boolean] * 3),
+        # GeneratorRobotMapping.py:42 (its arithmetic neighbour :43 is a different clause: no equivalence to check)
+        (lambda x: 1 if neg(x[0]) + neg(x[1]) + x[2] + neg(x[3]) + neg(x[4]) else 0, None, [boolean] * 5),
+        # a hybrid one: the branch picks which soft equality applies
+        (lambda x: M.eq_op(x[1], 0.1) if x[0] == 1 else 0.5 * M.eq_op(x[1], x[2]), None, [boolean, cont, cont]),
+    ]
+    for branching, arithmetic, domains in cases:
+        with pytest.raises(expr.FormulaNotTraceable):
+            expr.trace(branching, len(domains))
+        pot = M.MLNPotential(branching, w=1.7)
+        kind, par = pot.device_spec(domains)
+        nops = int(par[1])
+        prog = par[2:2 + 2 * nops]
+        disc = [i for i, d in enumerate(domains) if not d.continuous]
+        rng = np.random.default_rng(1)
+        for states in itertools.product(*[domains[i].values for i in disc]):
+            x = [float(rng.uniform(-3, 3)) for _ in domains]
+            for i, v in zip(disc, states):
+                x[i] = v
+            want = float(branching(x))
+            assert expr.run(prog, x) == pytest.approx(want, rel=1e-15, abs=1e-15)
+            assert pot.get(x) == pytest.approx(np.e ** (1.7 * want))
+            if arithmetic is not None:
+                assert want == float(arithmetic(x))
+        if any(d.continuous for d in domains):
+            assert par[2 + 2 * nops] == expr.CQ_MAGIC          # the hybrid one is conditionally quadratic: routed to the fast kernels
+        # same parameter row for the same graph position (cached per domains), and the flattening of a graph accepts it
+        assert pot.device_spec(domains)[1] == par
+    with pytest.raises(expr.FormulaNotTraceable):              # a branch on a CONTINUOUS value stays untraceable: fail loudly
+        M.MLNPotential(lambda x: 1 if x[1] > 0 else x[0], w=1).device_spec([boolean, cont])
+
+
 def test_relational_grounding_matches_rgm_template():
     d = G.Domain((-50, 50), continuous=True, integral_points=np.linspace(-50, 50, 100))
     p1, p2, p3 = (P.GaussianPotential([0., 0.], s) for s in ([[10., -7.], [-7., 10.]], [[10., 5.], [5., 10.]], [[10., 7.], [7., 10.]]))
