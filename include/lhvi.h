@@ -103,6 +103,10 @@ typedef struct lhvi_pots {
     const int32_t* kind;        /* [P] LHVI_POT_* */
     const int32_t* off;         /* [P+1] into param */
     const double* param;
+    int32_t interpreted;        /* (ABI 10) how many rows are formulas the device evaluates by interpreting their bytecode: MLN rows without a
+                                 * conditional-quadratic block (cq_off = 0) and MLN_HARD rows.  0 (every formula the reference ships): the
+                                 * kernels that evaluate general potentials run the builds compiled without the interpreter.  A caller that
+                                 * does not know passes -1 (treated as "some") */
 } lhvi_pots_t;
 
 int lhvi_version(void);

@@ -5,7 +5,7 @@
 // x[0] * eq_op(x[1], x[2]) (Demo/Data/HMLN/GeneratorPaperPopularity.py:28-40) and x[0] * eq_op(x[1], const)
 // (GeneratorRobotMapping.py:60-75) are, per value of the boolean x[0], quadratic forms -- the family the heavy / light
 // kernels of pbp.hip serve.  lhvi/expr.py::cq_block evaluates the traced formula symbolically per joint discrete state and
-// appends the coefficient table behind the potential's bytecode:
+// appends the coefficient table behind the potential's bytecode (row header [w, ncode, cq_off]; the block sits at par + cq_off):
 //     [CQ_MAGIC, arity, Nd, Nc, role[arity], dims[Nd], coef[ncfg][6]]
 //     role[a] >= 0: index among the discrete arguments;  role[a] = -1 - i: the i-th continuous argument (i < Nc <= 2)
 //     coef[cfg] = (a00, axy, a11, b0, b1, c):  log phi = a00 u^2 + axy u v + a11 v^2 + b0 u + b1 v + c,  (u, v) = the
@@ -39,8 +39,8 @@ struct CqView {
 // the conditional-quadratic block of potential row `par` of `len` doubles (MLN kinds only), if it has one
 __device__ __forceinline__ bool cq_view(int kind, const double* __restrict__ par, int len, CqView& v) {
     if (kind != LHVI_POT_MLN) return false;
-    const int head = 2 + 2 * (int)par[1];
-    if (len < head + 4 || par[head] != CQ_MAGIC) return false;
+    const int head = (int)par[2];                       // offset of the block in the row, 0 = none (lhvi/mln.py::device_spec)
+    if (head < 3 || len < head + 4 || par[head] != CQ_MAGIC) return false;
     const double* b = par + head;
     v.arity = (int)b[1]; v.Nd = (int)b[2]; v.Nc = (int)b[3];
     v.role = b + 4;

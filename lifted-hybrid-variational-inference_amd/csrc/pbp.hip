@@ -405,6 +405,8 @@ __device__ __forceinline__ int state_index(const lhvi_graph_t& g, int v, double 
 
 // message_f_to_rv(x, f, rv, sample) for any arity / potential kind (EPBP:176-194; HLBP:193-215):
 // sequential mixed-radix walk over the joint particles of the other arguments, last argument fastest.
+// INTERP = false: the build without the formula interpreter (lhvi_pots_t.interpreted == 0)
+template <bool INTERP = true>
 __device__ double f2v_point_generic(const lhvi_graph_t& g, const lhvi_pots_t& pots, const lhvi_pbp_t& s,
                                     const double* __restrict__ v2f, const double* __restrict__ partner_particles,
                                     int e, double x, int xi) {
@@ -441,7 +443,7 @@ __device__ double f2v_point_generic(const lhvi_graph_t& g, const lhvi_pots_t& po
                 if (withmsg[a]) m += v2f[(int64_t)ce[a] * n + it[a]];
             }
         }
-        res += pot_times_exp(kind, par, xs, ix, m);
+        res += pot_times_exp<INTERP>(kind, par, xs, ix, m);
         int a = arity - 1;
         while (a >= 0) {
             if (!fixed[a] && ++it[a] < cnt[a]) break;
@@ -1603,6 +1605,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_classify_kernel(lhvi_graph_t g, lhv
 // 2^pts_log2 lanes per edge (the host picks the smallest power of two that covers the largest point count in the work
 // list, so the 2-point messages of discrete x discrete table factors pack 32 edges into a wave); edges with more than
 // 64 points loop.
+template <bool INTERP>
 __global__ void __launch_bounds__(BLOCK) pbp_f2v_generic_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_pbp_t s,
                                                                const double* __restrict__ v2f, double* __restrict__ f2v,
                                                                int pts_log2) {
@@ -1628,7 +1631,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_generic_kernel(lhvi_graph_t g, 
         for (int p = pl; p < npts; p += (1 << pts_log2)) {
             const double x = p < np ? s.particles[(int64_t)tv * n + p] : g.dom_val[gb + p - np];
             const int xi = p < np ? p : p - np;
-            out[p < np ? p : n + (p - np)] = f2v_point_generic(g, pots, s, v2f, s.old_particles, e, x, xi);
+            out[p < np ? p : n + (p - np)] = f2v_point_generic<INTERP>(g, pots, s, v2f, s.old_particles, e, x, xi);
         }
     }
 }
@@ -2569,7 +2572,8 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     static const int fast_per_cu = blocks_per_cu((const void*)pbp_f2v_fast_kernel);
     static const int heavy_per_cu = blocks_per_cu((const void*)pbp_f2v_heavy_kernel, HEAVY_BLOCK);
     static const int light_per_cu = blocks_per_cu((const void*)pbp_f2v_light_kernel);
-    static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel);
+    static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel<true>);
+    static const int gen_slim_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel<false>);
     const int heavy_blocks = heavy_per_cu, side_blocks = 8;
     // LEAVE_ROOM (sharded runs): every persistent grid stays cus/8 workgroups short of filling the device, so a collective's
     // copy kernels on another stream can become resident while these waves run (no kernel here ever waits on another
@@ -2621,8 +2625,12 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
         int pts_log2 = s->generic_edges ? s->generic_pts_log2 : 6;
         if (pts_log2 < 0 || pts_log2 > 6) pts_log2 = 6;
         const int groups = (ngen + (64 >> pts_log2) - 1) / (64 >> pts_log2);
-        hipLaunchKernelGGL(pbp_f2v_generic_kernel, dim3(min((groups + 3) / 4, max(cus * min(gen_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0, as_stream(stream), *g, *pots,
-                           *s, v2f, f2v, pts_log2);
+        if (pots->interpreted == 0)
+            hipLaunchKernelGGL(pbp_f2v_generic_kernel<false>, dim3(min((groups + 3) / 4, max(cus * min(gen_slim_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0,
+                               as_stream(stream), *g, *pots, *s, v2f, f2v, pts_log2);
+        else
+            hipLaunchKernelGGL(pbp_f2v_generic_kernel<true>, dim3(min((groups + 3) / 4, max(cus * min(gen_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0,
+                               as_stream(stream), *g, *pots, *s, v2f, f2v, pts_log2);
     }
     return check_launch();
 }

@@ -8,7 +8,10 @@
 //   LINEAR_GAUSSIAN  [coeff, sig]   exp(-(x1 - coeff x0)^2 / (2 sig))          Potential.py:311-318
 //   X2               [coeff, sig]   exp(-coeff x0^2 / (2 sig))                 Potential.py:341-348
 //   XY               [coeff, sig]   exp(-coeff x0 x1 / (2 sig))                Potential.py:371-378
-//   MLN / MLN_HARD   [w, ncode, (op, val) * ncode]                            MLNPotential.py:30-49, lhvi/expr.py
+//   MLN / MLN_HARD   [w, ncode, cq_off, (op, val) * ncode, cq block]          MLNPotential.py:30-49, lhvi/expr.py
+//                    cq block at par + cq_off (cq_off = 0: none): [CQ_MAGIC, arity, Nd, Nc, role[arity], dims[Nd], coef[ncfg][6]]
+//                    -- the formula per joint discrete state as a polynomial of degree <= 2 in its (at most two) continuous
+//                    arguments, weight folded in: evaluated by cq_log_phi, a lookup and six multiply-adds, no bytecode
 //   IMAGE_NODE       [mu, sig]; IMAGE_EDGE [distant, scaling, max_threshold, v]  Potential.py:400-424
 //
 // Evaluators return log(phi) for the exponential-family kinds (so the caller can fold the incoming log
@@ -67,6 +70,29 @@ __device__ __forceinline__ double mln_formula_on(const double* __restrict__ code
     return st.get(0);
 }
 
+// log phi of an MLN formula through its conditional-quadratic block b = [CQ_MAGIC, arity, Nd, Nc, role[arity], dims[Nd],
+// coef[ncfg][6]] (lhvi/expr.py::cq_block): cfg = mixed-radix index of the discrete arguments' states (first one most
+// significant), (u, v) = the continuous arguments in argument order, log phi = (a00 u + axy v + b0) u + (a11 v + b1) v + c.
+// Straight-line: no opcode fetch, no evaluation stack.  idx[a] = state index of a discrete argument.
+__device__ __forceinline__ double cq_log_phi(const double* __restrict__ b, const double* x, const int* idx) {
+    const int arity = (int)b[1], Nd = (int)b[2];
+    const double* __restrict__ role = b + 4;
+    const double* __restrict__ dims = role + arity;
+    int cfg = 0;
+    double uv[2] = {0.0, 0.0};
+#pragma unroll
+    for (int a = 0; a < LHVI_MAX_ARITY; ++a) {
+        if (a >= arity) break;
+        const int r = (int)role[a];
+        if (r >= 0) cfg = cfg * (int)dims[r] + idx[a];
+        else if (r == -1) uv[0] = x[a];
+        else uv[1] = x[a];
+    }
+    const double* __restrict__ c = dims + Nd + 6 * cfg;
+    const double u = uv[0], v = uv[1];
+    return fma(fma(c[0], u, fma(c[1], v, c[3])), u, fma(fma(c[2], v, c[4]), v, c[5]));
+}
+
 __device__ __forceinline__ double mln_formula(const double* __restrict__ code, int ncode, const double* x) {
     MlnRegStack st;
     return mln_formula_on(code, ncode, x, st);
@@ -84,8 +110,10 @@ __device__ __forceinline__ double quad_form(const double* __restrict__ A, const 
     return res + c;
 }
 
-// value of the potential at the joint assignment x (idx = state indices of discrete arguments)
-template <class Stack>
+// value of the potential at the joint assignment x (idx = state indices of discrete arguments).
+// INTERP = false: the build for graphs without an interpreted formula (every MLN row carries a conditional-quadratic block, no
+// hard formula: lhvi_pots_t.interpreted == 0) -- the bytecode loop and its evaluation stack are not compiled in.
+template <bool INTERP = true, class Stack>
 __device__ __forceinline__ double pot_eval_on(int kind, const double* __restrict__ par, const double* x, const int* idx,
                                               bool& is_log, Stack& st) {
     is_log = true;
@@ -128,10 +156,16 @@ __device__ __forceinline__ double pot_eval_on(int kind, const double* __restrict
         }
         case LHVI_POT_X2: return -par[0] * (x[0] * x[0]) * 0.5 / par[1];
         case LHVI_POT_XY: return -par[0] * x[0] * x[1] * 0.5 / par[1];
-        case LHVI_POT_MLN: return mln_formula_on(par + 2, (int)par[1], x, st) * par[0];
+        case LHVI_POT_MLN: {
+            const int cq = (int)par[2];
+            if (cq) return cq_log_phi(par + cq, x, idx);
+            if (INTERP) return mln_formula_on(par + 3, (int)par[1], x, st) * par[0];
+            break;
+        }
         case LHVI_POT_MLN_HARD:
             is_log = false;
-            return mln_formula_on(par + 2, (int)par[1], x, st) > 0.0 ? 1.0 : 0.0;
+            if (INTERP) return mln_formula_on(par + 3, (int)par[1], x, st) > 0.0 ? 1.0 : 0.0;
+            break;
         case LHVI_POT_IMAGE_NODE: {
             is_log = false;
             const double u = (x[0] - x[1] - par[0]) / par[1];
@@ -147,17 +181,28 @@ __device__ __forceinline__ double pot_eval_on(int kind, const double* __restrict
     return NAN;
 }
 
+struct MlnNoStack {        // the INTERP = false builds: nothing to hold
+    __device__ __forceinline__ double get(int) const { return 0.0; }
+    __device__ __forceinline__ void set(int, double) {}
+};
+
+template <bool INTERP = true>
 __device__ __forceinline__ double pot_eval(int kind, const double* __restrict__ par, const double* x, const int* idx,
                                            bool& is_log) {
-    MlnRegStack st;
-    return pot_eval_on(kind, par, x, idx, is_log, st);
+    if (INTERP) {
+        MlnRegStack st;
+        return pot_eval_on<true>(kind, par, x, idx, is_log, st);
+    }
+    MlnNoStack st;
+    return pot_eval_on<false>(kind, par, x, idx, is_log, st);
 }
 
 // phi(x) * exp(m): one exp for the exponential-family kinds
+template <bool INTERP = true>
 __device__ __forceinline__ double pot_times_exp(int kind, const double* __restrict__ par, const double* x,
                                                 const int* idx, double m) {
     bool is_log;
-    const double v = pot_eval(kind, par, x, idx, is_log);
+    const double v = pot_eval<INTERP>(kind, par, x, idx, is_log);
     return is_log ? exp(v + m) : v * exp(m);
 }
 

@@ -424,20 +424,21 @@ __device__ __forceinline__ double group_sum(double v) {
 }
 
 // log(phi(x) + 1e-100)
+template <bool INTERP = true>
 __device__ __forceinline__ double pot_log_eps(int kind, const double* __restrict__ par, const double* x, const int* idx,
                                               const double* __restrict__ sh_tab, const LogRec* __restrict__ sh_log) {
     bool is_log;
-    const double v = pot_eval(kind, par, x, idx, is_log);
+    const double v = pot_eval<INTERP>(kind, par, x, idx, is_log);
     return is_log ? log_phi_eps(v, sh_tab, sh_log) : log_table(v + 1e-100, sh_log);
 }
 
 // rvs_belief (VI:336-353) at an arbitrary point (the pinned expectations leave the grid: under the reference's quirk a continuous
 // neighbour is evaluated at the TARGET's state values)
-template <class Stack>
+template <bool INTERP = true, class Stack>
 __device__ __forceinline__ double pot_log_eps_on(int kind, const double* __restrict__ par, const double* x, const int* idx,
                                                  const double* __restrict__ sh_tab, const LogRec* __restrict__ sh_log, Stack& st) {
     bool is_log;
-    const double v = pot_eval_on(kind, par, x, idx, is_log, st);
+    const double v = pot_eval_on<INTERP>(kind, par, x, idx, is_log, st);
     return is_log ? log_phi_eps(v, sh_tab, sh_log) : log_table(v + 1e-100, sh_log);
 }
 
@@ -462,7 +463,9 @@ __device__ __forceinline__ double belief_direct(const lhvi_graph_t& g, const lhv
     return s;
 }
 
-template <int MAXA, int L>
+// INTERP = false: the build for potential tables without an interpreted formula (lhvi_pots_t.interpreted == 0: every formula of the
+// graph is evaluated through its conditional-quadratic block) -- no bytecode loop, no evaluation stack
+template <int MAXA, int L, bool INTERP = true>
 __global__ void __launch_bounds__(VI_GRP_BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI_VI_GRP_WAVES, 8))) vi_factor_group_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef,
                                                                       double* __restrict__ pe_c, double* __restrict__ pe_d,
                                                                       const int32_t* __restrict__ list, int n_list) {
@@ -577,7 +580,7 @@ __global__ void __launch_bounds__(VI_GRP_BLOCK) __attribute__((amdgpu_waves_per_
             for (int a = 0; a < MAXA; ++a) if (axis[a]) t *= sc[kk * S + off[a] + it[a]];
             b += t;
         }
-        const double F = pot_log_eps(kind, par, x, idx, sh_tab, sh_log) - log_table(b + 1e-100, sh_log);
+        const double F = pot_log_eps<INTERP>(kind, par, x, idx, sh_tab, sh_log) - log_table(b + 1e-100, sh_log);
         E += w * F;
 #pragma unroll
         for (int a = 0; a < MAXA; ++a) {
@@ -650,7 +653,7 @@ __global__ void __launch_bounds__(VI_GRP_BLOCK) __attribute__((amdgpu_waves_per_
 #pragma unroll
                     for (int b = 0; b < MAXA; ++b) if (b == a) { x[b] = tvals[d]; idx[b] = d; }
                     const double bel = belief_direct<MAXA>(g, p, x, idx, vars, arity, hid, cont, axis, sp, sh_tab);
-                    acc += w * (pot_log_eps(kind, par, x, idx, sh_tab, sh_log) - log_table(bel + 1e-100, sh_log));
+                    acc += w * (pot_log_eps<INTERP>(kind, par, x, idx, sh_tab, sh_log) - log_table(bel + 1e-100, sh_log));
                 }
                 acc = group_sum<L>(acc);
                 if (gl == 0) pe_d[((int64_t)e * p.K + k) * p.Dmax + d] = c * acc;
@@ -680,17 +683,30 @@ constexpr int VI_TINY_PAR = 3072;      // doubles of parameter rows kept in LDS 
 #ifndef LHVI_VI_TINY_WAVES
 #define LHVI_VI_TINY_WAVES 2
 #endif
+#ifndef LHVI_VI_TINY_SLIM_WAVES
+#define LHVI_VI_TINY_SLIM_WAVES 3          // the build without the interpreter (measured: 2 waves 0.53 ms, 3 waves 0.50, 4 waves -- 304 B of scratch -- 0.64 on the scaled cfg 3)
+#endif
+constexpr int VI_TINY_PAR_SLIM = 1024;     // parameter rows it keeps in LDS (8 KB); larger tables take the general build
 
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI_VI_TINY_WAVES, 8)))
+template <bool INTERP>
+struct TinyStack { using type = MlnLdsStack<BLOCK>; };
+template <>
+struct TinyStack<false> { using type = MlnNoStack; };
+
+// INTERP = false: the build for potential tables without an interpreted formula (lhvi_pots_t.interpreted == 0) -- no bytecode
+// loop and no stack columns in LDS (24 KB less per workgroup)
+template <bool INTERP>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(INTERP ? LHVI_VI_TINY_WAVES : LHVI_VI_TINY_SLIM_WAVES, 8)))
 vi_factor_tiny_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __restrict__ ef, double* __restrict__ pe_c,
                       double* __restrict__ pe_d, const int32_t* __restrict__ list, int n_list) {
     __shared__ double sh_tab[EXP_TAB_N];
     __shared__ LogRec sh_log[LOG_TAB_N];
-    __shared__ double sh_stack[MLN_STACK * BLOCK];      // the formula interpreter's stack: a column per thread (in registers it is
-    MlnLdsStack<BLOCK> stack{sh_stack + threadIdx.x};   // a dynamically indexed array: 0.81 ms instead of 0.70 on the scaled cfg 3)
+    __shared__ double sh_stack[INTERP ? MLN_STACK * BLOCK : 1];      // the formula interpreter's stack: a column per thread (in registers it is
+    typename TinyStack<INTERP>::type stack;                          // a dynamically indexed array: 0.81 ms instead of 0.70 on the scaled cfg 3)
+    if constexpr (INTERP) stack.base = sh_stack + threadIdx.x;
     // the parameter rows of all potentials (for an MLN formula: its program) in LDS: the interpreter fetches an opcode per step, each
     // a dependent load -- 7 to 21 global round trips per evaluation otherwise
-    __shared__ double sh_par[VI_TINY_PAR];
+    __shared__ double sh_par[INTERP ? VI_TINY_PAR : VI_TINY_PAR_SLIM];
     for (int t = threadIdx.x; t < p.tiny_par_words; t += BLOCK) sh_par[t] = pots.param[t];     // (the launcher checks the size)
     load_log_table(sh_log);
     load_exp_table(sh_tab);
@@ -808,7 +824,7 @@ vi_factor_tiny_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __r
                 }
                 bel += t;
             }
-            const double F = pot_log_eps_on(kind, par, x, idx, sh_tab, sh_log, stack) - log_table(bel + 1e-100, sh_log);
+            const double F = pot_log_eps_on<INTERP>(kind, par, x, idx, sh_tab, sh_log, stack) - log_table(bel + 1e-100, sh_log);
             if (pa < 0) {
                 E += w * F;
 #pragma unroll
@@ -1190,6 +1206,7 @@ int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t
         // the caller's split of the factors (lhvi_vi_t.fac_list): [pairwise continuous | tiny grids | group kernel, arity <= 3 | group kernel,
         // arity 4..6 | thread-per-factor kernels for what fits neither]
         const int32_t* l = p->fac_list;
+        const bool slim = pots->interpreted == 0;          // no formula of this graph goes through the bytecode interpreter
         if (p->n_cc < 0 || p->n_tiny < 0 || p->n_grp3 < 0 || p->n_grp6 < 0 || p->n_rest3 < 0 || p->n_rest6 < 0 ||
             (int64_t)p->n_cc + p->n_tiny + p->n_grp3 + p->n_grp6 + p->n_rest3 + p->n_rest6 != g->F) return LHVI_E_ARG;
         if (p->n_cc > 0) {
@@ -1206,18 +1223,26 @@ int lhvi_vi_grad(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_vi_t
         if (p->n_tiny > 0) {
             if (!p->edge_axis || p->K > VI_TINY_K || p->tiny_par_words <= 0 || p->tiny_par_words > VI_TINY_PAR) return LHVI_E_ARG;
             // (4 096 workgroups, not the 512 resident ones: the hardware's dispatch balances the uneven items; 0.68 vs 0.76 ms)
-            hipLaunchKernelGGL(vi_factor_tiny_kernel, dim3(min(grid_for((int64_t)p->n_tiny * p->K), 4096u)), dim3(BLOCK), 0, st,
-                               *g, *pots, *p, ef, pe_c, pe_d, l, p->n_tiny);
+            if (slim && p->tiny_par_words <= VI_TINY_PAR_SLIM)
+                hipLaunchKernelGGL(vi_factor_tiny_kernel<false>, dim3(min(grid_for((int64_t)p->n_tiny * p->K), 4096u)), dim3(BLOCK), 0, st,
+                                   *g, *pots, *p, ef, pe_c, pe_d, l, p->n_tiny);
+            else
+                hipLaunchKernelGGL(vi_factor_tiny_kernel<true>, dim3(min(grid_for((int64_t)p->n_tiny * p->K), 4096u)), dim3(BLOCK), 0, st,
+                                   *g, *pots, *p, ef, pe_c, pe_d, l, p->n_tiny);
         }
         l += p->n_tiny;
         constexpr int GPB = VI_GRP_BLOCK / VI_GRP_L;
-        if (p->n_grp3 > 0)
-            hipLaunchKernelGGL((vi_factor_group_kernel<3, VI_GRP_L>), dim3(min(grid_for((int64_t)p->n_grp3 * p->K, GPB), 4096u)), dim3(VI_GRP_BLOCK), 0, st,
-                               *g, *pots, *p, ef, pe_c, pe_d, l, p->n_grp3);
+        if (p->n_grp3 > 0) {
+            const dim3 grid(min(grid_for((int64_t)p->n_grp3 * p->K, GPB), 4096u));
+            if (slim) hipLaunchKernelGGL((vi_factor_group_kernel<3, VI_GRP_L, false>), grid, dim3(VI_GRP_BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d, l, p->n_grp3);
+            else hipLaunchKernelGGL((vi_factor_group_kernel<3, VI_GRP_L, true>), grid, dim3(VI_GRP_BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d, l, p->n_grp3);
+        }
         l += p->n_grp3;
-        if (p->n_grp6 > 0)
-            hipLaunchKernelGGL((vi_factor_group_kernel<LHVI_MAX_ARITY, VI_GRP_L>), dim3(min(grid_for((int64_t)p->n_grp6 * p->K, GPB), 4096u)), dim3(VI_GRP_BLOCK), 0, st,
-                               *g, *pots, *p, ef, pe_c, pe_d, l, p->n_grp6);
+        if (p->n_grp6 > 0) {
+            const dim3 grid(min(grid_for((int64_t)p->n_grp6 * p->K, GPB), 4096u));
+            if (slim) hipLaunchKernelGGL((vi_factor_group_kernel<LHVI_MAX_ARITY, VI_GRP_L, false>), grid, dim3(VI_GRP_BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d, l, p->n_grp6);
+            else hipLaunchKernelGGL((vi_factor_group_kernel<LHVI_MAX_ARITY, VI_GRP_L, true>), grid, dim3(VI_GRP_BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d, l, p->n_grp6);
+        }
         l += p->n_grp6;
         if (p->n_rest3 > 0)
             hipLaunchKernelGGL(vi_factor_kernel<3>, dim3(grid_for((int64_t)p->n_rest3 * p->K)), dim3(BLOCK), 0, st, *g, *pots, *p, ef, pe_c, pe_d, l, p->n_rest3);

@@ -40,7 +40,7 @@ class GabpPlanStruct(C.Structure):
 
 
 class PotsStruct(C.Structure):
-    _fields_ = [('P', C.c_int32), ('kind', C.c_void_p), ('off', C.c_void_p), ('param', C.c_void_p)]
+    _fields_ = [('P', C.c_int32), ('kind', C.c_void_p), ('off', C.c_void_p), ('param', C.c_void_p), ('interpreted', C.c_int32)]
 
 
 class PbpStruct(C.Structure):
@@ -253,6 +253,28 @@ def upload(arrays, device=None):
     return out
 
 
+def device_potentials(flat):
+    """(pot_off, pot_param, interpreted) as they go to the device.  The host table keeps every formula's bytecode (the CPU oracle
+    interprets it); on the device a formula with a conditional-quadratic block is evaluated through the block alone
+    (``cq_log_phi``, csrc/potential.hpp), so its row travels as ``[w, 0, 3, block]`` -- no program: the table is a fraction of the
+    size (the variational kernels keep it in LDS).  `interpreted` = rows the device has to interpret (``lhvi_pots_t.interpreted``)."""
+    def build():
+        kind, off, par = flat.pot_kind, flat.pot_off, flat.pot_param
+        rows, interpreted = [], 0
+        for i in range(int(kind.size)):
+            row = par[off[i]:off[i + 1]]
+            if kind[i] == 8 and row.size > 2 and row[2] != 0:
+                row = np.concatenate([[row[0], 0.0, 3.0], row[int(row[2]):]])
+            elif kind[i] in (8, 9):
+                interpreted += 1
+            rows.append(row)
+        new_off = np.zeros(kind.size + 1, dtype=np.int32)
+        np.cumsum([r.size for r in rows], out=new_off[1:])
+        new_par = np.concatenate(rows) if rows else np.zeros(0)
+        return new_off, np.ascontiguousarray(new_par, dtype=np.float64), interpreted
+    return flat._cached('device_potentials', (flat.pot_kind, flat.pot_off, flat.pot_param), build)
+
+
 class DeviceGraph:
     """A ``FlatGraph`` resident in HBM plus the two C structs that point into it."""
 
@@ -261,7 +283,9 @@ class DeviceGraph:
         self.flat = flat
         host = {name: getattr(flat, name) for name in
                 ('fac_ptr', 'edge_var', 'edge_fac', 'var_ptr', 'var_edge', 'fac_pot', 'var_value', 'var_dom',
-                 'dom_cont', 'dom_lo', 'dom_hi', 'dom_ptr', 'dom_val', 'pot_kind', 'pot_off', 'pot_param')}
+                 'dom_cont', 'dom_lo', 'dom_hi', 'dom_ptr', 'dom_val', 'pot_kind')}
+        host['pot_off'], host['pot_param'], interpreted = device_potentials(flat)
+        self.pot_param_words = int(host['pot_param'].size)
         has_alias = flat._cached('has_alias', (flat.edge_canon,),
                                  lambda: bool((flat.edge_canon != np.arange(flat.E, dtype=np.int32)).any()))
         host['edge_canon'] = flat.edge_canon if has_alias else None
@@ -298,6 +322,9 @@ class DeviceGraph:
         p = PotsStruct()
         p.P = int(flat.pot_kind.size)
         p.kind, p.off, p.param = ptr(t['pot_kind']), ptr(t['pot_off']), ptr(t['pot_param'])
+        # formulas the device has to interpret (lhvi_pots_t.interpreted): hard formulas, and soft ones without a
+        # conditional-quadratic block (word 2 of the row, lhvi/mln.py::device_spec)
+        p.interpreted = int(interpreted)
         self.p = p
 
     def zeros(self, *shape, dtype=None):

@@ -241,7 +241,7 @@ def conditional_quadratic(flat, roles):
     """Evaluate a traced program symbolically for every joint state of its discrete arguments.
 
     ``roles[a]`` = tuple of the state values of a discrete argument, or ``None`` for a continuous one.  Returns
-    ``(dims, coef)``: ``coef[cfg]`` = ``(a00, axy, a11, b0, b1, c)`` with
+    ``(dims, coef)``: ``coef[cfg]`` = ``(a00, axy, a11, b0, b1, c)`` (no continuous argument: only ``c``, a table in log space) with
     ``formula(x) = a00 u^2 + axy u v + a11 v^2 + b0 u + b1 v + c`` for ``u, v`` = the continuous arguments in argument
     order and ``cfg`` the mixed-radix index of the discrete states (first discrete argument most significant).
     Raises ``NotConditionallyQuadratic`` when some state's restriction is not such a polynomial (or there are no / more
@@ -251,8 +251,8 @@ def conditional_quadratic(flat, roles):
     import itertools
     cont = [a for a, r in enumerate(roles) if r is None]
     disc = [a for a, r in enumerate(roles) if r is not None]
-    if not 1 <= len(cont) <= 2:
-        raise NotConditionallyQuadratic('needs one or two continuous arguments')
+    if len(cont) > 2:
+        raise NotConditionallyQuadratic('more than two continuous arguments')
     cpos = {a: i for i, a in enumerate(cont)}
     dims = [len(roles[a]) for a in disc]
     coef = []
@@ -308,7 +308,7 @@ def conditional_quadratic(flat, roles):
 
 def cq_block(flat, roles, w):
     """the parameter block appended behind an MLN potential's bytecode when its formula is conditionally quadratic:
-    ``[CQ_MAGIC, arity, Nd, Nc, role[arity], dims[Nd], coef[ncfg][6]]`` with ``role[a]`` = index among the discrete
+    ``[CQ_MAGIC, arity, Nd, Nc, role[arity], dims[Nd], coef[ncfg][6]]`` (Nc = 0, 1 or 2) with ``role[a]`` = index among the discrete
     arguments, or ``-1 - index`` among the continuous ones; coefficients already multiplied by the weight (log phi)"""
     dims, coef = conditional_quadratic(flat, roles)
     role, nd, nc = [], 0, 0

@@ -80,8 +80,12 @@ class _FormulaPotential(Potential):
             return self._programs[key]
 
     def device_spec(self, domains):
+        """parameter row ``[w, ncode, cq_off, (op, val) * ncode, conditional-quadratic block]`` (csrc/potential.hpp): ``cq_off`` =
+        offset of the block from the start of the row, 0 when the formula has none -- with it the device evaluates the formula
+        as a table lookup and at most six multiply-adds, never through the bytecode (which the CPU oracle keeps interpreting)"""
         program = self._program_for(domains)
-        return self.kind, [float(self.w), float(len(program) // 2)] + program + self._cq_tail(program, domains)
+        tail = self._cq_tail(program, domains)
+        return self.kind, [float(self.w), float(len(program) // 2), float(3 + len(program) if tail else 0)] + program + tail
 
     def _cq_tail(self, program, domains):
         return []

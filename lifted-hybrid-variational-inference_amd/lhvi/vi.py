@@ -63,8 +63,8 @@ def factor_lists(flat, K, T, obs_var=None, tiny_kernel=True):
     lg = np.concatenate([[0.0], np.cumsum(np.log2(axis_len.astype(np.float64)))])
     nodes = lg[flat.fac_ptr[1:]] - lg[flat.fac_ptr[:-1]]
     tiny = ~cc & small & (arity >= 1) & (nodes <= np.log2(_abi.VI_TINY_NODES) + 1e-9) & (K <= _abi.VI_TINY_K) & bool(tiny_kernel)
-    if flat.pot_param.size > _abi.VI_TINY_PAR:
-        tiny[:] = False                   # (the kernel keeps every parameter row in LDS)
+    if _abi.device_potentials(flat)[1].size > _abi.VI_TINY_PAR:
+        tiny[:] = False                   # (the kernel keeps every parameter row of the device table in LDS)
     if tiny_kernel != 'always' and int(tiny.sum()) * K < TINY_MIN_ITEMS:
         tiny[:] = False                   # too few items to fill the device with single threads: the 8-lane groups finish sooner
     grp = ~cc & ~tiny & (arity >= 1) & (S <= _abi.VI_GROUP_SLOTS) & (K * S <= _abi.VI_GROUP_COMP)
@@ -165,7 +165,7 @@ class _Variational:
         if getattr(self, '_fac_counts', None) is not None:
             p.fac_list, p.edge_axis = _abi.ptr(d['fac_list']), _abi.ptr(d['edge_axis'])
             p.n_cc, p.n_tiny, p.n_grp3, p.n_grp6, p.n_rest3, p.n_rest6 = self._fac_counts
-            p.tiny_par_words = int(self.flat.pot_param.size)
+            p.tiny_par_words = int(self.dg.pot_param_words)
         return p
 
     def _opt_struct(self):

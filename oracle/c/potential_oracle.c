@@ -98,9 +98,9 @@ double oracle_potential(int kind, const double *par, int arity, const double *x,
         case POT_XY: /* Potential.py:377-378 */
             return exp(-par[0] * x[0] * x[1] * 0.5 / par[1]);
         case POT_MLN: /* MLNPotential.get (MLNPotential.py:36-37): e ** (formula(x) * w) */
-            return pow(M_E, mln_formula(par + 2, (int)par[1], x) * par[0]);
+            return pow(M_E, mln_formula(par + 3, (int)par[1], x) * par[0]);      /* row = [w, ncode, cq_off, program, ...]: the oracle interprets the program */
         case POT_MLN_HARD: /* MLNHardPotential.get (MLNPotential.py:48-49) */
-            return mln_formula(par + 2, (int)par[1], x) > 0 ? 1.0 : 0.0;
+            return mln_formula(par + 3, (int)par[1], x) > 0 ? 1.0 : 0.0;
         case POT_IMAGE_NODE: { /* Potential.py:406-408 */
             double u = (x[0] - x[1] - par[0]) / par[1];
             return exp(-u * u * 0.5) / (2.506628274631 * par[1]);

@@ -137,6 +137,80 @@ if 'gauss_rel' in which:
             finite=bool(torch.isfinite(vb[torch.from_numpy(flat.var_hidden[flat.edge_var[flat.var_edge]]).to(vb.device)]).all().item()))
         del dg, va, vb, dev
 
+def cfg3_model(P_=300, T_=10, seed=0):
+    """cfg 3: the paper-popularity HMLN, 300 papers x 10 topics, evidence per Generator `generate_data`, as Python objects"""
+    from lhvi.graph import Domain
+    from lhvi.relational import LV, Atom, ParamF, RelationalGraph
+    from lhvi.mln import MLNPotential, eq_op
+    rng = np.random.default_rng(seed)
+    dom_b = Domain((0, 1))
+    dom_r = Domain((-15, 15), continuous=True, integral_points=np.linspace(0, 10, 32))
+    lvp, lvt = LV([f'p{i}' for i in range(P_)]), LV([f't{i}' for i in range(T_)])
+    atoms = (Atom(dom_b, (lvt, lvt), 'SameSession'), Atom(dom_b, (lvp, lvt), 'PaperIn'), Atom(dom_r, (lvt,), 'TopicPopularity'),
+             Atom(dom_r, (lvp,), 'PaperPopularity'))
+    pfs = (ParamF(MLNPotential(lambda x: eq_op(x[0], 1), w=0.3), nb=['PaperPopularity(p)']),
+           ParamF(MLNPotential(lambda x: x[0] * eq_op(x[1], x[2]), w=0.5), nb=['SameSession(t1,t2)', 'TopicPopularity(t1)', 'TopicPopularity(t2)'],
+                  constrain=lambda s: s['t1'] != s['t2']),
+           ParamF(MLNPotential(lambda x: x[0] * eq_op(x[1], x[2]), w=1), nb=['PaperIn(p,t)', 'PaperPopularity(p)', 'TopicPopularity(t)']))
+    rel = RelationalGraph(atoms, pfs)
+    g, table = rel.ground_graph()
+    data = {}
+    for i in rng.choice(P_, int(P_ * 0.7), replace=False):
+        data[('PaperPopularity', f'p{i}')] = float(rng.uniform(0, 10))
+    for i in rng.choice(T_, int(T_ * 0.7), replace=False):
+        data[('TopicPopularity', f't{i}')] = float(rng.uniform(0, 10))
+    for i in rng.choice(P_, int(P_ * 0.7), replace=False):
+        for j in rng.choice(T_, int(rng.integers(T_)), replace=False):
+            data[('PaperIn', f'p{i}', f't{j}')] = int(rng.integers(0, 2))
+    rel.add_evidence(data)
+    g.rvs, g.factors = sorted(g.rvs), sorted(g.factors)
+    g.init_nb()
+    return g, table
+
+
+def cold_warm(make, call, warm=5):
+    """wall seconds of the first call in this process (code-object loads, allocator growth, first flattening) and the median of
+    `warm` later calls on fresh solver objects; `make()` builds the solver (untimed), `call(solver)` is what the reference's script times"""
+    times = []
+    for _ in range(warm + 1):
+        obj = make()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        call(obj)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    return times[0], float(np.median(times[1:])), obj
+
+
+if 'refsize' in which:
+    # the calls the reference's own scripts make, at the reference's sizes, through the unchanged API: cold and warm wall time (the
+    # device's share comes from the kernel trace of this same run: scripts/profile_refsize.sh), the C oracle beside them
+    from lhvi.pbp import HybridLBP
+    from lhvi.gabp import GaLBP
+    only = os.environ.get('REFSIZE_ONLY', '')
+    prof = os.environ.get('REFSIZE_CPROFILE')
+    if not only or 'cfg3' in only:
+        g, table = cfg3_model()
+        E = sum(len(f.nb) for f in g.factors)
+
+        def make3():
+            np.random.seed(0)
+            return HybridLBP(g, n=10, proposal_approximation='simple')
+        cold, warmed, bp = cold_warm(make3, lambda b: b.run(10))
+        if prof:
+            import cProfile, pstats
+            b = make3()
+            pr = cProfile.Profile()
+            pr.enable(); b.run(10); torch.cuda.synchronize(); pr.disable()
+            pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
+        out(config='refsize cfg3: paper-popularity HMLN 300 x 10, HybridLBP(g, n=10, simple).run(10) through the objects (host sampler = the reference\'s RNG stream)',
+            edges=E, rv_clusters=bp.g.num_rv_clusters, cold_s=cold, warm_s=warmed, calls=6)
+
+        def make3d():
+            return HybridLBP(g, n=10, proposal_approximation='simple', sampler='device', seed=1)
+        cold, warmed, bp = cold_warm(make3d, lambda b: b.run(10))
+        out(config='refsize cfg3, device sampler', edges=E, cold_s=cold, warm_s=warmed, calls=6)
+
 if 'cfg3' in which:
     # cfg 3: paper-popularity HMLN (300 papers x 10 topics) through the object API, HybridLBP n=10, 10 sweeps
     from lhvi.graph import Domain

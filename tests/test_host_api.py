@@ -93,7 +93,7 @@ def test_formulas_that_branch_on_discrete_arguments_are_traced_per_state():
         pot = M.MLNPotential(branching, w=1.7)
         kind, par = pot.device_spec(domains)
         nops = int(par[1])
-        prog = par[2:2 + 2 * nops]
+        prog = par[3:3 + 2 * nops]
         disc = [i for i, d in enumerate(domains) if not d.continuous]
         rng = np.random.default_rng(1)
         for states in itertools.product(*[domains[i].values for i in disc]):
@@ -106,7 +106,7 @@ def test_formulas_that_branch_on_discrete_arguments_are_traced_per_state():
             if arithmetic is not None:
                 assert want == float(arithmetic(x))
         if any(d.continuous for d in domains):
-            assert par[2 + 2 * nops] == expr.CQ_MAGIC          # the hybrid one is conditionally quadratic: routed to the fast kernels
+            assert par[2] == 3 + 2 * nops and par[3 + 2 * nops] == expr.CQ_MAGIC          # the hybrid one is conditionally quadratic: routed to the fast kernels
         # same parameter row for the same graph position (cached per domains), and the flattening of a graph accepts it
         assert pot.device_spec(domains)[1] == par
     with pytest.raises(expr.FormulaNotTraceable):              # a branch on a CONTINUOUS value stays untraceable: fail loudly
@@ -515,7 +515,7 @@ def test_conditional_quadratic_view_of_the_reference_formulas():
         pot = MLNPotential(formula, w)
         kind, par = pot.device_spec(doms)
         ncode = int(par[1])
-        tail = par[2 + 2 * ncode:]
+        tail = par[3 + 2 * ncode:]
         assert tail and tail[0] == expr.CQ_MAGIC
         arity, nd, nc = int(tail[1]), int(tail[2]), int(tail[3])
         role, dims = [int(v) for v in tail[4:4 + arity]], [int(v) for v in tail[4 + arity:4 + arity + nd]]
@@ -536,9 +536,21 @@ def test_conditional_quadratic_view_of_the_reference_formulas():
             got = c[0] * u * u + c[1] * u * v + c[2] * v * v + c[3] * u + c[4] * v + c[5]
             assert got == pytest.approx(w * formula(x), rel=1e-12, abs=1e-10)
     for formula, doms in [(lambda x: x[0] * x[1] ** 2 * x[2], (b, r, r)), (lambda x: (x[1] > x[2]) * x[0], (b, r, r)),
-                          (lambda x: or_op(neg_op(x[0]), neg_op(x[1])), (b, b)), (lambda x: x[0] * x[1] * x[2], (r, r, r))]:
+                          (lambda x: x[0] * x[1] * x[2], (r, r, r))]:
         kind, par = MLNPotential(formula, 1.0).device_spec(doms)
-        assert len(par) == 2 + 2 * int(par[1])
+        assert len(par) == 3 + 2 * int(par[1]) and par[2] == 0
+    # a formula over discrete arguments only is the limiting case: a table in log space (Nc = 0, only the constants are set),
+    # so that no formula the reference ships is interpreted on the device (GeneratorRobotMapping.py:31-43)
+    for formula, w, doms in [(lambda x: or_op(neg_op(x[0]), neg_op(x[1])), 3.0, (b, b)),
+                             (lambda x: 1 - (x[0] == 1) * (x[1] == 1) * (x[2] == 0) * (x[3] == 1) * (1 - x[4]), 1.591, (b,) * 5),
+                             (lambda x: x[0], -0.737, (tri,))]:
+        kind, par = MLNPotential(formula, w).device_spec(doms)
+        tail = par[int(par[2]):]
+        assert par[2] == 3 + 2 * int(par[1]) and tail[0] == expr.CQ_MAGIC and (int(tail[2]), int(tail[3])) == (len(doms), 0)
+        coef = np.array(tail[4 + 2 * len(doms):]).reshape(-1, 6)
+        import itertools
+        for cfg, states in enumerate(itertools.product(*[d.values for d in doms])):
+            assert (coef[cfg, :5] == 0).all() and coef[cfg, 5] == pytest.approx(w * formula(list(states)), rel=1e-15, abs=1e-15)
 
 
 def test_robot_mapping_model_matches_the_reference_demo(golden_dir, tmp_path):
