@@ -435,6 +435,12 @@ class CompressedGraph:
 
 def build_lifted_objects(g, rv_color, f_color):
     """``SuperRV`` / ``SuperF`` sets for a partition; cluster representative = member with the smallest id."""
+    from .flat import gc_paused
+    with gc_paused():
+        return _build_lifted_objects(g, rv_color, f_color)
+
+
+def _build_lifted_objects(g, rv_color, f_color):
     rvs, factors = ground_order(g.rvs), ground_order(g.factors)
     groups = {}
     for rv, c in zip(rvs, rv_color.tolist()):

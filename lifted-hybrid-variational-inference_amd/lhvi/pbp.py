@@ -332,22 +332,26 @@ class _ParticleSweep:
         flat = self.flat
         q = self.q_dev.cpu().numpy()
         out = np.zeros((flat.V, self.n))
-        for v in range(flat.V):
-            if not flat.var_hidden[v]:
-                continue
-            d = flat.var_dom[v]
-            if flat.dom_cont[d]:
-                z = np.random.standard_normal(self.n)
-                out[v] = np.clip(z * sqrt(q[v, 1]) + q[v, 0], flat.dom_lo[d], flat.dom_hi[d])
+        rows = np.flatnonzero(flat.var_hidden & flat.var_cont)
+        if rows.size:
+            # one call for all rows: the legacy generator fills a (rows, n) array in order and keeps its spare Box-Muller value in
+            # its state, so this is the stream of one standard_normal(n) per variable in g.rvs order
+            z = np.random.standard_normal((rows.size, self.n))
+            d = flat.var_dom[rows]
+            out[rows] = np.clip(z * np.sqrt(q[rows, 1])[:, None] + q[rows, 0][:, None], flat.dom_lo[d][:, None], flat.dom_hi[d][:, None])
         return out
 
     def _install(self, host_particles):
         flat = self.flat
         p = np.nan_to_num(np.array(host_particles, dtype=np.float64), nan=0.0)
-        for v in np.flatnonzero(flat.var_hidden & ~flat.var_cont):
-            d = flat.var_dom[v]
-            vals = flat.dom_val[flat.dom_ptr[d]:flat.dom_ptr[d + 1]]
-            p[v, :vals.size] = vals
+        disc = np.flatnonzero(flat.var_hidden & ~flat.var_cont)
+        if disc.size:                                  # the particles of a discrete variable are its states
+            d = flat.var_dom[disc]
+            nst = (flat.dom_ptr[d + 1] - flat.dom_ptr[d]).astype(np.int64)
+            k = np.arange(int(nst.max()))[None, :]
+            live = k < nst[:, None]
+            rows, cols = np.nonzero(live)
+            p[disc[rows], cols] = flat.dom_val[flat.dom_ptr[d][rows] + cols]
         self.old_particles, self.particles = self.particles, self.old_particles
         self.particles.copy_(_abi.to_dev(p))
 
@@ -939,11 +943,12 @@ class HybridLBP(_ParticleSweep):
             if self.sampler == 'device':
                 return None                       # engine.install draws on the device
             out = np.zeros((flat.V, self.n))      # the reference's stream: standard_normal in cluster order (HLBP:75-87)
-            for v in range(flat.V):
-                if flat.var_hidden[v] and flat.var_cont[v]:
-                    dmn = flat.var_dom[v]
-                    z = np.random.standard_normal(self.n)
-                    out[v] = np.clip(z * sqrt(q_host[v, 1]) + q_host[v, 0], flat.dom_lo[dmn], flat.dom_hi[dmn])
+            rows = np.flatnonzero(flat.var_hidden & flat.var_cont)
+            if rows.size:                         # (one call: the same stream as one standard_normal(n) per cluster, see _host_draw)
+                z = np.random.standard_normal((rows.size, self.n))
+                dmn = flat.var_dom[rows]
+                out[rows] = np.clip(z * np.sqrt(q_host[rows, 1])[:, None] + q_host[rows, 0][:, None], flat.dom_lo[dmn][:, None],
+                                    flat.dom_hi[dmn][:, None])
             return out
         return draw
 
