@@ -381,6 +381,7 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lh
     constexpr int CAP = BLOCK + GABP_HUB_DEGREE;
     __shared__ double2 sh[CAP];
     __shared__ double2 shc[CAP / GABP_ROW_CHUNK + 1];       // sums of eight-entry chunks of the long rows (ground graphs)
+    __shared__ double2 sht[CAP / (GABP_ROW_DIRECT + 1) + 1]; // their totals: long rows start more than GABP_ROW_DIRECT slots apart
     __shared__ double sh_par[LDS_POTS ? GABP_LDS_POTS * GABP_POT_WORDS : 1];
     if (LDS_POTS) {
         for (int i = threadIdx.x; i < pots.P * GABP_POT_WORDS; i += BLOCK) sh_par[i] = pot_words[i];
@@ -421,6 +422,19 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lh
             shc[(j - lo_ext) / GABP_ROW_CHUNK] = make_double2(H, P);
         }
         __syncthreads();
+        // ... and one thread per long row adds its chunks up: a slot's leave-one-out sum is then (total - its own chunk) + the
+        // other entries of that chunk -- 1 + 8 LDS reads whatever the row's length (it used to walk all the row's chunks: a
+        // Kalman-filter row of 66 entries cost every one of its slots 16 reads)
+        for (int j = lo_ext + threadIdx.x; j < hi_ext; j += BLOCK) {
+            const int rz = rec[j].z;
+            const int len = (rz >> 10) & 1023;
+            if (((rz >> 21) & 1) || len <= GABP_ROW_DIRECT || (rz & 1023) != 0) continue;
+            const double2* __restrict__ cs = shc + (j - lo_ext) / GABP_ROW_CHUNK;
+            double H = 0.0, P = 0.0;
+            for (int c = 0; c < len / GABP_ROW_CHUNK; ++c) { H += cs[c].x; P += cs[c].y; }
+            sht[(j - lo_ext) / (GABP_ROW_DIRECT + 1)] = make_double2(H, P);
+        }
+        __syncthreads();
     }
     for (int k = lo_ext + threadIdx.x; k < hi_ext; k += BLOCK) {
     const int rz = rec[k].z;
@@ -455,15 +469,14 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lh
             }
             for (; j < n; ++j) { const double2 m = row[j]; LHVI_ROW_STEP(m, j) }
         } else {
-            // a long row: the chunks before the slot's own, the own chunk's other entries, the chunks after it -- ascending rv.nb
-            // order with the chunks' sums as intermediate results (O(len / 8 + 8) additions per slot instead of O(len); differs
-            // from the reference's left-to-right sum by rounding only: asserted at 1e-13 on the fixtures)
+            // a long row: the row's total less the slot's own chunk, plus that chunk's other entries (the chunks' sums and the
+            // total are intermediate results: O(8) additions per slot instead of O(len); differs from the reference's
+            // left-to-right sum by rounding only: asserted at 1e-13 on the fixtures)
             const int nc = n / GABP_ROW_CHUNK, q = min(own / GABP_ROW_CHUNK, nc - 1);
-            const double2* __restrict__ cs = shc + (lo - lo_ext) / GABP_ROW_CHUNK;
-            for (int c = 0; c < q; ++c) { H += cs[c].x; P += cs[c].y; }
+            const double2 tot = sht[(lo - lo_ext) / (GABP_ROW_DIRECT + 1)], mine = shc[(lo - lo_ext) / GABP_ROW_CHUNK + q];
+            H = tot.x - mine.x; P = tot.y - mine.y;
             const int b0 = q * GABP_ROW_CHUNK, b1 = q == nc - 1 ? n : b0 + GABP_ROW_CHUNK;
             for (int j = b0; j < b1; ++j) { const double2 m = row[j]; LHVI_ROW_STEP(m, j) }
-            for (int c = q + 1; c < nc; ++c) { H += cs[c].x; P += cs[c].y; }
         }
 #undef LHVI_ROW_STEP
     }

@@ -121,6 +121,8 @@ if 'gauss_rel' in which:
     data[rng.random(data.shape) < 0.3] = kalman.MISSING
     dom = Domain((-20, 20), continuous=True, integral_points=np.linspace(-20, 20, 8))
     graphs.append(('Kalman n=30 T=%d' % Tk, kalman.KalmanFilter(dom, A, 0.7, np.eye(nk), 0.4).grounded_flat(Tk, data)[0]))
+    if os.environ.get('GAUSS_REL_ONLY'):         # one graph per process: a PMC pass then averages a kernel over ONE graph's launches
+        graphs = [gr for gr in graphs if os.environ['GAUSS_REL_ONLY'].lower() in gr[0].lower()]
     for label, flat in graphs:
         dg = _abi.DeviceGraph(flat)
         l, st = _abi.lib(), _abi.stream_ptr()
@@ -179,6 +181,12 @@ def cold_warm(make, call, warm=5):
         call(obj)
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
+    if os.environ.get('REFSIZE_CPROFILE'):
+        import cProfile, pstats
+        o2 = make()
+        pr = cProfile.Profile()
+        pr.enable(); call(o2); torch.cuda.synchronize(); pr.disable()
+        pstats.Stats(pr).sort_stats('cumulative').print_stats(40)
     return times[0], float(np.median(times[1:])), obj
 
 
@@ -197,12 +205,6 @@ if 'refsize' in which:
             np.random.seed(0)
             return HybridLBP(g, n=10, proposal_approximation='simple')
         cold, warmed, bp = cold_warm(make3, lambda b: b.run(10))
-        if prof:
-            import cProfile, pstats
-            b = make3()
-            pr = cProfile.Profile()
-            pr.enable(); b.run(10); torch.cuda.synchronize(); pr.disable()
-            pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
         out(config='refsize cfg3: paper-popularity HMLN 300 x 10, HybridLBP(g, n=10, simple).run(10) through the objects (host sampler = the reference\'s RNG stream)',
             edges=E, rv_clusters=bp.g.num_rv_clusters, cold_s=cold, warm_s=warmed, calls=6)
 
