@@ -835,6 +835,11 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
 // behind WORK_CHUNK edges -- and a workgroup that reaches its CU late (another kernel's workgroups held the slot) simply
 // finds less left to claim.  Without a ticket every wave strides over the list: a late workgroup then still owes its
 // full static share.
+#ifndef LHVI_PBP_TAIL_PER_WAVE
+#define LHVI_PBP_TAIL_PER_WAVE 0            // entries per wave of a part's tail zone (claimed one at a time); 0: chunks to the end.
+                                            // Measured on the 8-rank rehearsal (profiles/r05_experiments.md): 0 -> 0.875 ms per heavy launch,
+                                            // 2 -> 0.948, 8 -> 1.20: a claim per entry costs more than the shorter tail returns
+#endif
 template <int WORK_CHUNK, int WAVES_PER_BLOCK = BLOCK / WAVE>
 struct WorkCursor {
     uint32_t* ticket;       // nullptr: static striding
@@ -863,7 +868,7 @@ struct WorkCursor {
             lo = min(part * per, nitems);
             limit = min(lo + per, nitems);
             const int waves = (gridDim.x + parts - 1) / parts * WAVES_PER_BLOCK;          // waves that draw from this counter
-            const int tail = min(limit - lo, 2 * waves);
+            const int tail = min(limit - lo, LHVI_PBP_TAIL_PER_WAVE * waves);
             body = (limit - lo - tail) / WORK_CHUNK * WORK_CHUNK;
             mid = lo + body;
             ticket = base + part;

@@ -918,6 +918,17 @@ class OwnerRunner:
         self.record_phases = False
         self._phase_events = []
         self.f2v_extra = []
+        # Two f -> v launches per sweep (factors without a ghost while the rows are in flight, the cut factors after them) pay when
+        # the first one hides a good part of the exchange.  With many ranks nearly every factor of an expander is cut: the first
+        # launch then hides next to nothing and costs a second ramp-up and tail of the persistent kernels (0.35 of 1.75 ms at 8
+        # ranks) -- below `min_interior` of the f -> v work ONE launch after the exchange serves both lists.
+        pc = bp.part_counts
+        total = bp.n_heavy + bp.n_pair + int(bp.generic_edges.numel()) + int(bp.fast_edges.numel()) + bp.n_small16 + bp.n_small32 + bp.n_cq
+        inner = pc['heavy'] + pc['pair'] + pc['generic'] + pc['fast'] + pc['small16'] + pc['small32'] + pc['cq']
+        self.interior_fraction = inner / float(max(total, 1))
+        self.split_f2v = self.interior_fraction >= self.min_interior
+
+    min_interior = 0.25         # least share of the f -> v work lists that must need no ghost for the two-launch schedule
 
     def message_rows(self):
         """the v -> f array with every edge's row at its own index ([E, n]): the continuous ghost edges' rows gathered from where
@@ -987,7 +998,8 @@ class OwnerRunner:
         bp._draws += 1
         bp._views = {}
         self._resample(0, self.n_owned)
-        bp._launch_f2v(self._edge_part(self._struct(leave_room=True), 0), f2v_events)
+        if self.split_f2v:
+            bp._launch_f2v(self._edge_part(self._struct(leave_room=True), 0), f2v_events)
 
     def boundary(self, recv, f2v_events=None):
         """the rest, once the peers' rows have arrived (after `interior`)"""
@@ -1000,7 +1012,7 @@ class OwnerRunner:
                                           _abi.ptr(ix['recv_row_off']), _abi.ptr(ix['recv_row_width']), _abi.ptr(bp.v2f),
                                           int(L['q_var'].size), _abi.ptr(ix['recv_q_var']), _abi.ptr(ix['recv_q_off']), _abi.ptr(bp.q_dev), st))
         self._resample(self.n_owned, self.n_owned + self.n_ghost)
-        bp._launch_f2v(self._edge_part(self._struct(), 1), f2v_events)
+        bp._launch_f2v(self._edge_part(self._struct(), 1) if self.split_f2v else self._struct(), f2v_events)
 
     def exchange(self, send, async_op=False):
         """the one collective of a sweep"""
@@ -1035,7 +1047,7 @@ class OwnerRunner:
         else:
             recv, work = self.recv[:0], None
         extra = None
-        if f2v_events:
+        if f2v_events and self.split_f2v:
             extra = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.f2v_extra.append(extra)
         self.interior(extra)
@@ -1059,6 +1071,7 @@ class OwnerRunner:
         n = len(self._phase_events)
         out = {k: v / n for k, v in acc.items()}
         out.update(sweeps=n, owned_variables=int(self.n_owned), ghost_variables=int(self.n_ghost),
+                   interior_fraction_of_f2v_lists=round(self.interior_fraction, 4), f2v_launches_per_sweep=2 if self.split_f2v else 1,
                    cut_edge_rows_sent=int(self.lay['send']['row_edge'].size + self.lay['send']['cont_edge'].size), exchange='owner computes: v->f rows of cut edges + ghost proposals',
                    exchanged_MB_per_sweep=8e-6 * self.lay['send']['size'])
         return out

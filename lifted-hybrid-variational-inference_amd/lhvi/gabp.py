@@ -260,8 +260,8 @@ class GaLBP(_GaussianSweep):
         # colour passing exactly as GaLBP.run does it (GaLBP.py:146-151)
         self.g.init_cluster()
         prev = -1
-        while len(self.g.rvs) != prev:
-            prev = len(self.g.rvs)
+        while self.g.num_rv_clusters != prev:           # (= len(self.g.rvs), without building the cluster objects every round)
+            prev = self.g.num_rv_clusters
             self.g.split_factors()
             self.g.split_rvs()
         self._sweep(self.g, iteration)

@@ -31,7 +31,7 @@ class SuperRV:
         first = next(iter(rvs))
         self.domain = first.domain if domain is None else domain
         self.value = self.get_value(rvs if order is None else order) if value is None and first.value is not None else value
-        self.variance = None if self.value is None else self.get_variance()
+        self._variance = None                    # (np.var of the members' values, formed when first asked for)
         self.nb = None
         self.N = 0
         self.count = None
@@ -55,6 +55,19 @@ class SuperRV:
 
     def get_variance(self):
         return np.var(tuple(rv.value for rv in (sorted(self.rvs) if self._order is None else self._order)))
+
+    @property
+    def variance(self):
+        """``SuperRV.variance`` (CGWO:22,38-39): None for a hidden cluster"""
+        if self.value is None:
+            return None
+        if self._variance is None:
+            self._variance = self.get_variance()
+        return self._variance
+
+    @variance.setter
+    def variance(self, v):
+        self._variance = v
 
     @property
     def sharing_count(self):
