@@ -436,6 +436,18 @@ int lhvi_pbp_belief_points(const lhvi_graph_t* g, const lhvi_pots_t* pots, const
  * qptr [nq + 1] / qedge / qmult: the row's belief is sum_k qmult[k] * message_f_to_rv(x, edge qedge[k]) for k in
  * [qptr[i], qptr[i+1]) -- a GROUND variable's factors on the lifted graph (belief_rv_query HLBP.py:313-317).
  * xout [nq] the minimiser, fout [nq] (optional) the log-belief there, nfev [nq] (optional) function evaluations used. */
+/* The three per-variable steps of a sweep fused for hidden continuous variables with few particles (s->n <= 32: the particle
+ * counts of the reference's demos): message_rv_to_f + log_message_balance (EPBP.py:165-174,204-215; HLBP.py:182-191), then
+ * update_proposal (EPBP.py:83-154; HLBP.py:100-171), then generate_sample with the counter-based sampler + the first-occurrence
+ * mask (EPBP.py:61-70) -- one pass over a variable's incident f -> v rows instead of three launches' worth.  Same bits as
+ * lhvi_pbp_v2f + lhvi_pbp_proposal + lhvi_pbp_resample_uniq on those variables (the caller runs those three on the others).
+ * desc: records of eight 32-bit words per variable -- 0 variable  1 incident edges (<= 64)  2 grid base in dom_val  3 T
+ * 4-5 dom_lo  6-7 dom_hi (doubles) -- in three blocks: n16 variables with np <= 16 and T <= 32, then n32_t32 with 16 < np <= 32
+ * and T <= 32, then n32_t64 with np <= 32 and 32 < T <= 64.  Reads s->particles / s->uniq / s->q (the current sample and
+ * proposal), writes v2f rows, eta, q, particles_out (must not be s->particles) and uniq_out rows of the listed variables. */
+int lhvi_pbp_var_fused(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* v2f, double* eta, double* q,
+                       const int64_t* var_gid, uint64_t seed, uint32_t iteration, double* particles_out, uint8_t* uniq_out,
+                       const int32_t* desc, int32_t n16, int32_t n32_t32, int32_t n32_t64, void* stream);
 /* The normaliser of EPBP.belief for nq query rows in ONE launch: EPBP.py:325-328 calls scipy.integrate.quad on e ** belief_rv over
  * [lo, hi] (= the domain widened by 20 on both sides).  A thread per row runs QUADPACK's 21-point Gauss-Kronrod rule (dqk21 and
  * its error estimate) inside dqage's globally adaptive bisection (at most 50 intervals) until the summed error estimate meets

@@ -284,7 +284,11 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_hub_kernel(lhvi_graph_t g, lhvi
         const double mean = wave_sum(uq ? res : 0.0) * rcnt;
         double shift = mean;
         if (__ballot(uq && (res - mean > s.max_log_value))) shift = wave_max(uq ? res : -__builtin_huge_val()) - s.max_log_value;
-        if (valid) v2f[(int64_t)e * n + lane] = res - shift;
+        if (valid) {
+            v2f[(int64_t)e * n + lane] = res - shift;
+            const int64_t halo = s.halo_off ? s.halo_off[e] : -1;         // (owner-computes shards: the copy for the send buffer)
+            if (halo >= 0) s.halo_buf[halo + lane] = res - shift;
+        }
     }
 }
 
@@ -333,7 +337,11 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_narrow_kernel(lhvi_graph_t g, l
         const double mean = quad_sum(uq ? res : 0.0) * rcnt;
         const double mx = quad_max(uq ? res : -__builtin_huge_val());
         const double shift = (mx - mean > s.max_log_value) ? mx - s.max_log_value : mean;
-        if (live && valid) v2f[(int64_t)e * n + j] = res - shift;
+        if (live && valid) {
+            v2f[(int64_t)e * n + j] = res - shift;
+            const int64_t halo = s.halo_off ? s.halo_off[e] : -1;
+            if (halo >= 0) s.halo_buf[halo + j] = res - shift;
+        }
     }
 }
 
@@ -390,7 +398,11 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_packed_kernel(lhvi_graph_t g, l
             const double mx = group_max(uq ? res : -__builtin_huge_val());
             if (mx - mean > s.max_log_value) shift = mx - s.max_log_value;
         }
-        if (live && valid) v2f[(int64_t)e * n + j] = res - shift;
+        if (live && valid) {
+            v2f[(int64_t)e * n + j] = res - shift;
+            const int64_t halo = s.halo_off ? s.halo_off[e] : -1;
+            if (halo >= 0) s.halo_buf[halo + j] = res - shift;
+        }
     }
 }
 
@@ -2450,6 +2462,165 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The three per-variable steps of a sweep in ONE pass over a variable's incident f -> v rows, for hidden continuous variables
+// with few particles (np <= W = 16 or 32: the particle counts of the reference's demos, Demo/RGM/demo.py:20,
+// RGMKLDivergence.py:54): message_rv_to_f + log_message_balance (EPBP:165-174,204-215; HLBP:182-191), update_proposal
+// (EPBP:83-154; HLBP:100-171) and generate_sample + the first-occurrence mask (EPBP:61-70).  With one kernel per step such a
+// variable's rows are fetched by three launches that each keep a handful of lanes busy and then wait out their own loads; here
+// a lane group of W lanes owns the variable through all three (64 / W variables per wavefront), the new proposal never leaves
+// registers between the second and the third, and the sweep has two launches and two passes over the rows less.
+//   step 1 = the body of pbp_v2f_packed_kernel<W> (lane = particle);
+//   step 2 = the body of pbp_proposal_kernel: an incident edge's T integral points over PW lanes (PW = 16 for T <= 32, 32 for
+//            T <= 64: the widths that kernel picks), W / PW edges of the variable per pass, the information-form sums kept
+//            per "edge index mod 64 / PW" and folded in that kernel's order;
+//   step 3 = the draw of pbp_resample_uniq_kernel (Philox block j, cosine branch, for particle j < 32) and the exact
+//            first-occurrence mask within the lane group.
+// Same expressions, same reduction networks at the same lane positions, same order of additions: the same bits as the three
+// kernels (tests/test_gpu_pbp.py::test_fused_variable_kernel_equals_the_three_kernels).  Records (lhvi_pbp_t.fused_desc):
+// eight 32-bit words per variable -- 0 variable  1 incident edges  2 grid base in dom_val  3 T  4-5 dom_lo  6-7 dom_hi.
+template <int W, int PW, bool EP>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
+pbp_var_fused_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v, double* __restrict__ v2f, double* __restrict__ eta,
+                     double* __restrict__ q, const int64_t* __restrict__ gid, uint64_t seed, uint32_t iteration,
+                     double* __restrict__ out, uint8_t* __restrict__ uniq, const int32_t* __restrict__ list, int count) {
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    load_log_table(sh_log);
+    __syncthreads();
+    constexpr int G = WAVE / W, SL = W / PW;                 // variables per wavefront; edges of a variable per proposal pass
+    const int lane = threadIdx.x & 63;
+    const int64_t slot = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * G + lane / W;
+    const int j = lane % W;
+    const bool on = slot < count;
+    const int32_t* rec = list + 8 * (on ? slot : 0);
+    const int v = on ? rec[0] : 0;
+    const int deg = on ? rec[1] : 0, gb = rec[2], T = on ? rec[3] : 0;
+    const double dlo = __hiloint2double(rec[5], rec[4]), dhi = __hiloint2double(rec[7], rec[6]);
+    const int n = s.n, S = s.n + s.T;
+    const int np = on ? s.np[v] : 0;
+    const bool valid = j < np;
+    const int lo = on ? g.var_ptr[v] : 0;
+    const bool lifted = g.edge_count != nullptr;
+    const double q0 = on ? s.q[2 * v] : 0.0, q1 = on ? s.q[2 * v + 1] : 1.0;
+    // every lane of the wave runs the longest row of its variables (the reductions are wave-wide instructions)
+    int maxdeg = deg;
+#pragma unroll
+    for (int off = 32; off >= W; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
+    // ---- step 1: v -> f (pbp_v2f_packed_kernel<W>)
+    {
+        double total = 0.0;
+        for (int k = 0; k < deg; ++k) {
+            const int e = g.var_edge[lo + k];
+            const double m = valid ? f2v[(int64_t)e * S + j] : 0.0;
+            total += lifted ? m * g.edge_count[e] : m;
+        }
+        double logw = 0.0;
+        bool uq = false;
+        if (valid) {
+            const int d = g.var_dom[v];
+            const double sd = sqrt_pos(q1);
+            logw = log_importance(g, s, v, d, s.particles[(int64_t)v * n + j], q0, rcp_newton(sd), log_pos(2.506628274631 * sd));
+            uq = s.uniq[(int64_t)v * n + j] != 0;
+        }
+        auto group_sum = [&](double x) { return W == 16 ? dpp_move<0x15F>(dpp_row_reduce(x, SumOp())) : dpp_half_reduce(x, SumOp(), lane); };
+        auto group_max = [&](double x) { return W == 16 ? dpp_row_reduce(x, MaxOp()) : dpp_half_reduce(x, MaxOp(), lane); };
+        const uint64_t mine = (W == 16 ? 0xffffull : 0xffffffffull) << (lane / W * W);
+        const double rcnt = rcp_newton(fmax((double)__builtin_popcountll(__ballot(uq) & mine), 1.0));
+        for (int k = 0; k < maxdeg; ++k) {
+            const bool live = k < deg;
+            const int e = live ? g.var_edge[lo + k] : 0;
+            const double m = (live && valid) ? f2v[(int64_t)e * S + j] : 0.0;
+            const double res = (total - m) + logw;
+            const double mean = group_sum(uq ? res : 0.0) * rcnt;
+            double shift = mean;
+            if (__ballot(uq && (res - mean > s.max_log_value))) {
+                const double mx = group_max(uq ? res : -__builtin_huge_val());
+                if (mx - mean > s.max_log_value) shift = mx - s.max_log_value;
+            }
+            if (live && valid) v2f[(int64_t)e * n + j] = res - shift;
+        }
+    }
+    // ---- step 2: the proposal (pbp_proposal_kernel<EP>)
+    double total = 0.0;
+    if (lifted) for (int k = 0; k < deg; ++k) total += g.edge_count[g.var_edge[lo + k]];
+    else total = (double)deg;
+    const double min_sig = total * s.var_threshold;
+    const int sub = j / PW, tl = j % PW;
+    double ps[4] = {0.0, 0.0, 0.0, 0.0}, pm[4] = {0.0, 0.0, 0.0, 0.0};      // sums of the edges with index = i (mod 64 / PW), slot `sub`'s share
+    for (int k0 = 0; k0 < maxdeg; k0 += SL) {
+        const int k = k0 + sub;
+        const bool live = k < deg;
+        const int e = on ? g.var_edge[lo + (live ? k : 0)] : 0;
+        const double* msg = f2v + (int64_t)e * S + n;
+        const double b0 = on ? eta[2 * e] : 0.0, b1 = on ? eta[2 * e + 1] : 1.0;
+        const bool use_cav = EP && !(q1 >= b1);
+        double c0 = 0.0, c1 = 1.0;
+        if (use_cav) gdiv(q0, q1, b0, b1, c0, c1);
+        const double csd = sqrt(c1);
+        double z = 0.0, a = 0.0, b = 0.0;
+        if (on)
+            for (int t = tl; t < T; t += PW) {
+                const double xg = g.dom_val[gb + t];
+                double w = exp(msg[t]);
+                if (use_cav) w = w * norm_pdf_std(xg, c0, csd);
+                z += w; a += w * xg; b += w * (xg * xg);
+            }
+        if (PW == 16) { z = dpp_row_reduce(z, SumOp()); a = dpp_row_reduce(a, SumOp()); b = dpp_row_reduce(b, SumOp()); }
+        else { z = dpp_half_reduce(z, SumOp(), lane); a = dpp_half_reduce(a, SumOp(), lane); b = dpp_half_reduce(b, SumOp(), lane); }
+        const double rz = rcp_newton(z);
+        double mu = a * rz;
+        double sig = b * rz - mu * mu;
+        if (use_cav) { const double m0 = mu, m1 = sig; gdiv(m0, m1, c0, c1, mu, sig); }
+        if (0.0 < sig && sig < __builtin_huge_val()) {
+            sig = fmax(sig, min_sig);
+            if (live && tl == 0) { eta[2 * e] = mu; eta[2 * e + 1] = sig; }
+        } else {
+            mu = b0; sig = b1;
+        }
+        if (live) {
+            const double p = rcp_newton(sig);
+            const int slot4 = k & (WAVE / PW - 1);             // the lane group of pbp_proposal_kernel this edge would fall to
+            const double c = lifted ? g.edge_count[e] : 1.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i == slot4) {
+                    if (lifted) { ps[i] += p * c; pm[i] += p * mu * c; }
+                    else { ps[i] += p; pm[i] += p * mu; }
+                }
+        }
+    }
+    // that kernel's fold of its lane groups: PW = 16: (g0 + g1) + (g2 + g3); PW = 32: g0 + g1
+    double fs, fm;
+    if (PW == 16 && SL == 1) { fs = (ps[0] + ps[1]) + (ps[2] + ps[3]); fm = (pm[0] + pm[1]) + (pm[2] + pm[3]); }
+    else if (PW == 16) {
+        // slot 0 holds g0 and g2, slot 1 (sixteen lanes on) g1 and g3
+        const double s01 = (sub == 0 ? ps[0] : ps[1]), s23 = (sub == 0 ? ps[2] : ps[3]);
+        const double m01 = (sub == 0 ? pm[0] : pm[1]), m23 = (sub == 0 ? pm[2] : pm[3]);
+        fs = (s01 + __shfl_xor(s01, 16)) + (s23 + __shfl_xor(s23, 16));
+        fm = (m01 + __shfl_xor(m01, 16)) + (m23 + __shfl_xor(m23, 16));
+    } else { fs = ps[0] + ps[1]; fm = pm[0] + pm[1]; }
+    fs = 1.0 / fs;
+    const double mu_new = fs * fm, var_new = fs;
+    if (on && j == 0) { q[2 * v] = mu_new; q[2 * v + 1] = var_new; }
+    // ---- step 3: the new particles and their first-occurrence mask (pbp_resample_uniq_kernel)
+    // (the values every lane of the group needs are the ones its first lane formed: that lane wrote q)
+    const int first_lane = lane / W * W;
+    const double mu_b = __shfl(mu_new, first_lane), sd_b = sqrt_pos(__shfl(var_new, first_lane));
+    double x = 0.0;
+    if (valid) {
+        double zc, zs;
+        philox_normal_pair(seed, gid ? (uint64_t)gid[v] : (uint64_t)v, (uint32_t)j, iteration, sh_log, zc, zs);
+        x = fmin(fmax(fma(sd_b, zc, mu_b), dlo), dhi) + 0.0;      // + 0.0: no -0, so that equality below is equality of the patterns
+        out[(int64_t)v * n + j] = x;
+    }
+    int u = valid;
+    for (int k = 0; k + 1 < W; ++k) {
+        const double xk = __shfl(x, first_lane + k);
+        if (k < j && k < np && xk == x) u = 0;
+    }
+    if (on && j < n) uniq[(int64_t)v * n + j] = (uint8_t)u;
+}
+
 static int validate_pbp(const lhvi_graph_t* g, const lhvi_pbp_t* s) {
     if (!g || !s) return LHVI_E_ARG;
     if (g->V < 0 || g->E < 0 || s->n <= 0 || s->T < 0) return LHVI_E_ARG;
@@ -2539,7 +2710,7 @@ int lhvi_debug_exp_acc(const double* x, const double* c, double* y, int64_t n, v
 int lhvi_pbp_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* v2f, void* stream) {
     if (int rc = validate_pbp(g, s)) return rc;
     if (!f2v || !v2f || !s->uniq || !s->q) return LHVI_E_ARG;
-    if (s->halo_off && (!s->halo_buf || s->v2f_wide || s->v2f_narrow)) return LHVI_E_ARG;      // (copies are made by the range form only)
+    if (s->halo_off && !s->halo_buf) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
     if (s->v2f_wide || s->v2f_narrow) {
         // the caller's split of the hidden variables: one wavefront per variable / sixteen variables per wavefront
@@ -2812,6 +2983,31 @@ int lhvi_pbp_map_brent(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhv
     QueryRows rows{row_var, qptr, qedge, qmult};
     hipLaunchKernelGGL(pbp_map_brent_kernel, dim3(grid_for(nq)), dim3(BLOCK), 0, as_stream(stream), *g, *pots, *s, v2f, nq, rows,
                        row_var, xtol / 3.0, maxfun, xout, fout, nfev);
+    return check_launch();
+}
+
+int lhvi_pbp_var_fused(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* v2f, double* eta, double* q,
+                       const int64_t* var_gid, uint64_t seed, uint32_t iteration, double* particles_out, uint8_t* uniq_out,
+                       const int32_t* desc, int32_t n16, int32_t n32_t32, int32_t n32_t64, void* stream) {
+    if (int rc = validate_pbp(g, s)) return rc;
+    if (!f2v || !v2f || !eta || !q || !particles_out || !uniq_out || !s->uniq || !s->q || !g->dom_lo || !g->dom_hi || !g->dom_val) return LHVI_E_ARG;
+    if (n16 < 0 || n32_t32 < 0 || n32_t64 < 0 || s->n > 32 || s->bslot || s->var_hi > s->var_lo || particles_out == s->particles) return LHVI_E_ARG;
+    if ((int64_t)n16 + n32_t32 + n32_t64 == 0) return LHVI_OK;
+    if (!desc) return LHVI_E_ARG;
+    hipStream_t st = as_stream(stream);
+    const bool ep = (s->flags & LHVI_PBP_EP) != 0;
+#define LHVI_FUSED(W, PW, list, cnt)                                                                                                  \
+    if ((cnt) > 0) {                                                                                                                  \
+        const dim3 grid(grid_for(((int64_t)(cnt) + WAVE / (W) - 1) / (WAVE / (W)) * WAVE));                                          \
+        if (ep) hipLaunchKernelGGL((pbp_var_fused_kernel<W, PW, true>), grid, dim3(BLOCK), 0, st, *g, *s, f2v, v2f, eta, q, var_gid, \
+                                   seed, iteration, particles_out, uniq_out, list, cnt);                                             \
+        else hipLaunchKernelGGL((pbp_var_fused_kernel<W, PW, false>), grid, dim3(BLOCK), 0, st, *g, *s, f2v, v2f, eta, q, var_gid,   \
+                                seed, iteration, particles_out, uniq_out, list, cnt);                                                \
+    }
+    LHVI_FUSED(16, 16, desc, n16)
+    LHVI_FUSED(32, 16, desc + 8 * (int64_t)n16, n32_t32)
+    LHVI_FUSED(32, 32, desc + 8 * ((int64_t)n16 + n32_t32), n32_t64)
+#undef LHVI_FUSED
     return check_launch();
 }
 

@@ -152,6 +152,7 @@ SIGNATURES = {
     'lhvi_pbp_resample_uniq': (C.c_int, [_G, _S, _vp, _u64, _u32, _vp, _vp, _vp]),
     'lhvi_pbp_belief_points': (C.c_int, [_G, _P, _S, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     'lhvi_pbp_map_brent': (C.c_int, [_G, _P, _S, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _i32, _vp, _vp, _vp, _vp]),
+    'lhvi_pbp_var_fused': (C.c_int, [_G, _S, _vp, _vp, _vp, _vp, _vp, _u64, _u32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'lhvi_pbp_quad': (C.c_int, [_G, _P, _S, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp]),
     'lhvi_vi_workspace_bytes': (_sz, [_G, _VI]),
     'lhvi_vi_grad': (C.c_int, [_G, _P, _VI, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -874,7 +874,9 @@ class OwnerRunner:
         canon, halo_rows = plan.ghost_rows(n)
         plan.flat.edge_canon = canon
         bp = EPBP(None, n=n, proposal_approximation=proposal_approximation, sampler='device', seed=seed)
-        bp._setup(None, flat=plan.flat, edge_key=plan.edge_key, edge_skip=plan.edge_skip)
+        # (the v -> f half and the proposal update address the OWNED variables through the same per-variable lists as a single-GPU
+        # run -- sixteen binary variables per wavefront, one record per continuous one -- not through a range of all local rows)
+        bp._setup(None, flat=plan.flat, edge_key=plan.edge_key, edge_skip=plan.edge_skip, owned=plan.n_owned)
         self.bp = bp
         bp.var_gid = _abi.to_dev(plan.var_gid)
         self.n = n
@@ -964,10 +966,13 @@ class OwnerRunner:
         half forms them (``halo_off``); a small pass adds the proposals of the owned variables that are ghosts elsewhere"""
         bp, l, st = self.bp, _abi.lib(), _abi.stream_ptr()
         if self.n_owned:
-            s = self._struct(0, self.n_owned)
+            s = bp._struct()                                  # the owned variables' lists (EPBP._setup(owned=...))
+            if bp.v2f_lists is None:
+                s.var_lo, s.var_hi = 0, int(self.n_owned)
             s.halo_off, s.halo_buf = _abi.ptr(self.idx['halo_off']), _abi.ptr(self.send)
             _abi.check(l.lhvi_pbp_v2f(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.v2f), st))
             s.halo_off = s.halo_buf = None
+            s.var_lo, s.var_hi = (0, 0) if s.prop_desc else (0, int(self.n_owned))
             _abi.check(l.lhvi_pbp_proposal(bp.dg.g, s, _abi.ptr(bp.f2v), _abi.ptr(bp.eta), _abi.ptr(bp.q_dev), st))
         L, ix = self.lay['send'], self.idx
         _abi.check(l.lhvi_pbp_halo_pack(_abi.ptr(bp.v2f), self.n, self.n_send_more, _abi.ptr(ix['send_more_edge']),

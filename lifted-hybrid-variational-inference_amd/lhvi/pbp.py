@@ -40,17 +40,21 @@ class _ParticleSweep:
     sliced_proposal = True          # rows of more than prop_slice incident edges are cut into slices, a wavefront per slice
     prop_slice = 64
     packed_v2f = True               # variables with at most four particles share a wavefront in the v -> f half (sixteen each)
+    fused_var_kernel = True         # n <= 32, device sampler: v -> f, proposal update and the new sample of a continuous variable in ONE
+                                    # pass over its rows (lhvi_pbp_var_fused) instead of three launches; same bits
     exact_queries = False           # map / probability / belief answer per-variable calls from ONE batched pass over all
                                     # variables, made at the first call after run() (True: one fminbound / log_area / quad per call)
     map_mode = 'fminbound'          # what the batched map() runs per variable: the reference's fminbound iteration (lhvi_pbp_map_brent)
                                     # or 'global': scan + bracket refinement (map_all)
 
     # ---- set-up ------------------------------------------------------------------------------
-    def _setup(self, graph_like, flat=None, edge_key=None, sides='vf', edge_skip=None):
+    def _setup(self, graph_like, flat=None, edge_key=None, sides='vf', edge_skip=None, owned=None):
         """`edge_key` (sharded runs): 0 / 1 per edge; every f2v work list is ordered key-0 edges first and ``part_counts``
         gives the length of that first part per list (heavy, light, fast, generic).
         `edge_skip` (owner-computes shards): boolean per edge; the f -> v message of a marked edge is somebody else's to compute,
         it enters no work list.
+        `owned` (owner-computes shards): the per-variable lists of the v -> f half and of the proposal update hold the variables
+        below this index only (the rank's own; the sampler's list keeps all of them: ghosts are drawn here too).
         `sides`: which half sweeps this state will run -- 'v' (v -> f, proposal, sampling: the variable-side state of a
         coarse-to-fine sweep), 'f' (f -> v and the queries: its factor-side state) or both; the work lists of the other half
         are not built."""
@@ -87,7 +91,8 @@ class _ParticleSweep:
         self.cq_desc, self.n_cq = None, 0
         self.fast_edges = self.generic_edges = self._fast_list = self._generic_list = torch.zeros(1, dtype=torch.int32, device=dg.device)
         # records of the hidden continuous variables for the proposal kernel (include/lhvi.h, lhvi_pbp_t.prop_desc)
-        pv = np.flatnonzero(flat.var_hidden & flat.var_cont)
+        pv_all = np.flatnonzero(flat.var_hidden & flat.var_cont)
+        pv = pv_all if owned is None else pv_all[pv_all < owned]
         pd = np.zeros((pv.size, 8), dtype=np.int32)
         pdeg = np.diff(flat.var_ptr)[pv]
         pdom = flat.var_dom[pv]
@@ -97,11 +102,12 @@ class _ParticleSweep:
             if flat.var_edge.size:
                 pd[:, 4 + k] = flat.var_edge[np.minimum(pbase + np.minimum(k, np.maximum(pdeg - 1, 0)), flat.var_edge.size - 1)]
         # the device sampler's list (include/lhvi.h, lhvi_pbp_t.resample_vars); the other rows are filled once, by the first draw
-        rr = np.zeros((pv.size, 8), dtype=np.int32)
-        rr[:, 0], rr[:, 1] = pv, self.np_host[pv]
-        rr[:, 2:4] = np.ascontiguousarray(flat.dom_lo[pdom], dtype=np.float64).view(np.int32).reshape(-1, 2)
-        rr[:, 4:6] = np.ascontiguousarray(flat.dom_hi[pdom], dtype=np.float64).view(np.int32).reshape(-1, 2)
-        host_lists['resample_vars'] = rr if pv.size else None
+        rdom = flat.var_dom[pv_all]
+        rr = np.zeros((pv_all.size, 8), dtype=np.int32)
+        rr[:, 0], rr[:, 1] = pv_all, self.np_host[pv_all]
+        rr[:, 2:4] = np.ascontiguousarray(flat.dom_lo[rdom], dtype=np.float64).view(np.int32).reshape(-1, 2)
+        rr[:, 4:6] = np.ascontiguousarray(flat.dom_hi[rdom], dtype=np.float64).view(np.int32).reshape(-1, 2)
+        host_lists['resample_vars'] = rr if pv_all.size else None
         self._static_rows = False
         static = np.flatnonzero(~(flat.var_hidden & flat.var_cont))
         host_lists['_static_idx'] = static.astype(np.int64) if static.size else None
@@ -128,6 +134,8 @@ class _ParticleSweep:
         self.n_prop_desc = int(pd.shape[0])
         # the v -> f half's split of the hidden variables (include/lhvi.h, lhvi_pbp_t.v2f_wide / v2f_narrow)
         hidden_v = np.flatnonzero(flat.var_hidden)
+        if owned is not None:
+            hidden_v = hidden_v[hidden_v < owned]
         narrow = self.np_host[hidden_v] <= 4
         self.v2f_lists = None
         hub = ~narrow & (np.diff(flat.var_ptr)[hidden_v] > 64) & (self.np_host[hidden_v] <= 64)
@@ -138,9 +146,43 @@ class _ParticleSweep:
             parts = (('wide', wide), ('narrow', narrow), ('hub', hub), ('mid16', mid16), ('mid32', mid32))
             for name, m in parts:
                 host_lists['v2f_' + name] = hidden_v[m].astype(np.int32) if m.any() else np.zeros(1, dtype=np.int32)
+        # ---- the fused per-variable kernel's records (lhvi_pbp_var_fused) and what is left for the three kernels
+        self._fused = None
+        pT = sizes[pdom] if pv.size else np.zeros(0, dtype=np.int64)
+        fz = (pdeg <= min(64, self.prop_slice)) & (pT <= 64) & (n <= 32) if pv.size else np.zeros(0, dtype=bool)
+        if self.fused_var_kernel and owned is None and self.sampler == 'device' and self.listed_proposal and self.listed_resample \
+                and 'v2f_wide' in host_lists and fz.any():
+            k16 = fz & (n <= 16) & (pT <= 32)
+            k32a = fz & ~k16 & (pT <= 32)
+            k32b = fz & ~k16 & ~k32a
+            fd = np.zeros((pv.size, 8), dtype=np.int32)
+            fd[:, 0], fd[:, 1], fd[:, 2], fd[:, 3] = pv, pdeg, flat.dom_ptr[pdom], pT
+            fd[:, 4:6] = np.ascontiguousarray(flat.dom_lo[pdom], dtype=np.float64).view(np.int32).reshape(-1, 2)
+            fd[:, 6:8] = np.ascontiguousarray(flat.dom_hi[pdom], dtype=np.float64).view(np.int32).reshape(-1, 2)
+            host_lists['fused_desc'] = np.ascontiguousarray(np.concatenate([fd[k16], fd[k32a], fd[k32b]]))
+            fused_var = np.zeros(flat.V, dtype=bool)
+            fused_var[pv[fz]] = True
+            # the rest: proposal records (slices of hub rows sit at the head of pd and are never fused), sampler records, v -> f lists
+            keep = ~fused_var[pd[:, 0]]
+            host_lists['prop_desc_rest'] = np.ascontiguousarray(pd[keep]) if keep.any() else np.zeros((1, 8), dtype=np.int32)
+            rkeep = ~fused_var[rr[:, 0]]
+            host_lists['resample_rest'] = np.ascontiguousarray(rr[rkeep]) if rkeep.any() else np.zeros((1, 8), dtype=np.int32)
+            rest_parts = []
+            if 'v2f_wide' in host_lists:
+                for name, m in parts:
+                    vs = hidden_v[m]
+                    vs = vs[~fused_var[vs]]
+                    host_lists['v2f_rest_' + name] = vs.astype(np.int32) if vs.size else np.zeros(1, dtype=np.int32)
+                    rest_parts.append((name, int(vs.size)))
+            self._fused = dict(counts=(int(k16.sum()), int(k32a.sum()), int(k32b.sum())), n_prop_rest=int(keep.sum()),
+                               n_resample_rest=int(rkeep.sum()), rest_parts=rest_parts)
         dev_lists = _abi.upload(host_lists)
         for name in ('np_dev', 'resample_vars', '_static_idx', 'prop_desc'):
             setattr(self, name, dev_lists[name])
+        if self._fused is not None:
+            F = self._fused
+            F['desc'], F['prop_desc_rest'], F['resample_rest'] = dev_lists['fused_desc'], dev_lists['prop_desc_rest'], dev_lists['resample_rest']
+            F['v2f_rest'] = tuple(x for name, cnt in F['rest_parts'] for x in (dev_lists['v2f_rest_' + name], cnt)) if F['rest_parts'] else None
         if 'prop_hub' in dev_lists:
             self.prop_hub = dev_lists['prop_hub']
         if 'v2f_wide' in dev_lists:
@@ -355,7 +397,9 @@ class _ParticleSweep:
         self.old_particles, self.particles = self.particles, self.old_particles
         self.particles.copy_(_abi.to_dev(p))
 
-    def _generate_sample(self):
+    def _generate_sample(self, rest_only=False):
+        """`rest_only`: the fused kernel has already drawn for its variables into the other buffer (``_fused_sweep_head``): swap,
+        then draw for the remaining listed variables only"""
         l, st = _abi.lib(), _abi.stream_ptr()
         k = self._draws
         self._draws += 1
@@ -363,6 +407,13 @@ class _ParticleSweep:
             self.old_particles, self.particles = self.particles, self.old_particles
             s = self._struct()
             gid = _abi.ptr(getattr(self, 'var_gid', None))
+            if rest_only:
+                F = self._fused
+                if F['n_resample_rest']:
+                    s.resample_vars, s.n_resample_vars = _abi.ptr(F['resample_rest']), int(F['n_resample_rest'])
+                    _abi.check(l.lhvi_pbp_resample_uniq(self.dg.g, s, gid, int(self.seed), int(k), _abi.ptr(self.particles), _abi.ptr(self.uniq), st))
+                self._views, self._batched = {}, {}
+                return
             if self.listed_resample and self.n <= 64 and getattr(self, 'resample_vars', None) is not None:
                 if not self._static_rows:
                     # first device draw of this state: the full (unlisted) draw into the CURRENT buffer only -- the other one may
@@ -401,6 +452,25 @@ class _ParticleSweep:
         """one flooding sweep: v2f, and unless `last`: proposal update, new sample, f2v.
         `f2v_events`: optional (start, end) torch.cuda.Event pair recorded around the f2v launch on its stream"""
         l, st, g, p = _abi.lib(), _abi.stream_ptr(), self.dg.g, self.dg.p
+        if not last and getattr(self, '_fused', None) is not None and self._static_rows and self.sampler == 'device':
+            # few particles: one pass per continuous variable does its v -> f messages, its proposal update and its new sample
+            # (lhvi_pbp_var_fused, into the buffer the swap below makes current); the three kernels serve the other variables
+            F = self._fused
+            s = self._struct()
+            n16, n32a, n32b = F['counts']
+            _abi.check(l.lhvi_pbp_var_fused(g, s, _abi.ptr(self.f2v), _abi.ptr(self.v2f), _abi.ptr(self.eta), _abi.ptr(self.q_dev),
+                                            _abi.ptr(getattr(self, 'var_gid', None)), int(self.seed), int(self._draws),
+                                            _abi.ptr(self.old_particles), _abi.ptr(self.uniq), _abi.ptr(F['desc']), n16, n32a, n32b, st))
+            w, nw, nr, nn, hb, nh, m16, c16, m32, c32 = F['v2f_rest']
+            s.v2f_wide, s.n_v2f_wide, s.v2f_narrow, s.n_v2f_narrow = _abi.ptr(w), nw, _abi.ptr(nr), nn
+            s.v2f_hub, s.n_v2f_hub = _abi.ptr(hb), nh
+            s.v2f_mid16, s.n_v2f_mid16, s.v2f_mid32, s.n_v2f_mid32 = _abi.ptr(m16), c16, _abi.ptr(m32), c32
+            _abi.check(l.lhvi_pbp_v2f(g, s, _abi.ptr(self.f2v), _abi.ptr(self.v2f), st))
+            s.prop_desc, s.n_prop_desc = _abi.ptr(F['prop_desc_rest']), int(F['n_prop_rest'])
+            _abi.check(l.lhvi_pbp_proposal(g, s, _abi.ptr(self.f2v), _abi.ptr(self.eta), _abi.ptr(self.q_dev), st))
+            self._generate_sample(rest_only=True)
+            self._launch_f2v(self._struct(), f2v_events)
+            return
         _abi.check(l.lhvi_pbp_v2f(g, self._struct(), _abi.ptr(self.f2v), _abi.ptr(self.v2f), st))
         if not last:
             _abi.check(l.lhvi_pbp_proposal(g, self._struct(), _abi.ptr(self.f2v), _abi.ptr(self.eta),

@@ -929,6 +929,52 @@ def test_packed_v2f_kernel_does_not_change_results(api, solver):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
 
 
+@pytest.mark.parametrize('case', ['n10', 'n16', 'n20', 'n32', 'n12 T48', 'n24 T64', 'n10 EP', 'n20 EP', 'hlbp n12', 'hlbp n20 EP', 'hmln hubs n16'])
+def test_fused_variable_kernel_equals_the_three_kernels(api, case):
+    """few particles (the reference's demos run 10 - 20): ``lhvi_pbp_var_fused`` does a continuous variable's v -> f messages, its
+    proposal update and its new sample + first-occurrence mask in one pass over its rows (lane groups of 16 / 32 lanes; T <= 32
+    points over 16 lanes, T <= 64 over 32) -- against ``lhvi_pbp_v2f`` + ``lhvi_pbp_proposal`` + ``lhvi_pbp_resample_uniq``: every
+    array of the state after whole sweeps, bit for bit ('simple' and 'EP' rule, ground and lifted with counts, hub rows left
+    to the three kernels)"""
+    import torch
+    from lhvi import synth
+    from lhvi.pbp import EPBP, HybridLBP
+    n = int(case.split()[-2 if case.endswith('EP') else -1][1:]) if not case.startswith('n') else int(case.split()[0][1:])
+    approx = 'EP' if case.endswith('EP') else 'simple'
+    T = int(case.split()[1][1:]) if ' T' in case else 32
+    runs = []
+    for fused in (True, False):
+        if case.startswith('hlbp'):
+            g, table = paper_popularity(30, 4, seed=9)
+            bp = HybridLBP(g, n=n, proposal_approximation=approx, sampler='device', seed=4)
+            bp.fused_var_kernel = fused
+            bp.run(5)
+        else:
+            if case.startswith('hmln'):
+                flat, keys = synth.paper_popularity_flat(150, 4, seed=2)          # topics touch > 64 factors: not fused
+            else:
+                flat = synth.hybrid_mrf_flat(V=9001, deg=4, seed=31, frac_discrete=0.3, T=T)
+            bp = EPBP(None, n=n, proposal_approximation=approx, sampler='device', seed=6)
+            bp.fused_var_kernel = fused
+            bp._setup(None, flat=flat)
+            _init(api, bp)
+            for _ in range(5):
+                bp.sweep(last=False)
+            bp.sweep(last=True)
+        torch.cuda.synchronize()
+        runs.append(bp)
+    a, b = runs
+    assert a._fused is not None and sum(a._fused['counts']) > 0 and b._fused is None
+    c16, c32a, c32b = a._fused['counts']
+    if not case.startswith('h'):
+        assert (c16 > 0) == (n <= 16 and T <= 32) and (c32a > 0) == (n > 16 and T <= 32) and (c32b > 0) == (T > 32)
+    if case.startswith('hmln'):
+        assert a._fused['n_prop_rest'] > 0 and a.n_prop_hub > 0                    # the hub rows stay with the three kernels
+    for name in ('q_dev', 'eta', 'particles', 'old_particles', 'uniq', 'v2f', 'f2v'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert bool(torch.isfinite(a.q_dev[torch.from_numpy(a.flat.var_hidden & a.flat.var_cont).to(a.q_dev.device)]).all())
+
+
 def test_v2f_hub_kernel_matches_the_one_wave_path(api):
     """template variables (more than 64 incident factors: the topics of the paper-popularity model) are swept by a workgroup
     each (pbp_v2f_hub_kernel: four partial totals added in a fixed order) instead of one wavefront walking the row: the same
