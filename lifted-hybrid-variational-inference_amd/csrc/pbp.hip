@@ -2479,8 +2479,11 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
 // Same expressions, same reduction networks at the same lane positions, same order of additions: the same bits as the three
 // kernels (tests/test_gpu_pbp.py::test_fused_variable_kernel_equals_the_three_kernels).  Records (lhvi_pbp_t.fused_desc):
 // eight 32-bit words per variable -- 0 variable  1 incident edges  2 grid base in dom_val  3 T  4-5 dom_lo  6-7 dom_hi.
+#ifndef LHVI_FUSED_WAVES
+#define LHVI_FUSED_WAVES 6
+#endif
 template <int W, int PW, bool EP>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI_FUSED_WAVES, 8)))
 pbp_var_fused_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v, double* __restrict__ v2f, double* __restrict__ eta,
                      double* __restrict__ q, const int64_t* __restrict__ gid, uint64_t seed, uint32_t iteration,
                      double* __restrict__ out, uint8_t* __restrict__ uniq, const int32_t* __restrict__ list, int count) {

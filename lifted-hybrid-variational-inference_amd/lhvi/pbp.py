@@ -17,6 +17,7 @@ draw when ``g.rvs`` is ordered; ``sampler='device'`` uses the counter-based Phil
 """
 from __future__ import annotations
 
+import os
 from math import e, log, sqrt
 
 import numpy as np
@@ -40,8 +41,10 @@ class _ParticleSweep:
     sliced_proposal = True          # rows of more than prop_slice incident edges are cut into slices, a wavefront per slice
     prop_slice = 64
     packed_v2f = True               # variables with at most four particles share a wavefront in the v -> f half (sixteen each)
-    fused_var_kernel = True         # n <= 32, device sampler: v -> f, proposal update and the new sample of a continuous variable in ONE
-                                    # pass over its rows (lhvi_pbp_var_fused) instead of three launches; same bits
+    fused_var_kernel = True         # few particles, device sampler: v -> f, proposal update and the new sample of a continuous variable in
+                                    # ONE pass over its rows (lhvi_pbp_var_fused) instead of three launches; same bits
+    fused_max_particles = 16        # ... up to this many particles: measured on the headline graph (profiles/r05_experiments.md) the
+                                    # 16-lane form wins 2-4 % of the sweep (n = 10, 16), the 32-lane form loses 5-8 % (n = 20, 32)
     exact_queries = False           # map / probability / belief answer per-variable calls from ONE batched pass over all
                                     # variables, made at the first call after run() (True: one fminbound / log_area / quad per call)
     map_mode = 'fminbound'          # what the batched map() runs per variable: the reference's fminbound iteration (lhvi_pbp_map_brent)
@@ -149,8 +152,8 @@ class _ParticleSweep:
         # ---- the fused per-variable kernel's records (lhvi_pbp_var_fused) and what is left for the three kernels
         self._fused = None
         pT = sizes[pdom] if pv.size else np.zeros(0, dtype=np.int64)
-        fz = (pdeg <= min(64, self.prop_slice)) & (pT <= 64) & (n <= 32) if pv.size else np.zeros(0, dtype=bool)
-        if self.fused_var_kernel and owned is None and self.sampler == 'device' and self.listed_proposal and self.listed_resample \
+        fz = (pdeg <= min(64, self.prop_slice)) & (pT <= 64) & (n <= min(32, self.fused_max_particles)) if pv.size else np.zeros(0, dtype=bool)
+        if (self.fused_var_kernel and os.environ.get('LHVI_PBP_FUSED', '1') != '0') and owned is None and self.sampler == 'device' and self.listed_proposal and self.listed_resample \
                 and 'v2f_wide' in host_lists and fz.any():
             k16 = fz & (n <= 16) & (pT <= 32)
             k32a = fz & ~k16 & (pT <= 32)

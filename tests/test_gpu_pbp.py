@@ -947,7 +947,7 @@ def test_fused_variable_kernel_equals_the_three_kernels(api, case):
         if case.startswith('hlbp'):
             g, table = paper_popularity(30, 4, seed=9)
             bp = HybridLBP(g, n=n, proposal_approximation=approx, sampler='device', seed=4)
-            bp.fused_var_kernel = fused
+            bp.fused_var_kernel, bp.fused_max_particles = fused, 32        # (the 32-lane forms are off by default: slower, measured)
             bp.run(5)
         else:
             if case.startswith('hmln'):
@@ -955,7 +955,7 @@ def test_fused_variable_kernel_equals_the_three_kernels(api, case):
             else:
                 flat = synth.hybrid_mrf_flat(V=9001, deg=4, seed=31, frac_discrete=0.3, T=T)
             bp = EPBP(None, n=n, proposal_approximation=approx, sampler='device', seed=6)
-            bp.fused_var_kernel = fused
+            bp.fused_var_kernel, bp.fused_max_particles = fused, 32
             bp._setup(None, flat=flat)
             _init(api, bp)
             for _ in range(5):
