@@ -51,7 +51,7 @@ def algorithmic_bytes_per_edge(n, T):
             'sweep': 32 * n + 16 * T + 16 + 12}
 
 
-TRAFFIC_PROFILE = 'profiles/r04_final_traffic.json'     # the PMC summary of THIS round's build (scripts/profile_round.sh r04_final)
+TRAFFIC_PROFILE = 'profiles/r05_final_traffic.json'     # the PMC summary of THIS round's build (scripts/profile_round.sh r05_final)
 
 
 def measured_traffic(kernel):

@@ -1,13 +1,13 @@
-"""Generate the measured-numbers block of DESIGN.md section 5 from the committed profile files, so that the document cannot
-quote a number that no file holds.
+"""Generate the measured-numbers block of docs/measurement.md (DESIGN.md section 5 until round 4) from the committed profile files,
+so that the document cannot quote a number that no file holds.
 
 usage: python scripts/design_numbers.py <tag>            -> prints the block (markdown)
-       python scripts/design_numbers.py <tag> --write    -> also rewrites the block between the markers in DESIGN.md
+       python scripts/design_numbers.py <tag> --write    -> also rewrites the block between the markers in docs/measurement.md
 
 Inputs (all under profiles/): <tag>_bench_default.json (bench.py's line, plain run), <tag>_final_bench_under_rocprof.json,
 <tag>_final_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py), <tag>_final_traffic.json / _pmc.md (separate
 --pmc passes, scripts/summarize_pmc.py), <tag>_secondary_configs.jsonl (scripts/bench_configs.py), <tag>_secondary_traffic.json.
-tests/test_host_api.py::test_design_numbers_are_the_committed_profiles keeps DESIGN.md equal to this script's output.
+tests/test_host_api.py::test_design_numbers_are_the_committed_profiles keeps docs/measurement.md equal to this script's output.
 """
 import csv
 import json
@@ -126,7 +126,9 @@ def block(tag):
     for extra, what in (('_c2f_configs.jsonl', 'particle coarse-to-fine on arrays, `scripts/bench_configs.py c2f_pbp`'),
                         ('_vi_configs.jsonl', 'the variational step on the models the reference published timings for, `scripts/bench_configs.py vi_models vi_scaled`'),
                         ('_particles.jsonl', 'the headline workload at the demos\' particle counts and with EP proposals, `scripts/profile_particles.sh`'),
-                        ('_demo_loop.jsonl', 'Demo/RGM/demo.py through the object API, `scripts/bench_configs.py demo_loop`')):
+                        ('_demo_loop.jsonl', 'Demo/RGM/demo.py through the object API, `scripts/bench_configs.py demo_loop`'),
+                        ('_refsize.jsonl', 'the reference\'s own calls at the reference\'s sizes through the unchanged API: cold (first call of a process) and warm wall time, '
+                                           'the C oracle beside; `scripts/bench_configs.py refsize`')):
         path = os.path.join(PROF, tag + extra)
         if not os.path.exists(path):
             continue
@@ -163,6 +165,45 @@ def block(tag):
         if parts:
             L.append('')
             L.append('Gaussian sweep at 10 M edges, HBM bytes per launch (`profiles/%s_secondary_traffic.json`): %s.' % (tag, '; '.join(sorted(parts))))
+    gt = os.path.join(PROF, tag + '_gauss_traffic.json')
+    if os.path.exists(gt):
+        t = json.load(open(gt))
+        L.append('')
+        L.append('Gaussian sweep, HBM bytes per launch PER GRAPH (`profiles/%s_gauss_traffic.json`: one pair of `--pmc` passes per graph, '
+                 '`scripts/profile_gauss.sh`; algorithmic = 76 B x edges):' % tag)
+        L.append('')
+        edges = {}
+        cfgs = os.path.join(PROF, tag + '_gauss_configs.jsonl')
+        if os.path.exists(cfgs):
+            for line in open(cfgs):
+                if line.startswith('{'):
+                    d = json.loads(line)
+                    key = 'random' if 'random' in d['config'] else ('rgm' if 'RGM' in d['config'] else 'kalman')
+                    if 'pull form' in d['config'] and 'graph arrays' not in d['config']:
+                        edges[key] = (d['edges'], d.get('sweep_ms'), d.get('hbm_frac'))
+        for gname, ks in t.items():
+            for k, v in sorted(ks.items()):
+                if 'pull' not in k or 'hub' in k:
+                    continue
+                e = edges.get(gname)
+                L.append('* %s, `%s`: %.3f GB read + %.3f GB written%s' % (
+                    gname, _short(k), v['read_bytes'] / 1e9, v['write_bytes'] / 1e9,
+                    (' = %.2f x the algorithmic %.3f GB; sweep %.3f ms, %.3f of the HBM roof'
+                     % (v['hbm_bytes'] / (76.0 * e[0]), 76.0 * e[0] / 1e9, e[1], e[2])) if e else ''))
+    sim = os.path.join(PROF, tag + '_sim_sharded.json')
+    if os.path.exists(sim):
+        t = json.load(open(sim))
+        L.append('')
+        L.append('One-GPU rehearsal of the sharded sweep (`profiles/%s_sim_sharded.json`; per-rank compute only, the exchange is NOT '
+                 'included -- not a throughput figure):' % tag)
+        L.append('')
+        for k, v in t.items():
+            if k == 'note' or not v.get('sweeps'):
+                continue
+            plan = v.get('plan', {})
+            L.append('* %s: %s; device time per rank and sweep %s ms%s' % (
+                k, v['sweeps'][-1].split(': ', 1)[1], v.get('device_ms_per_rank_and_sweep', {}).get('total'),
+                ('; payload %.3f GB per sweep, busiest pair %.1f MB' % (plan['total_payload_GB'], plan['busiest_pair_MB'])) if plan else ''))
     return '\n'.join(L)
 
 
@@ -170,11 +211,11 @@ def main():
     tag = sys.argv[1]
     text = block(tag)
     if '--write' in sys.argv:
-        path = os.path.join(ROOT, 'DESIGN.md')
+        path = os.path.join(ROOT, 'docs', 'measurement.md')
         s = open(path).read()
         pat = re.compile(re.escape(BEGIN) + '.*?' + re.escape(END), re.S)
         if not pat.search(s):
-            raise SystemExit('markers not found in DESIGN.md')
+            raise SystemExit('markers not found in docs/measurement.md')
         s = pat.sub(lambda m: BEGIN + '\n' + text + '\n' + END, s)
         open(path, 'w').write(s)
     print(text)

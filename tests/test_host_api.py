@@ -467,13 +467,13 @@ def test_kalman_flat_builder_matches_reference_structure(golden_dir):
 
 
 def test_design_numbers_are_the_committed_profiles():
-    """DESIGN.md section 5's measured-numbers block is the verbatim output of scripts/design_numbers.py on the committed
-    profiles/r04_* files: a number cannot be quoted there that no file holds"""
+    """the measured-numbers block of docs/measurement.md is the verbatim output of scripts/design_numbers.py on the committed
+    profiles/r05_* files: a number cannot be quoted there that no file holds"""
     import re
     import subprocess
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'design_numbers.py'), 'r04'], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'design_numbers.py'), 'r05'], capture_output=True, text=True,
                          check=True).stdout.strip()
-    text = open(os.path.join(ROOT, 'DESIGN.md')).read()
+    text = open(os.path.join(ROOT, 'docs', 'measurement.md')).read()
     m = re.search(r'<!-- numbers:begin \(scripts/design_numbers.py\) -->\n(.*?)\n<!-- numbers:end -->', text, re.S)
     assert m and m.group(1).strip() == out
 
