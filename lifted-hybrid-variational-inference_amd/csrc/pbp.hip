@@ -108,6 +108,9 @@ __global__ void __launch_bounds__(BLOCK) pbp_uniq_wave_kernel(int V, int n, cons
 // spills; rows beyond the cache are read a second time, out of L2).
 constexpr int V2F_CACHE = 4;
 
+// HALO: the build that also writes a cut edge's row into a shard's send buffer (s.halo_off / s.halo_buf); the other one carries
+// none of that code (the check alone cost the single-GPU launch 11 %: 1.66 -> 1.84 ms)
+template <bool HALO>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                        double* __restrict__ v2f) {
     const int lane = threadIdx.x & 63;
@@ -178,7 +181,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
             // ground: sum over nb != f; lifted: own factor keeps count-1 copies (HLBP:182-191) -> total - m either way
             const double res = (total - m) + logw;
             // owner-computes shards: the row of a cut edge goes to its place in the send buffer as it is formed (s.halo_off)
-            const int64_t halo = s.halo_off ? s.halo_off[e] : -1;
+            const int64_t halo = HALO ? s.halo_off[e] : -1;
             if (nchunk == 1) {
                 // log_message_balance over the distinct keys (EPBP:204-215)
                 const double tot = wave_sum(uq ? res : 0.0);
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
                     shift = wave_max(uq ? res : -__builtin_huge_val()) - s.max_log_value;
                 if (valid) {
                     v2f[(int64_t)e * n + j] = res - shift;
-                    if (halo >= 0) s.halo_buf[halo + j] = res - shift;
+                    if (HALO && halo >= 0) s.halo_buf[halo + j] = res - shift;
                 }
             } else if (valid) {
                 v2f[(int64_t)e * n + j] = res;       // balanced below once every chunk is written
@@ -219,13 +222,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
             const double mean = wave_sum(lsum) / (double)wave_sum_i(lcnt);
             const double mx = wave_max(lmax);
             const double shift = (mx - mean > s.max_log_value) ? mx - s.max_log_value : mean;
-            const int64_t halo = s.halo_off ? s.halo_off[e] : -1;
+            const int64_t halo = HALO ? s.halo_off[e] : -1;
             for (int c = 0; c < nchunk; ++c) {
                 const int j = c * 64 + lane;
                 if (j < np) {
                     const double val = v2f[(int64_t)e * n + j] - shift;
                     v2f[(int64_t)e * n + j] = val;
-                    if (halo >= 0) s.halo_buf[halo + j] = val;
+                    if (HALO && halo >= 0) s.halo_buf[halo + j] = val;
                 }
             }
         }
@@ -237,6 +240,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
 // long as its longest chain.  Here a workgroup shares the row: wavefront w takes the entries k = w (mod 4), four row loads in
 // flight each; the four partial totals are added in wavefront order (fixed, so the result is deterministic; it differs from the
 // one-wave sum by rounding, like any other summation order), then every wavefront emits the messages of its own entries.
+template <bool HALO>
 __global__ void __launch_bounds__(BLOCK) pbp_v2f_hub_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                            double* __restrict__ v2f) {
     __shared__ double part[BLOCK / WAVE][WAVE];
@@ -286,8 +290,8 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_hub_kernel(lhvi_graph_t g, lhvi
         if (__ballot(uq && (res - mean > s.max_log_value))) shift = wave_max(uq ? res : -__builtin_huge_val()) - s.max_log_value;
         if (valid) {
             v2f[(int64_t)e * n + lane] = res - shift;
-            const int64_t halo = s.halo_off ? s.halo_off[e] : -1;         // (owner-computes shards: the copy for the send buffer)
-            if (halo >= 0) s.halo_buf[halo + lane] = res - shift;
+            const int64_t halo = HALO ? s.halo_off[e] : -1;         // (owner-computes shards: the copy for the send buffer)
+            if (HALO && halo >= 0) s.halo_buf[halo + lane] = res - shift;
         }
     }
 }
@@ -296,6 +300,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_hub_kernel(lhvi_graph_t g, lhvi
 // leave 60 of a wavefront's lanes idle in the kernel above, and every such wave still costs its chain of dependent loads.
 // Here a wavefront serves sixteen of them, four lanes each (lane & 3 = particle); the balance step's mean and max are quad
 // reductions.  Same expressions per message as above (total minus own; mean over the distinct particles; max - 700 rule).
+template <bool HALO>
 __global__ void __launch_bounds__(BLOCK) pbp_v2f_narrow_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                               double* __restrict__ v2f) {
     const int lane = threadIdx.x & 63;
@@ -339,8 +344,8 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_narrow_kernel(lhvi_graph_t g, l
         const double shift = (mx - mean > s.max_log_value) ? mx - s.max_log_value : mean;
         if (live && valid) {
             v2f[(int64_t)e * n + j] = res - shift;
-            const int64_t halo = s.halo_off ? s.halo_off[e] : -1;
-            if (halo >= 0) s.halo_buf[halo + j] = res - shift;
+            const int64_t halo = HALO ? s.halo_off[e] : -1;
+            if (HALO && halo >= 0) s.halo_buf[halo + j] = res - shift;
         }
     }
 }
@@ -348,7 +353,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_narrow_kernel(lhvi_graph_t g, l
 // The same for variables with 5-16 / 17-32 particles (the particle counts of the reference's demos): a lane group of W = 16 / 32
 // lanes per variable, four / two variables per wavefront; the balance step's mean and max are the row / half-wave DPP reductions,
 // whose steps inside a group are the ones the one-variable kernel's wave reduction performs on those lanes -- same bits.
-template <int W>
+template <int W, bool HALO>
 __global__ void __launch_bounds__(BLOCK) pbp_v2f_packed_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                               double* __restrict__ v2f, const int32_t* __restrict__ list, int count) {
     constexpr int G = WAVE / W;
@@ -400,8 +405,8 @@ __global__ void __launch_bounds__(BLOCK) pbp_v2f_packed_kernel(lhvi_graph_t g, l
         }
         if (live && valid) {
             v2f[(int64_t)e * n + j] = res - shift;
-            const int64_t halo = s.halo_off ? s.halo_off[e] : -1;
-            if (halo >= 0) s.halo_buf[halo + j] = res - shift;
+            const int64_t halo = HALO ? s.halo_off[e] : -1;
+            if (HALO && halo >= 0) s.halo_buf[halo + j] = res - shift;
         }
     }
 }
@@ -852,6 +857,7 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_fast_kernel(lhvi_graph_t g, lhv
                                             // Measured on the 8-rank rehearsal (profiles/r05_experiments.md): 0 -> 0.875 ms per heavy launch,
                                             // 2 -> 0.948, 8 -> 1.20: a claim per entry costs more than the shorter tail returns
 #endif
+#if LHVI_PBP_TAIL_PER_WAVE > 0
 template <int WORK_CHUNK, int WAVES_PER_BLOCK = BLOCK / WAVE>
 struct WorkCursor {
     uint32_t* ticket;       // nullptr: static striding
@@ -905,6 +911,51 @@ struct WorkCursor {
         item = nxt;
     }
 };
+#else
+// (no tail zone: the cursor of rounds 2-4, without the position arithmetic of the form above)
+template <int WORK_CHUNK, int WAVES_PER_BLOCK = BLOCK / WAVE>
+struct WorkCursor {
+    uint32_t* ticket;       // nullptr: static striding
+    int item, limit, left, stride, pending, lo;
+    __device__ __forceinline__ int claim(int lane) const {
+        int v = 0;
+        if (lane == 0) v = lo + (int)atomicAdd(ticket, (uint32_t)WORK_CHUNK);
+        return v;                                           // valid in lane 0
+    }
+    // with tickets the list is cut into one contiguous range per XCD (workgroup i runs on XCD i mod 8, and each XCD has
+    // its own L2: its waves then walk one region of the descriptors, particles and messages), each with its own counter
+    __device__ __forceinline__ bool start(uint32_t* base, int nitems, int lane) {
+        stride = gridDim.x * WAVES_PER_BLOCK;
+        left = 0; pending = 0; lo = 0; limit = nitems;
+        ticket = base;
+        if (ticket) {
+            const int parts = min((int)gridDim.x, LHVI_PBP_TICKET_COUNTERS);
+            const int part = blockIdx.x % parts;
+            const int per = ((nitems + parts - 1) / parts + WORK_CHUNK - 1) / WORK_CHUNK * WORK_CHUNK;
+            lo = min(part * per, nitems);
+            limit = min(lo + per, nitems);
+            ticket = base + part;
+            item = __builtin_amdgcn_readfirstlane(claim(lane));
+            pending = claim(lane);
+            left = WORK_CHUNK - 1;
+        } else {
+            item = blockIdx.x * WAVES_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        }
+        return item < limit;
+    }
+    __device__ __forceinline__ int next() const {           // the entry after `item` (>= limit: none)
+        if (!ticket) return item + stride;
+        return left > 0 ? item + 1 : __builtin_amdgcn_readfirstlane(pending);
+    }
+    __device__ __forceinline__ void advance(int nxt, int lane) {     // move to `nxt` = next()
+        if (ticket) {
+            if (left > 0) --left;
+            else { left = WORK_CHUNK - 1; pending = claim(lane); }
+        }
+        item = nxt;
+    }
+};
+#endif
 
 struct HeavyData { double y, m, x0, x1; };
 
@@ -2637,6 +2688,32 @@ static int validate_pbp(const lhvi_graph_t* g, const lhvi_pbp_t* s) {
 
 using namespace lhvi;
 
+template <bool HALO>
+static int launch_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, double* v2f, void* stream) {
+    if (s->v2f_wide || s->v2f_narrow) {
+        // the caller's split of the hidden variables: one wavefront per variable / sixteen variables per wavefront
+        if (!s->v2f_wide || !s->v2f_narrow || s->n_v2f_wide < 0 || s->n_v2f_narrow < 0 || s->bslot || s->var_hi > s->var_lo) return LHVI_E_ARG;
+        if (s->n_v2f_wide > 0)
+            hipLaunchKernelGGL(pbp_v2f_kernel<HALO>, dim3(grid_for((int64_t)s->n_v2f_wide * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, v2f);
+        if (s->v2f_hub && s->n_v2f_hub > 0)
+            hipLaunchKernelGGL(pbp_v2f_hub_kernel<HALO>, dim3((unsigned)s->n_v2f_hub), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, v2f);
+        if (s->n_v2f_narrow > 0)
+            hipLaunchKernelGGL(pbp_v2f_narrow_kernel<HALO>, dim3(grid_for(((int64_t)s->n_v2f_narrow + 15) / 16 * WAVE)), dim3(BLOCK), 0,
+                               as_stream(stream), *g, *s, f2v, v2f);
+        if (s->n_v2f_mid16 < 0 || s->n_v2f_mid32 < 0 || (s->n_v2f_mid16 > 0 && !s->v2f_mid16) || (s->n_v2f_mid32 > 0 && !s->v2f_mid32)) return LHVI_E_ARG;
+        if (s->n_v2f_mid16 > 0)
+            hipLaunchKernelGGL((pbp_v2f_packed_kernel<16, HALO>), dim3(grid_for(((int64_t)s->n_v2f_mid16 + 3) / 4 * WAVE)), dim3(BLOCK), 0,
+                               as_stream(stream), *g, *s, f2v, v2f, s->v2f_mid16, s->n_v2f_mid16);
+        if (s->n_v2f_mid32 > 0)
+            hipLaunchKernelGGL((pbp_v2f_packed_kernel<32, HALO>), dim3(grid_for(((int64_t)s->n_v2f_mid32 + 1) / 2 * WAVE)), dim3(BLOCK), 0,
+                               as_stream(stream), *g, *s, f2v, v2f, s->v2f_mid32, s->n_v2f_mid32);
+        return check_launch();
+    }
+    hipLaunchKernelGGL(pbp_v2f_kernel<HALO>, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0, as_stream(stream),
+                       *g, *s, f2v, v2f);
+    return check_launch();
+}
+
 extern "C" {
 
 int lhvi_pbp_uniq(const lhvi_graph_t* g, int32_t n, const double* particles, const int32_t* np, uint8_t* uniq, void* stream) {
@@ -2715,28 +2792,7 @@ int lhvi_pbp_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* f2v, 
     if (!f2v || !v2f || !s->uniq || !s->q) return LHVI_E_ARG;
     if (s->halo_off && !s->halo_buf) return LHVI_E_ARG;
     if (g->V == 0) return LHVI_OK;
-    if (s->v2f_wide || s->v2f_narrow) {
-        // the caller's split of the hidden variables: one wavefront per variable / sixteen variables per wavefront
-        if (!s->v2f_wide || !s->v2f_narrow || s->n_v2f_wide < 0 || s->n_v2f_narrow < 0 || s->bslot || s->var_hi > s->var_lo) return LHVI_E_ARG;
-        if (s->n_v2f_wide > 0)
-            hipLaunchKernelGGL(pbp_v2f_kernel, dim3(grid_for((int64_t)s->n_v2f_wide * WAVE)), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, v2f);
-        if (s->v2f_hub && s->n_v2f_hub > 0)
-            hipLaunchKernelGGL(pbp_v2f_hub_kernel, dim3((unsigned)s->n_v2f_hub), dim3(BLOCK), 0, as_stream(stream), *g, *s, f2v, v2f);
-        if (s->n_v2f_narrow > 0)
-            hipLaunchKernelGGL(pbp_v2f_narrow_kernel, dim3(grid_for(((int64_t)s->n_v2f_narrow + 15) / 16 * WAVE)), dim3(BLOCK), 0,
-                               as_stream(stream), *g, *s, f2v, v2f);
-        if (s->n_v2f_mid16 < 0 || s->n_v2f_mid32 < 0 || (s->n_v2f_mid16 > 0 && !s->v2f_mid16) || (s->n_v2f_mid32 > 0 && !s->v2f_mid32)) return LHVI_E_ARG;
-        if (s->n_v2f_mid16 > 0)
-            hipLaunchKernelGGL(pbp_v2f_packed_kernel<16>, dim3(grid_for(((int64_t)s->n_v2f_mid16 + 3) / 4 * WAVE)), dim3(BLOCK), 0,
-                               as_stream(stream), *g, *s, f2v, v2f, s->v2f_mid16, s->n_v2f_mid16);
-        if (s->n_v2f_mid32 > 0)
-            hipLaunchKernelGGL(pbp_v2f_packed_kernel<32>, dim3(grid_for(((int64_t)s->n_v2f_mid32 + 1) / 2 * WAVE)), dim3(BLOCK), 0,
-                               as_stream(stream), *g, *s, f2v, v2f, s->v2f_mid32, s->n_v2f_mid32);
-        return check_launch();
-    }
-    hipLaunchKernelGGL(pbp_v2f_kernel, dim3(grid_for((int64_t)(var_limit(*g, *s) - var_first(*s)) * WAVE)), dim3(BLOCK), 0, as_stream(stream),
-                       *g, *s, f2v, v2f);
-    return check_launch();
+    return s->halo_off ? launch_v2f<true>(g, s, f2v, v2f, stream) : launch_v2f<false>(g, s, f2v, v2f, stream);
 }
 
 int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_t* s, const double* v2f, double* f2v, void* stream) {
