@@ -6,8 +6,12 @@ particles, T = 32 integral points, 'simple' proposal, counter-based device sampl
 sweep = v2f + proposal update + resample + f2v (everything EPBP.run does per iteration, EPBPLogVersion.py:245-285).
 Inputs are generated on the host, uploaded once, and resident in HBM before the timed region.
 
-N > 1: the same graph is edge-sharded (factor-partitioned) over the ranks, one RCCL all-to-all of boundary-variable
-partials per sweep (lhvi/dist.py); total work is fixed, so scaling is "strong".
+N > 1: the same graph is edge-sharded over the ranks, ONE RCCL all-to-all per sweep (lhvi/dist.py); total work is fixed, so
+scaling is "strong".  Two splits are built, timed and freed in the same launch -- owner computes (variables partitioned, every
+message computed where its target lives; bit-identical to one GPU; `value` is quoted on it) and factor-partitioned (boundary
+partial sums) -- and both are printed under `exchanges` with their phase times (`--exchange` / `--also` choose).  Every rank
+names its phases on stderr; a phase that outlasts LHVI_BENCH_PHASE_TIMEOUT (600 s) or a collective that outlasts
+LHVI_BENCH_COLLECTIVE_TIMEOUT (300 s) ends the run non-zero with its name.
 
 ``python3 bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts its own ranks: the parent (which
 never touches the GPU) runs ``python -m torch.distributed.run --nproc-per-node N`` on this same file and exits with
@@ -298,11 +302,16 @@ def main():
                     'phases_ms': r.phase_ms() if getattr(r, 'phase_ms', None) else None}
         exchanges = {primary: line(runner, elapsed)}
         for other in also:
-            # build, time, free: the other split of the same graph in the same launch, so that one node run compares them
-            r2 = build(other)
-            el2, _ = time_runner(r2, other)
-            exchanges[other] = line(r2, el2)
-            del r2
+            # build, time, free: the other split of the same graph in the same launch, so that one node run compares them.
+            # (a failure here must not cost the run its line: `value` is already measured)
+            try:
+                r2 = build(other)
+                el2, _ = time_runner(r2, other)
+                exchanges[other] = line(r2, el2)
+                del r2
+            except Exception as exc:                      # noqa: BLE001 -- reported in the line, and on stderr with the phase
+                progress('rank %d: %s FAILED: %s: %s' % (rank, other, type(exc).__name__, exc))
+                exchanges[other] = {'error': '%s: %s' % (type(exc).__name__, str(exc)[:300])}
             torch.cuda.empty_cache()
     del flat
     if rank == 0:
