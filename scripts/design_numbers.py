@@ -182,14 +182,16 @@ def block(tag):
                     if 'pull form' in d['config'] and 'graph arrays' not in d['config']:
                         edges[key] = (d['edges'], d.get('sweep_ms'), d.get('hbm_frac'))
         for gname, ks in t.items():
-            for k, v in sorted(ks.items()):
-                if 'pull' not in k or 'hub' in k:
-                    continue
-                e = edges.get(gname)
-                L.append('* %s, `%s`: %.3f GB read + %.3f GB written%s' % (
-                    gname, _short(k), v['read_bytes'] / 1e9, v['write_bytes'] / 1e9,
-                    (' = %.2f x the algorithmic %.3f GB; sweep %.3f ms, %.3f of the HBM roof'
-                     % (v['hbm_bytes'] / (76.0 * e[0]), 76.0 * e[0] / 1e9, e[1], e[2])) if e else ''))
+            # one sweep of the records form = the row kernel + the hub-row kernel (rows of more than 512 entries: the RGM's templates)
+            rec = [v for k, v in ks.items() if 'pull' in k and 'rec' in k]
+            if not rec:
+                continue
+            rd, wr = sum(v['read_bytes'] for v in rec), sum(v['write_bytes'] for v in rec)
+            e = edges.get(gname)
+            L.append('* %s (%s): %.3f GB read + %.3f GB written%s' % (
+                gname, ' + '.join('`%s`' % _short(k) for k in sorted(ks) if 'pull' in k and 'rec' in k), rd / 1e9, wr / 1e9,
+                (' = %.2f x the algorithmic %.3f GB; sweep %.3f ms, %.3f of the HBM roof'
+                 % ((rd + wr) / (76.0 * e[0]), 76.0 * e[0] / 1e9, e[1], e[2])) if e else ''))
     sim = os.path.join(PROF, tag + '_sim_sharded.json')
     if os.path.exists(sim):
         t = json.load(open(sim))
