@@ -1027,6 +1027,40 @@ __device__ __forceinline__ double grid_sums32(double& g, double q, int lane) {
     }
     return fold_bit0(fold_bit1(fold_bit2(z[0], z[1]), fold_bit2(z[2], z[3]), (lane >> 1) & 1));
 }
+// The same reduce-scatter inside lane groups of W = 32 / 16 lanes (the few-particle kernel: lane = partner particle of its group's
+// edge).  W = 32: folds over bits 4..0, every lane ends with the sum of ONE of 32 consecutive points; W = 16: bits 3..0, two points
+// per lane (s0: points 0-15, s1: points 16-31 of the batch).  small_grid_point<W>(lane, k) names the point of sum k.
+__device__ __forceinline__ double fold_bit0_xy(double x, double y, bool bit0) {   // lane ^ 1 = quad_perm [1,0,3,2]
+    const double send = bit0 ? x : y, keep = bit0 ? y : x;
+    return keep + dpp_move<0xb1>(send);
+}
+template <int W>
+__device__ __forceinline__ void small_grid_sums32(double& g, double q, int lane, double& s0, double& s1) {
+    double z[4];
+    const bool b1 = (lane >> 1) & 1, b0 = lane & 1;
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) {
+        double v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = g; g *= q; }
+        if (W == 32) {
+            const double u0 = fold_bit3(fold_bit4(v[0], v[1]), fold_bit4(v[2], v[3]));
+            const double u1 = fold_bit3(fold_bit4(v[4], v[5]), fold_bit4(v[6], v[7]));
+            z[bt] = fold_bit2(u0, u1);
+        } else {
+            const double u0 = fold_bit2(fold_bit3(v[0], v[1]), fold_bit3(v[2], v[3]));
+            const double u1 = fold_bit2(fold_bit3(v[4], v[5]), fold_bit3(v[6], v[7]));
+            z[bt] = fold_bit1(u0, u1, b1);
+        }
+    }
+    if (W == 32) { s0 = fold_bit0_xy(fold_bit1(z[0], z[1], b1), fold_bit1(z[2], z[3], b1), b0); s1 = 0.0; }
+    else { s0 = fold_bit0_xy(z[0], z[1], b0); s1 = fold_bit0_xy(z[2], z[3], b0); }
+}
+template <int W>
+__device__ __forceinline__ int small_grid_point(int lane, int k) {
+    if (W == 32) return 8 * (((lane >> 1) & 1) + 2 * (lane & 1)) + ((lane >> 4) & 1) + 2 * ((lane >> 3) & 1) + 4 * ((lane >> 2) & 1);
+    return 16 * k + 8 * (lane & 1) + ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + 4 * ((lane >> 1) & 1);
+}
 constexpr int GRID_MIN_NJ = 24;         // fewer partner particles: the direct loop is cheaper than 32 multiplications + 6 folds
 constexpr double GRID_MAX_EXPONENT = 600.0;
 constexpr int GRID_MAX_T = 128;         // batches of 32 points; the recurrence carries ~t ulp (the reference's RGM domain has 100 points, Demo/Data/RGM/Generator.py:16)
@@ -1203,11 +1237,24 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
 // cross-lane reduction is needed at all, and every load, store and wait is shared by 64 / W edges.  Same term arithmetic as the
 // heavy kernel's direct form (fast_accumulate_floor): an edge gets the same message from either kernel up to the order of the sum
 // when the heavy kernel splits a short round across lane groups.
+#ifndef LHVI_SMALL_HOIST
+#define LHVI_SMALL_HOIST 2          // 0: round 4's loads (a global round trip per descriptor piece and per round); 1: two round trips per step;
+#endif                              // 2: + the next step's descriptor touched a step ahead (scripts/diag/small_hoist.sh: 2.71 / 2.55 / 2.51 ms at n = 16)
+#ifndef LHVI_SMALL_GRID
+#define LHVI_SMALL_GRID 1         // integral points on a uniform grid by the recurrence along the grid (0: one exponential per point and particle)
+#endif
+#ifndef LHVI_SMALL_PAD
+#define LHVI_SMALL_PAD 1          // a group's block of W 16-byte records starts one record further than W records after the one before it:
+#endif                            // unpadded, record j of every group lies in the same four banks
+#ifndef LHVI_SMALL_WAVES
+#define LHVI_SMALL_WAVES 6
+#endif
 template <int W>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) pbp_f2v_small_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI_SMALL_WAVES, 8))) pbp_f2v_small_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
                                                             double* __restrict__ f2v, const FastDesc* __restrict__ descs, int nitems) {
     constexpr int G = WAVE / W;                              // edges per wavefront
-    __shared__ AB sh_all[BLOCK / WAVE][WAVE];
+    constexpr int GS = W + LHVI_SMALL_PAD;                    // records between two groups' blocks (padded: see LHVI_SMALL_PAD)
+    __shared__ AB sh_all[BLOCK / WAVE][G * GS];
     __shared__ double sh_tab[EXP_TAB_N];
     __shared__ LogRec sh_log[LOG_TAB_N];
     load_log_table(sh_log);
@@ -1216,46 +1263,144 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8
     const int lane = threadIdx.x & 63;
     const int grp = lane / W, gl = lane % W;
     AB* sh = sh_all[wid];
-    const AB* mine_recs = sh + grp * W;
+    const AB* mine_recs = sh + grp * GS;
     const int n = s.n, S = s.n + s.T;
     const int nsteps = (nitems + G - 1) / G;
     const int nwaves = gridDim.x * (BLOCK / WAVE);
     for (int step = blockIdx.x * (BLOCK / WAVE) + wid; step < nsteps; step += nwaves) {
         const int idx = step * G + grp;
         const bool live = idx < nitems;
+#if LHVI_SMALL_HOIST
+        // One round trip for the descriptor (all 128 bytes at once, whatever the branches below use of it), one for everything it
+        // points to: the partner's particles and message and the output points of the first three rounds (all of them for
+        // n + T <= 3 W), loaded without branches from addresses clamped into their rows.  A round that loads its own points, or a
+        // descriptor read field by field where the branches need it, costs a dependent global round trip each -- five or six per
+        // step, which seven waves per SIMD do not cover.
+        union { FastDesc d; int4 q[sizeof(FastDesc) / 16]; } u;
+        {
+            const int4* dp = reinterpret_cast<const int4*>(descs + (live ? idx : nitems - 1));
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(FastDesc) / 16); ++k) u.q[k] = dp[k];
+        }
+#if LHVI_SMALL_HOIST >= 2
+        // the next step's descriptor (one 128-byte line, streamed from HBM) is touched now, so that its read at the head of the
+        // next step finds it in the cache; the word is consumed at the end of this step
+        const int touch = reinterpret_cast<const int*>(descs + min((step + nwaves) * G + grp, nitems - 1))[0];
+#endif
+        const FastDesc& d = u.d;
+        const int e = d.e, tv = d.tv, nj = d.nj, np = d.np, T = d.T, gb = d.gb;
+        const double pval = d.pval, kx = d.kx;
+        const int npts = np + T;
+        const int jl = min(gl, nj - 1);
+        const double yl = s.old_particles[(int64_t)d.pv * n + jl], ml = v2f[(int64_t)d.pce * n + jl];
+        double xs[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int p = r * W + gl;
+            const double* src = p < np ? s.particles + ((int64_t)tv * n + p) : g.dom_val + (gb + max(min(p - np, T - 1), 0));
+            xs[r] = *src;
+        }
+        const bool hidden_partner = is_hidden(pval);
+        const double y = hidden_partner ? yl : pval, m = hidden_partner ? ml : 0.0;
+#else
         const FastDesc& d = descs[live ? idx : nitems - 1];  // (a group past the end repeats the last entry and stores nothing)
         const int e = d.e, tv = d.tv, nj = d.nj, np = d.np, T = d.T, gb = d.gb;
         const double pval = d.pval, kx = d.kx;
+        const int npts = np + T;
         // staging: lane = partner particle of its group's edge
-        AB rec;
-        rec.a = PAD_LOG_TERM * LHVI_EXP_INV_STEP; rec.b = 0.0;     // padding: underflows to exactly 0 whatever the point's own constant adds
+        double y = pval, m = 0.0;
+        if (gl < nj && is_hidden(pval)) { y = s.old_particles[(int64_t)d.pv * n + gl]; m = v2f[(int64_t)d.pce * n + gl]; }
+#endif
+        double ua = PAD_LOG_TERM, ub = 0.0;                        // padding: underflows to exactly 0 whatever the point's own constant adds
         if (gl < nj) {
-            double y = pval, m = 0.0;
-            if (is_hidden(pval)) { y = s.old_particles[(int64_t)d.pv * n + gl]; m = v2f[(int64_t)d.pce * n + gl]; }
-            rec.a = ((d.ay * y + d.by) * y + d.c + m) * LHVI_EXP_INV_STEP;        // (records in units of the table step: floor form)
-            rec.b = (d.axy * y + d.bx) * LHVI_EXP_INV_STEP;
+            ua = (d.ay * y + d.by) * y + d.c + m;
+            ub = d.axy * y + d.bx;
         }
-        LHVI_WAVE_SYNC();
-        sh[lane] = rec;
-        LHVI_WAVE_SYNC();
+        AB rec;
+        rec.a = ua * LHVI_EXP_INV_STEP; rec.b = ub * LHVI_EXP_INV_STEP;      // (records in units of the table step: floor form)
+#if LHVI_SMALL_GRID
+        // Integral points on a uniform grid: the recurrence of the heavy kernel inside the lane group (small_grid_sums32), when every
+        // exponent of the edge stays far inside the double range over the whole grid -- a property of the edge alone, so an edge
+        // gets the same bits whatever shares its wavefront.  A group that fails the test takes the direct rounds for all its points.
+        const double gx0 = d.pad2[0], gh = d.pad2[1];
+        bool gok = false;
+        if (d.pad[1] && T <= GRID_MAX_T && !(s.flags & (LHVI_PBP_SKIP_TERMS | LHVI_PBP_NO_GRID))) {
+            const double X = fmax(fabs(gx0), fabs(fma((double)(T - 1), gh, gx0)));
+            const double bound = fma(fabs(ub) + fabs(kx) * X, X, fabs(ua));
+            const uint64_t bad = __ballot(gl < nj && !(bound < GRID_MAX_EXPONENT));
+            gok = ((bad >> (grp * W)) & (W == 32 ? 0xffffffffull : 0xffffull)) == 0;
+        }
+        const int lim = gok ? np : npts;                           // points of this group's edge that the direct rounds serve
+        const bool any_grid = __ballot(gok && live) != 0;
+#else
+        const int lim = npts;
+#endif
         // the longest record list and the most output points of the wave's edges (wave-uniform loop bounds)
         int jmax = 0, pmax = 0;
 #pragma unroll
         for (int k = 0; k < G; ++k) {
             jmax = max(jmax, __builtin_amdgcn_readlane(nj, k * W));
-            pmax = max(pmax, __builtin_amdgcn_readlane(np + T, k * W));
+            pmax = max(pmax, __builtin_amdgcn_readlane(lim, k * W));
         }
         if (s.flags & LHVI_PBP_SKIP_TERMS) jmax = 0;
-        const int npts = np + T;
         double* out = f2v + (int64_t)e * S;
+        LHVI_WAVE_SYNC();
+        sh[grp * GS + gl] = rec;
+        LHVI_WAVE_SYNC();
+#if LHVI_SMALL_HOIST
+        // the three prefetched rounds written out: each waits for ITS points only (loads return in order), not -- as a loop whose
+        // later rounds load their own points makes the compiler assume -- for everything in flight, the previous round's stores included
+        // (the three loads were issued together and arrive together: taking all of them here costs nothing, and no later round then
+        // waits on the memory counter, which would include the stores of the rounds before it)
+        asm volatile("" : "+v"(xs[0]), "+v"(xs[1]), "+v"(xs[2]));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (r * W < pmax) {
+                const int p = r * W + gl;
+                const bool valid = live && p < lim;
+                const double x = valid ? xs[r] : 0.0;
+                const double acc = fast_accumulate_floor<4>(mine_recs, sh_tab, jmax, x, kx * x * x);
+                if (valid) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
+            }
+        }
+#pragma unroll 1
+        for (int p0 = 3 * W; p0 < pmax; p0 += W) {
+#else
+#pragma unroll 1
         for (int p0 = 0; p0 < pmax; p0 += W) {
+#endif
             const int p = p0 + gl;
-            const bool valid = live && p < npts;
+            const bool valid = live && p < lim;
             double x = 0.0;
             if (valid) x = p < np ? s.particles[(int64_t)tv * n + p] : g.dom_val[gb + p - np];
             const double acc = fast_accumulate_floor<4>(mine_recs, sh_tab, jmax, x, kx * x * x);
             if (valid) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
         }
+#if LHVI_SMALL_GRID
+        if (any_grid) {
+            double gv = exp_core(fma(ub, gx0, ua), sh_tab);
+            const double q = exp_core(ub * gh, sh_tab);
+            int tmax = 0;
+#pragma unroll
+            for (int k = 0; k < G; ++k) tmax = max(tmax, __builtin_amdgcn_readlane(gok ? T : 0, k * W));
+#pragma unroll 1
+            for (int t0 = 0; t0 < tmax; t0 += 32) {
+                double sum[2];
+                small_grid_sums32<W>(gv, q, lane, sum[0], sum[1]);
+#pragma unroll
+                for (int k = 0; k < (W == 16 ? 2 : 1); ++k) {
+                    const int t = t0 + small_grid_point<W>(gl, k);
+                    if (live && gok && t < T) {
+                        const double xt = fma((double)t, gh, gx0);
+                        out[n + t] = sum[k] > 0.0 ? fma(kx * xt, xt, log_table(sum[k], sh_log)) : -700.0;
+                    }
+                }
+            }
+        }
+#endif
+#if LHVI_SMALL_HOIST >= 2
+        asm volatile("" :: "v"(touch));
+#endif
     }
 }
 
@@ -2531,7 +2676,11 @@ __global__ void __launch_bounds__(BLOCK) pbp_resample_uniq_kernel(lhvi_graph_t g
 // kernels (tests/test_gpu_pbp.py::test_fused_variable_kernel_equals_the_three_kernels).  Records (lhvi_pbp_t.fused_desc):
 // eight 32-bit words per variable -- 0 variable  1 incident edges  2 grid base in dom_val  3 T  4-5 dom_lo  6-7 dom_hi.
 #ifndef LHVI_FUSED_WAVES
-#define LHVI_FUSED_WAVES 6
+#define LHVI_FUSED_WAVES 4
+#endif
+constexpr int FUSED_CH = 8;          // edges of a row whose loads are in flight together
+#ifndef LHVI_FUSED_NB
+#define LHVI_FUSED_NB 2          // (scripts/diag/fused_batch.sh: 2 passes in flight at 4 waves/SIMD beat 4 passes, which spill)
 #endif
 template <int W, int PW, bool EP>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI_FUSED_WAVES, 8)))
@@ -2560,13 +2709,41 @@ pbp_var_fused_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2
     int maxdeg = deg;
 #pragma unroll
     for (int off = 32; off >= W; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
+    // A row is walked in chunks of FUSED_CH edges (one chunk for the rows of the benchmark and of the reference's models): lane j
+    // of the group fetches edge j of the chunk, the ids are handed round with shuffles, and the row loads of ALL the chunk's edges
+    // are issued before the first one is used.  Walked edge by edge -- id, then row, then the next id -- a variable costs 2 deg
+    // dependent global round trips in step 1 and as many again in step 2, and the kernel's time is those latencies (2.6 ms at
+    // n = 16 on the headline graph whatever its occupancy).  The arithmetic is the same expressions in the same order on the same
+    // values as in the three kernels.
+    constexpr int CH = FUSED_CH;
+    static_assert(W >= CH && CH % SL == 0, "lane j of a group holds edge j of the chunk");
+    const int first_lane = lane / W * W;
+    const int nch = (maxdeg + CH - 1) / CH;                    // (wave-uniform, like maxdeg)
+    int my_e = 0, held = -1;
+    auto hold_chunk = [&](int c) {                             // lane j < CH: edge c CH + j of its variable's row
+        if (c == held) return;
+        held = c;
+        my_e = (j < CH && c * CH + j < deg) ? g.var_edge[lo + c * CH + j] : 0;
+    };
     // ---- step 1: v -> f (pbp_v2f_packed_kernel<W>)
     {
         double total = 0.0;
-        for (int k = 0; k < deg; ++k) {
-            const int e = g.var_edge[lo + k];
-            const double m = valid ? f2v[(int64_t)e * S + j] : 0.0;
-            total += lifted ? m * g.edge_count[e] : m;
+        int ee[CH];
+        double mm[CH];
+        auto load_rows = [&](int c) {
+            hold_chunk(c);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) ee[i] = __shfl(my_e, first_lane + i);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) mm[i] = f2v[(int64_t)ee[i] * S + (valid ? j : 0)];        // (beyond the row: edge 0's row, never used)
+        };
+        for (int c = 0; c < nch; ++c) {
+            load_rows(c);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const double m = valid ? mm[i] : 0.0;
+                if (c * CH + i < deg) total += lifted ? m * g.edge_count[ee[i]] : m;
+            }
         }
         double logw = 0.0;
         bool uq = false;
@@ -2580,18 +2757,23 @@ pbp_var_fused_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2
         auto group_max = [&](double x) { return W == 16 ? dpp_row_reduce(x, MaxOp()) : dpp_half_reduce(x, MaxOp(), lane); };
         const uint64_t mine = (W == 16 ? 0xffffull : 0xffffffffull) << (lane / W * W);
         const double rcnt = rcp_newton(fmax((double)__builtin_popcountll(__ballot(uq) & mine), 1.0));
-        for (int k = 0; k < maxdeg; ++k) {
-            const bool live = k < deg;
-            const int e = live ? g.var_edge[lo + k] : 0;
-            const double m = (live && valid) ? f2v[(int64_t)e * S + j] : 0.0;
-            const double res = (total - m) + logw;
-            const double mean = group_sum(uq ? res : 0.0) * rcnt;
-            double shift = mean;
-            if (__ballot(uq && (res - mean > s.max_log_value))) {
-                const double mx = group_max(uq ? res : -__builtin_huge_val());
-                if (mx - mean > s.max_log_value) shift = mx - s.max_log_value;
+        for (int c = 0; c < nch; ++c) {
+            if (nch > 1) load_rows(c);                          // (a one-chunk row still holds its messages)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int k = c * CH + i;
+                if (k >= maxdeg) break;
+                const bool live = k < deg;
+                const double m = (live && valid) ? mm[i] : 0.0;
+                const double res = (total - m) + logw;
+                const double mean = group_sum(uq ? res : 0.0) * rcnt;
+                double shift = mean;
+                if (__ballot(uq && (res - mean > s.max_log_value))) {
+                    const double mx = group_max(uq ? res : -__builtin_huge_val());
+                    if (mx - mean > s.max_log_value) shift = mx - s.max_log_value;
+                }
+                if (live && valid) v2f[(int64_t)ee[i] * n + j] = res - shift;
             }
-            if (live && valid) v2f[(int64_t)e * n + j] = res - shift;
         }
     }
     // ---- step 2: the proposal (pbp_proposal_kernel<EP>)
@@ -2601,46 +2783,75 @@ pbp_var_fused_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2
     const double min_sig = total * s.var_threshold;
     const int sub = j / PW, tl = j % PW;
     double ps[4] = {0.0, 0.0, 0.0, 0.0}, pm[4] = {0.0, 0.0, 0.0, 0.0};      // sums of the edges with index = i (mod 64 / PW), slot `sub`'s share
-    for (int k0 = 0; k0 < maxdeg; k0 += SL) {
-        const int k = k0 + sub;
-        const bool live = k < deg;
-        const int e = on ? g.var_edge[lo + (live ? k : 0)] : 0;
-        const double* msg = f2v + (int64_t)e * S + n;
-        const double b0 = on ? eta[2 * e] : 0.0, b1 = on ? eta[2 * e + 1] : 1.0;
-        const bool use_cav = EP && !(q1 >= b1);
-        double c0 = 0.0, c1 = 1.0;
-        if (use_cav) gdiv(q0, q1, b0, b1, c0, c1);
-        const double csd = sqrt(c1);
-        double z = 0.0, a = 0.0, b = 0.0;
-        if (on)
-            for (int t = tl; t < T; t += PW) {
-                const double xg = g.dom_val[gb + t];
-                double w = exp(msg[t]);
-                if (use_cav) w = w * norm_pdf_std(xg, c0, csd);
-                z += w; a += w * xg; b += w * (xg * xg);
-            }
-        if (PW == 16) { z = dpp_row_reduce(z, SumOp()); a = dpp_row_reduce(a, SumOp()); b = dpp_row_reduce(b, SumOp()); }
-        else { z = dpp_half_reduce(z, SumOp(), lane); a = dpp_half_reduce(a, SumOp(), lane); b = dpp_half_reduce(b, SumOp(), lane); }
-        const double rz = rcp_newton(z);
-        double mu = a * rz;
-        double sig = b * rz - mu * mu;
-        if (use_cav) { const double m0 = mu, m1 = sig; gdiv(m0, m1, c0, c1, mu, sig); }
-        if (0.0 < sig && sig < __builtin_huge_val()) {
-            sig = fmax(sig, min_sig);
-            if (live && tl == 0) { eta[2 * e] = mu; eta[2 * e + 1] = sig; }
-        } else {
-            mu = b0; sig = b1;
-        }
-        if (live) {
-            const double p = rcp_newton(sig);
-            const int slot4 = k & (WAVE / PW - 1);             // the lane group of pbp_proposal_kernel this edge would fall to
-            const double c = lifted ? g.edge_count[e] : 1.0;
+    // an edge's T integral points over PW lanes: at most two per lane (T <= 2 PW by the lists' definition, include/lhvi.h)
+    const int t0 = min(tl, max(T - 1, 0)), t1 = min(tl + PW, max(T - 1, 0));           // (clamped: the loads need no branch)
+    const double xg0 = g.dom_val[gb + t0], xg1 = g.dom_val[gb + t1];
+    constexpr int NB = LHVI_FUSED_NB;                          // passes (SL edges of a variable each) whose loads are in flight together
+    for (int c = 0; c < nch; ++c) {
+        hold_chunk(c);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i == slot4) {
-                    if (lifted) { ps[i] += p * c; pm[i] += p * mu * c; }
-                    else { ps[i] += p; pm[i] += p * mu; }
+        for (int p0 = 0; p0 < CH / SL; p0 += NB) {
+            if (c * CH + p0 * SL >= maxdeg) break;
+            int ee[NB];
+            double b0[NB], b1[NB], g0[NB], g1[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int kc = (p0 + i) * SL + sub;               // position in the chunk
+                ee[i] = __shfl(my_e, first_lane + min(kc, CH - 1));
+                if (kc >= CH || c * CH + kc >= deg) ee[i] = 0;   // (beyond the row: edge 0's, loaded and dropped)
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const double* msg = f2v + (int64_t)ee[i] * S + n;
+                b0[i] = eta[2 * ee[i]]; b1[i] = eta[2 * ee[i] + 1];
+                g0[i] = msg[t0]; g1[i] = msg[t1];
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (p0 + i >= CH / SL || c * CH + (p0 + i) * SL >= maxdeg) break;
+                const int k = c * CH + (p0 + i) * SL + sub;
+                const bool live = k < deg;
+                const int e = ee[i];
+                const double e0 = on ? b0[i] : 0.0, e1 = on ? b1[i] : 1.0;
+                const bool use_cav = EP && !(q1 >= e1);
+                double c0 = 0.0, c1 = 1.0;
+                if (use_cav) gdiv(q0, q1, e0, e1, c0, c1);
+                const double csd = sqrt(c1);
+                double z = 0.0, a = 0.0, b = 0.0;
+                if (on && tl < T) {
+                    double w = exp(g0[i]);
+                    if (use_cav) w = w * norm_pdf_std(xg0, c0, csd);
+                    z += w; a += w * xg0; b += w * (xg0 * xg0);
                 }
+                if (on && tl + PW < T) {
+                    double w = exp(g1[i]);
+                    if (use_cav) w = w * norm_pdf_std(xg1, c0, csd);
+                    z += w; a += w * xg1; b += w * (xg1 * xg1);
+                }
+                if (PW == 16) { z = dpp_row_reduce(z, SumOp()); a = dpp_row_reduce(a, SumOp()); b = dpp_row_reduce(b, SumOp()); }
+                else { z = dpp_half_reduce(z, SumOp(), lane); a = dpp_half_reduce(a, SumOp(), lane); b = dpp_half_reduce(b, SumOp(), lane); }
+                const double rz = rcp_newton(z);
+                double mu = a * rz;
+                double sig = b * rz - mu * mu;
+                if (use_cav) { const double m0 = mu, m1 = sig; gdiv(m0, m1, c0, c1, mu, sig); }
+                if (0.0 < sig && sig < __builtin_huge_val()) {
+                    sig = fmax(sig, min_sig);
+                    if (live && tl == 0) { eta[2 * e] = mu; eta[2 * e + 1] = sig; }
+                } else {
+                    mu = e0; sig = e1;
+                }
+                if (live) {
+                    const double p = rcp_newton(sig);
+                    const int slot4 = k & (WAVE / PW - 1);             // the lane group of pbp_proposal_kernel this edge would fall to
+                    const double cnt = lifted ? g.edge_count[e] : 1.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r == slot4) {
+                            if (lifted) { ps[r] += p * cnt; pm[r] += p * mu * cnt; }
+                            else { ps[r] += p; pm[r] += p * mu; }
+                        }
+                }
+            }
         }
     }
     // that kernel's fold of its lane groups: PW = 16: (g0 + g1) + (g2 + g3); PW = 32: g0 + g1
@@ -2658,7 +2869,6 @@ pbp_var_fused_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2
     if (on && j == 0) { q[2 * v] = mu_new; q[2 * v + 1] = var_new; }
     // ---- step 3: the new particles and their first-occurrence mask (pbp_resample_uniq_kernel)
     // (the values every lane of the group needs are the ones its first lane formed: that lane wrote q)
-    const int first_lane = lane / W * W;
     const double mu_b = __shfl(mu_new, first_lane), sd_b = sqrt_pos(__shfl(var_new, first_lane));
     double x = 0.0;
     if (valid) {

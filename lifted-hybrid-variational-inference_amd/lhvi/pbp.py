@@ -43,8 +43,9 @@ class _ParticleSweep:
     packed_v2f = True               # variables with at most four particles share a wavefront in the v -> f half (sixteen each)
     fused_var_kernel = True         # few particles, device sampler: v -> f, proposal update and the new sample of a continuous variable in
                                     # ONE pass over its rows (lhvi_pbp_var_fused) instead of three launches; same bits
-    fused_max_particles = 16        # ... up to this many particles: measured on the headline graph (profiles/r05_experiments.md) the
-                                    # 16-lane form wins 2-4 % of the sweep (n = 10, 16), the 32-lane form loses 5-8 % (n = 20, 32)
+    fused_max_particles = 32        # ... up to this many particles.  With a row's loads in flight together (csrc/pbp.hip, FUSED_CH) the fused kernel
+                                    # wins at every width: n = 10 / 16 / 20 / 32: 5.65 / 5.83 / 8.56 / 9.53 -> 4.97 / 5.03 / 8.25 / 9.30 ms per sweep
+                                    # (profiles/r05_experiments.md item 7; walked edge by edge it was a draw at n <= 16 and a loss beyond)
     exact_queries = False           # map / probability / belief answer per-variable calls from ONE batched pass over all
                                     # variables, made at the first call after run() (True: one fminbound / log_area / quad per call)
     map_mode = 'fminbound'          # what the batched map() runs per variable: the reference's fminbound iteration (lhvi_pbp_map_brent)
@@ -152,7 +153,8 @@ class _ParticleSweep:
         # ---- the fused per-variable kernel's records (lhvi_pbp_var_fused) and what is left for the three kernels
         self._fused = None
         pT = sizes[pdom] if pv.size else np.zeros(0, dtype=np.int64)
-        fz = (pdeg <= min(64, self.prop_slice)) & (pT <= 64) & (n <= min(32, self.fused_max_particles)) if pv.size else np.zeros(0, dtype=bool)
+        fused_max = int(os.environ.get('LHVI_PBP_FUSED_MAX', self.fused_max_particles))          # (tuning aid: scripts/diag/fused_batch.sh)
+        fz = (pdeg <= min(64, self.prop_slice)) & (pT <= 64) & (n <= min(32, fused_max)) if pv.size else np.zeros(0, dtype=bool)
         if (self.fused_var_kernel and os.environ.get('LHVI_PBP_FUSED', '1') != '0') and owned is None and self.sampler == 'device' and self.listed_proposal and self.listed_resample \
                 and 'v2f_wide' in host_lists and fz.any():
             k16 = fz & (n <= 16) & (pT <= 32)
@@ -272,7 +274,8 @@ class _ParticleSweep:
             self.heavy_terms = int(((hw[:, 8] + hw[:, 9]) * hw[:, 7]).sum().item())
             # of those, the terms at the integral points of edges served by the grid recurrence (word 15: uniform grid;
             # at least 24 partner particles, T <= 128; the kernel's range guard is data dependent and assumed to pass)
-            on_grid = (hw[:, 15] == 1) & (hw[:, 7] >= 24) & (hw[:, 9] <= 128) & ~small[heavy]
+            # (the few-particle kernel takes the recurrence for every edge with a uniform grid, whatever its particle count)
+            on_grid = (hw[:, 15] == 1) & (hw[:, 9] <= 128) & ((hw[:, 7] >= 24) | small[heavy])
             self.heavy_grid_terms = int((hw[:, 9] * hw[:, 7])[on_grid].sum().item())
             light = ~heavy & (words[:, 14] != 0)          # word 14: set by lhvi_pbp_describe for the light kernel's edges
             self.light_desc = rows[light].contiguous()
