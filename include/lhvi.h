@@ -27,13 +27,14 @@
 extern "C" {
 #endif
 
-#define LHVI_ABI_VERSION 10  /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
+#define LHVI_ABI_VERSION 11  /* 2: lhvi_graph_t gained edge_value / slot_var / hub_vars, lhvi_pbp_t the heavy / light descriptor lists, 128-byte descriptors;
                               * 3: lhvi_pbp_t gained var_lo / var_hi;  4: f2v_ticket;  5: prop_desc;  6: lhvi_vi_t gained obs_var, lhvi_gabp_plan_t;  7: lhvi_pbp_t gained pair_desc;
                               * 8: lhvi_pbp_t gained cq_desc / n_cq, lhvi_pbp_classify takes the particle state, lhvi_pbp_describe_cq; the colour
                               *    refinement calls take a method and return four result words; lhvi_vi_t gained var_N; lhvi_vi_opt_t, lhvi_vi_adam_run;
                               *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub / v2f_mid16 / v2f_mid32, prop_hub / prop_partial, resample_vars, small16_desc / small32_desc; 16 ticket words; lhvi_pbp_boundary_reduce;
                               * 9: lhvi_vi_t gained fac_list / n_cc / n_tiny / n_grp3 / n_grp6 / n_rest3 / n_rest6 / edge_axis; lhvi_color_first_members, lhvi_color_segment_sums, lhvi_pbp_halo_pack / _unpack; lhvi_gabp_plan_t.rec;
-                              * 10: lhvi_pbp_t gained halo_off / halo_buf, LHVI_PBP_NO_UNIQ, edge_canon may name rows beyond E; lhvi_pbp_map_brent, lhvi_pbp_quad */
+                              * 10: lhvi_pbp_t gained halo_off / halo_buf, LHVI_PBP_NO_UNIQ, edge_canon may name rows beyond E; lhvi_pbp_map_brent, lhvi_pbp_quad;
+                              * 11: LHVI_PBP_V2F_RECORDS (v2f_wide as 8-word records) */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -210,6 +211,9 @@ int lhvi_log_likelihood(const lhvi_graph_t* g, const lhvi_pots_t* pots, const do
                                         * (lhvi_pbp_boundary_reduce); without it the rows are the peers' sums and the kernels add them */
 #define LHVI_PBP_NO_UNIQ 4096u   /* lhvi_pbp_resample_uniq with a resample_vars list: draw the particles only, leave uniq_out untouched (ghost variables of
                                   * the owner-computes split: their first-occurrence masks are read by nobody on this rank) */
+#define LHVI_PBP_V2F_RECORDS 8192u /* v2f_wide holds one 8-word record per variable instead of its id: 0 variable  1 incident edges  2 particles (np)
+                                    * 3 domain  4-7 the first four incident edges, in row order (a shorter row: its last edge repeated).  The
+                                    * kernel then reaches the f -> v rows after ONE dependent load instead of three (id -> var_ptr / np -> var_edge) */
 #define LHVI_PBP_NO_GRID 128u    /* lhvi_pbp_f2v: integral points always by the direct form (one exponential per term), never by the
                                    * uniform-grid recurrence (testing / profiling aid) */
 
@@ -286,7 +290,7 @@ typedef struct lhvi_pbp {
     /* optional, lhvi_pbp_v2f only (single-GPU runs: not with bslot or a variable range): the hidden variables split by particle
      * count -- v2f_wide: more than four particles, one wavefront each; v2f_narrow: at most four (binary variables, boolean
      * atoms), sixteen per wavefront.  Both or neither; together they must list every hidden variable once.  NULL: one wavefront
-     * per variable of the range. */
+     * per variable of the range.  With LHVI_PBP_V2F_RECORDS in flags, v2f_wide is an array of 8-word records (see the flag). */
     const int32_t* v2f_wide;
     int32_t n_v2f_wide;
     const int32_t* v2f_narrow;

@@ -114,21 +114,35 @@ template <bool HALO>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) pbp_v2f_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v,
                                                        double* __restrict__ v2f) {
     const int lane = threadIdx.x & 63;
-    int v;
-    if (s.v2f_wide) {                                      // the caller's list: hidden variables with more than four particles
+    int v, np, deg, d, lo;
+    int e4[V2F_CACHE] = {0, 0, 0, 0};
+    const bool records = s.v2f_wide && (s.flags & LHVI_PBP_V2F_RECORDS);
+    if (records) {
+        // one 32-byte record per variable (one scalar load), then the rows: walked through the graph -- id -> var_value / np /
+        // var_ptr -> var_edge -> rows -- a wave waits out four dependent global round trips, and with every wave slot taken the
+        // launch lasts as long as those chains (1.79 ms on the headline graph at 0.65 of the HBM roof in algorithmic bytes)
         const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
         if (item >= s.n_v2f_wide) return;
-        v = s.v2f_wide[item];
+        const int32_t* rec = s.v2f_wide + 8 * (int64_t)item;
+        v = rec[0]; deg = rec[1]; np = rec[2]; d = rec[3];
+        e4[0] = rec[4]; e4[1] = rec[5]; e4[2] = rec[6]; e4[3] = rec[7];
+        lo = (deg > V2F_CACHE || np > WAVE) ? g.var_ptr[v] : 0;          // (the row's place in var_edge: only rows the record does not cover)
     } else {
-        v = __builtin_amdgcn_readfirstlane(var_first(s) + blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
-        if (v >= var_limit(g, s)) return;
+        if (s.v2f_wide) {                                  // the caller's list: hidden variables with more than four particles
+            const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+            if (item >= s.n_v2f_wide) return;
+            v = s.v2f_wide[item];
+        } else {
+            v = __builtin_amdgcn_readfirstlane(var_first(s) + blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+            if (v >= var_limit(g, s)) return;
+        }
+        if (!is_hidden(g.var_value[v])) return;
+        np = s.np[v];
+        lo = g.var_ptr[v];
+        deg = g.var_ptr[v + 1] - lo;
+        d = g.var_dom[v];
     }
-    if (!is_hidden(g.var_value[v])) return;
     const int n = s.n, S = s.n + s.T;
-    const int np = s.np[v];
-    const int lo = g.var_ptr[v], hi = g.var_ptr[v + 1];
-    const int deg = hi - lo;
-    const int d = g.var_dom[v];
     const bool lifted = g.edge_count != nullptr;
     const int nchunk = (np + 63) / 64;
     // per-variable constants through the short routines (a few ulp from the libm ones; same value in every lane)
@@ -140,7 +154,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8
         int ecache[V2F_CACHE];
         double row[V2F_CACHE];
 #pragma unroll
-        for (int k = 0; k < V2F_CACHE; ++k) ecache[k] = k < deg ? g.var_edge[lo + k] : 0;
+        for (int k = 0; k < V2F_CACHE; ++k) ecache[k] = records ? e4[k] : (k < deg ? g.var_edge[lo + k] : 0);
 #pragma unroll
         for (int k = 0; k < V2F_CACHE; ++k) row[k] = (k < deg && valid) ? f2v[(int64_t)ecache[k] * S + j] : 0.0;
         const double x = valid ? s.particles[(int64_t)v * n + j] : 0.0;

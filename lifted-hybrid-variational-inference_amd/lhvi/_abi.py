@@ -96,8 +96,9 @@ PBP_LEAVE_ROOM = 256
 PBP_BOUNDARY_TOTALS = 2048
 PBP_CQ = 512
 PBP_NO_UNIQ = 4096
+PBP_V2F_RECORDS = 8192
 PBP_SKIP_CQ = 1024
-ABI_VERSION = 10            # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
+ABI_VERSION = 11            # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
 PBP_DESC_BYTES = 128
 COLOR_HASH, COLOR_SORT = 0, 1     # method of lhvi_color_refine_* (LHVI_COLOR_HASH / LHVI_COLOR_SORT)
 HUB_DEGREE = 64              # LHVI_HUB_DEGREE

@@ -150,6 +150,8 @@ class _ParticleSweep:
             parts = (('wide', wide), ('narrow', narrow), ('hub', hub), ('mid16', mid16), ('mid32', mid32))
             for name, m in parts:
                 host_lists['v2f_' + name] = hidden_v[m].astype(np.int32) if m.any() else np.zeros(1, dtype=np.int32)
+            if os.environ.get('LHVI_PBP_V2F_REC', '1') != '0':
+                host_lists['v2f_wide'] = self._v2f_records(flat, hidden_v[wide])
         # ---- the fused per-variable kernel's records (lhvi_pbp_var_fused) and what is left for the three kernels
         self._fused = None
         pT = sizes[pdom] if pv.size else np.zeros(0, dtype=np.int64)
@@ -177,7 +179,8 @@ class _ParticleSweep:
                 for name, m in parts:
                     vs = hidden_v[m]
                     vs = vs[~fused_var[vs]]
-                    host_lists['v2f_rest_' + name] = vs.astype(np.int32) if vs.size else np.zeros(1, dtype=np.int32)
+                    host_lists['v2f_rest_' + name] = (self._v2f_records(flat, vs) if name == 'wide' and os.environ.get('LHVI_PBP_V2F_REC', '1') != '0' else
+                                                      vs.astype(np.int32) if vs.size else np.zeros(1, dtype=np.int32))
                     rest_parts.append((name, int(vs.size)))
             self._fused = dict(counts=(int(k16.sum()), int(k32a.sum()), int(k32b.sum())), n_prop_rest=int(keep.sum()),
                                n_resample_rest=int(rkeep.sum()), rest_parts=rest_parts)
@@ -192,6 +195,8 @@ class _ParticleSweep:
             self.prop_hub = dev_lists['prop_hub']
         if 'v2f_wide' in dev_lists:
             self.v2f_lists = tuple(x for name, m in parts for x in (dev_lists['v2f_' + name], int(m.sum())))
+            if os.environ.get('LHVI_PBP_V2F_REC', '1') != '0':          # (tuning aid: scripts/diag/v2f_records.sh)
+                self.flags |= _abi.PBP_V2F_RECORDS         # the wide list travels as records: _v2f_records
         # static work lists of the f -> v half sweep (which kernel serves which edge)
         pad = torch.zeros(1, dtype=torch.int32, device=dg.device)       # keeps the pointers non-null when a list is empty
         self.cq_edges = pad[:0]
@@ -290,6 +295,19 @@ class _ParticleSweep:
                                     fast=first_part(self.fast_edges), small16=first_part(all_fast[small16]),
                                     small32=first_part(all_fast[small32]))
             self._build_pairs(key_dev)
+
+    def _v2f_records(self, flat, vs):
+        """``lhvi_pbp_t.v2f_wide`` as records (LHVI_PBP_V2F_RECORDS, include/lhvi.h): variable, incident edges, particles, domain and
+        the first four incident edges in row order, so that the kernel's row loads hang on one scalar load"""
+        rec = np.zeros((max(int(vs.size), 1), 8), dtype=np.int32)
+        if vs.size:
+            deg = np.diff(flat.var_ptr)[vs]
+            rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3] = vs, deg, self.np_host[vs], flat.var_dom[vs]
+            base = flat.var_ptr[vs].astype(np.int64)
+            for k in range(4):
+                if flat.var_edge.size:
+                    rec[:, 4 + k] = flat.var_edge[np.minimum(base + np.minimum(k, np.maximum(deg - 1, 0)), flat.var_edge.size - 1)]
+        return rec
 
     def _build_pairs(self, key_dev):
         """``lhvi_pbp_t.pair_desc``: one record per HybridQuadratic(1 discrete, 1 continuous) factor from the per-edge light
