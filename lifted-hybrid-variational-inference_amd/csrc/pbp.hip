@@ -1518,6 +1518,9 @@ struct PairDesc {
 static_assert(sizeof(PairDesc) == LHVI_PBP_DESC_BYTES, "PairDesc is part of the ABI (LHVI_PBP_DESC_BYTES)");
 
 struct PairData { double x0, x1, m0, m1, y, mj; };
+#ifndef LHVI_PAIR_AHEAD
+#define LHVI_PAIR_AHEAD 1          // (two entries ahead costs a wave slot to the scalar registers: 1.12 -> 1.18 ms, scripts/diag/pair_ahead.sh)
+#endif
 
 __device__ __forceinline__ PairData pair_fetch(const PairDesc& d, const lhvi_graph_t& g, const lhvi_pbp_t& s,
                                                const double* __restrict__ v2f, int lane) {
@@ -1548,17 +1551,28 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_pair_kernel(lhvi_graph_t g, lhv
     const int lane = threadIdx.x & 63;
     const int last = nitems - 1;
     const int n = s.n, S = s.n + s.T;
-    WorkCursor<64> work;
-    if (!work.start(nullptr, nitems, lane)) return;
+    // static striding, descriptors TWO entries ahead: an iteration is short (a few hundred instructions), so a descriptor requested at
+    // its head and needed at once for the next entry's loads -- as in the heavy kernel, whose iterations are fifty times longer --
+    // would put a scalar load's full latency (the list streams from HBM) into every iteration
+    const int stride = gridDim.x * (BLOCK / WAVE);
+    int item = blockIdx.x * (BLOCK / WAVE) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (item >= nitems) return;
     struct { int32_t e_c, e_d, np_c, T, ns; double val_c, A0, b0, c0, A1, b1, c1; } d;
-    PairDesc dn = descs[work.item];
+    PairDesc dn = descs[item];
+#if LHVI_PAIR_AHEAD >= 2
+    PairDesc dn2 = descs[__builtin_amdgcn_readfirstlane(min(item + stride, last))];
+#endif
     PairData h = pair_fetch(dn, g, s, v2f, lane);
     for (;;) {
         d.e_c = dn.e_c; d.e_d = dn.e_d; d.np_c = dn.np_c; d.T = dn.T; d.ns = dn.ns; d.val_c = dn.val_c;
         d.A0 = dn.A0; d.b0 = dn.b0; d.c0 = dn.c0; d.A1 = dn.A1; d.b1 = dn.b1; d.c1 = dn.c1;
-        const int nxt = work.next();
-        const bool more = nxt < work.limit;
-        dn = descs[__builtin_amdgcn_readfirstlane(min(nxt, last))];
+        const bool more = item + stride < nitems;
+#if LHVI_PAIR_AHEAD >= 2
+        dn = dn2;
+        dn2 = descs[__builtin_amdgcn_readfirstlane(min(item + 2 * stride, last))];
+#else
+        dn = descs[__builtin_amdgcn_readfirstlane(min(item + stride, last))];
+#endif
         const PairData cur = h;
         if (more) h = pair_fetch(dn, g, s, v2f, lane);
         if (d.e_c >= 0) {
@@ -1588,7 +1602,95 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_pair_kernel(lhvi_graph_t g, lhv
             if (lane < d.ns) out[lane] = res > 0.0 ? log_table(res, sh_log) : -700.0;
         }
         if (!more) break;
-        work.advance(nxt, lane);
+        item += stride;
+    }
+}
+
+#ifndef LHVI_PAIR_SMALL
+#define LHVI_PAIR_SMALL 1
+#endif
+// PAIRS with FEW particles (every variable of the run has at most W = 16 or 32: lhvi_pbp_t.n <= W): 64 / W list entries per
+// wavefront, a lane group of W lanes each -- the one-entry-per-wave kernel above keeps 48 of 64 lanes busy for two exponentials
+// and then waits for its own loads.  Same expressions per output point, and the sums over the continuous variable's particles
+// run through the same reduction network at the same positions inside the group (dpp_row_reduce / dpp_reduce_rows32 are the first
+// stages of wave_sum, whose later stages add the zeros of the empty rows): the same bits as the kernel above.  Descriptor and
+// operands in two round trips, as in pbp_f2v_small_kernel.
+template <int W>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
+pbp_f2v_pair_small_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f, double* __restrict__ f2v,
+                          const PairDesc* __restrict__ descs, int nitems) {
+    constexpr int G = WAVE / W;
+    __shared__ double sh_tab[EXP_TAB_N];
+    __shared__ LogRec sh_log[LOG_TAB_N];
+    load_log_table(sh_log);
+    load_exp_table(sh_tab);
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / W, gl = lane % W;
+    const int n = s.n, S = s.n + s.T;
+    const int nsteps = (nitems + G - 1) / G;
+    const int nwaves = gridDim.x * (BLOCK / WAVE);
+    for (int step = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); step < nsteps; step += nwaves) {
+        const int idx = step * G + grp;
+        const bool live = idx < nitems;
+        union { PairDesc d; int4 q[sizeof(PairDesc) / 16]; } u;
+        {
+            const int4* dp = reinterpret_cast<const int4*>(descs + (live ? idx : nitems - 1));
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(PairDesc) / 16); ++k) u.q[k] = dp[k];
+        }
+        const int touch = reinterpret_cast<const int*>(descs + min((step + nwaves) * G + grp, nitems - 1))[0];   // (the next step's line)
+        const PairDesc& d = u.d;
+        const bool to_c = live && d.e_c >= 0, to_d = live && d.e_d >= 0;
+        const int np = d.np_c, T = d.T, npts = d.np_c + d.T;
+        // everything the descriptor points to, without branches (addresses clamped into their rows; unused values dropped)
+        double xs[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int p = r * W + gl;
+            const double* src = p < np ? s.particles + ((int64_t)d.v_c * n + p) : g.dom_val + (d.gb + max(min(p - np, T - 1), 0));
+            xs[r] = *src;
+        }
+        const int mc = max(d.mc, 0), md = max(d.md, 0), jl = min(gl, max(np - 1, 0));
+        const double m0l = v2f[(int64_t)mc * n], m1l = v2f[(int64_t)mc * n + (d.ns > 1 ? 1 : 0)];
+        const double yl = s.old_particles[(int64_t)d.v_c * n + jl], mjl = v2f[(int64_t)md * n + jl];
+        asm volatile("" : "+v"(xs[0]), "+v"(xs[1]), "+v"(xs[2]));
+        const bool hid_d = is_hidden(d.val_d), hid_c = is_hidden(d.val_c);
+        const double m0 = (to_c && hid_d) ? m0l : 0.0, m1 = (to_c && hid_d && d.ns > 1) ? m1l : 0.0;
+        // ---- message to the continuous variable: lane = output point, log sum over the discrete variable's live states
+        int pmax = 0;
+#pragma unroll
+        for (int k = 0; k < G; ++k) pmax = max(pmax, __builtin_amdgcn_readlane(to_c ? npts : 0, k * W));
+        double* out_c = f2v + (int64_t)max(d.e_c, 0) * S;
+        auto point = [&](int p, double x) {
+            double acc = exp_core(fma(x, fma(x, d.A0, d.b0), d.c0 + m0), sh_tab);
+            if (d.ns > 1) acc += exp_core(fma(x, fma(x, d.A1, d.b1), d.c1 + m1), sh_tab);
+            if (to_c && p < npts) out_c[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
+        };
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            if (r * W < pmax) point(r * W + gl, xs[r]);
+#pragma unroll 1
+        for (int p0 = 3 * W; p0 < pmax; p0 += W) {
+            const int p = p0 + gl;
+            double x = 0.0;
+            if (to_c && p < npts) x = p < np ? s.particles[(int64_t)d.v_c * n + p] : g.dom_val[d.gb + p - np];
+            point(p, x);
+        }
+        // ---- message to the discrete variable: lane = particle of the continuous variable, one group reduction per state
+        if (__ballot(to_d)) {
+            const int nj = hid_c ? np : 1;
+            const double y = hid_c ? yl : d.val_c, m = hid_c ? mjl : 0.0;
+            auto group_sum = [&](double x) {
+                if (W == 16) return dpp_move<0x15F>(dpp_row_reduce(x, SumOp()));      // lane 15's sum: the one wave_sum hands on (each lane adds in its own order)
+                x = dpp_reduce_rows32(x, SumOp());
+                return lane < 32 ? readlane_f64(x, 31) : readlane_f64(x, 63);
+            };
+            double res = group_sum((to_d && gl < nj) ? exp_core(fma(y, fma(y, d.A0, d.b0), d.c0 + m), sh_tab) : 0.0);
+            const double sum1 = group_sum((to_d && d.ns > 1 && gl < nj) ? exp_core(fma(y, fma(y, d.A1, d.b1), d.c1 + m), sh_tab) : 0.0);
+            if (d.ns > 1 && gl == 1) res = sum1;
+            if (to_d && gl < d.ns) f2v[(int64_t)d.e_d * S + gl] = res > 0.0 ? log_table(res, sh_log) : -700.0;
+        }
+        asm volatile("" :: "v"(touch));
     }
 }
 
@@ -3064,7 +3166,15 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
                                    as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->small32_desc), s->n_small32);
             }
         }
-        if (s->pair_desc && s->n_pair > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT)) {
+        if (s->pair_desc && s->n_pair > 0 && !(s->flags & (LHVI_PBP_SKIP_LIGHT | LHVI_PBP_WIDE_PAIRS)) && s->n <= 16 && LHVI_PAIR_SMALL) {
+            static const int per_cu = blocks_per_cu((const void*)pbp_f2v_pair_small_kernel<16>);       // (every variable has at most 16 particles)
+            hipLaunchKernelGGL(pbp_f2v_pair_small_kernel<16>, dim3(min((s->n_pair + 15) / 16, max(cus * per_cu - spare, 1))), dim3(BLOCK), 0,
+                               as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const PairDesc*>(s->pair_desc), s->n_pair);
+        } else if (s->pair_desc && s->n_pair > 0 && !(s->flags & (LHVI_PBP_SKIP_LIGHT | LHVI_PBP_WIDE_PAIRS)) && s->n <= 32 && LHVI_PAIR_SMALL) {
+            static const int per_cu = blocks_per_cu((const void*)pbp_f2v_pair_small_kernel<32>);
+            hipLaunchKernelGGL(pbp_f2v_pair_small_kernel<32>, dim3(min((s->n_pair + 7) / 8, max(cus * per_cu - spare, 1))), dim3(BLOCK), 0,
+                               as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const PairDesc*>(s->pair_desc), s->n_pair);
+        } else if (s->pair_desc && s->n_pair > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT)) {
             static const int pair_per_cu = blocks_per_cu((const void*)pbp_f2v_pair_kernel);
             hipLaunchKernelGGL(pbp_f2v_pair_kernel, dim3(min((s->n_pair + 3) / 4, max(cus * min(pair_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0,
                                as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const PairDesc*>(s->pair_desc), s->n_pair);

@@ -947,7 +947,7 @@ def test_fused_variable_kernel_equals_the_three_kernels(api, case):
         if case.startswith('hlbp'):
             g, table = paper_popularity(30, 4, seed=9)
             bp = HybridLBP(g, n=n, proposal_approximation=approx, sampler='device', seed=4)
-            bp.fused_var_kernel, bp.fused_max_particles = fused, 32        # (the 32-lane forms are off by default: slower, measured)
+            bp.fused_var_kernel, bp.fused_max_particles = fused, 32
             bp.run(5)
         else:
             if case.startswith('hmln'):
@@ -973,6 +973,34 @@ def test_fused_variable_kernel_equals_the_three_kernels(api, case):
     for name in ('q_dev', 'eta', 'particles', 'old_particles', 'uniq', 'v2f', 'f2v'):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert bool(torch.isfinite(a.q_dev[torch.from_numpy(a.flat.var_hidden & a.flat.var_cont).to(a.q_dev.device)]).all())
+
+
+@pytest.mark.parametrize('n', [5, 10, 16, 24, 32])
+def test_packed_pair_kernel_equals_the_one_entry_per_wave_kernel(api, n):
+    """few particles: the HybridQuadratic(1 discrete, 1 continuous) factors' list goes four (n <= 16) or two (n <= 32) entries to a
+    wavefront (``pbp_f2v_pair_small_kernel``); LHVI_PBP_WIDE_PAIRS keeps the one-entry-per-wave kernel: every array of the
+    state after whole sweeps, bit for bit (observed variables on either side, one-sided records included)"""
+    import torch
+    from lhvi import _abi, synth
+    from lhvi.pbp import EPBP
+    runs = []
+    for wide in (False, True):
+        flat = synth.hybrid_mrf_flat(V=6001, deg=4, seed=17, frac_discrete=0.4, evidence_ratio=0.25)
+        bp = EPBP(None, n=n, proposal_approximation='simple', sampler='device', seed=3)
+        bp._setup(None, flat=flat)
+        assert bp.n_pair > 0
+        if wide:
+            bp.flags |= _abi.PBP_WIDE_PAIRS
+        _init(api, bp)
+        for _ in range(4):
+            bp.sweep(last=False)
+        bp.sweep(last=True)
+        torch.cuda.synchronize()
+        runs.append(bp)
+    a, b = runs
+    for name in ('f2v', 'v2f', 'q_dev', 'eta', 'particles'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert bool(torch.isfinite(a.f2v).all())
 
 
 def test_v2f_hub_kernel_matches_the_one_wave_path(api):
