@@ -281,7 +281,8 @@ typedef struct lhvi_pbp {
      *   4 np_c  5 T  6 grid base  7 live states of v_d   8-9 val_c  10-11 val_d (doubles, NaN = hidden)
      *   12-23 A0 b0 c0 A1 b1 c1 (doubles)   24 / 25 rows of v2f with the discrete / continuous variable's message
      * When set, one kernel over these records replaces the light kernel (twice the bytes in flight per wave, half the
-     * descriptor traffic; same messages bit for bit).  NULL: light_desc is used. */
+     * descriptor traffic; same messages bit for bit).  NULL: light_desc is used.  With n <= 16 / n <= 32 particles four / two records
+     * share a wavefront (same bits again; LHVI_PBP_WIDE_PAIRS keeps one record per wavefront). */
     const void* pair_desc;
     int32_t n_pair;
     /* optional, lhvi_pbp_f2v only: [n_cq][2 * LHVI_PBP_DESC_BYTES] records from lhvi_pbp_describe_cq for the edges of class 4
@@ -324,8 +325,10 @@ typedef struct lhvi_pbp {
     /* optional, lhvi_pbp_f2v only: heavy-class descriptors (same rows as heavy_desc would hold, and NOT in heavy_desc) of the edges
      * whose target AND partner have at most 16 / at most 32 particles (nj <= 16 and np <= 16; the rest with nj <= 32 and np <= 32);
      * any number of integral points.  Served four / two edges per wavefront by their own kernel: with the particle counts of the
-     * reference's demos (10-20) an edge per wavefront is bound by its own latencies, not by its terms.  NULL: such edges stay in
-     * heavy_desc.  Skipped with LHVI_PBP_SKIP_HEAVY. */
+     * reference's demos (10-20) an edge per wavefront is bound by its own latencies, not by its terms.  Integral points on a uniform
+     * grid (descriptor word 15) are tabulated by the recurrence along the grid inside the lane group, like the heavy kernel's (to
+     * rounding the same values as the direct form; LHVI_PBP_NO_GRID forces that one).  NULL: such edges stay in heavy_desc.  Skipped
+     * with LHVI_PBP_SKIP_HEAVY. */
     const void* small16_desc;
     int32_t n_small16;
     const void* small32_desc;

@@ -340,6 +340,53 @@ def test_integral_points_by_grid_recurrence_match_the_direct_form(api, grid):
         assert same[live].any()                                 # ... and the guard did reject edges with exponents ~ +-800
 
 
+@pytest.mark.parametrize('case', ['n10', 'n16', 'n20', 'n32', 'n12 uneven', 'n10 wide', 'n24 wide', 'n16 T100', 'n20 T48'])
+def test_few_particle_kernel_grid_recurrence_matches_the_direct_form(api, case):
+    """``pbp_f2v_small_kernel<16 / 32>`` (four / two edges per wavefront): the integral points of an edge with a uniform grid by the
+    recurrence inside its lane group against the direct form (LHVI_PBP_NO_GRID) -- the particle part identical, the grid part to
+    1e-12; identical throughout on a grid that is not uniform; on the domain [-40, 40] the range guard sends an edge's points
+    through the direct rounds (decided per edge: the same bits whatever shares its wavefront)"""
+    import torch
+    from lhvi import synth, _abi
+    from lhvi.graph import Domain
+    from lhvi.pbp import EPBP
+    n = int(case.split()[0][1:])
+    kind = case.split()[1] if ' ' in case else 'uniform'
+    lo, hi = (-40.0, 40.0) if kind == 'wide' else (-10.0, 10.0)
+    pts = np.linspace(lo, hi, {'T48': 48, 'T100': 100}.get(kind, 32))
+    if kind == 'uneven':
+        pts = np.sign(pts) * np.abs(pts) ** 1.3 / 10 ** 0.3
+    flat = _with_domain(synth.hybrid_mrf_flat(V=3000, deg=4, seed=12, frac_discrete=0.1),
+                        Domain((lo, hi), continuous=True, integral_points=pts))
+    bp = EPBP(None, n=n, proposal_approximation='simple', sampler='device', seed=5)
+    bp._setup(None, flat=flat)
+    _init(api, bp)
+    for _ in range(2):
+        bp.sweep(last=False)
+    l, st = api.lib(), api.stream_ptr()
+    s = bp._struct()
+    api.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, api.ptr(bp.v2f), api.ptr(bp.f2v), st))
+    with_grid = bp.f2v.clone()
+    s.flags |= _abi.PBP_NO_GRID
+    api.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, api.ptr(bp.v2f), api.ptr(bp.f2v), st))
+    desc = bp.small16_desc if n <= 16 else bp.small32_desc
+    assert (bp.n_small16 if n <= 16 else bp.n_small32) > 1000 and bp.n_heavy == 0
+    words = desc.view(torch.int32).view(-1, 32).cpu().numpy()
+    e = words[:, 0]
+    a, b = with_grid.cpu().numpy()[e], bp.f2v.cpu().numpy()[e]
+    assert np.isfinite(a).all()
+    assert (a[:, :n] == b[:, :n]).all()
+    if kind == 'uneven':
+        assert (words[:, 15] == 0).all() and (a == b).all()
+        return
+    assert (words[:, 15] == 1).all()
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12)
+    same = (a[:, n:] == b[:, n:]).all(axis=1)
+    assert not same.all()                                       # the recurrence did run ...
+    if kind == 'wide':
+        assert same.any()                                       # ... and the guard did reject edges with exponents ~ +-800
+
+
 def test_device_sampler_statistics(api):
     """Philox/Box-Muller particles: mean/variance of the clipped normal draws, determinism per (seed, iteration)"""
     from lhvi import synth

@@ -651,3 +651,26 @@ def test_ground_order_of_set_based_graphs_is_node_id_order():
     assert super_rvs[0].value == total / 6 and super_rvs[0].value != sum(sorted(vals[:6])) / 6
     R = lifting._lift_reduce_host(flat, rv_color, f_color)
     assert R['val'][0] == total / 6
+
+
+def test_v2f_records_name_the_row_the_graph_holds():
+    """``lhvi_pbp_t.v2f_wide`` as records (LHVI_PBP_V2F_RECORDS): variable, degree, particle count, domain and the first four
+    incident edges in row order -- what ``pbp_v2f_kernel`` would otherwise read through var_ptr / var_edge (host side only)"""
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    flat = synth.hybrid_mrf_flat(V=700, deg=4, seed=3)
+    bp = EPBP.__new__(EPBP)
+    bp.np_host = np.where(flat.var_cont, 64, 2).astype(np.int64)
+    vs = np.flatnonzero(flat.var_hidden & flat.var_cont)
+    rec = bp._v2f_records(flat, vs)
+    assert rec.shape == (vs.size, 8) and rec.dtype == np.int32
+    deg = np.diff(flat.var_ptr)[vs]
+    np.testing.assert_array_equal(rec[:, 0], vs)
+    np.testing.assert_array_equal(rec[:, 1], deg)
+    np.testing.assert_array_equal(rec[:, 2], 64)
+    np.testing.assert_array_equal(rec[:, 3], flat.var_dom[vs])
+    for i in range(0, vs.size, 37):
+        row = flat.var_edge[flat.var_ptr[vs[i]]:flat.var_ptr[vs[i] + 1]]
+        want = [row[min(k, row.size - 1)] for k in range(4)] if row.size else [0] * 4
+        assert rec[i, 4:].tolist() == [int(x) for x in want]
+    assert bp._v2f_records(flat, vs[:0]).shape == (1, 8)          # an empty list keeps a non-null pointer
