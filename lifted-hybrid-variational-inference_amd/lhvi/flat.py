@@ -91,7 +91,15 @@ def ground_order(items):
     """the order in which a graph's rvs / factors are numbered: a list as it stands; a Python ``set`` (what the reference's
     ``Graph`` / ``RelationalGraph.ground_graph`` hold) sorted by node id, i.e. in creation order -- iterating the set itself would
     number the ground graph by object hashes, differently in every process"""
-    return sorted(items) if isinstance(items, (set, frozenset)) else list(items)
+    if not isinstance(items, (set, frozenset)):
+        return list(items)
+    try:
+        return sorted(items, key=_node_id)        # (the nodes' own __lt__ compares ids: the same order, without a Python call per comparison)
+    except AttributeError:
+        return sorted(items)
+
+
+_node_id = __import__('operator').attrgetter('id')
 
 
 def _value_or_nan(v):
@@ -160,55 +168,53 @@ def _flatten(g, require_device_potentials=False):
         dom_ptr[k + 1] = dom_ptr[k] + pts.size
     dom_val = np.concatenate(vals) if vals else np.zeros(0)
 
-    # edges, factor-major
-    arity = np.array([len(f.nb) for f in factors], dtype=np.int64)
+    # edges, factor-major.  The per-edge Python work is one dictionary lookup; duplicates (a lifted factor whose scope repeats a
+    # cluster) and the variable rows are resolved on arrays: an object graph of 20 000 edges is flattened twice per lifted run
+    # (the ground graph for the refinement, the lifted graph for the sweep), and element-wise NumPy stores made that 2 x 27 ms
+    nbs = [f.nb for f in factors]
+    arity = np.fromiter((len(nb) for nb in nbs), dtype=np.int64, count=F)
     if F and arity.max() > MAX_ARITY:
         raise NotImplementedError('factor arity %d exceeds LHVI_MAX_ARITY=%d' % (arity.max(), MAX_ARITY))
     fac_ptr = np.zeros(F + 1, dtype=np.int32)
     np.cumsum(arity, out=fac_ptr[1:])
     E = int(fac_ptr[-1])
-    edge_var = np.zeros(E, dtype=np.int32)
-    edge_fac = np.zeros(E, dtype=np.int32)
-    edge_pos = np.zeros(E, dtype=np.int32)
-    edge_canon = np.arange(E, dtype=np.int32)
-    pair_edge = {}
-    e = 0
-    for fi, f in enumerate(factors):
-        for pos, rv in enumerate(f.nb):
-            vi = var_index[rv]
-            edge_var[e], edge_fac[e], edge_pos[e] = vi, fi, pos
-            key = (fi, vi)
-            if key in pair_edge:
-                if not lifted:
-                    raise NotImplementedError('ground factor #%d repeats a variable in its scope' % fi)
-                edge_canon[e] = pair_edge[key]
-            else:
-                pair_edge[key] = e
-            e += 1
+    edge_var = np.fromiter((var_index[rv] for nb in nbs for rv in nb), dtype=np.int32, count=E)
+    edge_fac = np.repeat(np.arange(F, dtype=np.int32), arity)
+    edge_pos = (np.arange(E, dtype=np.int64) - fac_ptr[:-1].astype(np.int64)[edge_fac]).astype(np.int32)
+    # canonical edge of a (factor, variable) pair = its first edge
+    pair_key = edge_fac.astype(np.int64) * max(V, 1) + edge_var
+    uniq_key, first_edge, inverse = np.unique(pair_key, return_index=True, return_inverse=True)
+    edge_canon = first_edge[inverse].astype(np.int32)
+    if not lifted and uniq_key.size != E:
+        e_dup = int(np.flatnonzero(edge_canon != np.arange(E))[0])
+        raise NotImplementedError('ground factor #%d repeats a variable in its scope' % int(edge_fac[e_dup]))
 
     # variable CSR in rv.nb order
+    vnbs = [rv.nb for rv in rvs]
+    deg = np.fromiter((len(nb) for nb in vnbs), dtype=np.int64, count=V)
     var_ptr = np.zeros(V + 1, dtype=np.int32)
-    var_edge = []
+    np.cumsum(deg, out=var_ptr[1:])
+    nnz = int(var_ptr[-1])
+    row_fac = np.fromiter((fac_index[f] for nb in vnbs for f in nb), dtype=np.int64, count=nnz)
+    row_key = row_fac * max(V, 1) + np.repeat(np.arange(V, dtype=np.int64), deg)
+    at = np.searchsorted(uniq_key, row_key)
+    if nnz and (at.max(initial=0) >= uniq_key.size or (uniq_key[np.minimum(at, uniq_key.size - 1)] != row_key).any()):
+        bad = int(np.flatnonzero((at >= uniq_key.size) | (uniq_key[np.minimum(at, uniq_key.size - 1)] != row_key))[0])
+        raise KeyError((int(row_fac[bad]), int(np.repeat(np.arange(V), deg)[bad])))       # rv.nb names a factor whose scope lacks rv
+    var_edge = first_edge[at].astype(np.int32).reshape(-1)
     edge_count = np.ones(E, dtype=np.float64)
-    for vi, rv in enumerate(rvs):
-        for f in rv.nb:
-            ce = pair_edge[(fac_index[f], vi)]
-            var_edge.append(ce)
-            if lifted:
-                edge_count[ce] = float(rv.count[f])
-        var_ptr[vi + 1] = len(var_edge)
-    var_edge = np.array(var_edge, dtype=np.int32).reshape(-1)
-    if lifted:   # give alias edges their canonical count so kernels can read either
-        edge_count = edge_count[edge_canon]
+    if lifted:
+        edge_count[var_edge] = np.fromiter((rv.count[f] for rv, nb in zip(rvs, vnbs) for f in nb), dtype=np.float64, count=nnz)
+        edge_count = edge_count[edge_canon]          # alias edges carry their canonical count so kernels can read either
 
     # potentials
     potentials, pot_index = [], {}
     pot_kind, pot_off, params = [], [0], []
     fac_pot = np.zeros(F, dtype=np.int32)
-    for fi, f in enumerate(factors):
-        doms = tuple(rv.domain for rv in f.nb)
-        key = (id(f.potential), tuple(id(d) for d in doms))
+    for fi, (f, nb) in enumerate(zip(factors, nbs)):
+        key = (id(f.potential),) + tuple(id(rv.domain) for rv in nb)
         if key not in pot_index:
+            doms = tuple(rv.domain for rv in nb)
             spec = getattr(f.potential, 'device_spec', None)
             if spec is None:
                 if require_device_potentials:
