@@ -686,6 +686,9 @@ constexpr int VI_TINY_PAR = 3072;      // doubles of parameter rows kept in LDS 
 #ifndef LHVI_VI_TINY_SLIM_WAVES
 #define LHVI_VI_TINY_SLIM_WAVES 3          // the build without the interpreter (measured: 2 waves 0.53 ms, 3 waves 0.50, 4 waves -- 304 B of scratch -- 0.64 on the scaled cfg 3)
 #endif
+#ifndef LHVI_VI_TINY_HOIST
+#define LHVI_VI_TINY_HOIST 1
+#endif
 constexpr int VI_TINY_PAR_SLIM = 1024;     // parameter rows it keeps in LDS (8 KB); larger tables take the general build
 
 template <bool INTERP>
@@ -717,6 +720,9 @@ vi_factor_tiny_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __r
         int av[3], alen[3], afix[3], adom[3];
         bool hid[3], cont[3], axis[3], gauss[3];      // gauss: integrated with Gauss-Hermite nodes (hidden continuous / Gaussian observation)
         double mu[3], var[3], sd[3], val[3], inv[3][VI_TINY_K];
+#if LHVI_VI_TINY_HOIST
+        double mk[3][VI_TINY_K];                      // every component's mean of a Gauss-Hermite argument: read per point, component and
+#endif                                                // argument inside the loop below, it is a dependent global load each time
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int4 r = a < arity ? recs[base + a] : make_int4(0, 1, 0, 0);
@@ -729,11 +735,20 @@ vi_factor_tiny_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __r
             mu[a] = 0.0; var[a] = 1.0; sd[a] = 0.0;
 #pragma unroll
             for (int kk = 0; kk < VI_TINY_K; ++kk) inv[a][kk] = 0.0;
+#if LHVI_VI_TINY_HOIST
+#pragma unroll
+            for (int kk = 0; kk < VI_TINY_K; ++kk) mk[a][kk] = val[a];
+#endif
             if (hid[a] && cont[a]) {
                 const double* e = p.eta_c + (int64_t)av[a] * p.K * 2;
                 mu[a] = e[2 * k]; var[a] = e[2 * k + 1]; sd[a] = sqrt(2 * var[a]);
 #pragma unroll
-                for (int kk = 0; kk < VI_TINY_K; ++kk) if (kk < p.K) inv[a][kk] = 1.0 / e[2 * kk + 1];
+                for (int kk = 0; kk < VI_TINY_K; ++kk) if (kk < p.K) {
+                    inv[a][kk] = 1.0 / e[2 * kk + 1];
+#if LHVI_VI_TINY_HOIST
+                    mk[a][kk] = e[2 * kk];
+#endif
+                }
             } else if (gobs) {
                 const double ov = p.obs_var[av[a]];
                 mu[a] = val[a]; sd[a] = sqrt(2 * ov);
@@ -818,7 +833,11 @@ vi_factor_tiny_kernel(lhvi_graph_t g, lhvi_pots_t pots, lhvi_vi_t p, double* __r
                 for (int b = 0; b < 3; ++b) {
                     if (!axis[b]) continue;
                     if (gauss[b]) {
+#if LHVI_VI_TINY_HOIST
+                        const double m = mk[b][kk];
+#else
                         const double m = hid[b] ? p.eta_c[((int64_t)av[b] * p.K + kk) * 2] : val[b];
+#endif
                         t *= norm_pdf_inv(x[b], m, inv[b][kk], inv[b][kk] * (1.0 / 2.506628274631), sh_tab);
                     } else t *= p.eta_d[((int64_t)av[b] * p.K + kk) * p.Dmax + idx[b]];
                 }
