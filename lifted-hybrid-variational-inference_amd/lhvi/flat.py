@@ -126,6 +126,12 @@ def flatten(g, require_device_potentials=False):
     """Build a ``FlatGraph`` from ``g`` (see ``_flatten``); the garbage collector rests meanwhile."""
     if isinstance(g, FlatGraph):
         return g
+    if getattr(g, 'array_flat', False):
+        # a compressed graph whose partition is stable (lifting.CompressedGraph after run / the solvers' colour-passing loops):
+        # the lifted arrays straight from the ground arrays and the colours, the cluster objects only attached
+        lf = g.lifted_flat(require_device_potentials)
+        if lf is not None:
+            return lf
     with gc_paused():
         return _flatten(g, require_device_potentials)
 

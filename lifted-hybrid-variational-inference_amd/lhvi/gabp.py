@@ -264,6 +264,7 @@ class GaLBP(_GaussianSweep):
             prev = self.g.num_rv_clusters
             self.g.split_factors()
             self.g.split_rvs()
+        self.g.array_flat = True                        # (a stable partition: the lifted arrays come from the ground arrays, lifting.lifted_flat)
         self._sweep(self.g, iteration)
 
     def belief(self, x, ground_rv):

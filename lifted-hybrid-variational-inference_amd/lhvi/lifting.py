@@ -333,6 +333,7 @@ class CompressedGraph:
 
     # ---- reference API -----------------------------------------------------------------------
     def init_cluster(self, is_split_cont_evidence=True):
+        self.array_flat = False
         self._rv_color, self._f_color = initial_colors(self.g, is_split_cont_evidence)
         self.num_rv_clusters = int(self._rv_color.max()) + 1 if self._rv_color.size else 0
         self.num_factor_clusters = int(self._f_color.max()) + 1 if self._f_color.size else 0
@@ -360,6 +361,7 @@ class CompressedGraph:
         return out
 
     def _half_round(self, call, what):
+        self.array_flat = False                  # (the partition moves: the loops that reach its fixed point set the flag again)
         """one refinement half round on the device: hash-table relabelling, repeated through the radix sort if the table
         overflowed (more than half a million distinct colours); returns the number of colours"""
         d = self._upload_colors()
@@ -402,6 +404,7 @@ class CompressedGraph:
             prev = self.num_rv_clusters
             self.split_factors()
             self.split_rvs()
+        self.array_flat = True                   # stable: flatten() may lift on arrays (lifted_flat)
         return self
 
     # ---- colours / objects -------------------------------------------------------------------
@@ -414,6 +417,7 @@ class CompressedGraph:
 
     def set_colors(self, rv_color, f_color):
         """Inject a partition (tests use this to exercise the host logic without a GPU)."""
+        self.array_flat = False
         self._rv_color = np.asarray(rv_color, dtype=np.int32)
         self._f_color = np.asarray(f_color, dtype=np.int32)
         self.num_rv_clusters = int(self._rv_color.max()) + 1 if self._rv_color.size else 0
@@ -422,6 +426,42 @@ class CompressedGraph:
         if self._dev is not None:
             for k in ('rvc', 'fc', 'rvc2', 'fc2'):
                 self._dev.pop(k, None)
+
+    array_flat = False          # set by the callers that ran the colour passing to its fixed point: flatten() may take lifted_flat()
+
+    def lifted_flat(self, require_device_potentials=False):
+        """The lifted ``FlatGraph`` from the ground arrays and the colours (``lift_flat``) with the cluster objects attached --
+        what ``flatten`` builds from the ``SuperRV`` / ``SuperF`` objects, edge for edge (same incidences, canonical edges, rows
+        and counts: a cluster's edges are its representative's either way; the potential and domain tables are the ground
+        graph's), without walking 15 000 objects a second time.  None when there is no uploaded ground graph, or the partition is
+        not stable (the caller then flattens the objects)."""
+        if self._dev is None or self._rv_color is None:
+            return None
+        from .potentials import POT_GENERIC
+        rvc, fc = self.colors()
+        gflat = self._dev['flat']
+        # (the ground arrays were made when the graph was first uploaded: evidence set on the rv objects since then is taken over)
+        now = np.fromiter((np.nan if rv.value is None else rv.value for rv in gflat.rvs), dtype=np.float64, count=gflat.V)
+        if not np.array_equal(now, gflat.var_value, equal_nan=True):
+            gflat.var_value = now
+        try:
+            lf = lift_flat(gflat, np.asarray(rvc), np.asarray(fc))
+        except _abi.LhviError:
+            return None
+        rvs, factors = self.rvs_list, self.factors_list
+        if len(rvs) != lf.V or len(factors) != lf.F or (lf.V and (rvs[0].id != 0 or rvs[-1].id != lf.V - 1)) \
+                or (lf.F and (factors[0].id != 0 or factors[-1].id != lf.F - 1)):
+            return None
+        if require_device_potentials:
+            used = np.unique(lf.fac_pot)
+            generic = used[lf.pot_kind[used] == POT_GENERIC]
+            if generic.size:
+                raise NotImplementedError('potential %r has no device encoding (device_spec); refusing to fall back to the CPU'
+                                          % type(lf.potentials[int(generic[0])]).__name__)
+        lf.rvs, lf.factors = rvs, factors
+        lf.var_index = {c: i for i, c in enumerate(rvs)}
+        lf.fac_index = {c: i for i, c in enumerate(factors)}
+        return lf
 
     def _build(self):
         if self._objects is None:

@@ -1077,6 +1077,7 @@ class HybridLBP(_ParticleSweep):
                 prev = self.g.num_rv_clusters
                 self.g.split_factors()
                 self.g.split_rvs()
+            self.g.array_flat = True                        # (stable: lifting.lifted_flat instead of walking the cluster objects)
             self._setup(self.g)
             self._run_sweeps(iteration)
             self.g.split_factors()                          # HLBP:536 (a no-op on a stable partition)

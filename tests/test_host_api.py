@@ -674,3 +674,46 @@ def test_v2f_records_name_the_row_the_graph_holds():
         want = [row[min(k, row.size - 1)] for k in range(4)] if row.size else [0] * 4
         assert rec[i, 4:].tolist() == [int(x) for x in want]
     assert bp._v2f_records(flat, vs[:0]).shape == (1, 8)          # an empty list keeps a non-null pointer
+
+
+@pytest.mark.parametrize('model', ['rgm', 'rgm pooled', 'hmln'])
+def test_lift_flat_equals_flatten_of_the_cluster_objects(model):
+    """a stable partition's lifted graph two ways: ``flatten`` of the SuperRV / SuperF objects and ``lifting.lift_flat`` on the ground
+    arrays (what ``CompressedGraph.lifted_flat`` hands to ``flatten`` once the colour passing has reached its fixed point) --
+    the same incidences, canonical edges, rows, counts, multiplicities and cluster values, the same potential and domain per
+    factor / variable (the tables themselves are numbered differently), cluster ids = indices"""
+    from lhvi import flat as F, generators, lifting
+    from oracle import oracle
+    rng = np.random.default_rng(4)
+    if model == 'hmln':
+        rel = generators.paper_popularity(30, 4)
+        rel.ground_graph()
+        data = {k: (int(rng.integers(0, 2)) if k[0] in ('SameSession', 'PaperIn') else float(np.round(rng.uniform(0, 10), 1)))
+                for k in sorted(rel.rvs_dict) if rng.random() < 0.3}
+    else:
+        rel = generators.rgm(40, 20)
+        rel.ground_graph()
+        keys = sorted(rel.rvs_dict)
+        pick = rng.choice(len(keys), len(keys) // 4, replace=False)
+        data = {keys[i]: (float(rng.choice([1.5, -2.0, 7.25])) if 'pooled' in model else float(np.round(rng.uniform(-30, 30), 2))) for i in pick}
+    g, _ = rel.add_evidence(data)
+    fl = F.flatten(g)
+    rv0, f0 = lifting.initial_colors(g, True)
+    sym = np.array([1 if getattr(f.potential, 'symmetric', False) else 0 for f in fl.factors], dtype=np.uint8)
+    rvc, fc = oracle.color_passing(fl, sym, rv0, f0)
+    rvs, factors = lifting.build_lifted_objects(g, rvc, fc)[:2]
+
+    class Lifted:
+        pass
+    lg = Lifted()
+    lg.rvs, lg.factors = rvs, factors
+    a, b = F.flatten(lg), lifting.lift_flat(fl, rvc, fc)
+    for name in ('fac_ptr', 'edge_var', 'edge_fac', 'edge_pos', 'edge_canon', 'var_ptr', 'var_edge', 'edge_count', 'var_mult', 'fac_mult'):
+        np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg=name)
+    np.testing.assert_array_equal(a.var_value, b.var_value)
+    assert all(a.domains[i] is b.domains[j] for i, j in zip(a.var_dom, b.var_dom))
+    assert all(a.potentials[i] is b.potentials[j] for i, j in zip(a.fac_pot, b.fac_pot))
+    row = lambda t, i: (int(t.pot_kind[i]), tuple(t.pot_param[t.pot_off[i]:t.pot_off[i + 1]]))
+    assert [row(a, i) for i in a.fac_pot] == [row(b, i) for i in b.fac_pot]
+    assert [c.id for c in a.rvs] == list(range(a.V)) and [c.id for c in a.factors] == list(range(a.F))
+    assert a.V < fl.V or 'pooled' not in model
