@@ -716,4 +716,3 @@ def test_lift_flat_equals_flatten_of_the_cluster_objects(model):
     row = lambda t, i: (int(t.pot_kind[i]), tuple(t.pot_param[t.pot_off[i]:t.pot_off[i + 1]]))
     assert [row(a, i) for i in a.fac_pot] == [row(b, i) for i in b.fac_pot]
     assert [c.id for c in a.rvs] == list(range(a.V)) and [c.id for c in a.factors] == list(range(a.F))
-    assert a.V < fl.V or 'pooled' not in model
