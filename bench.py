@@ -361,7 +361,7 @@ def main():
                         'roof and every other kernel at the HBM peak the sweep would take %.2f ms, an HBM fraction of %.2f, so the '
                         'arithmetic does NOT excuse missing the %.2f target here: the per-variable kernels (v->f, proposal, sampler) read '
                         'each variable\'s f->v rows in scattered pieces of 80-384 bytes and are bound by those accesses '
-                        '(profiles/r05_experiments.md item 3); the unbuilt lever is a variable-major f->v table (DESIGN.md section 8)'
+                        '(profiles/r05_experiments.md items 3 and 7); the unbuilt lever is a variable-major f->v table (DESIGN.md section 8)'
                         % (n, intensity, FP64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS, 1e3 * t_min, hbm_ceiling, HBM_TARGET_FRAC))
         traffic, traffic_src = measured_traffic('pbp_f2v_heavy_kernel') if world == 1 and args.edges == 10_000_000 else (None, None)
         out = {
