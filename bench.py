@@ -295,6 +295,20 @@ def main():
 
     runner = build(primary if world > 1 else None)
     elapsed, f2v_ms = time_runner(runner, primary if world > 1 else 'single GPU')
+    # single GPU: the dominant kernel shares the CUs with the short f -> v kernels on a second stream (lhvi/pbp.py, overlap_f2v); a few
+    # sweeps on ONE stream after the timed region give its duration alone, reported beside the timed one (never in `value`)
+    f2v_alone_ms = None
+    bp0 = getattr(runner, 'bp', None)
+    if world == 1 and bp0 is not None and getattr(bp0, 'overlap_f2v', False) and os.environ.get('LHVI_PBP_OVERLAP') != '0' \
+            and getattr(bp0, 'n_heavy', 0) >= getattr(bp0, 'overlap_min_heavy', 1 << 62):
+        phase('single GPU: five sweeps on one stream (the dominant kernel alone)')
+        bp0.overlap_f2v = False
+        ev1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for i in range(5):
+            runner.sweep(f2v_events=ev1[i])
+        torch.cuda.synchronize()
+        bp0.overlap_f2v = True
+        f2v_alone_ms = float(np.mean([a.elapsed_time(b) for a, b in ev1[1:]]))
     exchanges = None
     if world > 1:
         def line(r, el):
@@ -364,6 +378,14 @@ def main():
                         '(profiles/r05_experiments.md items 3 and 7); the unbuilt lever is a variable-major f->v table (DESIGN.md section 8)'
                         % (n, intensity, FP64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS, 1e3 * t_min, hbm_ceiling, HBM_TARGET_FRAC))
         traffic, traffic_src = measured_traffic('pbp_f2v_heavy_kernel') if world == 1 and args.edges == 10_000_000 else (None, None)
+        # single GPU: the short f -> v kernels run on a second stream beside the dominant one (lhvi/pbp.py, overlap_f2v), which then
+        # shares the CUs with them: its launch duration -- what `achieved` is computed from -- includes that sharing
+        bp_ = getattr(runner, 'bp', None)
+        concurrent = None
+        if bp_ is not None and getattr(bp_, 'overlap_f2v', False) and os.environ.get('LHVI_PBP_OVERLAP') != '0' \
+                and getattr(bp_, 'n_heavy', 0) >= getattr(bp_, 'overlap_min_heavy', 1 << 62):
+            concurrent = ('pbp_f2v_pair_kernel + pbp_f2v_generic_kernel on a second stream beside this kernel, which leaves a workgroup per CU '
+                          'free (LHVI_PBP_SHARE_CUS); alone it takes ~0.6 ms less, the sweep ~0.55 ms more (profiles/r05_experiments.md item 11)')
         out = {
             'metric': 'lbp_sweeps_per_sec_10M_edge_hybrid_mrf' if args.edges == 10_000_000
                       else 'lbp_sweeps_per_sec_%d_edge_hybrid_mrf' % args.edges, 'value': sweeps_per_s, 'unit': 'sweeps/s',
@@ -392,6 +414,9 @@ def main():
                                               % (FLOP_PER_PARTICLE_TERM, FLOP_PER_GRID_TERM)},
                          'traffic': traffic, 'traffic_source': ('from_committed_profile: ' + traffic_src) if traffic_src else None,
                          'kernel_ms': f2v_ms, 'edges_per_launch': heavy_edges, 'joint_terms_per_launch': terms,
+                         'concurrent': concurrent,
+                         'alone': None if f2v_alone_ms is None else {'kernel_ms': f2v_alone_ms, 'frac': terms * FLOP_PER_TERM / (f2v_alone_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                                                        'note': 'the same kernel in sweeps on one stream, after the timed region'},
                          'note': 'achieved = algorithmic count, 16 flop per (output point, partner particle) term, over the HIP-event '
                                  'time of the launch.  Terms at the particles cost 8 fp64 + 2 int32 issue slots (36 cycles per '
                                  'wave-term) + 2 LDS reads (36.8 LDS-pipe cycles per four wave-terms of a CU) each: both ceilings sit at '

@@ -34,7 +34,7 @@ extern "C" {
                               *    lhvi_gabp_plan_t.n_hub_rows, lhvi_gabp_graph_*; lhvi_pbp_t gained v2f_wide / v2f_narrow / v2f_hub / v2f_mid16 / v2f_mid32, prop_hub / prop_partial, resample_vars, small16_desc / small32_desc; 16 ticket words; lhvi_pbp_boundary_reduce;
                               * 9: lhvi_vi_t gained fac_list / n_cc / n_tiny / n_grp3 / n_grp6 / n_rest3 / n_rest6 / edge_axis; lhvi_color_first_members, lhvi_color_segment_sums, lhvi_pbp_halo_pack / _unpack; lhvi_gabp_plan_t.rec;
                               * 10: lhvi_pbp_t gained halo_off / halo_buf, LHVI_PBP_NO_UNIQ, edge_canon may name rows beyond E; lhvi_pbp_map_brent, lhvi_pbp_quad;
-                              * 11: LHVI_PBP_V2F_RECORDS (v2f_wide as 8-word records), LHVI_PBP_WIDE_PAIRS */
+                              * 11: LHVI_PBP_V2F_RECORDS (v2f_wide as 8-word records), LHVI_PBP_WIDE_PAIRS, LHVI_PBP_SHARE_CUS */
 #define LHVI_MAX_ARITY 6
 
 /* error codes */
@@ -216,6 +216,9 @@ int lhvi_log_likelihood(const lhvi_graph_t* g, const lhvi_pots_t* pots, const do
                                     * kernel then reaches the f -> v rows after ONE dependent load instead of three (id -> var_ptr / np -> var_edge) */
 #define LHVI_PBP_WIDE_PAIRS 16384u /* lhvi_pbp_f2v: the pair_desc list always through the one-entry-per-wavefront kernel, also when n <= 32 would let
                                    * four / two entries share a wavefront (testing aid: the two kernels give the same bits) */
+#define LHVI_PBP_SHARE_CUS 32768u /* lhvi_pbp_f2v: the persistent grids of the long kernels (heavy_desc, small16 / small32) take one workgroup per CU less than
+                                   * fits, so that the short kernels of the same half sweep, launched by a second call on ANOTHER stream (the pair /
+                                   * light / cq / generic lists: disjoint rows of f2v), find a wave slot and LDS on every CU and run beside them */
 #define LHVI_PBP_NO_GRID 128u    /* lhvi_pbp_f2v: integral points always by the direct form (one exponential per term), never by the
                                    * uniform-grid recurrence (testing / profiling aid) */
 

@@ -3135,7 +3135,8 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
     static const int light_per_cu = blocks_per_cu((const void*)pbp_f2v_light_kernel);
     static const int gen_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel<true>);
     static const int gen_slim_per_cu = blocks_per_cu((const void*)pbp_f2v_generic_kernel<false>);
-    const int heavy_blocks = heavy_per_cu, side_blocks = 8;
+    const int share = (s->flags & LHVI_PBP_SHARE_CUS) ? 1 : 0;          // a workgroup per CU left to the kernels of another stream
+    const int heavy_blocks = max(heavy_per_cu - share, 1), side_blocks = 8;
     // LEAVE_ROOM (sharded runs): every persistent grid stays cus/8 workgroups short of filling the device, so a collective's
     // copy kernels on another stream can become resident while these waves run (no kernel here ever waits on another
     // workgroup, so a full device could only delay such a kernel, never block it -- but a delayed collective is an exposed one)
@@ -3157,12 +3158,12 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
         if (!(s->flags & LHVI_PBP_SKIP_HEAVY)) {
             if (s->small16_desc && s->n_small16 > 0) {
                 static const int per_cu = blocks_per_cu((const void*)pbp_f2v_small_kernel<16>);
-                hipLaunchKernelGGL(pbp_f2v_small_kernel<16>, dim3(min((s->n_small16 + 15) / 16, max(cus * per_cu - spare, 1))), dim3(BLOCK), 0,
+                hipLaunchKernelGGL(pbp_f2v_small_kernel<16>, dim3(min((s->n_small16 + 15) / 16, max(cus * max(per_cu - share, 1) - spare, 1))), dim3(BLOCK), 0,
                                    as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->small16_desc), s->n_small16);
             }
             if (s->small32_desc && s->n_small32 > 0) {
                 static const int per_cu = blocks_per_cu((const void*)pbp_f2v_small_kernel<32>);
-                hipLaunchKernelGGL(pbp_f2v_small_kernel<32>, dim3(min((s->n_small32 + 7) / 8, max(cus * per_cu - spare, 1))), dim3(BLOCK), 0,
+                hipLaunchKernelGGL(pbp_f2v_small_kernel<32>, dim3(min((s->n_small32 + 7) / 8, max(cus * max(per_cu - share, 1) - spare, 1))), dim3(BLOCK), 0,
                                    as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->small32_desc), s->n_small32);
             }
         }

@@ -41,6 +41,10 @@ class _ParticleSweep:
     sliced_proposal = True          # rows of more than prop_slice incident edges are cut into slices, a wavefront per slice
     prop_slice = 64
     packed_v2f = True               # variables with at most four particles share a wavefront in the v -> f half (sixteen each)
+    overlap_f2v = True              # the short f -> v kernels (pair / light / cq / generic lists) on a second stream beside the heavy kernel, which
+                                    # then leaves a workgroup per CU free (LHVI_PBP_SHARE_CUS): 15.20 -> 14.66 ms per sweep on the headline graph (the
+                                    # heavy kernel 10.65 -> 11.26 ms, the 1.25 ms of the others hidden; same bits).  Only for a heavy list of at
+    overlap_min_heavy = 1 << 16     # least this many edges: the few-particle kernels lose by it (4.55 -> 4.60 ms at n = 16), small graphs gain nothing
     fused_var_kernel = True         # few particles, device sampler: v -> f, proposal update and the new sample of a continuous variable in
                                     # ONE pass over its rows (lhvi_pbp_var_fused) instead of three launches; same bits
     fused_max_particles = 32        # ... up to this many particles.  With a row's loads in flight together (csrc/pbp.hip, FUSED_CH) the fused kernel
@@ -509,6 +513,36 @@ class _ParticleSweep:
         if not getattr(self, '_has_f_side', True):
             raise _abi.LhviError('this state was set up for the v -> f half only (sides="v")')
         args = (_abi.ptr(self.v2f), _abi.ptr(self.f2v))
+        want = os.environ.get('LHVI_PBP_OVERLAP')                     # (tuning aid: scripts/diag/f2v_overlap.sh)
+        if (self.overlap_f2v or want == '1') and want != '0' and self.n_heavy >= self.overlap_min_heavy:
+            # the long kernel(s) of the half sweep on this stream, one workgroup per CU short of a full device; the short kernels
+            # (pair / light / cq / fast, then generic: other rows of f2v) on a second stream beside them.  The heavy kernel is bound
+            # by VALU issue and the LDS and indifferent to 6 or 7 waves per SIMD; the pair kernel waits for its loads most of its
+            # 1.1 ms -- side by side the second one costs next to nothing.
+            torch = _abi.require_gpu()
+            main = torch.cuda.current_stream()
+            if getattr(self, '_side', None) is None:
+                self._side = torch.cuda.Stream(device=self.dg.device)
+                self._fork, self._join = torch.cuda.Event(), torch.cuda.Event()
+            base = s.flags
+            self._fork.record(main)
+            self._side.wait_event(self._fork)
+            with torch.cuda.stream(self._side):
+                sst = _abi.stream_ptr()
+                s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_HEAVY
+                _abi.check(l.lhvi_pbp_f2v(g, p, s, *args, sst))
+                s.flags = base | _abi.PBP_SKIP_FAST
+                _abi.check(l.lhvi_pbp_f2v(g, p, s, *args, sst))
+                self._join.record(self._side)
+            s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_LIGHT | _abi.PBP_SHARE_CUS
+            if f2v_events:
+                f2v_events[0].record()
+            _abi.check(l.lhvi_pbp_f2v(g, p, s, *args, st))
+            if f2v_events:
+                f2v_events[1].record()
+            main.wait_event(self._join)
+            s.flags = base
+            return
         if f2v_events:
             base = s.flags
             s.flags = base | _abi.PBP_SKIP_GENERIC | _abi.PBP_SKIP_LIGHT

@@ -1050,6 +1050,33 @@ def test_packed_pair_kernel_equals_the_one_entry_per_wave_kernel(api, n):
     assert bool(torch.isfinite(a.f2v).all())
 
 
+def test_f2v_half_sweep_on_two_streams_gives_the_same_bits(api, monkeypatch):
+    """``EPBP.overlap_f2v``: the heavy kernel on the caller's stream (LHVI_PBP_SHARE_CUS: a workgroup per CU left free) and the pair /
+    generic kernels beside it on a second stream write disjoint rows of f2v -- every array of the state after whole sweeps equals
+    the one-stream run's bit for bit, and the next v -> f half waits for both streams"""
+    import torch
+    from lhvi import synth
+    from lhvi.pbp import EPBP
+    runs = []
+    for overlap in ('1', '0'):
+        monkeypatch.setenv('LHVI_PBP_OVERLAP', overlap)
+        flat = synth.hybrid_mrf_flat(V=30000, deg=4, seed=8, frac_discrete=0.3)
+        bp = EPBP(None, n=64, proposal_approximation='EP', sampler='device', seed=9)
+        bp.overlap_min_heavy = 1
+        bp._setup(None, flat=flat)
+        assert bp.n_heavy > 0 and bp.n_pair > 0
+        _init(api, bp)
+        for _ in range(5):
+            bp.sweep(last=False)
+        bp.sweep(last=True)
+        torch.cuda.synchronize()
+        runs.append(bp)
+    a, b = runs
+    assert getattr(a, '_side', None) is not None and getattr(b, '_side', None) is None
+    for name in ('f2v', 'v2f', 'q_dev', 'eta', 'particles'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
 def test_v2f_hub_kernel_matches_the_one_wave_path(api):
     """template variables (more than 64 incident factors: the topics of the paper-popularity model) are swept by a workgroup
     each (pbp_v2f_hub_kernel: four partial totals added in a fixed order) instead of one wavefront walking the row: the same
