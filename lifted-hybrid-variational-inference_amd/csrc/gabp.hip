@@ -369,8 +369,11 @@ __device__ __forceinline__ double2 pull_incoming_rec(const lhvi_graph_t& g, cons
     return f2v_closed_form(kind, par, arity, pos, partner_hidden, u, sv, y);
 }
 
+#ifndef LHVI_GABP_PULL_WAVES
+#define LHVI_GABP_PULL_WAVES 8         // 64 registers: 0.557 / 0.514 / 0.472 ms on the Kalman-filter graph at 4 / 6 / 8 waves per SIMD (scripts/diag/pull_regs.sh)
+#endif
 template <bool LDS_POTS>
-__global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lhvi_pots_t pots, const int4* __restrict__ rec,
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI_GABP_PULL_WAVES, 8))) gabp_pull_rec_kernel(lhvi_graph_t g, lhvi_pots_t pots, const int4* __restrict__ rec,
                                                              const int2* __restrict__ seg, const double* __restrict__ pot_words,
                                                              const double* __restrict__ count, const double* __restrict__ vprev,
                                                              double* __restrict__ vnext, int first) {
@@ -379,65 +382,111 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lh
     // (workgroups of fixed 256-slot ranges staged the rows straddling their ends whole: 1.5x the gathers and closed forms on a
     // graph with rows of 66 entries)
     constexpr int CAP = BLOCK + GABP_HUB_DEGREE;
+    constexpr int IT = CAP / BLOCK;                         // slots of a segment a thread serves (the same ones in every pass)
     __shared__ double2 sh[CAP];
     __shared__ double2 shc[CAP / GABP_ROW_CHUNK + 1];       // sums of eight-entry chunks of the long rows (ground graphs)
     __shared__ double2 sht[CAP / (GABP_ROW_DIRECT + 1) + 1]; // their totals: long rows start more than GABP_ROW_DIRECT slots apart
     __shared__ double sh_par[LDS_POTS ? GABP_LDS_POTS * GABP_POT_WORDS : 1];
-    if (LDS_POTS) {
-        for (int i = threadIdx.x; i < pots.P * GABP_POT_WORDS; i += BLOCK) sh_par[i] = pot_words[i];
-        __syncthreads();
-    }
-    const double* __restrict__ pw = LDS_POTS ? sh_par : pot_words;
     const int2 sg = seg[blockIdx.x];
     const int lo_ext = sg.x, hi_ext = sg.y;
     // a segment longer than the LDS stage (a plan not built by the rule of lhvi_gabp_plan_t.seg) is left unswept rather than
     // written past the stage; the whole workgroup takes this exit, ahead of every barrier
     if (hi_ext - lo_ext > CAP || hi_ext < lo_ext || lo_ext < 0 || hi_ext > g.nnz) return;
+    // Round 5: a thread's slot records are fetched together, ahead of everything else, and kept in registers for all passes (each
+    // pass used to read its record again -- a dependent L2 round trip in front of every pass, three more of them on a graph whose
+    // rows are long), and the partners' messages of all its slots are in flight together (the second slot's gather used to wait
+    // for the first slot's closed form).  Same expressions in the same order: the same bits.
+    int4 r[IT];
+    bool in[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int j = lo_ext + threadIdx.x + it * BLOCK;
+        in[it] = j < hi_ext;
+        r[it] = rec[in[it] ? j : lo_ext];
+    }
+    if (LDS_POTS) {
+        for (int i = threadIdx.x; i < pots.P * GABP_POT_WORDS; i += BLOCK) sh_par[i] = pot_words[i];
+        __syncthreads();
+    }
+    const double* __restrict__ pw = LDS_POTS ? sh_par : pot_words;
+    double2 pm[IT];                                         // the partner's previous v -> f message (a hidden partner of a pairwise factor)
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const bool want = in[it] && !first && !((r[it].z >> 21) & 1) && ((r[it].z >> 20) & 1) && r[it].x >= 0 && (r[it].y & 3) != 0 && (r[it].y & 3) != 3;
+        pm[it] = make_double2(0.0, 0.0);
+        if (want) pm[it] = ld2(vprev, r[it].x);
+    }
     int long_rows = 0;
-    for (int j = lo_ext + threadIdx.x; j < hi_ext; j += BLOCK) {
-        const int4 r = rec[j];
-        if ((r.z >> 21) & 1) continue;
-        long_rows |= ((r.z >> 10) & 1023) > GABP_ROW_DIRECT;
-        const bool hid = (r.z >> 20) & 1;
-        const double2 m = (hid && !first) ? pull_incoming_rec<LDS_POTS>(g, pots, r, vprev, pw) : make_double2(0.0, 1.0);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        if (!in[it] || ((r[it].z >> 21) & 1)) continue;
+        long_rows |= ((r[it].z >> 10) & 1023) > GABP_ROW_DIRECT;
+        const bool hid = (r[it].z >> 20) & 1;
+        double2 m = make_double2(0.0, 1.0);
+        if (hid && !first) {
+            const int code = r[it].y & 3, pot = r[it].y >> 2;
+            const double* par = pw + (int64_t)pot * GABP_POT_WORDS;
+            const int kind = (int)par[GABP_POT_WORDS - 1];
+            const int arity = code == 0 ? 1 : (code == 3 ? 3 : 2), pos = code == 2 ? 1 : 0;
+            const bool partner_hidden = arity == 2 && r[it].x >= 0;
+            const double y = (arity == 2 && r[it].x < 0) ? g.var_value[-1 - r[it].x] : 0.0;
+            m = f2v_closed_form(kind, par, arity, pos, partner_hidden, partner_hidden ? pm[it].x : 0.0, partner_hidden ? pm[it].y : 0.0, y);
+        }
         const double p = 1.0 / m.y;
         // staged as the entry's CONTRIBUTION (h, p) to the row sums -- (p mu, p), or (-mu, 0) for a `None` variance (GaBP.py:27-33: a
         // linear term only) -- so that the sums below are additions (times the count on a lifted graph) without a case distinction
-        sh[j - lo_ext] = (m.y != m.y) ? make_double2(-m.x, 0.0) : make_double2(p * m.x, p);
+        sh[threadIdx.x + it * BLOCK] = (m.y != m.y) ? make_double2(-m.x, 0.0) : make_double2(p * m.x, p);
     }
     long_rows = __syncthreads_or(long_rows);                    // (the staging barrier; most blocks of most graphs have no long row)
     if (!count && long_rows) {
         // rows of more than GABP_ROW_DIRECT entries: one thread per chunk of eight entries (the last chunk takes the remainder)
         // adds its chunk up in rv.nb order.  Chunk starts lie at least eight apart, so (start >> 3) names a chunk uniquely.
-        for (int j = lo_ext + threadIdx.x; j < hi_ext; j += BLOCK) {
-            const int rz = rec[j].z;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int rz = r[it].z;
             const int len = (rz >> 10) & 1023, pos = rz & 1023;
-            if (((rz >> 21) & 1) || len <= GABP_ROW_DIRECT || (pos % GABP_ROW_CHUNK) != 0) continue;
+            if (!in[it] || ((rz >> 21) & 1) || len <= GABP_ROW_DIRECT || (pos % GABP_ROW_CHUNK) != 0) continue;
             const int nc = len / GABP_ROW_CHUNK, q = pos / GABP_ROW_CHUNK;
             if (q >= nc) continue;
             const int end = q == nc - 1 ? len - pos : GABP_ROW_CHUNK;
-            const double2* __restrict__ e = sh + (j - lo_ext);
+            const double2* __restrict__ e = sh + (threadIdx.x + it * BLOCK);
+            // the first eight entries are read together (every chunk has them), the last chunk's remainder behind them
+            double2 c[GABP_ROW_CHUNK];
+#pragma unroll
+            for (int i = 0; i < GABP_ROW_CHUNK; ++i) c[i] = e[i];
             double H = 0.0, P = 0.0;
-            for (int i = 0; i < end; ++i) { H += e[i].x; P += e[i].y; }
-            shc[(j - lo_ext) / GABP_ROW_CHUNK] = make_double2(H, P);
+#pragma unroll
+            for (int i = 0; i < GABP_ROW_CHUNK; ++i) { H += c[i].x; P += c[i].y; }
+            for (int i = GABP_ROW_CHUNK; i < end; ++i) { H += e[i].x; P += e[i].y; }
+            shc[(threadIdx.x + it * BLOCK) / GABP_ROW_CHUNK] = make_double2(H, P);
         }
         __syncthreads();
         // ... and one thread per long row adds its chunks up: a slot's leave-one-out sum is then (total - its own chunk) + the
         // other entries of that chunk -- 1 + 8 LDS reads whatever the row's length (it used to walk all the row's chunks: a
         // Kalman-filter row of 66 entries cost every one of its slots 16 reads)
-        for (int j = lo_ext + threadIdx.x; j < hi_ext; j += BLOCK) {
-            const int rz = rec[j].z;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int rz = r[it].z;
             const int len = (rz >> 10) & 1023;
-            if (((rz >> 21) & 1) || len <= GABP_ROW_DIRECT || (rz & 1023) != 0) continue;
-            const double2* __restrict__ cs = shc + (j - lo_ext) / GABP_ROW_CHUNK;
+            if (!in[it] || ((rz >> 21) & 1) || len <= GABP_ROW_DIRECT || (rz & 1023) != 0) continue;
+            const double2* __restrict__ cs = shc + (threadIdx.x + it * BLOCK) / GABP_ROW_CHUNK;
+            const int nc = len / GABP_ROW_CHUNK;
             double H = 0.0, P = 0.0;
-            for (int c = 0; c < len / GABP_ROW_CHUNK; ++c) { H += cs[c].x; P += cs[c].y; }
-            sht[(j - lo_ext) / (GABP_ROW_DIRECT + 1)] = make_double2(H, P);
+            int c = 0;
+            for (; c + 4 <= nc; c += 4) {                       // four reads in flight, added in the chunks' order
+                const double2 c0 = cs[c], c1 = cs[c + 1], c2 = cs[c + 2], c3 = cs[c + 3];
+                H += c0.x; P += c0.y; H += c1.x; P += c1.y; H += c2.x; P += c2.y; H += c3.x; P += c3.y;
+            }
+            for (; c < nc; ++c) { H += cs[c].x; P += cs[c].y; }
+            sht[(threadIdx.x + it * BLOCK) / (GABP_ROW_DIRECT + 1)] = make_double2(H, P);
         }
         __syncthreads();
     }
-    for (int k = lo_ext + threadIdx.x; k < hi_ext; k += BLOCK) {
-    const int rz = rec[k].z;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+    if (!in[it]) continue;
+    const int k = lo_ext + threadIdx.x + it * BLOCK;
+    const int rz = r[it].z;
     if (!((rz >> 20) & 1)) { st2(vnext, k, NAN, NAN); continue; }
     const int lo = k - (rz & 1023), hi = lo + ((rz >> 10) & 1023);
     double H = 0.0, P = 0.0;
@@ -476,7 +525,13 @@ __global__ void __launch_bounds__(BLOCK) gabp_pull_rec_kernel(lhvi_graph_t g, lh
             const double2 tot = sht[(lo - lo_ext) / (GABP_ROW_DIRECT + 1)], mine = shc[(lo - lo_ext) / GABP_ROW_CHUNK + q];
             H = tot.x - mine.x; P = tot.y - mine.y;
             const int b0 = q * GABP_ROW_CHUNK, b1 = q == nc - 1 ? n : b0 + GABP_ROW_CHUNK;
-            for (int j = b0; j < b1; ++j) { const double2 m = row[j]; LHVI_ROW_STEP(m, j) }
+            // (the chunk's first eight entries read together, the last chunk's remainder behind them)
+            double2 c[GABP_ROW_CHUNK];
+#pragma unroll
+            for (int i = 0; i < GABP_ROW_CHUNK; ++i) c[i] = row[b0 + i];
+#pragma unroll
+            for (int i = 0; i < GABP_ROW_CHUNK; ++i) LHVI_ROW_STEP(c[i], b0 + i)
+            for (int j = b0 + GABP_ROW_CHUNK; j < b1; ++j) { const double2 m = row[j]; LHVI_ROW_STEP(m, j) }
         }
 #undef LHVI_ROW_STEP
     }

@@ -1075,6 +1075,59 @@ __device__ __forceinline__ int small_grid_point(int lane, int k) {
     if (W == 32) return 8 * (((lane >> 1) & 1) + 2 * (lane & 1)) + ((lane >> 4) & 1) + 2 * ((lane >> 3) & 1) + 4 * ((lane >> 2) & 1);
     return 16 * k + 8 * (lane & 1) + ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + 4 * ((lane >> 1) & 1);
 }
+// Lane groups whose width is NOT a power of two (10, 12, 20 lanes: six, five, three edges per wavefront for the particle counts
+// the reference's demos run -- a 16- / 32-lane group would idle 6 / 4 / 12 of its lanes): the folds stay inside the quad (lane ^ 1,
+// and lane ^ 2 when the width is a multiple of four, so that no fold leaves its group), which leaves P = W / 2 or W / 4 partial
+// sums per point; those go through wave-private LDS, eight points at a time, and the lane that OWNS a point (point p of a batch
+// of 32 belongs to lane p % W of its group, as its (p / W)-th) adds them up in the order of the partial's index.  The grouping
+// depends on the lane's place in its group only: an edge gets the same bits whatever shares its wavefront.
+template <int W>
+struct SmallGeom {
+    static constexpr int G = WAVE / W;                                  // edges per wavefront
+    static constexpr bool POW2 = (W & (W - 1)) == 0;
+    static constexpr int L = POW2 ? 0 : (W % 4 == 0 ? 2 : 1);           // folds before the partials go through LDS
+    static constexpr int P = W >> L;                                    // partial sums per point
+    static constexpr int R = (32 + W - 1) / W;                          // points of a batch of 32 that a lane owns
+    static constexpr int BUF_AB = POW2 ? 0 : G * 4 * P;                 // the partials of eight points, in 16-byte units
+};
+template <int W, typename Emit>
+__device__ __forceinline__ void small_grid_sums_lds(double& g, double q, int lane, int grp, int gl, bool lane_ok,
+                                                    double* __restrict__ buf, Emit&& emit /* (owns a point of the chunk, the point, its sum) */) {
+    using Geo = SmallGeom<W>;
+    constexpr int L = Geo::L, P = Geo::P;
+    const bool b0 = lane & 1, b1 = (lane >> 1) & 1;
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) {
+        double v[8], w[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = g; g *= q; }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) w[m] = fold_bit0_xy(v[2 * m], v[2 * m + 1], b0);           // point 2 m + b0 of the chunk
+        if (L == 1) {
+            if (lane_ok) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) buf[(grp * 8 + 2 * m + (int)b0) * P + (gl >> 1)] = w[m];
+            }
+        } else {
+            const double u0 = fold_bit1(w[0], w[1], b1), u1 = fold_bit1(w[2], w[3], b1);       // points 4 k + 2 b1 + b0
+            if (lane_ok) {
+                buf[(grp * 8 + 2 * (int)b1 + (int)b0) * P + (gl >> 2)] = u0;
+                buf[(grp * 8 + 4 + 2 * (int)b1 + (int)b0) * P + (gl >> 2)] = u1;
+            }
+        }
+        LHVI_WAVE_SYNC();
+        // the point of this chunk that the lane owns, if any (chunks hold 8 <= W points: at most one)
+        int off = gl - (8 * bt) % W;
+        if (off < 0) off += W;
+        const bool has = off < 8;
+        const double* __restrict__ row = buf + (grp * 8 + (has ? off : 0)) * P;
+        double sum = row[0];
+#pragma unroll
+        for (int k = 1; k < P; ++k) sum += row[k];
+        emit(has, 8 * bt + off, sum);
+        LHVI_WAVE_SYNC();
+    }
+}
 constexpr int GRID_MIN_NJ = 24;         // fewer partner particles: the direct loop is cheaper than 32 multiplications + 6 folds
 constexpr double GRID_MAX_EXPONENT = 600.0;
 constexpr int GRID_MAX_T = 128;         // batches of 32 points; the recurrence carries ~t ulp (the reference's RGM domain has 100 points, Demo/Data/RGM/Generator.py:16)
@@ -1263,19 +1316,29 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
 #ifndef LHVI_SMALL_WAVES
 #define LHVI_SMALL_WAVES 6
 #endif
+#ifndef LHVI_SMALL_WAVES10
+#define LHVI_SMALL_WAVES10 5      // the 10-lane groups (six edges per wavefront) spill 12 words per lane at 80 registers
+#endif
 template <int W>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI_SMALL_WAVES, 8))) pbp_f2v_small_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(W == 10 ? LHVI_SMALL_WAVES10 : LHVI_SMALL_WAVES, 8))) pbp_f2v_small_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
                                                             double* __restrict__ f2v, const FastDesc* __restrict__ descs, int nitems) {
-    constexpr int G = WAVE / W;                              // edges per wavefront
+    using Geo = SmallGeom<W>;
+    constexpr int G = Geo::G;                                // edges per wavefront
     constexpr int GS = W + LHVI_SMALL_PAD;                    // records between two groups' blocks (padded: see LHVI_SMALL_PAD)
-    __shared__ AB sh_all[BLOCK / WAVE][G * GS];
+    // (a group width that is not a power of two: the partial sums of the grid recurrence use the records' space once the
+    // direct rounds are through with them -- DS operations of a wavefront execute in order)
+    constexpr int SH_AB = G * GS > Geo::BUF_AB ? G * GS : Geo::BUF_AB;
+    __shared__ AB sh_all[BLOCK / WAVE][SH_AB];
     __shared__ double sh_tab[EXP_TAB_N];
     __shared__ LogRec sh_log[LOG_TAB_N];
     load_log_table(sh_log);
     load_exp_table(sh_tab);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int grp = lane / W, gl = lane % W;
+    // (a width that does not divide 64 leaves 64 - G W lanes without an edge: they follow the last lane of the last group,
+    // store nothing and write nothing to LDS; the folds of the recurrence never leave a quad, and G W is a multiple of four)
+    const bool lane_ok = lane < G * W;
+    const int grp = lane_ok ? lane / W : G - 1, gl = lane_ok ? lane % W : W - 1;
     AB* sh = sh_all[wid];
     const AB* mine_recs = sh + grp * GS;
     const int n = s.n, S = s.n + s.T;
@@ -1283,7 +1346,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI
     const int nwaves = gridDim.x * (BLOCK / WAVE);
     for (int step = blockIdx.x * (BLOCK / WAVE) + wid; step < nsteps; step += nwaves) {
         const int idx = step * G + grp;
-        const bool live = idx < nitems;
+        const bool live = idx < nitems && lane_ok;
 #if LHVI_SMALL_HOIST
         // One round trip for the descriptor (all 128 bytes at once, whatever the branches below use of it), one for everything it
         // points to: the partner's particles and message and the output points of the first three rounds (all of them for
@@ -1292,7 +1355,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI
         // step, which seven waves per SIMD do not cover.
         union { FastDesc d; int4 q[sizeof(FastDesc) / 16]; } u;
         {
-            const int4* dp = reinterpret_cast<const int4*>(descs + (live ? idx : nitems - 1));
+            const int4* dp = reinterpret_cast<const int4*>(descs + min(idx, nitems - 1));
 #pragma unroll
             for (int k = 0; k < (int)(sizeof(FastDesc) / 16); ++k) u.q[k] = dp[k];
         }
@@ -1342,7 +1405,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI
             const double X = fmax(fabs(gx0), fabs(fma((double)(T - 1), gh, gx0)));
             const double bound = fma(fabs(ub) + fabs(kx) * X, X, fabs(ua));
             const uint64_t bad = __ballot(gl < nj && !(bound < GRID_MAX_EXPONENT));
-            gok = ((bad >> (grp * W)) & (W == 32 ? 0xffffffffull : 0xffffull)) == 0;
+            gok = ((bad >> (grp * W)) & ((1ull << W) - 1)) == 0;
         }
         const int lim = gok ? np : npts;                           // points of this group's edge that the direct rounds serve
         const bool any_grid = __ballot(gok && live) != 0;
@@ -1359,7 +1422,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI
         if (s.flags & LHVI_PBP_SKIP_TERMS) jmax = 0;
         double* out = f2v + (int64_t)e * S;
         LHVI_WAVE_SYNC();
-        sh[grp * GS + gl] = rec;
+        if (lane_ok) sh[grp * GS + gl] = rec;
         LHVI_WAVE_SYNC();
 #if LHVI_SMALL_HOIST
         // the three prefetched rounds written out: each waits for ITS points only (loads return in order), not -- as a loop whose
@@ -1399,14 +1462,44 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI
             for (int k = 0; k < G; ++k) tmax = max(tmax, __builtin_amdgcn_readlane(gok ? T : 0, k * W));
 #pragma unroll 1
             for (int t0 = 0; t0 < tmax; t0 += 32) {
-                double sum[2];
-                small_grid_sums32<W>(gv, q, lane, sum[0], sum[1]);
+                if constexpr (Geo::POW2) {
+                    double sum[2];
+                    small_grid_sums32<W>(gv, q, lane, sum[0], sum[1]);
 #pragma unroll
-                for (int k = 0; k < (W == 16 ? 2 : 1); ++k) {
-                    const int t = t0 + small_grid_point<W>(gl, k);
-                    if (live && gok && t < T) {
-                        const double xt = fma((double)t, gh, gx0);
-                        out[n + t] = sum[k] > 0.0 ? fma(kx * xt, xt, log_table(sum[k], sh_log)) : -700.0;
+                    for (int k = 0; k < (W == 16 ? 2 : 1); ++k) {
+                        const int t = t0 + small_grid_point<W>(gl, k);
+                        if (live && gok && t < T) {
+                            const double xt = fma((double)t, gh, gx0);
+                            out[n + t] = sum[k] > 0.0 ? fma(kx * xt, xt, log_table(sum[k], sh_log)) : -700.0;
+                        }
+                    }
+                } else {
+                    if constexpr (Geo::R >= 4) {
+                        // a lane owns a point in (almost) every chunk of eight: the logarithm and the store right there
+                        small_grid_sums_lds<W>(gv, q, lane, grp, gl, lane_ok, reinterpret_cast<double*>(sh), [&](bool has, int p, double sum) {
+                            const int t = t0 + p;
+                            if (has && live && gok && t < T) {
+                                const double xt = fma((double)t, gh, gx0);
+                                out[n + t] = sum > 0.0 ? fma(kx * xt, xt, log_table(sum, sh_log)) : -700.0;
+                            }
+                        });
+                    } else {
+                        // fewer owned points than chunks: the sums are kept and go through the logarithm together
+                        double sum[Geo::R];
+#pragma unroll
+                        for (int r = 0; r < Geo::R; ++r) sum[r] = 0.0;
+                        small_grid_sums_lds<W>(gv, q, lane, grp, gl, lane_ok, reinterpret_cast<double*>(sh), [&](bool has, int p, double v) {
+#pragma unroll
+                            for (int r = 0; r < Geo::R; ++r) sum[r] = (has && p >= r * W && p < (r + 1) * W) ? v : sum[r];
+                        });
+#pragma unroll
+                        for (int r = 0; r < Geo::R; ++r) {
+                            const int p = r * W + gl, t = t0 + p;
+                            if (live && gok && p < 32 && t < T) {
+                                const double xt = fma((double)t, gh, gx0);
+                                out[n + t] = sum[r] > 0.0 ? fma(kx * xt, xt, log_table(sum[r], sh_log)) : -700.0;
+                            }
+                        }
                     }
                 }
             }
@@ -3040,6 +3133,15 @@ static int launch_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* 
     return check_launch();
 }
 
+template <int W>
+static void launch_f2v_small(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* v2f, double* f2v, const void* desc, int nitems,
+                             int cus, int share, int spare, void* stream) {
+    static const int per_cu = blocks_per_cu((const void*)pbp_f2v_small_kernel<W>);
+    constexpr int PER_BLOCK = (BLOCK / WAVE) * (WAVE / W);                // edges per workgroup and step
+    hipLaunchKernelGGL(pbp_f2v_small_kernel<W>, dim3(min((nitems + PER_BLOCK - 1) / PER_BLOCK, max(cus * max(per_cu - share, 1) - spare, 1))),
+                       dim3(BLOCK), 0, as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(desc), nitems);
+}
+
 extern "C" {
 
 int lhvi_pbp_uniq(const lhvi_graph_t* g, int32_t n, const double* particles, const int32_t* np, uint8_t* uniq, void* stream) {
@@ -3156,15 +3258,17 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
                                *g, sh, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy,
                                s->f2v_ticket ? s->f2v_ticket + LHVI_PBP_TICKET_COUNTERS : (uint32_t*)nullptr);
         if (!(s->flags & LHVI_PBP_SKIP_HEAVY)) {
+            // lane groups as wide as the particle count asks for: 10 / 12 / 16 lanes for the small16 list, 20 / 32 for small32
+            // (no variable holds more than s->n particles; LHVI_PBP_POW2_GROUPS keeps the 16- / 32-lane kernels)
+            const bool narrow = !(s->flags & LHVI_PBP_POW2_GROUPS);
             if (s->small16_desc && s->n_small16 > 0) {
-                static const int per_cu = blocks_per_cu((const void*)pbp_f2v_small_kernel<16>);
-                hipLaunchKernelGGL(pbp_f2v_small_kernel<16>, dim3(min((s->n_small16 + 15) / 16, max(cus * max(per_cu - share, 1) - spare, 1))), dim3(BLOCK), 0,
-                                   as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->small16_desc), s->n_small16);
+                if (narrow && s->n <= 10) launch_f2v_small<10>(g, s, v2f, f2v, s->small16_desc, s->n_small16, cus, share, spare, stream);
+                else if (narrow && s->n <= 12) launch_f2v_small<12>(g, s, v2f, f2v, s->small16_desc, s->n_small16, cus, share, spare, stream);
+                else launch_f2v_small<16>(g, s, v2f, f2v, s->small16_desc, s->n_small16, cus, share, spare, stream);
             }
             if (s->small32_desc && s->n_small32 > 0) {
-                static const int per_cu = blocks_per_cu((const void*)pbp_f2v_small_kernel<32>);
-                hipLaunchKernelGGL(pbp_f2v_small_kernel<32>, dim3(min((s->n_small32 + 7) / 8, max(cus * max(per_cu - share, 1) - spare, 1))), dim3(BLOCK), 0,
-                                   as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(s->small32_desc), s->n_small32);
+                if (narrow && s->n <= 20) launch_f2v_small<20>(g, s, v2f, f2v, s->small32_desc, s->n_small32, cus, share, spare, stream);
+                else launch_f2v_small<32>(g, s, v2f, f2v, s->small32_desc, s->n_small32, cus, share, spare, stream);
             }
         }
         if (s->pair_desc && s->n_pair > 0 && !(s->flags & (LHVI_PBP_SKIP_LIGHT | LHVI_PBP_WIDE_PAIRS)) && s->n <= 16 && LHVI_PAIR_SMALL) {

@@ -93,7 +93,8 @@ class _ParticleSweep:
         self.f2v_ticket = torch.zeros(16, dtype=torch.int32, device=dg.device)    # work counters + statistics of the heavy f2v kernel (LHVI_PBP_TICKET_WORDS)
         self.flags = (_abi.PBP_EP if self.proposal_approximation == 'EP' else 0) | \
                      (_abi.PBP_EPBP_DISCRETE if self._epbp_discrete else 0) | \
-                     (_abi.PBP_CQ if self.cq_routing and bool((flat.pot_kind == 8).any()) else 0)
+                     (_abi.PBP_CQ if self.cq_routing and bool((flat.pot_kind == 8).any()) else 0) | \
+                     (_abi.PBP_POW2_GROUPS if os.environ.get('LHVI_PBP_POW2_GROUPS', '0') == '1' else 0)   # (tuning aid: scripts/diag/narrow_groups.sh)
         self._views, self._batched = {}, {}
         self._draws = 0
         self.cq_desc, self.n_cq = None, 0

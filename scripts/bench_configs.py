@@ -117,6 +117,8 @@ if 'gauss_rel' in which:
     rng = np.random.default_rng(0)
     nk, Tk = 30, int(os.environ.get('KALMAN_T', 20000))
     A = rng.normal(size=(nk, nk)) * (rng.random((nk, nk)) < 0.4) * 0.2 + np.eye(nk) * 0.5
+    if os.environ.get('KALMAN_CONST_A'):         # (diagnosis aid: two distinct transition coefficients -> the potential table fits the kernel's LDS copy)
+        A = np.where(A != 0, 0.1, 0.0) + np.eye(nk) * 0.4
     data = rng.normal(size=(nk, Tk))
     data[rng.random(data.shape) < 0.3] = kalman.MISSING
     dom = Domain((-20, 20), continuous=True, integral_points=np.linspace(-20, 20, 8))

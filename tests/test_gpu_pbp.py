@@ -387,6 +387,58 @@ def test_few_particle_kernel_grid_recurrence_matches_the_direct_form(api, case):
         assert same.any()                                       # ... and the guard did reject edges with exponents ~ +-800
 
 
+
+@pytest.mark.parametrize('case', ['n10', 'n9', 'n12', 'n11 T48', 'n20', 'n18 T100', 'n10 wide', 'n20 uneven'])
+def test_few_particle_kernel_lane_groups_of_10_12_20_match_the_16_and_32_lane_groups(api, case):
+    """``pbp_f2v_small_kernel<10 / 12 / 20>`` (six / five / three edges per wavefront when no variable holds more than 10 / 12 / 20
+    particles; partial sums of the grid recurrence through wave-private LDS) against the 16- / 32-lane groups
+    (LHVI_PBP_POW2_GROUPS): the particle part bit for bit -- the same term loop over the same records -- the grid part to 1e-12
+    (another order of the sum over the partner's particles), ragged list ends and rejected edges (domain [-40, 40]) included"""
+    import torch
+    from lhvi import synth, _abi
+    from lhvi.graph import Domain
+    from lhvi.pbp import EPBP
+    n = int(case.split()[0][1:])
+    kind = case.split()[1] if ' ' in case else 'uniform'
+    lo, hi = (-40.0, 40.0) if kind == 'wide' else (-10.0, 10.0)
+    pts = np.linspace(lo, hi, {'T48': 48, 'T100': 100}.get(kind, 32))
+    if kind == 'uneven':
+        pts = np.sign(pts) * np.abs(pts) ** 1.3 / 10 ** 0.3
+    flat = _with_domain(synth.hybrid_mrf_flat(V=3001, deg=4, seed=14, frac_discrete=0.1),
+                        Domain((lo, hi), continuous=True, integral_points=pts))
+    bp = EPBP(None, n=n, proposal_approximation='simple', sampler='device', seed=6)
+    bp._setup(None, flat=flat)
+    _init(api, bp)
+    for _ in range(2):
+        bp.sweep(last=False)
+    l, st = api.lib(), api.stream_ptr()
+    s = bp._struct()
+    bp.f2v.zero_()
+    api.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, api.ptr(bp.v2f), api.ptr(bp.f2v), st))
+    narrow = bp.f2v.clone()
+    bp.f2v.zero_()
+    s.flags |= _abi.PBP_POW2_GROUPS
+    api.check(l.lhvi_pbp_f2v(bp.dg.g, bp.dg.p, s, api.ptr(bp.v2f), api.ptr(bp.f2v), st))
+    desc = bp.small16_desc if n <= 16 else bp.small32_desc
+    nitems = bp.n_small16 if n <= 16 else bp.n_small32
+    assert nitems > 1000 and bp.n_heavy == 0
+    words = desc.view(torch.int32).view(-1, 32).cpu().numpy()
+    e = words[:, 0]
+    a, b = narrow.cpu().numpy()[e], bp.f2v.cpu().numpy()[e]
+    assert np.isfinite(a).all()
+    assert (a[:, :n] == b[:, :n]).all()
+    # (log-messages below -690 come out of sums the term loop holds as denormals -- it carries them scaled by 2^-24 -- with a
+    # handful of significant bits: there the two builds of the same loop differ by their last-bit roundings, 1e-3 at most)
+    deep = b < -690.0
+    np.testing.assert_allclose(a[~deep], b[~deep], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(a[deep], b[deep], rtol=0, atol=2e-3)
+    assert torch.equal(narrow.cpu()[np.setdiff1d(np.arange(flat.E), e)], bp.f2v.cpu()[np.setdiff1d(np.arange(flat.E), e)])
+    if kind == 'uneven':
+        assert (a == b).all()                                   # no recurrence on a grid that is not uniform
+    else:
+        assert not (a[:, n:] == b[:, n:]).all()                 # the two reductions do differ in the last bits somewhere
+
+
 def test_device_sampler_statistics(api):
     """Philox/Box-Muller particles: mean/variance of the clipped normal draws, determinism per (seed, iteration)"""
     from lhvi import synth
