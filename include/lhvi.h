@@ -221,6 +221,9 @@ int lhvi_log_likelihood(const lhvi_graph_t* g, const lhvi_pots_t* pots, const do
                                    * light / cq / generic lists: disjoint rows of f2v), find a wave slot and LDS on every CU and run beside them */
 #define LHVI_PBP_NO_GRID 128u    /* lhvi_pbp_f2v: integral points always by the direct form (one exponential per term), never by the
                                    * uniform-grid recurrence (testing / profiling aid) */
+#define LHVI_PBP_FUSED_RECORDS16 131072u /* lhvi_pbp_var_fused: desc holds SIXTEEN 32-bit words per variable (64-byte aligned) -- words 0-7 as documented
+                                   * there, then 8 particles of the variable (s->np[v])  9 g->var_ptr[v]  10-15 its first six incident edges
+                                   * (var_edge[var_ptr[v] + 0 .. 5]; unused ones 0) -- so that a variable's rows hang on one load behind its record */
 #define LHVI_PBP_POW2_GROUPS 65536u /* lhvi_pbp_f2v: the small16 / small32 lists always through lane groups of 16 / 32 lanes (four / two edges per
                                    * wavefront), also when s->n <= 10 / 12 / 20 would let six / five / three edges share one (testing / profiling aid) */
 

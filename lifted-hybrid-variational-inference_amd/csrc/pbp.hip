@@ -2891,7 +2891,7 @@ constexpr int FUSED_CH = 8;          // edges of a row whose loads are in flight
 #ifndef LHVI_FUSED_NB
 #define LHVI_FUSED_NB 2          // (scripts/diag/fused_batch.sh: 2 passes in flight at 4 waves/SIMD beat 4 passes, which spill)
 #endif
-template <int W, int PW, bool EP>
+template <int W, int PW, bool EP, bool R16>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LHVI_FUSED_WAVES, 8)))
 pbp_var_fused_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2v, double* __restrict__ v2f, double* __restrict__ eta,
                      double* __restrict__ q, const int64_t* __restrict__ gid, uint64_t seed, uint32_t iteration,
@@ -2904,14 +2904,26 @@ pbp_var_fused_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2
     const int64_t slot = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * G + lane / W;
     const int j = lane % W;
     const bool on = slot < count;
-    const int32_t* rec = list + 8 * (on ? slot : 0);
-    const int v = on ? rec[0] : 0;
-    const int deg = on ? rec[1] : 0, gb = rec[2], T = on ? rec[3] : 0;
-    const double dlo = __hiloint2double(rec[5], rec[4]), dhi = __hiloint2double(rec[7], rec[6]);
+    // R16 (LHVI_PBP_FUSED_RECORDS16): records of sixteen words -- the eight above, then 8 particles (np)  9 var_ptr[v]  10-15 the
+    // first six incident edges: the rows hang on ONE load behind the record instead of record -> np / var_ptr -> var_edge -> rows
+    const int32_t* rec = list + (R16 ? 16 : 8) * (on ? slot : 0);
+    int4 ra, rb;
+    int2 rc = make_int2(0, 0);
+    int e_rec = 0;                                             // lane j < 6: edge j of the row, straight from the record
+    if (R16) {
+        const int4* r4 = reinterpret_cast<const int4*>(rec);
+        ra = r4[0]; rb = r4[1]; rc = reinterpret_cast<const int2*>(rec)[4];
+        e_rec = rec[10 + min(lane % W, 5)];
+    } else {
+        ra = make_int4(rec[0], rec[1], rec[2], rec[3]); rb = make_int4(rec[4], rec[5], rec[6], rec[7]);
+    }
+    const int v = on ? ra.x : 0;
+    const int deg = on ? ra.y : 0, gb = ra.z, T = on ? ra.w : 0;
+    const double dlo = __hiloint2double(rb.y, rb.x), dhi = __hiloint2double(rb.w, rb.z);
     const int n = s.n, S = s.n + s.T;
-    const int np = on ? s.np[v] : 0;
+    const int np = on ? (R16 ? rc.x : s.np[v]) : 0;
     const bool valid = j < np;
-    const int lo = on ? g.var_ptr[v] : 0;
+    const int lo = on ? (R16 ? rc.y : g.var_ptr[v]) : 0;
     const bool lifted = g.edge_count != nullptr;
     const double q0 = on ? s.q[2 * v] : 0.0, q1 = on ? s.q[2 * v + 1] : 1.0;
     // every lane of the wave runs the longest row of its variables (the reductions are wave-wide instructions)
@@ -2932,6 +2944,10 @@ pbp_var_fused_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2
     auto hold_chunk = [&](int c) {                             // lane j < CH: edge c CH + j of its variable's row
         if (c == held) return;
         held = c;
+        if (R16 && c == 0) {                                   // the first six edges travel in the record
+            my_e = j < deg ? (j < 6 ? e_rec : (j < CH ? g.var_edge[lo + j] : 0)) : 0;
+            return;
+        }
         my_e = (j < CH && c * CH + j < deg) ? g.var_edge[lo + c * CH + j] : 0;
     };
     // ---- step 1: v -> f (pbp_v2f_packed_kernel<W>)
@@ -3497,14 +3513,20 @@ int lhvi_pbp_var_fused(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double*
 #define LHVI_FUSED(W, PW, list, cnt)                                                                                                  \
     if ((cnt) > 0) {                                                                                                                  \
         const dim3 grid(grid_for(((int64_t)(cnt) + WAVE / (W) - 1) / (WAVE / (W)) * WAVE));                                          \
-        if (ep) hipLaunchKernelGGL((pbp_var_fused_kernel<W, PW, true>), grid, dim3(BLOCK), 0, st, *g, *s, f2v, v2f, eta, q, var_gid, \
+        if (ep && r16) hipLaunchKernelGGL((pbp_var_fused_kernel<W, PW, true, true>), grid, dim3(BLOCK), 0, st, *g, *s, f2v, v2f, eta, q, var_gid, \
                                    seed, iteration, particles_out, uniq_out, list, cnt);                                             \
-        else hipLaunchKernelGGL((pbp_var_fused_kernel<W, PW, false>), grid, dim3(BLOCK), 0, st, *g, *s, f2v, v2f, eta, q, var_gid,   \
+        else if (ep) hipLaunchKernelGGL((pbp_var_fused_kernel<W, PW, true, false>), grid, dim3(BLOCK), 0, st, *g, *s, f2v, v2f, eta, q, var_gid, \
+                                   seed, iteration, particles_out, uniq_out, list, cnt);                                             \
+        else if (r16) hipLaunchKernelGGL((pbp_var_fused_kernel<W, PW, false, true>), grid, dim3(BLOCK), 0, st, *g, *s, f2v, v2f, eta, q, var_gid,   \
+                                seed, iteration, particles_out, uniq_out, list, cnt);                                                \
+        else hipLaunchKernelGGL((pbp_var_fused_kernel<W, PW, false, false>), grid, dim3(BLOCK), 0, st, *g, *s, f2v, v2f, eta, q, var_gid,   \
                                 seed, iteration, particles_out, uniq_out, list, cnt);                                                \
     }
+    const bool r16 = (s->flags & LHVI_PBP_FUSED_RECORDS16) != 0;
+    const int64_t rw = r16 ? 16 : 8;
     LHVI_FUSED(16, 16, desc, n16)
-    LHVI_FUSED(32, 16, desc + 8 * (int64_t)n16, n32_t32)
-    LHVI_FUSED(32, 32, desc + 8 * ((int64_t)n16 + n32_t32), n32_t64)
+    LHVI_FUSED(32, 16, desc + rw * (int64_t)n16, n32_t32)
+    LHVI_FUSED(32, 32, desc + rw * ((int64_t)n16 + n32_t32), n32_t64)
 #undef LHVI_FUSED
     return check_launch();
 }

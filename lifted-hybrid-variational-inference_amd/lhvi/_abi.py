@@ -100,6 +100,7 @@ PBP_V2F_RECORDS = 8192
 PBP_WIDE_PAIRS = 16384
 PBP_SHARE_CUS = 32768
 PBP_POW2_GROUPS = 65536
+PBP_FUSED_RECORDS16 = 131072
 PBP_SKIP_CQ = 1024
 ABI_VERSION = 11            # LHVI_ABI_VERSION of include/lhvi.h (struct layouts)
 PBP_DESC_BYTES = 128

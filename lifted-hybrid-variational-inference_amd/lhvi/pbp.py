@@ -167,10 +167,19 @@ class _ParticleSweep:
             k16 = fz & (n <= 16) & (pT <= 32)
             k32a = fz & ~k16 & (pT <= 32)
             k32b = fz & ~k16 & ~k32a
-            fd = np.zeros((pv.size, 8), dtype=np.int32)
+            # sixteen words per variable (LHVI_PBP_FUSED_RECORDS16): the eight of include/lhvi.h, then np, var_ptr[v] and the first six
+            # incident edges -- the kernel's row loads then hang on one load behind the record (LHVI_PBP_FUSED_REC16=0: eight words)
+            wide_rec = os.environ.get('LHVI_PBP_FUSED_REC16', '1') != '0'
+            fd = np.zeros((pv.size, 16 if wide_rec else 8), dtype=np.int32)
             fd[:, 0], fd[:, 1], fd[:, 2], fd[:, 3] = pv, pdeg, flat.dom_ptr[pdom], pT
             fd[:, 4:6] = np.ascontiguousarray(flat.dom_lo[pdom], dtype=np.float64).view(np.int32).reshape(-1, 2)
             fd[:, 6:8] = np.ascontiguousarray(flat.dom_hi[pdom], dtype=np.float64).view(np.int32).reshape(-1, 2)
+            if wide_rec:
+                fd[:, 8], fd[:, 9] = self.np_host[pv], flat.var_ptr[pv]
+                for k in range(6):
+                    has = pdeg > k
+                    fd[has, 10 + k] = flat.var_edge[pbase[has] + k]
+                self.flags |= _abi.PBP_FUSED_RECORDS16
             host_lists['fused_desc'] = np.ascontiguousarray(np.concatenate([fd[k16], fd[k32a], fd[k32b]]))
             fused_var = np.zeros(flat.V, dtype=bool)
             fused_var[pv[fz]] = True
