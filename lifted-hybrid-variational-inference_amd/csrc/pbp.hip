@@ -2960,7 +2960,11 @@ pbp_var_fused_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2
 #pragma unroll
             for (int i = 0; i < CH; ++i) ee[i] = __shfl(my_e, first_lane + i);
 #pragma unroll
+#ifdef LHVI_DIAG_FUSED_SLOT_ROWS          // timing aid (never defined in the product build): the rows of a variable read as if the table were in slot order
+            for (int i = 0; i < CH; ++i) mm[i] = f2v[(int64_t)(lo + min(c * CH + i, max(deg - 1, 0))) * S + (valid ? j : 0)];
+#else
             for (int i = 0; i < CH; ++i) mm[i] = f2v[(int64_t)ee[i] * S + (valid ? j : 0)];        // (beyond the row: edge 0's row, never used)
+#endif
         };
         for (int c = 0; c < nch; ++c) {
             load_rows(c);
@@ -3027,8 +3031,14 @@ pbp_var_fused_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ f2
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
+#ifdef LHVI_DIAG_FUSED_SLOT_ROWS
+                const int ks = min(c * CH + (p0 + i) * SL + sub, max(deg - 1, 0));
+                const double* msg = f2v + (int64_t)(lo + ks) * S + n;
+                b0[i] = eta[2 * (lo + ks)]; b1[i] = eta[2 * (lo + ks) + 1];
+#else
                 const double* msg = f2v + (int64_t)ee[i] * S + n;
                 b0[i] = eta[2 * ee[i]]; b1[i] = eta[2 * ee[i] + 1];
+#endif
                 g0[i] = msg[t0]; g1[i] = msg[t1];
             }
 #pragma unroll
