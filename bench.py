@@ -373,9 +373,10 @@ def main():
         else:
             hbm_note = ('n = %d: %.1f fp64 flop per algorithmic byte in the dominant f->v kernel (machine balance %.1f); with it at its '
                         'roof and every other kernel at the HBM peak the sweep would take %.2f ms, an HBM fraction of %.2f, so the '
-                        'arithmetic does NOT excuse missing the %.2f target here: the per-variable kernels (v->f, proposal, sampler) read '
-                        'each variable\'s f->v rows in scattered pieces of 80-384 bytes and are bound by those accesses '
-                        '(profiles/r05_experiments.md items 3 and 7); the unbuilt lever is a variable-major f->v table (DESIGN.md section 8)'
+                        'arithmetic does NOT excuse missing the %.2f target here: the f->v few-particle kernel is at its vector-issue '
+                        'ceiling (94 %% busy) and the fused per-variable kernel (v->f, proposal, sampler in one pass) is bound by its own '
+                        'instruction count and its partial-sector writes, not by where the rows lie -- a build that reads a variable\'s rows '
+                        'contiguously is no faster (profiles/r05_experiments.md items 12 and 16)'
                         % (n, intensity, FP64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS, 1e3 * t_min, hbm_ceiling, HBM_TARGET_FRAC))
         traffic, traffic_src = measured_traffic('pbp_f2v_heavy_kernel') if world == 1 and args.edges == 10_000_000 else (None, None)
         # single GPU: the short f -> v kernels run on a second stream beside the dominant one (lhvi/pbp.py, overlap_f2v), which then
