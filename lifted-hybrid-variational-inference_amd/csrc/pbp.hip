@@ -1294,8 +1294,8 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
     if (stats && lane == 0) { atomicAdd(stats, (uint32_t)n_grid); atomicAdd(stats + 1, (uint32_t)n_direct); }
 }
 
-// HEAVY-class edges with FEW particles (target and partner both at most W = 16 or 32: the particle counts of the reference's
-// demos), 64 / W edges per wavefront.  With one edge per wavefront such an edge keeps 64 lanes busy for a dozen terms and then
+// HEAVY-class edges with FEW particles (target and partner both at most W = 10, 12, 16, 20 or 32: the particle counts of the
+// reference's demos; the launcher picks the narrowest width that holds lhvi_pbp_t.n), floor(64 / W) edges per wavefront.  With one edge per wavefront such an edge keeps 64 lanes busy for a dozen terms and then
 // waits out the latencies of its own loads, LDS hand-off and stores (gfx950 counts loads and stores in one in-order counter, so
 // the wait for the next edge's operands includes this edge's store acknowledgements): ~10 us per edge whatever it holds.  Here a
 // lane group of W lanes owns an edge: lane = partner particle while the records are staged (wave-private LDS, one block of W
