@@ -702,7 +702,13 @@ template <int UNROLL = 4>
 __device__ __forceinline__ double fast_accumulate_floor(const AB* __restrict__ sh, const double* __restrict__ tab, int jn_, double X1,
                                                         double C) {
     const int jn = __builtin_amdgcn_readfirstlane(jn_);
-    const ExpShiftFloor sft = exp_shift_floor(C);
+    // The compiler may move plain fp64 arithmetic across the two mode writes (they are volatile asm, the arithmetic is not): the
+    // shift's constants of an unrolled NEXT call computed inside this call's round-down window, the closing additions after it.
+    // The empty volatile asm statements pin both ends -- what is computed under which rounding mode is then the same in every
+    // instantiation of every kernel that calls this, so an edge gets the same bits from each of them.
+    asm volatile("" : "+v"(C));
+    ExpShiftFloor sft = exp_shift_floor(C);
+    asm volatile("" : "+v"(sft.magic), "+v"(sft.scale));
     double acc0 = 0.0, acc1 = 0.0;
     int j = 0;
     round_down_on();
@@ -722,6 +728,7 @@ __device__ __forceinline__ double fast_accumulate_floor(const AB* __restrict__ s
         if (j + 1 < jn) { const AB r1 = sh[j + 1]; acc1 = exp_accumulate_floor(acc1, fma(r1.b, X1, r1.a), sft.magic, tab); }
         if (j + 2 < jn) { const AB r2 = sh[j + 2]; acc2 = exp_accumulate_floor(acc2, fma(r2.b, X1, r2.a), sft.magic, tab); }
         acc0 += acc2; acc1 += acc3;
+        asm volatile("" : "+v"(acc0), "+v"(acc1));
         round_down_off();
         return (acc0 + acc1) * sft.scale;
     }
@@ -731,6 +738,7 @@ __device__ __forceinline__ double fast_accumulate_floor(const AB* __restrict__ s
         acc1 = exp_accumulate_floor(acc1, fma(r1.b, X1, r1.a), sft.magic, tab);
     }
     if (j < jn) { const AB r0 = sh[j]; acc0 = exp_accumulate_floor(acc0, fma(r0.b, X1, r0.a), sft.magic, tab); }
+    asm volatile("" : "+v"(acc0), "+v"(acc1));
     round_down_off();
     return (acc0 + acc1) * sft.scale;
 }
@@ -1048,15 +1056,15 @@ __device__ __forceinline__ double fold_bit0_xy(double x, double y, bool bit0) { 
     const double send = bit0 ? x : y, keep = bit0 ? y : x;
     return keep + dpp_move<0xb1>(send);
 }
-template <int W>
-__device__ __forceinline__ void small_grid_sums32(double& g, double q, int lane, double& s0, double& s1) {
+template <int W, typename Step>
+__device__ __forceinline__ void small_grid_sums32(Step&& step /* the lane's value at the next grid point */, int lane, double& s0, double& s1) {
     double z[4];
     const bool b1 = (lane >> 1) & 1, b0 = lane & 1;
 #pragma unroll
     for (int bt = 0; bt < 4; ++bt) {
         double v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { v[i] = g; g *= q; }
+        for (int i = 0; i < 8; ++i) v[i] = step();
         if (W == 32) {
             const double u0 = fold_bit3(fold_bit4(v[0], v[1]), fold_bit4(v[2], v[3]));
             const double u1 = fold_bit3(fold_bit4(v[4], v[5]), fold_bit4(v[6], v[7]));
@@ -1084,14 +1092,14 @@ __device__ __forceinline__ int small_grid_point(int lane, int k) {
 template <int W>
 struct SmallGeom {
     static constexpr int G = WAVE / W;                                  // edges per wavefront
-    static constexpr bool POW2 = (W & (W - 1)) == 0;
+    static constexpr bool POW2 = W == 16 || W == 32;                    // (the butterfly networks of small_grid_sums32; 8 lanes take the LDS form)
     static constexpr int L = POW2 ? 0 : (W % 4 == 0 ? 2 : 1);           // folds before the partials go through LDS
     static constexpr int P = W >> L;                                    // partial sums per point
     static constexpr int R = (32 + W - 1) / W;                          // points of a batch of 32 that a lane owns
     static constexpr int BUF_AB = POW2 ? 0 : G * 4 * P;                 // the partials of eight points, in 16-byte units
 };
-template <int W, typename Emit>
-__device__ __forceinline__ void small_grid_sums_lds(double& g, double q, int lane, int grp, int gl, bool lane_ok,
+template <int W, typename Step, typename Emit>
+__device__ __forceinline__ void small_grid_sums_lds(Step&& step /* the lane's value at the next grid point */, int lane, int grp, int gl, bool lane_ok,
                                                     double* __restrict__ buf, Emit&& emit /* (owns a point of the chunk, the point, its sum) */) {
     using Geo = SmallGeom<W>;
     constexpr int L = Geo::L, P = Geo::P;
@@ -1100,7 +1108,7 @@ __device__ __forceinline__ void small_grid_sums_lds(double& g, double q, int lan
     for (int bt = 0; bt < 4; ++bt) {
         double v[8], w[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { v[i] = g; g *= q; }
+        for (int i = 0; i < 8; ++i) v[i] = step();
 #pragma unroll
         for (int m = 0; m < 4; ++m) w[m] = fold_bit0_xy(v[2 * m], v[2 * m + 1], b0);           // point 2 m + b0 of the chunk
         if (L == 1) {
@@ -1319,12 +1327,21 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
 #ifndef LHVI_SMALL_WAVES10
 #define LHVI_SMALL_WAVES10 5      // the 10-lane groups (six edges per wavefront) spill 12 words per lane at 80 registers
 #endif
-template <int W>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(W == 10 ? LHVI_SMALL_WAVES10 : LHVI_SMALL_WAVES, 8))) pbp_f2v_small_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
+#ifndef LHVI_SMALL_WAVES2
+#define LHVI_SMALL_WAVES2 5       // two particles per lane: two sets of record / recurrence values live (90-96 registers, no scratch)
+#endif
+// PPL = 2: a lane holds TWO partner particles (j and j + W) and serves two rounds of output points per W particles -- a group of W
+// lanes then owns an edge with up to 2 W particles on both sides, so twice as many edges share a wavefront (n = 20: six instead of
+// three, n = 32: four instead of two).  The direct rounds cost the same per edge (a round of W points over 2 W records instead of
+// half as many rounds of 2 W points); the grid recurrence adds a lane's two values before the folds, which are then paid once
+// for twice the edges, and so are the descriptor fetch, the staging and every wait.  Same record order, same term loop: the
+// particle part of a message keeps its bits.
+template <int W, int PPL = 1>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPL == 2 ? LHVI_SMALL_WAVES2 : W == 10 ? LHVI_SMALL_WAVES10 : LHVI_SMALL_WAVES, 8))) pbp_f2v_small_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f,
                                                             double* __restrict__ f2v, const FastDesc* __restrict__ descs, int nitems) {
     using Geo = SmallGeom<W>;
     constexpr int G = Geo::G;                                // edges per wavefront
-    constexpr int GS = W + LHVI_SMALL_PAD;                    // records between two groups' blocks (padded: see LHVI_SMALL_PAD)
+    constexpr int GS = PPL * W + LHVI_SMALL_PAD;              // records between two groups' blocks (padded: see LHVI_SMALL_PAD)
     // (a group width that is not a power of two: the partial sums of the grid recurrence use the records' space once the
     // direct rounds are through with them -- DS operations of a wavefront execute in order)
     constexpr int SH_AB = G * GS > Geo::BUF_AB ? G * GS : Geo::BUF_AB;
@@ -1368,8 +1385,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(W ==
         const int e = d.e, tv = d.tv, nj = d.nj, np = d.np, T = d.T, gb = d.gb;
         const double pval = d.pval, kx = d.kx;
         const int npts = np + T;
-        const int jl = min(gl, nj - 1);
-        const double yl = s.old_particles[(int64_t)d.pv * n + jl], ml = v2f[(int64_t)d.pce * n + jl];
+        double yl[PPL], ml[PPL];
+#pragma unroll
+        for (int pp = 0; pp < PPL; ++pp) {
+            const int jl = min(gl + pp * W, nj - 1);
+            yl[pp] = s.old_particles[(int64_t)d.pv * n + jl]; ml[pp] = v2f[(int64_t)d.pce * n + jl];
+        }
         double xs[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -1378,23 +1399,29 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(W ==
             xs[r] = *src;
         }
         const bool hidden_partner = is_hidden(pval);
-        const double y = hidden_partner ? yl : pval, m = hidden_partner ? ml : 0.0;
 #else
+        static_assert(PPL == 1, "the round-4 loads know one particle per lane");
         const FastDesc& d = descs[live ? idx : nitems - 1];  // (a group past the end repeats the last entry and stores nothing)
         const int e = d.e, tv = d.tv, nj = d.nj, np = d.np, T = d.T, gb = d.gb;
         const double pval = d.pval, kx = d.kx;
         const int npts = np + T;
         // staging: lane = partner particle of its group's edge
-        double y = pval, m = 0.0;
-        if (gl < nj && is_hidden(pval)) { y = s.old_particles[(int64_t)d.pv * n + gl]; m = v2f[(int64_t)d.pce * n + gl]; }
+        const bool hidden_partner = is_hidden(pval);
+        double yl[1] = {pval}, ml[1] = {0.0};
+        if (gl < nj && hidden_partner) { yl[0] = s.old_particles[(int64_t)d.pv * n + gl]; ml[0] = v2f[(int64_t)d.pce * n + gl]; }
 #endif
-        double ua = PAD_LOG_TERM, ub = 0.0;                        // padding: underflows to exactly 0 whatever the point's own constant adds
-        if (gl < nj) {
-            ua = (d.ay * y + d.by) * y + d.c + m;
-            ub = d.axy * y + d.bx;
+        double ua[PPL], ub[PPL];
+        AB rec[PPL];
+#pragma unroll
+        for (int pp = 0; pp < PPL; ++pp) {
+            const double y = hidden_partner ? yl[pp] : pval, m = hidden_partner ? ml[pp] : 0.0;
+            ua[pp] = PAD_LOG_TERM; ub[pp] = 0.0;                   // padding: underflows to exactly 0 whatever the point's own constant adds
+            if (gl + pp * W < nj) {
+                ua[pp] = (d.ay * y + d.by) * y + d.c + m;
+                ub[pp] = d.axy * y + d.bx;
+            }
+            rec[pp].a = ua[pp] * LHVI_EXP_INV_STEP; rec[pp].b = ub[pp] * LHVI_EXP_INV_STEP;      // (records in units of the table step: floor form)
         }
-        AB rec;
-        rec.a = ua * LHVI_EXP_INV_STEP; rec.b = ub * LHVI_EXP_INV_STEP;      // (records in units of the table step: floor form)
 #if LHVI_SMALL_GRID
         // Integral points on a uniform grid: the recurrence of the heavy kernel inside the lane group (small_grid_sums32), when every
         // exponent of the edge stays far inside the double range over the whole grid -- a property of the edge alone, so an edge
@@ -1403,8 +1430,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(W ==
         bool gok = false;
         if (d.pad[1] && T <= GRID_MAX_T && !(s.flags & (LHVI_PBP_SKIP_TERMS | LHVI_PBP_NO_GRID))) {
             const double X = fmax(fabs(gx0), fabs(fma((double)(T - 1), gh, gx0)));
-            const double bound = fma(fabs(ub) + fabs(kx) * X, X, fabs(ua));
-            const uint64_t bad = __ballot(gl < nj && !(bound < GRID_MAX_EXPONENT));
+            bool mine_bad = false;
+#pragma unroll
+            for (int pp = 0; pp < PPL; ++pp) {
+                const double bound = fma(fabs(ub[pp]) + fabs(kx) * X, X, fabs(ua[pp]));
+                mine_bad |= gl + pp * W < nj && !(bound < GRID_MAX_EXPONENT);
+            }
+            const uint64_t bad = __ballot(mine_bad);
             gok = ((bad >> (grp * W)) & ((1ull << W) - 1)) == 0;
         }
         const int lim = gok ? np : npts;                           // points of this group's edge that the direct rounds serve
@@ -1422,7 +1454,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(W ==
         if (s.flags & LHVI_PBP_SKIP_TERMS) jmax = 0;
         double* out = f2v + (int64_t)e * S;
         LHVI_WAVE_SYNC();
-        if (lane_ok) sh[grp * GS + gl] = rec;
+        if (lane_ok) {
+#pragma unroll
+            for (int pp = 0; pp < PPL; ++pp) sh[grp * GS + gl + pp * W] = rec[pp];
+        }
         LHVI_WAVE_SYNC();
 #if LHVI_SMALL_HOIST
         // the three prefetched rounds written out: each waits for ITS points only (loads return in order), not -- as a loop whose
@@ -1455,8 +1490,15 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(W ==
         }
 #if LHVI_SMALL_GRID
         if (any_grid) {
-            double gv = exp_core(fma(ub, gx0, ua), sh_tab);
-            const double q = exp_core(ub * gh, sh_tab);
+            double gv[PPL], q[PPL];
+#pragma unroll
+            for (int pp = 0; pp < PPL; ++pp) { gv[pp] = exp_core(fma(ub[pp], gx0, ua[pp]), sh_tab); q[pp] = exp_core(ub[pp] * gh, sh_tab); }
+            auto next_value = [&]() {                              // the lane's particles' sum at the next grid point
+                double v = gv[0];
+                gv[0] *= q[0];
+                if constexpr (PPL == 2) { v += gv[1]; gv[1] *= q[1]; }
+                return v;
+            };
             int tmax = 0;
 #pragma unroll
             for (int k = 0; k < G; ++k) tmax = max(tmax, __builtin_amdgcn_readlane(gok ? T : 0, k * W));
@@ -1464,7 +1506,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(W ==
             for (int t0 = 0; t0 < tmax; t0 += 32) {
                 if constexpr (Geo::POW2) {
                     double sum[2];
-                    small_grid_sums32<W>(gv, q, lane, sum[0], sum[1]);
+                    small_grid_sums32<W>(next_value, lane, sum[0], sum[1]);
 #pragma unroll
                     for (int k = 0; k < (W == 16 ? 2 : 1); ++k) {
                         const int t = t0 + small_grid_point<W>(gl, k);
@@ -1476,7 +1518,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(W ==
                 } else {
                     if constexpr (Geo::R >= 4) {
                         // a lane owns a point in (almost) every chunk of eight: the logarithm and the store right there
-                        small_grid_sums_lds<W>(gv, q, lane, grp, gl, lane_ok, reinterpret_cast<double*>(sh), [&](bool has, int p, double sum) {
+                        small_grid_sums_lds<W>(next_value, lane, grp, gl, lane_ok, reinterpret_cast<double*>(sh), [&](bool has, int p, double sum) {
                             const int t = t0 + p;
                             if (has && live && gok && t < T) {
                                 const double xt = fma((double)t, gh, gx0);
@@ -1488,7 +1530,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(W ==
                         double sum[Geo::R];
 #pragma unroll
                         for (int r = 0; r < Geo::R; ++r) sum[r] = 0.0;
-                        small_grid_sums_lds<W>(gv, q, lane, grp, gl, lane_ok, reinterpret_cast<double*>(sh), [&](bool has, int p, double v) {
+                        small_grid_sums_lds<W>(next_value, lane, grp, gl, lane_ok, reinterpret_cast<double*>(sh), [&](bool has, int p, double v) {
 #pragma unroll
                             for (int r = 0; r < Geo::R; ++r) sum[r] = (has && p >= r * W && p < (r + 1) * W) ? v : sum[r];
                         });
@@ -3159,12 +3201,12 @@ static int launch_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* 
     return check_launch();
 }
 
-template <int W>
+template <int W, int PPL = 1>
 static void launch_f2v_small(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* v2f, double* f2v, const void* desc, int nitems,
                              int cus, int share, int spare, void* stream) {
-    static const int per_cu = blocks_per_cu((const void*)pbp_f2v_small_kernel<W>);
+    static const int per_cu = blocks_per_cu((const void*)pbp_f2v_small_kernel<W, PPL>);
     constexpr int PER_BLOCK = (BLOCK / WAVE) * (WAVE / W);                // edges per workgroup and step
-    hipLaunchKernelGGL(pbp_f2v_small_kernel<W>, dim3(min((nitems + PER_BLOCK - 1) / PER_BLOCK, max(cus * max(per_cu - share, 1) - spare, 1))),
+    hipLaunchKernelGGL((pbp_f2v_small_kernel<W, PPL>), dim3(min((nitems + PER_BLOCK - 1) / PER_BLOCK, max(cus * max(per_cu - share, 1) - spare, 1))),
                        dim3(BLOCK), 0, as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const FastDesc*>(desc), nitems);
 }
 
@@ -3290,10 +3332,14 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
             if (s->small16_desc && s->n_small16 > 0) {
                 if (narrow && s->n <= 10) launch_f2v_small<10>(g, s, v2f, f2v, s->small16_desc, s->n_small16, cus, share, spare, stream);
                 else if (narrow && s->n <= 12) launch_f2v_small<12>(g, s, v2f, f2v, s->small16_desc, s->n_small16, cus, share, spare, stream);
+                else if (narrow) launch_f2v_small<8, 2>(g, s, v2f, f2v, s->small16_desc, s->n_small16, cus, share, spare, stream);   // 13-16 particles: eight edges per wavefront
                 else launch_f2v_small<16>(g, s, v2f, f2v, s->small16_desc, s->n_small16, cus, share, spare, stream);
             }
             if (s->small32_desc && s->n_small32 > 0) {
-                if (narrow && s->n <= 20) launch_f2v_small<20>(g, s, v2f, f2v, s->small32_desc, s->n_small32, cus, share, spare, stream);
+                // (two particles per lane: groups of 10 / 12 / 16 lanes for up to 20 / 24 / 32 particles)
+                if (narrow && s->n <= 20) launch_f2v_small<10, 2>(g, s, v2f, f2v, s->small32_desc, s->n_small32, cus, share, spare, stream);
+                else if (narrow && s->n <= 24) launch_f2v_small<12, 2>(g, s, v2f, f2v, s->small32_desc, s->n_small32, cus, share, spare, stream);
+                else if (narrow) launch_f2v_small<16, 2>(g, s, v2f, f2v, s->small32_desc, s->n_small32, cus, share, spare, stream);
                 else launch_f2v_small<32>(g, s, v2f, f2v, s->small32_desc, s->n_small32, cus, share, spare, stream);
             }
         }
