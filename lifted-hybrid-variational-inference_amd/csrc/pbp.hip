@@ -696,19 +696,24 @@ __device__ __forceinline__ double fast_accumulate_uniform(const AB* __restrict__
     return (acc0 + acc1) * sft.scale;
 }
 
+#define LHVI_PIN1(a) do { if (PIN) asm volatile("" : "+v"(a)); } while (0)
+#define LHVI_PIN2(a, b) do { if (PIN) asm volatile("" : "+v"(a), "+v"(b)); } while (0)
 // The MODE_CONST loop on records pre-divided by the table step (a_j / step, b_j / step): exp_accumulate_floor, one fp64 operation
 // less per term (fastmath.hpp).  The fp64 rounding mode is round-down between the two mode writes.
-template <int UNROLL = 4>
+template <int UNROLL = 4, bool PIN = false>
 __device__ __forceinline__ double fast_accumulate_floor(const AB* __restrict__ sh, const double* __restrict__ tab, int jn_, double X1,
                                                         double C) {
     const int jn = __builtin_amdgcn_readfirstlane(jn_);
     // The compiler may move plain fp64 arithmetic across the two mode writes (they are volatile asm, the arithmetic is not): the
-    // shift's constants of an unrolled NEXT call computed inside this call's round-down window, the closing additions after it.
-    // The empty volatile asm statements pin both ends -- what is computed under which rounding mode is then the same in every
-    // instantiation of every kernel that calls this, so an edge gets the same bits from each of them.
-    asm volatile("" : "+v"(C));
+    // shift's constants of an unrolled NEXT call computed inside this call's round-down window, the closing additions after it --
+    // differently in different instantiations, so the last bit of a sum (a few percent of a sum that is denormal) depends on the
+    // kernel it was formed in.  PIN: empty volatile asm statements pin both ends; what is computed under which rounding mode is then
+    // the same wherever the call is inlined.  The few-particle kernels pin (their instantiations -- lane groups of 8 to 32 lanes,
+    // one or two particles per lane -- serve the same edge depending on lhvi_pbp_t.n and must give it the same bits); the heavy
+    // kernel, a single instantiation, does not: the pins cost it 0.7 % (scripts/diag/pin_ab.sh).
+    LHVI_PIN1(C);
     ExpShiftFloor sft = exp_shift_floor(C);
-    asm volatile("" : "+v"(sft.magic), "+v"(sft.scale));
+    LHVI_PIN2(sft.magic, sft.scale);
     double acc0 = 0.0, acc1 = 0.0;
     int j = 0;
     round_down_on();
@@ -728,7 +733,7 @@ __device__ __forceinline__ double fast_accumulate_floor(const AB* __restrict__ s
         if (j + 1 < jn) { const AB r1 = sh[j + 1]; acc1 = exp_accumulate_floor(acc1, fma(r1.b, X1, r1.a), sft.magic, tab); }
         if (j + 2 < jn) { const AB r2 = sh[j + 2]; acc2 = exp_accumulate_floor(acc2, fma(r2.b, X1, r2.a), sft.magic, tab); }
         acc0 += acc2; acc1 += acc3;
-        asm volatile("" : "+v"(acc0), "+v"(acc1));
+        LHVI_PIN2(acc0, acc1);
         round_down_off();
         return (acc0 + acc1) * sft.scale;
     }
@@ -738,7 +743,7 @@ __device__ __forceinline__ double fast_accumulate_floor(const AB* __restrict__ s
         acc1 = exp_accumulate_floor(acc1, fma(r1.b, X1, r1.a), sft.magic, tab);
     }
     if (j < jn) { const AB r0 = sh[j]; acc0 = exp_accumulate_floor(acc0, fma(r0.b, X1, r0.a), sft.magic, tab); }
-    asm volatile("" : "+v"(acc0), "+v"(acc1));
+    LHVI_PIN2(acc0, acc1);
     round_down_off();
     return (acc0 + acc1) * sft.scale;
 }
@@ -1471,7 +1476,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPL 
                 const int p = r * W + gl;
                 const bool valid = live && p < lim;
                 const double x = valid ? xs[r] : 0.0;
-                const double acc = fast_accumulate_floor<4>(mine_recs, sh_tab, jmax, x, kx * x * x);
+                const double acc = fast_accumulate_floor<4, true>(mine_recs, sh_tab, jmax, x, kx * x * x);
                 if (valid) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
             }
         }
@@ -1485,7 +1490,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPL 
             const bool valid = live && p < lim;
             double x = 0.0;
             if (valid) x = p < np ? s.particles[(int64_t)tv * n + p] : g.dom_val[gb + p - np];
-            const double acc = fast_accumulate_floor<4>(mine_recs, sh_tab, jmax, x, kx * x * x);
+            const double acc = fast_accumulate_floor<4, true>(mine_recs, sh_tab, jmax, x, kx * x * x);
             if (valid) out[p < np ? p : n + (p - np)] = acc > 0.0 ? log_table(acc, sh_log) : -700.0;
         }
 #if LHVI_SMALL_GRID

@@ -17,10 +17,14 @@ if [ $part = 1 ]; then
   cp $O/${tag}_final_bench_under_rocprof.json profiles/ 2>/dev/null
   cp profiles/${tag}_final_* $O/ 2>/dev/null
   bash scripts/profile_particles.sh ${tag}_particles || exit 1
-else
+elif [ $part = 2 ]; then
   bash scripts/profile_secondary.sh ${tag}_secondary || exit 1
   python3 scripts/summarize_pmc.py ${tag}_secondary $O/${tag}_secondary_stats $O/${tag}_secondary_fetch $O/${tag}_secondary_write || exit 1
   cp profiles/${tag}_secondary_* $O/ 2>/dev/null
   bash scripts/profile_gauss.sh ${tag}_gauss || exit 1
   bash scripts/profile_fewparticles_pmc.sh ${tag}_n10 10 || exit 1
+fi
+if [ $part = 3 ]; then        # PMC passes of the few-particle sweeps only
+  for n in 16 20; do bash scripts/profile_fewparticles_pmc.sh ${tag}_n$n $n > $O/${tag}_n$n.log 2>&1 || exit 1; done
+  grep -h -E "small_kernel|var_fused" $O/${tag}_n16.log $O/${tag}_n20.log | cut -c1-160
 fi
