@@ -225,7 +225,7 @@ int lhvi_log_likelihood(const lhvi_graph_t* g, const lhvi_pots_t* pots, const do
                                    * there, then 8 particles of the variable (s->np[v])  9 g->var_ptr[v]  10-15 its first six incident edges
                                    * (var_edge[var_ptr[v] + 0 .. 5]; unused ones 0) -- so that a variable's rows hang on one load behind its record */
 #define LHVI_PBP_POW2_GROUPS 65536u /* lhvi_pbp_f2v: the small16 / small32 lists always through lane groups of 16 / 32 lanes (four / two edges per
-                                   * wavefront), also when s->n <= 10 / 12 / 20 would let six / five / three edges share one (testing / profiling aid) */
+                                   * wavefront), also when s->n would let up to eight edges share one (narrower groups, two particles per lane; testing / profiling aid) */
 
 typedef struct lhvi_pbp {
     int32_t n;                  /* particle slots per variable */
@@ -332,9 +332,10 @@ typedef struct lhvi_pbp {
     int32_t n_resample_vars;
     /* optional, lhvi_pbp_f2v only: heavy-class descriptors (same rows as heavy_desc would hold, and NOT in heavy_desc) of the edges
      * whose target AND partner have at most 16 / at most 32 particles (nj <= 16 and np <= 16; the rest with nj <= 32 and np <= 32);
-     * any number of integral points.  Served four / two edges per wavefront by their own kernel -- six / five for the small16 list
-     * when s->n <= 10 / 12, three for the small32 list when s->n <= 20 (lane groups as wide as the particle count; no variable may
-     * then hold more than s->n particles; LHVI_PBP_POW2_GROUPS keeps four / two): with the particle counts of the
+     * any number of integral points.  Served four / two edges per wavefront by their own kernel -- six / five / eight for the small16
+     * list when s->n <= 10 / 12 / 16, six / five / four for the small32 list when s->n <= 20 / 24 / 32 (lane groups as narrow as
+     * the particle count allows, two particles per lane beyond 12; no variable may then hold more than s->n particles;
+     * LHVI_PBP_POW2_GROUPS keeps four / two): with the particle counts of the
      * reference's demos (10-20) an edge per wavefront is bound by its own latencies, not by its terms.  Integral points on a uniform
      * grid (descriptor word 15) are tabulated by the recurrence along the grid inside the lane group, like the heavy kernel's (to
      * rounding the same values as the direct form; LHVI_PBP_NO_GRID forces that one).  NULL: such edges stay in heavy_desc.  Skipped

@@ -1307,8 +1307,8 @@ __global__ void __launch_bounds__(HEAVY_BLOCK) __attribute__((amdgpu_waves_per_e
     if (stats && lane == 0) { atomicAdd(stats, (uint32_t)n_grid); atomicAdd(stats + 1, (uint32_t)n_direct); }
 }
 
-// HEAVY-class edges with FEW particles (target and partner both at most W = 10, 12, 16, 20 or 32: the particle counts of the
-// reference's demos; the launcher picks the narrowest width that holds lhvi_pbp_t.n), floor(64 / W) edges per wavefront.  With one edge per wavefront such an edge keeps 64 lanes busy for a dozen terms and then
+// HEAVY-class edges with FEW particles (target and partner both at most PPL * W, W = 8 ... 32 lanes, PPL = 1 or 2 particles per
+// lane: the particle counts of the reference's demos; the launcher picks by lhvi_pbp_t.n), floor(64 / W) edges per wavefront.  With one edge per wavefront such an edge keeps 64 lanes busy for a dozen terms and then
 // waits out the latencies of its own loads, LDS hand-off and stores (gfx950 counts loads and stores in one in-order counter, so
 // the wait for the next edge's operands includes this edge's store acknowledgements): ~10 us per edge whatever it holds.  Here a
 // lane group of W lanes owns an edge: lane = partner particle while the records are staged (wave-private LDS, one block of W
@@ -3331,7 +3331,8 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
                                *g, sh, v2f, f2v, reinterpret_cast<const FastDesc*>(s->heavy_desc), s->n_heavy,
                                s->f2v_ticket ? s->f2v_ticket + LHVI_PBP_TICKET_COUNTERS : (uint32_t*)nullptr);
         if (!(s->flags & LHVI_PBP_SKIP_HEAVY)) {
-            // lane groups as wide as the particle count asks for: 10 / 12 / 16 lanes for the small16 list, 20 / 32 for small32
+            // lane groups as narrow as the particle count allows: 10 / 12 lanes, or 8 with two particles per lane, for the small16 list;
+            // 10 / 12 / 16 lanes with two particles per lane for small32
             // (no variable holds more than s->n particles; LHVI_PBP_POW2_GROUPS keeps the 16- / 32-lane kernels)
             const bool narrow = !(s->flags & LHVI_PBP_POW2_GROUPS);
             if (s->small16_desc && s->n_small16 > 0) {
