@@ -332,9 +332,9 @@ typedef struct lhvi_pbp {
     int32_t n_resample_vars;
     /* optional, lhvi_pbp_f2v only: heavy-class descriptors (same rows as heavy_desc would hold, and NOT in heavy_desc) of the edges
      * whose target AND partner have at most 16 / at most 32 particles (nj <= 16 and np <= 16; the rest with nj <= 32 and np <= 32);
-     * any number of integral points.  Served four / two edges per wavefront by their own kernel -- six / five / eight for the small16
+     * any number of integral points.  Served four / two edges per wavefront by their own kernel -- six / ten / eight for the small16
      * list when s->n <= 10 / 12 / 16, six / five / four for the small32 list when s->n <= 20 / 24 / 32 (lane groups as narrow as
-     * the particle count allows, two particles per lane beyond 12; no variable may then hold more than s->n particles;
+     * the particle count allows, two particles per lane beyond 10; no variable may then hold more than s->n particles;
      * LHVI_PBP_POW2_GROUPS keeps four / two): with the particle counts of the
      * reference's demos (10-20) an edge per wavefront is bound by its own latencies, not by its terms.  Integral points on a uniform
      * grid (descriptor word 15) are tabulated by the recurrence along the grid inside the lane group, like the heavy kernel's (to

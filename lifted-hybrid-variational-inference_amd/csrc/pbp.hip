@@ -1098,7 +1098,8 @@ template <int W>
 struct SmallGeom {
     static constexpr int G = WAVE / W;                                  // edges per wavefront
     static constexpr bool POW2 = W == 16 || W == 32;                    // (the butterfly networks of small_grid_sums32; 8 lanes take the LDS form)
-    static constexpr int L = POW2 ? 0 : (W % 4 == 0 ? 2 : 1);           // folds before the partials go through LDS
+    static constexpr int L = POW2 ? 0 : (W % 4 == 0 ? 2 : 1);           // folds before the partials go through LDS (W even)
+    static constexpr int OWN = (8 + W - 1) / W;                         // points of a chunk of eight that a lane can own (W < 8: two)
     static constexpr int P = W >> L;                                    // partial sums per point
     static constexpr int R = (32 + W - 1) / W;                          // points of a batch of 32 that a lane owns
     static constexpr int BUF_AB = POW2 ? 0 : G * 4 * P;                 // the partials of eight points, in 16-byte units
@@ -1111,33 +1112,41 @@ __device__ __forceinline__ void small_grid_sums_lds(Step&& step /* the lane's va
     const bool b0 = lane & 1, b1 = (lane >> 1) & 1;
 #pragma unroll
     for (int bt = 0; bt < 4; ++bt) {
-        double v[8], w[4];
+        double v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = step();
+        static_assert(L >= 1, "an even width: the fold over lane ^ 1 stays inside the group");
+        {
+            double w[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) w[m] = fold_bit0_xy(v[2 * m], v[2 * m + 1], b0);           // point 2 m + b0 of the chunk
-        if (L == 1) {
-            if (lane_ok) {
+            for (int m = 0; m < 4; ++m) w[m] = fold_bit0_xy(v[2 * m], v[2 * m + 1], b0);       // point 2 m + b0 of the chunk
+            if (L == 1) {
+                if (lane_ok) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) buf[(grp * 8 + 2 * m + (int)b0) * P + (gl >> 1)] = w[m];
-            }
-        } else {
-            const double u0 = fold_bit1(w[0], w[1], b1), u1 = fold_bit1(w[2], w[3], b1);       // points 4 k + 2 b1 + b0
-            if (lane_ok) {
-                buf[(grp * 8 + 2 * (int)b1 + (int)b0) * P + (gl >> 2)] = u0;
-                buf[(grp * 8 + 4 + 2 * (int)b1 + (int)b0) * P + (gl >> 2)] = u1;
+                    for (int m = 0; m < 4; ++m) buf[(grp * 8 + 2 * m + (int)b0) * P + (gl >> 1)] = w[m];
+                }
+            } else {
+                const double u0 = fold_bit1(w[0], w[1], b1), u1 = fold_bit1(w[2], w[3], b1);   // points 4 k + 2 b1 + b0
+                if (lane_ok) {
+                    buf[(grp * 8 + 2 * (int)b1 + (int)b0) * P + (gl >> 2)] = u0;
+                    buf[(grp * 8 + 4 + 2 * (int)b1 + (int)b0) * P + (gl >> 2)] = u1;
+                }
             }
         }
         LHVI_WAVE_SYNC();
-        // the point of this chunk that the lane owns, if any (chunks hold 8 <= W points: at most one)
-        int off = gl - (8 * bt) % W;
-        if (off < 0) off += W;
-        const bool has = off < 8;
-        const double* __restrict__ row = buf + (grp * 8 + (has ? off : 0)) * P;
-        double sum = row[0];
+        // the points of this chunk that the lane owns (point p of the batch belongs to lane p % W: one per chunk for W >= 8, up to two below)
+        int first = gl - (8 * bt) % W;
+        if (first < 0) first += W;
 #pragma unroll
-        for (int k = 1; k < P; ++k) sum += row[k];
-        emit(has, 8 * bt + off, sum);
+        for (int o = 0; o < Geo::OWN; ++o) {
+            const int off = first + o * W;
+            const bool has = off < 8;
+            const double* __restrict__ row = buf + (grp * 8 + (has ? off : 0)) * P;
+            double sum = row[0];
+#pragma unroll
+            for (int k = 1; k < P; ++k) sum += row[k];
+            emit(has, 8 * bt + off, sum);
+        }
         LHVI_WAVE_SYNC();
     }
 }
@@ -3336,8 +3345,11 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
             // (no variable holds more than s->n particles; LHVI_PBP_POW2_GROUPS keeps the 16- / 32-lane kernels)
             const bool narrow = !(s->flags & LHVI_PBP_POW2_GROUPS);
             if (s->small16_desc && s->n_small16 > 0) {
+                // (measured, scripts/diag/narrow_groups.sh + profiles/r05_experiments.md item 19: ten lanes beat two particles per lane in
+                // groups of five at n = 10 -- 1.42 against 1.46 ms, the five-lane build needs 107 registers and 34 KB of LDS -- and lose to
+                // groups of six at n = 12: 1.64 against 1.54 ms)
                 if (narrow && s->n <= 10) launch_f2v_small<10>(g, s, v2f, f2v, s->small16_desc, s->n_small16, cus, share, spare, stream);
-                else if (narrow && s->n <= 12) launch_f2v_small<12>(g, s, v2f, f2v, s->small16_desc, s->n_small16, cus, share, spare, stream);
+                else if (narrow && s->n <= 12) launch_f2v_small<6, 2>(g, s, v2f, f2v, s->small16_desc, s->n_small16, cus, share, spare, stream);
                 else if (narrow) launch_f2v_small<8, 2>(g, s, v2f, f2v, s->small16_desc, s->n_small16, cus, share, spare, stream);   // 13-16 particles: eight edges per wavefront
                 else launch_f2v_small<16>(g, s, v2f, f2v, s->small16_desc, s->n_small16, cus, share, spare, stream);
             }

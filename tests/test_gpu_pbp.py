@@ -391,9 +391,9 @@ def test_few_particle_kernel_grid_recurrence_matches_the_direct_form(api, case):
 @pytest.mark.parametrize('case', ['n10', 'n9', 'n12', 'n11 T48', 'n20', 'n18 T100', 'n10 wide', 'n20 uneven', 'n24', 'n22 T48', 'n32', 'n28 T100',
                                   'n17 wide', 'n32 uneven', 'n16', 'n13 T48', 'n16 wide', 'n14 uneven', 'n15 T100'])
 def test_few_particle_kernel_narrow_lane_groups_match_the_16_and_32_lane_groups(api, case):
-    """``pbp_f2v_small_kernel<10 / 12>`` (six / five edges per wavefront when no variable holds more than 10 / 12 particles; partial
-    sums of the grid recurrence through wave-private LDS) and ``<8 / 10 / 12 / 16, 2>`` (two particles per lane: eight / six / five / four edges per
-    wavefront for up to 16 / 20 / 24 / 32 particles) against the 16- / 32-lane groups (LHVI_PBP_POW2_GROUPS): the particle part bit for bit
+    """``pbp_f2v_small_kernel<10>`` (six edges per wavefront when no variable holds more than 10 particles; partial
+    sums of the grid recurrence through wave-private LDS) and ``<6 / 8 / 10 / 12 / 16, 2>`` (two particles per lane: ten / eight / six / five /
+    four edges per wavefront for up to 12 / 16 / 20 / 24 / 32 particles) against the 16- / 32-lane groups (LHVI_PBP_POW2_GROUPS): the particle part bit for bit
     -- the same term loop over the same records -- the grid part to 1e-12 (another order of the sum over the partner's particles),
     ragged list ends and rejected edges (domain [-40, 40]) included"""
     import torch
