@@ -1758,32 +1758,38 @@ __global__ void __launch_bounds__(BLOCK) pbp_f2v_pair_kernel(lhvi_graph_t g, lhv
 #ifndef LHVI_PAIR_SMALL
 #define LHVI_PAIR_SMALL 1
 #endif
-// PAIRS with FEW particles (every variable of the run has at most W = 16 or 32: lhvi_pbp_t.n <= W): 64 / W list entries per
+// PAIRS with FEW particles (every variable of the run has at most W = 16, 20 or 32: lhvi_pbp_t.n <= W): floor(64 / W) list entries per
 // wavefront, a lane group of W lanes each -- the one-entry-per-wave kernel above keeps 48 of 64 lanes busy for two exponentials
 // and then waits for its own loads.  Same expressions per output point, and the sums over the continuous variable's particles
 // run through the same reduction network at the same positions inside the group (dpp_row_reduce / dpp_reduce_rows32 are the first
-// stages of wave_sum, whose later stages add the zeros of the empty rows): the same bits as the kernel above.  Descriptor and
-// operands in two round trips, as in pbp_f2v_small_kernel.
+// stages of wave_sum, whose later stages add the zeros of the empty rows; a group of 20 lanes, which is no row of that network,
+// spells the same tree out over shuffled pair sums): the same bits as the kernel above.  Descriptor and operands in two round
+// trips, as in pbp_f2v_small_kernel.
 template <int W>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
 pbp_f2v_pair_small_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict__ v2f, double* __restrict__ f2v,
                           const PairDesc* __restrict__ descs, int nitems) {
     constexpr int G = WAVE / W;
+    static_assert(W % 2 == 0, "pairs of lanes (lane ^ 1) stay inside a group");
     __shared__ double sh_tab[EXP_TAB_N];
     __shared__ LogRec sh_log[LOG_TAB_N];
     load_log_table(sh_log);
     load_exp_table(sh_tab);
     const int lane = threadIdx.x & 63;
-    const int grp = lane / W, gl = lane % W;
+    // (a width that does not divide 64 -- 20 lanes: three entries per wavefront -- leaves 64 - G W lanes without an entry: they follow
+    // the last lane of the last group and store nothing)
+    const bool lane_ok = lane < G * W;
+    const int grp = lane_ok ? lane / W : G - 1, gl = lane_ok ? lane % W : W - 1;
+    const int first_lane = grp * W;
     const int n = s.n, S = s.n + s.T;
     const int nsteps = (nitems + G - 1) / G;
     const int nwaves = gridDim.x * (BLOCK / WAVE);
     for (int step = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); step < nsteps; step += nwaves) {
         const int idx = step * G + grp;
-        const bool live = idx < nitems;
+        const bool live = idx < nitems && lane_ok;
         union { PairDesc d; int4 q[sizeof(PairDesc) / 16]; } u;
         {
-            const int4* dp = reinterpret_cast<const int4*>(descs + (live ? idx : nitems - 1));
+            const int4* dp = reinterpret_cast<const int4*>(descs + min(idx, nitems - 1));
 #pragma unroll
             for (int k = 0; k < (int)(sizeof(PairDesc) / 16); ++k) u.q[k] = dp[k];
         }
@@ -1830,9 +1836,35 @@ pbp_f2v_pair_small_kernel(lhvi_graph_t g, lhvi_pbp_t s, const double* __restrict
             const int nj = hid_c ? np : 1;
             const double y = hid_c ? yl : d.val_c, m = hid_c ? mjl : 0.0;
             auto group_sum = [&](double x) {
-                if (W == 16) return dpp_move<0x15F>(dpp_row_reduce(x, SumOp()));      // lane 15's sum: the one wave_sum hands on (each lane adds in its own order)
-                x = dpp_reduce_rows32(x, SumOp());
-                return lane < 32 ? readlane_f64(x, 31) : readlane_f64(x, 63);
+                if constexpr (W == 16) return dpp_move<0x15F>(dpp_row_reduce(x, SumOp()));      // lane 15's sum: the one wave_sum hands on (each lane adds in its own order)
+                else if constexpr (W == 32) {
+                    x = dpp_reduce_rows32(x, SumOp());
+                    return lane < 32 ? readlane_f64(x, 31) : readlane_f64(x, 63);
+                } else {
+                    // a group that is no row of the DPP network: the SAME tree, spelled out.  wave_sum's lane 63 (and the 16- / 32-lane
+                    // forms' lanes 15 / 31) hold  rows added in order, a row = (Q0 + Q1) + (Q2 + Q3), a quad Q = (v0 + v1) + (v2 + v3);
+                    // the lanes beyond the particles hold zeros there, and adding a zero changes nothing -- so the tree over the live
+                    // pairs alone has the same bits.  Pair sums by lane ^ 1 (group bases are even), gathered by shuffle.
+                    const double pr = x + dpp_move<0xb1>(x);
+                    double p[W / 2];
+#pragma unroll
+                    for (int k = 0; k < W / 2; ++k) p[k] = __shfl(pr, first_lane + 2 * k);
+                    double total = 0.0;
+#pragma unroll
+                    for (int r0 = 0; r0 < W / 2; r0 += 8) {                 // a row of sixteen lanes = eight pairs
+                        double q[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int a = r0 + 2 * k;
+                            q[k] = a + 1 < W / 2 ? p[a] + p[a + 1] : (a < W / 2 ? p[a] : 0.0);
+                        }
+                        const double lo = r0 + 2 < W / 2 ? q[0] + q[1] : q[0];
+                        const double hi = r0 + 6 < W / 2 ? q[2] + q[3] : q[2];
+                        const double row = r0 + 4 < W / 2 ? lo + hi : lo;
+                        total = r0 == 0 ? row : total + row;
+                    }
+                    return total;
+                }
             };
             double res = group_sum((to_d && gl < nj) ? exp_core(fma(y, fma(y, d.A0, d.b0), d.c0 + m), sh_tab) : 0.0);
             const double sum1 = group_sum((to_d && d.ns > 1 && gl < nj) ? exp_core(fma(y, fma(y, d.A1, d.b1), d.c1 + m), sh_tab) : 0.0);
@@ -3215,6 +3247,14 @@ static int launch_v2f(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* 
     return check_launch();
 }
 
+template <int W>
+static void launch_f2v_pair_small(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* v2f, double* f2v, int cus, int spare, void* stream) {
+    static const int per_cu = blocks_per_cu((const void*)pbp_f2v_pair_small_kernel<W>);
+    constexpr int PER_BLOCK = (BLOCK / WAVE) * (WAVE / W);                // entries per workgroup and step
+    hipLaunchKernelGGL(pbp_f2v_pair_small_kernel<W>, dim3(min((s->n_pair + PER_BLOCK - 1) / PER_BLOCK, max(cus * per_cu - spare, 1))), dim3(BLOCK), 0,
+                       as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const PairDesc*>(s->pair_desc), s->n_pair);
+}
+
 template <int W, int PPL = 1>
 static void launch_f2v_small(const lhvi_graph_t* g, const lhvi_pbp_t* s, const double* v2f, double* f2v, const void* desc, int nitems,
                              int cus, int share, int spare, void* stream) {
@@ -3361,14 +3401,14 @@ int lhvi_pbp_f2v(const lhvi_graph_t* g, const lhvi_pots_t* pots, const lhvi_pbp_
                 else launch_f2v_small<32>(g, s, v2f, f2v, s->small32_desc, s->n_small32, cus, share, spare, stream);
             }
         }
-        if (s->pair_desc && s->n_pair > 0 && !(s->flags & (LHVI_PBP_SKIP_LIGHT | LHVI_PBP_WIDE_PAIRS)) && s->n <= 16 && LHVI_PAIR_SMALL) {
-            static const int per_cu = blocks_per_cu((const void*)pbp_f2v_pair_small_kernel<16>);       // (every variable has at most 16 particles)
-            hipLaunchKernelGGL(pbp_f2v_pair_small_kernel<16>, dim3(min((s->n_pair + 15) / 16, max(cus * per_cu - spare, 1))), dim3(BLOCK), 0,
-                               as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const PairDesc*>(s->pair_desc), s->n_pair);
-        } else if (s->pair_desc && s->n_pair > 0 && !(s->flags & (LHVI_PBP_SKIP_LIGHT | LHVI_PBP_WIDE_PAIRS)) && s->n <= 32 && LHVI_PAIR_SMALL) {
-            static const int per_cu = blocks_per_cu((const void*)pbp_f2v_pair_small_kernel<32>);
-            hipLaunchKernelGGL(pbp_f2v_pair_small_kernel<32>, dim3(min((s->n_pair + 7) / 8, max(cus * per_cu - spare, 1))), dim3(BLOCK), 0,
-                               as_stream(stream), *g, *s, v2f, f2v, reinterpret_cast<const PairDesc*>(s->pair_desc), s->n_pair);
+        if (s->pair_desc && s->n_pair > 0 && !(s->flags & (LHVI_PBP_SKIP_LIGHT | LHVI_PBP_WIDE_PAIRS)) && s->n <= 32 && LHVI_PAIR_SMALL) {
+            // (every variable has at most s->n particles: four / three / two entries per wavefront.  Groups of 10 / 12 lanes for n <= 10 / 12
+            // were measured too: 0.52 / 0.51 ms against 0.47-0.51 in groups of 16 -- the shuffles of their summation tree cost what six
+            // or five entries per wavefront save; groups of 20 lanes for n <= 20: 0.65 against 0.77 ms in groups of 32)
+            const bool narrow_pairs = !(s->flags & LHVI_PBP_POW2_GROUPS);
+            if (s->n <= 16) launch_f2v_pair_small<16>(g, s, v2f, f2v, cus, spare, stream);
+            else if (narrow_pairs && s->n <= 20) launch_f2v_pair_small<20>(g, s, v2f, f2v, cus, spare, stream);
+            else launch_f2v_pair_small<32>(g, s, v2f, f2v, cus, spare, stream);
         } else if (s->pair_desc && s->n_pair > 0 && !(s->flags & LHVI_PBP_SKIP_LIGHT)) {
             static const int pair_per_cu = blocks_per_cu((const void*)pbp_f2v_pair_kernel);
             hipLaunchKernelGGL(pbp_f2v_pair_kernel, dim3(min((s->n_pair + 3) / 4, max(cus * min(pair_per_cu, side_blocks) - spare, 1))), dim3(BLOCK), 0,

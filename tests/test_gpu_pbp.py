@@ -1076,10 +1076,11 @@ def test_fused_variable_kernel_equals_the_three_kernels(api, case):
     assert bool(torch.isfinite(a.q_dev[torch.from_numpy(a.flat.var_hidden & a.flat.var_cont).to(a.q_dev.device)]).all())
 
 
-@pytest.mark.parametrize('n', [5, 10, 16, 24, 32])
+@pytest.mark.parametrize('n', [5, 9, 10, 12, 16, 18, 20, 24, 32])
 def test_packed_pair_kernel_equals_the_one_entry_per_wave_kernel(api, n):
-    """few particles: the HybridQuadratic(1 discrete, 1 continuous) factors' list goes four (n <= 16) or two (n <= 32) entries to a
-    wavefront (``pbp_f2v_pair_small_kernel``); LHVI_PBP_WIDE_PAIRS keeps the one-entry-per-wave kernel: every array of the
+    """few particles: the HybridQuadratic(1 discrete, 1 continuous) factors' list goes four / three / two entries to a
+    wavefront for n <= 16 / 20 / 32 (``pbp_f2v_pair_small_kernel<16 / 20 / 32>``; the groups of 20 lanes spell out the summation
+    tree of the DPP networks); LHVI_PBP_WIDE_PAIRS keeps the one-entry-per-wave kernel: every array of the
     state after whole sweeps, bit for bit (observed variables on either side, one-sided records included)"""
     import torch
     from lhvi import _abi, synth
